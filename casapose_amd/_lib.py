@@ -1,0 +1,117 @@
+"""ctypes binding of libcasapose_hip.so (the C ABI declared in include/casapose_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails,
+`CasaposeHipError` is raised.  Build the library with `python __graft_entry__.py` (or
+`make -C casapose_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcasapose_hip.so")
+
+
+class CasaposeHipError(RuntimeError):
+    pass
+
+
+class ConvSource(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("channels", C.c_int),
+        ("ld", C.c_int),
+        ("mode", C.c_int),
+        ("sel", C.c_void_p),
+        ("pre_scale", C.c_void_p),
+        ("pre_shift", C.c_void_p),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int),
+        ("in_h", C.c_int),
+        ("in_w", C.c_int),
+        ("out_h", C.c_int),
+        ("out_w", C.c_int),
+        ("cout", C.c_int),
+        ("kh", C.c_int),
+        ("kw", C.c_int),
+        ("stride", C.c_int),
+        ("dilation", C.c_int),
+        ("pad", C.c_int),
+        ("num_sources", C.c_int),
+        ("src", ConvSource * 2),
+        ("weights", C.c_void_p),
+        ("tap_label", C.c_void_p),
+        ("row_scale", C.c_void_p),
+        ("residual", C.c_void_p),
+        ("residual_ld", C.c_int),
+        ("scale", C.c_void_p),
+        ("shift", C.c_void_p),
+        ("epi_label", C.c_void_p),
+        ("act", C.c_int),
+        ("out_raw", C.c_void_p),
+        ("out_raw_ld", C.c_int),
+        ("out_act", C.c_void_p),
+        ("out_act_ld", C.c_int),
+        ("tile_hint", C.c_int),
+    ]
+
+
+SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32 = range(7)
+
+# every symbol include/casapose_hip.h declares: (name, restype, argtypes)
+_vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+SYMBOLS = [
+    ("cp_last_error", C.c_char_p, []),
+    ("cp_version", _i, []),
+    ("cp_device_count", _i, []),
+    ("cp_conv_ktot", _i, [_i, _i, _i, C.POINTER(_i)]),
+    ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
+    ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),
+    ("cp_maxpool3x3s2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    ("cp_upsample_bilinear_x2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cp_guided_upsample_x2_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cp_argmax_labels", _i, [_vp, _i, _i, _ll, _vp, _vp]),
+    ("cp_label_pyramid", _i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    ("cp_ls_vote_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_ls_vote_workspace_bytes", C.c_size_t, [_i, _i, _i]),
+    ("cp_ccl_filter_labels", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
+    ("cp_ransac_vote_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("cp_ransac_workspace_bytes", C.c_size_t, [_i, _i, _i, _i, _i, _i]),
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every declared symbol.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CasaposeHipError(
+            "libcasapose_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(there is no CPU fallback for the product path)" % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().cp_last_error()
+        raise CasaposeHipError("%s failed (%d): %s" % (what or "casapose_hip call", status, (msg or b"").decode()))

@@ -1,0 +1,428 @@
+"""Host-side execution of the CASAPose forward on MI355X.
+
+The arithmetic lives in libcasapose_hip.so (casapose_amd/csrc); this module only owns
+device memory (PyTorch-ROCm tensors), folds the inference-mode normalisation layers into
+per-channel / per-class affine tables, packs the Keras-layout kernels into the K order
+the implicit-GEMM kernel expects, and issues the launches in graph order.
+
+Graph followed: CASAPoseConditional5 (casapose/pose_models/models/pose_models.py:513-635)
+over ResNet-18 with output stride 8 (models/resnet.py:183-328).  Layer / weight names are
+the Keras names of the reference so weights map 1:1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+BN_EPS = 2e-5  # resnet.py:44; _normalization_layers.py:108
+
+STAGE_FILTERS = (64, 128, 256, 512)
+STAGE_STRIDE = (1, 2, 1, 1)  # resnet.py:262-290 (output_stride 8)
+STAGE_DILATION = (1, 1, 2, 4)
+DECODER_DIMS_DEFAULT = (256, 128, 64, 32, 32)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def fold_bn(params: Dict[str, np.ndarray], name: str, pad_to: Optional[int] = None):
+    """Inference-mode (Sync)BatchNormalization as y = x*scale + shift (fp64 fold, fp32 store)."""
+    var = params[name + ".moving_variance"].astype(np.float64)
+    mean = params[name + ".moving_mean"].astype(np.float64)
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    gamma = params.get(name + ".gamma")
+    beta = params.get(name + ".beta")
+    scale = rstd if gamma is None else gamma.astype(np.float64) * rstd
+    shift = -mean * scale
+    if beta is not None:
+        shift = shift + beta.astype(np.float64)
+    if pad_to is not None and pad_to > scale.size:
+        scale = np.concatenate([scale, np.zeros(pad_to - scale.size)])
+        shift = np.concatenate([shift, np.zeros(pad_to - shift.size)])
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+def fold_clade(params: Dict[str, np.ndarray], name: str):
+    """ClassAdaptiveWeightedNormalization with a hard label (one-hot mask):
+    y = gamma[l]*(x-mean)*rstd + beta[l]  ->  tables [classes][C]
+    (_normalization_layers.py:119-139)."""
+    var = params[name + ".moving_variance"].astype(np.float64)
+    mean = params[name + ".moving_mean"].astype(np.float64)
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    gamma = params[name + ".gamma"].astype(np.float64)
+    beta = params[name + ".beta"].astype(np.float64)
+    scale = gamma * rstd[None, :]
+    shift = beta - gamma * (mean * rstd)[None, :]
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+class FusedConv:
+    """One cp_conv2d_fwd_f32 launch with its packed weights and descriptor."""
+
+    def __init__(self, name: str, kernel: np.ndarray, layout: int, kh: int, kw: int, cout: int,
+                 sources: Sequence[Tuple[int, int]], device: torch.device):
+        lib = _lib.load()
+        self.name = name
+        self.kh, self.kw, self.cout = kh, kw, cout
+        self.sources = list(sources)
+        ns = len(sources)
+        chans = (C.c_int * 2)(*([s[0] for s in sources] + [0] * (2 - ns)))
+        real = (C.c_int * 2)(*([s[1] for s in sources] + [0] * (2 - ns)))
+        self.ktot = lib.cp_conv_ktot(kh, kw, ns, chans)
+        w = np.ascontiguousarray(kernel, dtype=np.float32)
+        cin = sum(s[1] for s in sources)
+        expect = (kh, kw, cin, cout) if layout == 0 else (cin, kh, kw, cout)
+        if tuple(w.shape) != expect:
+            raise ValueError("%s: kernel shape %s, expected %s" % (name, w.shape, expect))
+        packed = np.empty((cout, self.ktot), dtype=np.float32)
+        check(lib.cp_conv_pack_weights_host(w.ctypes.data, layout, kh, kw, cout, ns, chans, real, packed.ctypes.data),
+              "cp_conv_pack_weights_host(%s)" % name)
+        self.wp = torch.from_numpy(packed).to(device)
+        self.desc = ConvDesc()
+        self._keep: List[torch.Tensor] = []
+
+    def bind(self, *, batch, in_h, in_w, stride=1, dilation=1, pad=0, srcs, tap_label=None, row_scale=None,
+             residual=None, scale=None, shift=None, epi_label=None, act=0, out_raw=None, out_raw_ld=None,
+             out_act=None, out_act_ld=None, tile_hint=0):
+        """srcs: list of dicts(data=tensor, ld=int, mode=int, sel=tensor|None, pre=(scale,shift)|None)."""
+        d = self.desc
+        eh = (self.kh - 1) * dilation + 1
+        ew = (self.kw - 1) * dilation + 1
+        d.batch, d.in_h, d.in_w = batch, in_h, in_w
+        d.out_h = (in_h + 2 * pad - eh) // stride + 1
+        d.out_w = (in_w + 2 * pad - ew) // stride + 1
+        d.cout, d.kh, d.kw = self.cout, self.kh, self.kw
+        d.stride, d.dilation, d.pad = stride, dilation, pad
+        d.num_sources = len(srcs)
+        keep = [self.wp]
+        for i, s in enumerate(srcs):
+            cs = d.src[i]
+            cs.data = _ptr(s["data"])
+            cs.channels = self.sources[i][0]
+            cs.ld = s["ld"]
+            cs.mode = s.get("mode", _lib.SRC_DIRECT)
+            cs.sel = _ptr(s.get("sel"))
+            pre = s.get("pre")
+            cs.pre_scale = _ptr(pre[0]) if pre else None
+            cs.pre_shift = _ptr(pre[1]) if pre else None
+            keep += [s["data"], s.get("sel")] + (list(pre) if pre else [])
+        d.weights = _ptr(self.wp)
+        d.tap_label = _ptr(tap_label)
+        d.row_scale = _ptr(row_scale)
+        d.residual = _ptr(residual)
+        d.residual_ld = self.cout
+        d.scale, d.shift = _ptr(scale), _ptr(shift)
+        d.epi_label = _ptr(epi_label)
+        d.act = act
+        d.out_raw = _ptr(out_raw)
+        d.out_raw_ld = out_raw_ld if out_raw_ld is not None else self.cout
+        d.out_act = _ptr(out_act)
+        d.out_act_ld = out_act_ld if out_act_ld is not None else self.cout
+        d.tile_hint = tile_hint
+        keep += [tap_label, row_scale, residual, scale, shift, epi_label, out_raw, out_act]
+        self._keep = [k for k in keep if k is not None]
+        return d.out_h, d.out_w
+
+    def run(self, stream: int):
+        check(_lib.load().cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)
+
+    @property
+    def flops(self) -> float:
+        d = self.desc
+        cin = sum(s[1] for s in self.sources)
+        return 2.0 * d.batch * d.out_h * d.out_w * self.kh * self.kw * cin * self.cout
+
+
+class ForwardPlan:
+    """All buffers, descriptors and the launch order for one (batch, H, W) input shape."""
+
+    def __init__(self, net: "CasaposeNet", batch: int, h: int, w: int, fuse_upsample: bool = True):
+        if h % 8 or w % 8:
+            raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
+        self.net, self.batch, self.h, self.w = net, batch, h, w
+        self.fuse_upsample = fuse_upsample
+        dev = net.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        B = batch
+        K, V = net.seg_dim, net.ver_dim
+        self.out_ld = K + V
+        self.steps: List = []  # callables taking (stream)
+        self.convs: List[FusedConv] = []
+        lib = _lib.load()
+        P = net.device_tables
+        hs = [h, h // 2, h // 4, h // 8]
+        ws = [w, w // 2, w // 4, w // 8]
+
+        def new(*shape):
+            return torch.empty(*shape, **f32)
+
+        # ---- buffers that are (re)bound per call ------------------------------------------
+        self.img4 = new(B, h, w, 4)
+        self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
+        self.pnorm = [new(B, hs[l], ws[l]) for l in range(4)]
+        self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
+        self._out_bound: List[Tuple[FusedConv, int]] = []  # convs writing into the per-call output
+        self._bufs: List[torch.Tensor] = []
+
+        def conv(layer: FusedConv, **kw):
+            layer.bind(batch=B, **kw)
+            self.convs.append(layer)
+            self.steps.append(layer.run)
+
+        L = net.layers_by_name
+        # ---- encoder (resnet.py:246-305) ---------------------------------------------------
+        x2s = new(B, hs[1], ws[1], 64)
+        conv(L["conv0"], in_h=h, in_w=w, stride=2, pad=3,
+             srcs=[dict(data=self.img4, ld=4, pre=P["bn_data"])],
+             scale=P["bn0"][0], shift=P["bn0"][1], act=_lib.ACT_RELU, out_act=x2s)
+        a = new(B, hs[2], ws[2], 64)
+        s1, b1 = P["stage1_unit1_bn1"]
+
+        def pool(stream, src=x2s, dst=a, s1=s1, b1=b1):
+            check(lib.cp_maxpool3x3s2_f32(src.data_ptr(), B, hs[1], ws[1], 64, s1.data_ptr(), b1.data_ptr(), 1,
+                                          dst.data_ptr(), stream), "cp_maxpool3x3s2_f32")
+
+        self.steps.append(pool)
+        self._bufs += [x2s, a]
+        cur_h, cur_w, cin = hs[2], ws[2], 64
+        x_raw = None
+        taps: Dict[str, torch.Tensor] = {"x2s": x2s}
+        tap_names = ["x4s", "x8s", "x16s", "x32s"]
+        for s, f in enumerate(STAGE_FILTERS):
+            d = STAGE_DILATION[s]
+            for u in range(2):
+                base = "stage%d_unit%d_" % (s + 1, u + 1)
+                stride = STAGE_STRIDE[s] if u == 0 else 1
+                oh, ow = (cur_h - 1) // stride + 1, (cur_w - 1) // stride + 1
+                t = new(B, oh, ow, f)
+                bn2 = P[base + "bn2"]
+                if u == 0:
+                    sc = new(B, oh, ow, f)
+                    conv(L[base + "sc"], in_h=cur_h, in_w=cur_w, stride=stride, srcs=[dict(data=a, ld=cin)], out_raw=sc)
+                    shortcut = sc
+                else:
+                    shortcut = x_raw
+                conv(L[base + "conv1"], in_h=cur_h, in_w=cur_w, stride=stride, dilation=d, pad=d,
+                     srcs=[dict(data=a, ld=cin)], scale=bn2[0], shift=bn2[1], act=_lib.ACT_RELU, out_act=t)
+                if u == 0:
+                    nxt = P["stage%d_unit2_bn1" % (s + 1)]
+                    x_raw = new(B, oh, ow, f)
+                else:
+                    nxt = P["stage%d_unit1_bn1" % (s + 2)] if s < 3 else P["bn1"]
+                    x_raw = None
+                a_next = new(B, oh, ow, f)
+                conv(L[base + "conv2"], in_h=oh, in_w=ow, dilation=d, pad=d, srcs=[dict(data=t, ld=f)],
+                     residual=shortcut, out_raw=x_raw, scale=nxt[0], shift=nxt[1], act=_lib.ACT_RELU, out_act=a_next)
+                self._bufs += [t, shortcut, a_next]
+                a, cur_h, cur_w, cin = a_next, oh, ow, f
+                if u == 1:
+                    taps[tap_names[s]] = a
+        self.taps = taps
+        x32s, x8s, x4s = taps["x32s"], taps["x8s"], taps["x4s"]
+        skips = [None, (x8s, 128), (x4s, 64), (x2s, 64), (self.img4, 4)]
+        dims = net.decoder_dims
+        lvl = [3, 3, 2, 1, 0]  # pyramid level each decoder block runs at
+
+        # ---- decoder 1 (pose_models.py:541-546) -------------------------------------------
+        self.out = None  # bound per call
+        prev, prev_c = None, 0
+        for i in range(5):
+            name = "pv_block_%d_conv2d" % (i + 1)
+            bn = P["pv_block_%d_bn" % (i + 1)]
+            l = lvl[i]
+            o = new(B, hs[l], ws[l], dims[i])
+            if i == 0:
+                srcs = [dict(data=x32s, ld=512)]
+            else:
+                up = i >= 2  # blocks 2,3,4 upsample their OUTPUT (casapose.py:109-140): consumed by block i+1
+                src0 = prev
+                mode = _lib.SRC_DIRECT
+                if up:
+                    if fuse_upsample:
+                        mode = _lib.SRC_BILINEAR_X2
+                    else:
+                        big = new(B, hs[l], ws[l], prev_c)
+                        self.steps.append(self._bilinear_step(prev, big, hs[l] // 2, ws[l] // 2, prev_c))
+                        self._bufs.append(big)
+                        src0 = big
+                srcs = [dict(data=src0, ld=prev_c, mode=mode), dict(data=skips[i][0], ld=skips[i][1])]
+            conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1],
+                 act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+            self._bufs.append(o)
+            prev, prev_c = o, dims[i]
+        seg_head = L["pv_final_conv_segmentation"]
+        conv(seg_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
+        self._out_bound.append((seg_head, 0))
+
+        # ---- hard label map + pyramid (pose_models.py:547-559) -----------------------------
+        self.seg_input_ptr = None  # set per call when the model has a data_segmentation input
+
+        def label_step(stream):
+            if self.seg_input_ptr is not None:
+                src, ld = self.seg_input_ptr, K
+            else:
+                src, ld = self.out.data_ptr(), self.out_ld
+            check(lib.cp_argmax_labels(src, ld, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
+            lab = (C.c_void_p * 4)(*[t.data_ptr() for t in self.labels])
+            pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
+            sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])
+            check(lib.cp_label_pyramid(self.labels[0].data_ptr(), B, h, w, lab, pn, sl, stream), "cp_label_pyramid")
+
+        self.steps.append(label_step)
+
+        # ---- decoder 2 (pose_models.py:561-616) -------------------------------------------
+        prev, prev_c = None, 0
+        for i in range(5):
+            name = "pv_block_%d_prepare_conv2d" % (i + 6)
+            tab = P["pv_block_%d_clade" % (i + 6)]
+            l = lvl[i]
+            o = new(B, hs[l], ws[l], dims[i])
+            if i == 0:
+                srcs = [dict(data=x32s, ld=512)]
+            else:
+                up = i >= 2
+                src0, mode, sel = prev, _lib.SRC_DIRECT, None
+                if up:
+                    if fuse_upsample:
+                        mode, sel = _lib.SRC_NEAREST_SEL, self.sel[l]
+                    else:
+                        big = new(B, hs[l], ws[l], prev_c)
+                        self.steps.append(self._guided_step(prev, self.sel[l], big, hs[l] // 2, ws[l] // 2, prev_c))
+                        self._bufs.append(big)
+                        src0 = big
+                srcs = [dict(data=src0, ld=prev_c, mode=mode, sel=sel), dict(data=skips[i][0], ld=skips[i][1])]
+            conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
+                 scale=tab[0], shift=tab[1], epi_label=self.labels[l],
+                 act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+            self._bufs.append(o)
+            prev, prev_c = o, dims[i]
+        ver_head = L["pv_final_conv_vertex"]
+        conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
+        self._out_bound.append((ver_head, K))
+
+    def _bilinear_step(self, src, dst, sh, sw, c):
+        lib = _lib.load()
+        B = self.batch
+
+        def step(stream):
+            check(lib.cp_upsample_bilinear_x2_f32(src.data_ptr(), B, sh, sw, c, dst.data_ptr(), stream), "cp_upsample_bilinear_x2_f32")
+
+        return step
+
+    def _guided_step(self, src, sel, dst, sh, sw, c):
+        lib = _lib.load()
+        B = self.batch
+
+        def step(stream):
+            check(lib.cp_guided_upsample_x2_f32(src.data_ptr(), sel.data_ptr(), B, sh, sw, c, dst.data_ptr(), stream), "cp_guided_upsample_x2_f32")
+
+        return step
+
+    def conv_flops(self) -> float:
+        return sum(c.flops for c in self.convs)
+
+    def run(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        lib = _lib.load()
+        B, h, w = self.batch, self.h, self.w
+        if tuple(img.shape) != (B, h, w, 3) or img.dtype != torch.float32 or not img.is_contiguous():
+            raise ValueError("image must be a contiguous float32 [%d,%d,%d,3] tensor" % (B, h, w))
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        if out is None:
+            out = torch.empty(B, h, w, self.out_ld, dtype=torch.float32, device=img.device)
+        self.out = out
+        for layer, off in self._out_bound:
+            layer.desc.out_raw = out.data_ptr() + 4 * off
+        if seg_input is not None:
+            if tuple(seg_input.shape) != (B, h, w, self.net.seg_dim) or seg_input.dtype != torch.float32 or not seg_input.is_contiguous():
+                raise ValueError("segmentation input must be a contiguous float32 [%d,%d,%d,%d] tensor" % (B, h, w, self.net.seg_dim))
+            self.seg_input_ptr = seg_input.data_ptr()
+        else:
+            self.seg_input_ptr = None
+        check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
+        for step in self.steps:
+            step(stream)
+        return out
+
+
+class CasaposeNet:
+    """Parameters + launch plans of casapose_c_gcu5 on one GPU."""
+
+    def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
+                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True):
+        _lib.load()  # fail loudly if the HIP library is missing
+        if device.type != "cuda":
+            raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
+        self.device = device
+        self.seg_dim, self.ver_dim = seg_dim, ver_dim
+        self.decoder_dims = tuple(decoder_dims)
+        self.fuse_upsample = fuse_upsample
+        self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
+        self.set_params(params)
+
+    def set_params(self, params: Dict[str, np.ndarray]):
+        self.params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
+        dev = self.device
+        p = self.params
+        tabs: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+        def put(name, pair):
+            tabs[name] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in pair)
+
+        put("bn_data", fold_bn(p, "bn_data", pad_to=4))
+        put("bn0", fold_bn(p, "bn0"))
+        put("bn1", fold_bn(p, "bn1"))
+        for s in range(4):
+            for u in range(2):
+                base = "stage%d_unit%d_" % (s + 1, u + 1)
+                put(base + "bn1", fold_bn(p, base + "bn1"))
+                put(base + "bn2", fold_bn(p, base + "bn2"))
+        for i in range(5):
+            put("pv_block_%d_bn" % (i + 1), fold_bn(p, "pv_block_%d_bn" % (i + 1)))
+            put("pv_block_%d_clade" % (i + 6), fold_clade(p, "pv_block_%d_clade" % (i + 6)))
+        self.device_tables = tabs
+
+        L: Dict[str, FusedConv] = {}
+
+        def add(name, key, layout, k, cout, sources):
+            L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev)
+
+        add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])
+        cin = 64
+        for s, f in enumerate(STAGE_FILTERS):
+            for u in range(2):
+                base = "stage%d_unit%d_" % (s + 1, u + 1)
+                if u == 0:
+                    add(base + "sc", base + "sc.kernel", 0, 1, f, [(cin, cin)])
+                add(base + "conv1", base + "conv1.kernel", 0, 3, f, [(cin, cin)])
+                add(base + "conv2", base + "conv2.kernel", 0, 3, f, [(f, f)])
+                cin = f
+        dims = self.decoder_dims
+        skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
+        for i in range(5):
+            srcs = [(512, 512)] if i == 0 else [(dims[i - 1], dims[i - 1]), skip_c[i]]
+            add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
+            add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs)
+        add("pv_final_conv_segmentation", "pv_final_conv_segmentation.kernel", 0, 1, self.seg_dim, [(dims[4], dims[4])])
+        add("pv_final_conv_vertex", "pv_final_conv_vertex.kernel", 0, 1, self.ver_dim, [(dims[4], dims[4])])
+        self.layers_by_name = L
+        self.plans.clear()
+
+    def plan(self, batch: int, h: int, w: int) -> ForwardPlan:
+        key = (batch, h, w)
+        if key not in self.plans:
+            # descriptors live inside the FusedConv objects, so one plan is active at a time
+            self.plans.clear()
+            self.plans[key] = ForwardPlan(self, batch, h, w, self.fuse_upsample)
+        return self.plans[key]
+
+    def forward(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        b, h, w, _ = img.shape
+        return self.plan(b, h, w).run(img, seg_input, out)

@@ -1,0 +1,39 @@
+"""Generic builder surface (casapose/pose_models/models/casapose.py:18-39,145-163)."""
+from __future__ import annotations
+
+import collections
+
+from .model import CasaposeModel
+
+DecoderParams = collections.namedtuple(
+    "DecoderParams", ["weighted_clade", "partial_conv", "guided_upsampling", "bilinear_upsampling", "reuse_conv"]
+)
+
+# decoder-2 configuration of the five blocks "6".."10" (casapose.py:27-35)
+CASAPOSE_PARAMS = {
+    "clade": [
+        DecoderParams(True, True, False, False, False),
+        DecoderParams(True, True, True, False, False),
+        DecoderParams(True, True, True, False, False),
+        DecoderParams(True, True, True, False, False),
+        DecoderParams(True, True, False, False, False),
+    ],
+}
+
+_GCU5 = [tuple(p) for p in CASAPOSE_PARAMS["clade"]]
+
+
+def CASAPose(layer_params, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
+             input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18", backbone=None,
+             output_lablemap=False, learn_upsampling=False, **kwargs):
+    if [tuple(p) for p in layer_params] != _GCU5 or learn_upsampling:
+        raise NotImplementedError("only the `clade` DecoderParams set (== casapose_c_gcu5) is built for MI355X so far")
+    if base_model != "resnet18":
+        raise NotImplementedError("backbone %s is not built for MI355X yet" % base_model)
+    return CasaposeModel("casapose_custom", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
+                         input_segmentation_shape=input_segmentation_shape, weights=weights, output_lablemap=output_lablemap,
+                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True))
+
+
+def CASAPoseConditional(*args, **kwargs):
+    return CASAPose(CASAPOSE_PARAMS["clade"], *args, **kwargs, learn_upsampling=False)

@@ -1,0 +1,203 @@
+"""The model object handed back by the constructors: the subset of the Keras `Model`
+surface the reference's scripts use (train_casapose.py:374-406,537,592,903;
+test_casapose.py:228,235-238,299), backed by casapose_amd.engine.CasaposeNet.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ... import engine
+
+
+def _he_uniform(rng, shape, fan_in):
+    lim = math.sqrt(6.0 / fan_in)
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """Keras-default initial state: he_uniform kernels (resnet.py:31; _normalization_layers.py:317),
+    BN gamma 1 / beta 0 / moving mean 0 / moving variance 1, CLADE gamma 1 / beta 0
+    (_normalization_layers.py:96-107).  Keys are `<keras layer name>.<weight>`."""
+    rng = np.random.default_rng(seed)
+    p: Dict[str, np.ndarray] = {}
+
+    def bn(name, c, gamma=True, beta=True):
+        if gamma:
+            p[name + ".gamma"] = np.ones(c, np.float32)
+        if beta:
+            p[name + ".beta"] = np.zeros(c, np.float32)
+        p[name + ".moving_mean"] = np.zeros(c, np.float32)
+        p[name + ".moving_variance"] = np.ones(c, np.float32)
+
+    p["conv0.kernel"] = _he_uniform(rng, (7, 7, 3, 64), 147)
+    bn("bn_data", 3, gamma=False)
+    bn("bn0", 64)
+    cin = 64
+    for s, f in enumerate(engine.STAGE_FILTERS):
+        for u in range(2):
+            base = "stage%d_unit%d_" % (s + 1, u + 1)
+            if u == 0:
+                p[base + "sc.kernel"] = _he_uniform(rng, (1, 1, cin, f), cin)
+            p[base + "conv1.kernel"] = _he_uniform(rng, (3, 3, cin, f), 9 * cin)
+            p[base + "conv2.kernel"] = _he_uniform(rng, (3, 3, f, f), 9 * f)
+            bn(base + "bn1", cin)
+            bn(base + "bn2", f)
+            cin = f
+    bn("bn1", 512)
+    dec_in = (512, dims[0] + 128, dims[1] + 64, dims[2] + 64, dims[3] + 3)
+    for i in range(5):
+        ci, co = dec_in[i], dims[i]
+        p["pv_block_%d_conv2d.kernel" % (i + 1)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
+        bn("pv_block_%d_bn" % (i + 1), co)
+        p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
+        bn("pv_block_%d_clade" % (i + 6), co, gamma=False, beta=False)
+        p["pv_block_%d_clade.gamma" % (i + 6)] = np.ones((seg_dim, co), np.float32)
+        p["pv_block_%d_clade.beta" % (i + 6)] = np.zeros((seg_dim, co), np.float32)
+    p["pv_final_conv_segmentation.kernel"] = _he_uniform(rng, (1, 1, dims[4], seg_dim), dims[4])
+    p["pv_final_conv_vertex.kernel"] = _he_uniform(rng, (1, 1, dims[4], ver_dim), dims[4])
+    return p
+
+
+class Layer:
+    """Named view of one layer's weights (`net.get_layer(name).get_weights()/set_weights()`,
+    train_casapose.py:403-406)."""
+
+    def __init__(self, model: "CasaposeModel", name: str, keys: List[str]):
+        self._model, self.name, self._keys = model, name, keys
+        self.trainable = True
+
+    def get_weights(self) -> List[np.ndarray]:
+        return [self._model._params[k].copy() for k in self._keys]
+
+    def set_weights(self, weights: Sequence[np.ndarray]):
+        if len(weights) != len(self._keys):
+            raise ValueError("layer %s expects %d arrays, got %d" % (self.name, len(self._keys), len(weights)))
+        new = dict(self._model._params)
+        for k, w in zip(self._keys, weights):
+            w = np.asarray(w, dtype=np.float32)
+            if w.shape != new[k].shape:
+                raise ValueError("layer %s: weight %s has shape %s, expected %s" % (self.name, k, w.shape, new[k].shape))
+            new[k] = w
+        self._model.set_parameters(new)
+
+
+class CasaposeModel:
+    def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
+                 input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
+                 fuse_upsample: bool = True):
+        if output_lablemap:
+            raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
+        self.name = name
+        self.ver_dim, self.seg_dim = int(ver_dim), int(seg_dim)
+        self.input_shape = tuple(input_shape) if input_shape is not None else None
+        self.input_segmentation_shape = tuple(input_segmentation_shape) if input_segmentation_shape is not None else None
+        self.input_names = ["data"] + (["data_segmentation"] if self.input_segmentation_shape is not None else [])
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self._dims = tuple(dims)
+        if isinstance(weights, str) and weights == "imagenet":
+            warnings.warn("weights='imagenet': the reference downloads ImageNet ResNet-18 weights (weights.py:13-39); "
+                          "no network here -- using he_uniform initialisation; call load_weights() for real weights")
+            weights = None
+        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed)
+        self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample)
+        if isinstance(weights, str):
+            self.load_weights(weights)
+        self._layers = self._build_layers()
+
+    # ---- Keras-like surface ----------------------------------------------------------------
+    def _build_layers(self) -> List[Layer]:
+        groups: Dict[str, List[str]] = {}
+        for k in self._params:
+            groups.setdefault(k.split(".")[0], []).append(k)
+        order = {"kernel": 0, "weights": 0, "gamma": 1, "beta": 2, "moving_mean": 3, "moving_variance": 4}
+        return [Layer(self, n, sorted(ks, key=lambda k: order[k.split(".")[1]])) for n, ks in groups.items()]
+
+    @property
+    def layers(self) -> List[Layer]:
+        return self._layers
+
+    def get_layer(self, name: str) -> Layer:
+        for l in self._layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: %s" % name)
+
+    @property
+    def trainable_variables(self) -> List[str]:
+        frozen = {l.name for l in self._layers if not l.trainable}
+        return [k for k in self._params if not k.endswith(("moving_mean", "moving_variance")) and k.split(".")[0] not in frozen]
+
+    def count_params(self) -> int:
+        return int(sum(v.size for v in self._params.values()))
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s"  (MI355X / gfx950 backend)' % self.name)
+        for l in self._layers:
+            shapes = ", ".join("%s%s" % (k.split(".")[1], tuple(self._params[k].shape)) for k in l._keys)
+            print_fn("  %-36s %s" % (l.name, shapes))
+        print_fn("Total params: {:,}".format(self.count_params()))
+
+    def get_parameters(self) -> Dict[str, np.ndarray]:
+        return {k: v.copy() for k, v in self._params.items()}
+
+    def set_parameters(self, params: Dict[str, np.ndarray]):
+        missing = set(self._params) - set(params)
+        if missing:
+            raise ValueError("missing parameters: %s" % sorted(missing)[:5])
+        for k, v in self._params.items():
+            if tuple(np.shape(params[k])) != v.shape:
+                raise ValueError("parameter %s has shape %s, expected %s" % (k, np.shape(params[k]), v.shape))
+        self._params = {k: np.asarray(params[k], dtype=np.float32) for k in self._params}
+        self._net.set_params(self._params)
+
+    def save_weights(self, path: str):
+        """Reference writes Keras .h5 (train_casapose.py:903); h5py is unavailable here, so the
+        same name->array mapping is stored as .npz (any extension is kept as given)."""
+        with open(path, "wb") as f:
+            np.savez(f, **self._params)
+
+    def load_weights(self, path: str, by_name: bool = True, skip_mismatch: bool = True):
+        """by_name / skip_mismatch follow test_casapose.py:225-228: unknown names are ignored and
+        shape mismatches are skipped (with a warning) instead of raising."""
+        data = np.load(path)
+        new = dict(self._params)
+        for k in data.files:
+            if k not in new:
+                continue
+            if data[k].shape != new[k].shape:
+                if skip_mismatch:
+                    warnings.warn("load_weights: skipping %s, shape %s != %s" % (k, data[k].shape, new[k].shape))
+                    continue
+                raise ValueError("load_weights: %s has shape %s, expected %s" % (k, data[k].shape, new[k].shape))
+            new[k] = data[k].astype(np.float32)
+        self.set_parameters(new)
+
+    # ---- forward -----------------------------------------------------------------------------
+    def _to_device(self, x) -> torch.Tensor:
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def __call__(self, inputs, training: bool = False) -> torch.Tensor:
+        """inputs: [img] or [img, seg_onehot] (NHWC float32, torch or numpy).  Returns the
+        device tensor [B,H,W,seg_dim+ver_dim] = concat(seg logits, vertex) (pose_models.py:628)."""
+        if training:
+            raise NotImplementedError("training=True (batch-statistics BN + backward) is not built yet")
+        if isinstance(inputs, (torch.Tensor, np.ndarray)):
+            inputs = [inputs]
+        if len(inputs) != len(self.input_names):
+            raise ValueError("model %s expects inputs %s, got %d tensors" % (self.name, self.input_names, len(inputs)))
+        img = self._to_device(inputs[0])
+        seg = self._to_device(inputs[1]) if len(inputs) > 1 else None
+        if self.input_shape is not None and tuple(img.shape[1:]) != self.input_shape:
+            raise ValueError("input `data` has shape %s, model was built for %s" % (tuple(img.shape[1:]), self.input_shape))
+        return self._net.forward(img, seg)
+
+    predict = __call__

@@ -1,0 +1,79 @@
+"""Name -> constructor registry (reference: casapose/pose_models/models_factory.py:8-60).
+
+`Classifiers.get(name)` returns a constructor with the reference's signature
+(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
+input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18",
+backbone=None, output_lablemap=False).  Unknown names raise ValueError like the reference
+(:55-56).  Registry entries whose graphs are not yet built for MI355X raise
+NotImplementedError when CALLED (the name lookup still succeeds), never a silent fallback.
+"""
+from __future__ import annotations
+
+import functools
+
+from .models import casapose as _cp
+from .models import pose_models as _pm
+
+
+def _not_built(name):
+    def ctor(*args, **kwargs):
+        raise NotImplementedError(
+            "model `%s` is registered by the reference but its graph has not been built for MI355X yet; "
+            "available: casapose_c_gcu5, casapose_custom" % name
+        )
+
+    ctor.__name__ = name
+    return ctor
+
+
+class ModelsFactory:
+    _models = {
+        # reference registry keys (models_factory.py:9-32)
+        "resnet18": _not_built("resnet18"),
+        "resnet34": _not_built("resnet34"),
+        "resnet50": _not_built("resnet50"),
+        "resnet101": _not_built("resnet101"),
+        "resnet152": _not_built("resnet152"),
+        "casapose_c": _not_built("casapose_c"),
+        "casapose_c_gu": _not_built("casapose_c_gu"),
+        "casapose_c_gcu3": _not_built("casapose_c_gcu3"),
+        "casapose_c_gcu4": _not_built("casapose_c_gcu4"),
+        "casapose_c_gcu5": _pm.CASAPoseConditional5,
+        "pvnet_combined": _not_built("pvnet_combined"),
+        "casapose_custom": _cp.CASAPoseConditional,
+        "casapose_c_gcu5_sw5": _not_built("casapose_c_gcu5_sw5"),
+        "casapose_c_gcu4_sw1": _not_built("casapose_c_gcu4_sw1"),
+        "casapose_c_gcu5_sw1": _not_built("casapose_c_gcu5_sw1"),
+        "casapose_c_gcu4_bilat": _not_built("casapose_c_gcu4_bilat"),
+        "casapose_c_gcu4_sw2": _not_built("casapose_c_gcu4_sw2"),
+        "pvnet": _not_built("pvnet"),
+    }
+
+    @property
+    def models(self):
+        return self._models
+
+    def models_names(self):
+        return list(self.models.keys())
+
+    @staticmethod
+    def get_kwargs():
+        # the reference injects the four Keras sub-modules here (tfkeras.py:8-14); nothing to inject
+        return {}
+
+    def inject_submodules(self, func):
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            merged = dict(kwargs)
+            merged.update(self.get_kwargs())
+            return func(*args, **merged)
+
+        return wrapper
+
+    def get(self, name):
+        if name not in self.models_names():
+            raise ValueError("No such model `{}`, available models: {}".format(name, list(self.models_names())))
+        return self.inject_submodules(self.models[name])
+
+
+Classifiers = ModelsFactory()

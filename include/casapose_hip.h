@@ -1,0 +1,211 @@
+/*
+ * casapose_hip.h -- C ABI of libcasapose_hip.so (gfx950 / MI355X).
+ *
+ * The reference (fraunhoferhhi/casapose) has no FFI: its hot path bottoms out in
+ * TensorFlow / tensorflow-addons ops.  Each entry point below replaces the native
+ * work behind one group of reference call sites (cited as file:line relative to the
+ * reference tree).  The Python host (casapose_amd/) binds these with ctypes; a
+ * maintainer of the reference would bind them the same way.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative cp_status otherwise; nothing
+ *     throws across the boundary; cp_last_error() returns a thread-local message.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns
+ *     every buffer (inputs, outputs, workspaces); no hidden allocation.
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream); calls are
+ *     asynchronous with respect to the host and re-entrant across streams.
+ *   - tensors are NHWC, fp32 unless stated; label maps are uint8 (0 = background).
+ */
+#ifndef CASAPOSE_HIP_H
+#define CASAPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cp_status {
+    CP_OK = 0,
+    CP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    CP_ERR_LAUNCH = -2,    /* hipLaunch / runtime failure */
+    CP_ERR_NO_DEVICE = -3
+} cp_status;
+
+const char* cp_last_error(void);
+int cp_version(void);
+/* number of visible gfx950 devices (0 on a CPU-only host); never initialises a context */
+int cp_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Fused implicit-GEMM convolution, forward, fp32 on v_mfma_f32_32x32x2_f32.
+ *
+ * Replaces: layers.Conv2D in the encoder (casapose/pose_models/models/resnet.py:85-87,
+ * 97-99,103,249) and decoder 1 (models/casapose.py:71-74, pose_models.py:546,616);
+ * PartialConvolution.calc (models/_normalization_layers.py:325-373);
+ * inference-mode SyncBatchNormalization + ReLU / leaky pair (resnet.py:78-79,100-101,
+ * 250-251,303-304; casapose.py:77,98-107); ClassAdaptiveWeightedNormalization.calc
+ * (_normalization_layers.py:119-139); layers.Add (resnet.py:110); layers.concatenate
+ * (pose_models.py:542-545,571,583,595,607); GuidedUpsampling gather
+ * (_normalization_layers.py:554-558) and UpSampling2D(bilinear) (casapose.py:135-140)
+ * when fused into the consumer's operand load.
+ *
+ *  out[n,oy,ox,co] = EPI( sum_{s in sources} sum_{ky,kx} sum_c
+ *                         A_s(n, oy*stride+ky*dil-pad, ox*stride+kx*dil-pad, c) * Wp[co, k(s,ky,kx,c)] )
+ *
+ *  A_s(n,y,x,c) is 0 outside [0,in_h)x[0,in_w), else the source value fetched through
+ *  the source's spatial mode, optionally (source 0/1 individually) passed through a
+ *  per-channel affine `v*pre_scale[c]+pre_shift[c]`, and, when `tap_label` is set,
+ *  multiplied by [tap_label[n,y,x] == tap_label[n,oy,ox]] (partial convolution; needs
+ *  stride 1 so both live on the same grid).
+ *
+ *  EPI(v): v *= row_scale[n,oy,ox] (partial-conv 9/count)      if row_scale
+ *          v += residual[n,oy,ox,co]                           if residual
+ *          out_raw = v                                         if out_raw
+ *          t = v*sc + sh ; (sc,sh) = (scale[co],shift[co]) or, if epi_label,
+ *                          (scale[epi_label[n,oy,ox]*cout+co], shift[...])   (CLADE table)
+ *          t = act(t): 0 none, 1 relu, 2 leaky 0.1 (relu(t)-relu(-0.1t))
+ *          out_act = t                                         if out_act
+ *
+ *  Packed weights Wp: row-major [cout][ktot] fp32, produced by cp_conv_pack_weights
+ *  (K order: source 0 chunks, then source 1 chunks; see cp_conv_ktot).
+ * ---------------------------------------------------------------------------------- */
+
+enum { CP_SRC_DIRECT = 0, CP_SRC_NEAREST_SEL = 1, CP_SRC_BILINEAR_X2 = 2 };
+enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY01 = 2 };
+
+typedef struct cp_conv_source {
+    const float* data;      /* NHWC, pixel stride `ld` floats                                 */
+    int channels;           /* multiple of 32, or exactly 4 ("C4" mode: 8 taps per K chunk)  */
+    int ld;                 /* floats between consecutive pixels (>= channels)               */
+    int mode;               /* CP_SRC_*: DIRECT reads an in_h x in_w grid; the X2 modes read  */
+                            /* an (in_h/2) x (in_w/2) grid                                   */
+    const uint8_t* sel;     /* CP_SRC_NEAREST_SEL: [n,in_h,in_w] neighbour index 0..3         */
+    const float* pre_scale; /* optional per-channel affine applied to in-bounds values       */
+    const float* pre_shift;
+} cp_conv_source;
+
+typedef struct cp_conv_desc {
+    int batch, in_h, in_w;      /* conv-input grid (after any fused x2 upsampling)           */
+    int out_h, out_w, cout;
+    int kh, kw, stride, dilation, pad;
+    int num_sources;            /* 1 or 2 (channel concatenation, source 0 first)            */
+    cp_conv_source src[2];
+    const float* weights;       /* packed [cout][ktot]                                        */
+    const uint8_t* tap_label;   /* optional [n,in_h,in_w] -> partial-conv tap mask            */
+    /* epilogue */
+    const float* row_scale;     /* optional [n,out_h,out_w]                                   */
+    const float* residual;      /* optional NHWC, pixel stride residual_ld                    */
+    int residual_ld;
+    const float* scale;         /* optional [cout] or [classes][cout] with epi_label          */
+    const float* shift;
+    const uint8_t* epi_label;   /* optional [n,out_h,out_w]                                   */
+    int act;                    /* CP_ACT_* applied to out_act only                          */
+    float* out_raw;             /* optional, pixel stride out_raw_ld                          */
+    int out_raw_ld;
+    float* out_act;             /* optional, pixel stride out_act_ld                          */
+    int out_act_ld;
+    int tile_hint;              /* 0 = auto; otherwise a CP_TILE_* value (benchmark / tests) */
+} cp_conv_desc;
+
+enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
+       CP_TILE_64x64 = 5, CP_TILE_256x32 = 6 };
+
+/* K extent (multiple of 32) of the packed weight rows for a conv with the given sources */
+int cp_conv_ktot(int kh, int kw, int num_sources, const int* channels);
+/* HOST helper: pack a Keras-layout kernel into Wp.  `layout` 0 = HWIO [kh][kw][cin][cout]
+ * (layers.Conv2D), 1 = IHWO [cin][kh][kw][cout] (PartialConvolution.conv_w,
+ * _normalization_layers.py:314-319).  cin = sum of real source channels; a source with
+ * channels==4 in the descriptor may carry `real_channels[s]` < 4 real input channels.
+ * dst has cout*ktot floats.  All pointers are host memory. */
+int cp_conv_pack_weights_host(const float* w_host, int layout, int kh, int kw, int cout, int num_sources,
+                              const int* channels, const int* real_channels, float* dst_host);
+int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small streaming kernels around the convolutions
+ * ---------------------------------------------------------------------------------- */
+
+/* [n,h,w,3] -> [n,h,w,4] (4th channel 0): operand layout for the C4 source mode.
+ * Replaces nothing arithmetic; feeds conv0 (resnet.py:247-249) and blocks 5/10
+ * (pose_models.py:545,607). */
+int cp_pad_channels_3to4(const float* src, float* dst, long long pixels, void* stream);
+
+/* ZeroPadding2D(1) + MaxPooling2D(3x3, stride 2) (resnet.py:253-254) with an optional fused
+ * per-channel affine + ReLU of the consumer's BatchNorm (resnet.py:78-79).  channels % 4 == 0. */
+int cp_maxpool3x3s2_f32(const float* src, int batch, int h, int w, int channels, const float* scale,
+                        const float* shift, int relu, float* dst, void* stream);
+
+/* UpSampling2D(size 2, bilinear) == tf.image.resize half-pixel centres (casapose.py:135-140).
+ * Stand-alone form; channels % 4 == 0. */
+int cp_upsample_bilinear_x2_f32(const float* src, int batch, int h, int w, int channels, float* dst,
+                                void* stream);
+
+/* GuidedUpsampling gather (_normalization_layers.py:554-565), stand-alone form, given the
+ * neighbour-selection map from cp_label_pyramid.  src [n,h,w,c] -> dst [n,2h,2w,c]. */
+int cp_guided_upsample_x2_f32(const float* src, const uint8_t* sel, int batch, int h, int w, int channels,
+                              float* dst, void* stream);
+
+/* arg-max over `classes` contiguous values per pixel (pixel stride ld) -> uint8 label.
+ * Replaces softmax(1e6*x) as a hard one-hot (pose_models.py:547-554; voting_layers_2d.py:38-41).
+ * First maximum wins (ties are undefined behaviour in the reference). */
+int cp_argmax_labels(const float* logits, int ld, int classes, long long pixels, uint8_t* labels,
+                     void* stream);
+
+/* Everything decoder 2 derives from the label map (pose_models.py:556-559;
+ * _normalization_layers.py:294-299,333-352,512-551):
+ *   levels 0..3 = full, 1/2, 1/4, 1/8 resolution (HalfSize == [::2,::2]);
+ *   labels[l]    uint8 [n,h_l,w_l]                 (labels[0] is the INPUT)
+ *   pnorm[l]     float [n,h_l,w_l]  9 / #{3x3 taps in bounds with the centre's label}
+ *   sel[l]       uint8 [n,h_l,w_l]  for l = 0..2: which neighbour of level l+1 the guided
+ *                                   upsampling picks for each pixel of level l (0..3)
+ * Any output pointer may be NULL.  h, w are the level-0 size; h_l = h_{l-1}/2 (floor). */
+int cp_label_pyramid(const uint8_t* labels0, int batch, int h, int w, uint8_t* const* labels /*[4]*/,
+                     float* const* pnorm /*[4]*/, uint8_t* const* sel /*[3]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Keypoint voting
+ * ---------------------------------------------------------------------------------- */
+
+/* CoordLSVotingWeighted.calc (casapose/pose_estimation/voting_layers_2d.py:83-122):
+ * per (image, object, keypoint) fp64 sums of w(I-nn^T) and w(I-nn^T)c over the object's
+ * pixels, then the 2x2 pseudo-inverse solve.  `field` is the network output
+ * [n,h,w,ld] with seg logits at channel seg_off (classes = objects+1 values), directions
+ * (dy,dx)*kp at dir_off and confidence logits at conf_off.  If `labels` is non-NULL it is
+ * used as the hard object map instead of the arg-max of the logits (this is how the
+ * connected-component filter of :43-79 is applied).  sums_ws: fp64 [n][objects][kp][5]
+ * workspace (zeroed by the call).  keypoints: fp32 [n][objects][kp][2] in (y,x) pixels. */
+int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels,
+                   int batch, int h, int w, int objects, int kp, double* sums_ws, float* keypoints,
+                   void* stream);
+size_t cp_ls_vote_workspace_bytes(int batch, int objects, int kp);
+
+/* Largest-connected-component filter of voting_layers_2d.py:43-79 (tfa.image.connected_components,
+ * 4-connectivity, keep the largest component of each object if it has >= min_size pixels):
+ * labels_in uint8 [n,h,w] -> labels_out (pixels outside the kept component become 0).
+ * ws: int32 workspace of cp_ccl_workspace_bytes. */
+int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size,
+                         void* ws, uint8_t* labels_out, void* stream);
+size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects);
+
+/* ransac_voting_layer_all_masks (casapose/pose_estimation/ransac_voting.py:276-368,447-484).
+ * One call votes all (image, object) pairs.  labels: uint8 [n,h,w] hard object map
+ * (arg-max one-hot of pose_evaluation.py:37-38); vertex: [n,h,w,ld] with (dy,dx)*kp at
+ * dir_off.  idx: int32 [max_iter][n][objects][hyp][kp][2] uniform random numbers in
+ * [0, 2^31) supplied by the caller (the reference draws tf.random.uniform per round,
+ * :319-321); the kernel maps them to pixel indices by `idx % tn`.  Objects with fewer
+ * than min_num pixels give zeros (:290-292).  Objects with more than max_num pixels are
+ * rejected with CP_ERR_INVALID unless the caller sub-sampled the label map (:295-301).
+ * out: fp32 [n][objects][kp][2] in (x,y); rounds_out (optional) int32 [n][objects].
+ * ws: workspace of cp_ransac_workspace_bytes. */
+int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h,
+                       int w, int objects, int kp, const int32_t* idx, int hyp, float inlier_thresh,
+                       float confidence, int max_iter, int min_num, int max_num, void* ws, float* out,
+                       int32_t* rounds_out, void* stream);
+size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASAPOSE_HIP_H */

@@ -1,0 +1,229 @@
+"""GPU parity: the fused implicit-GEMM convolution (cp_conv2d_fwd_f32, through the C ABI)
+against the fp64 NumPy oracle, on seeded inputs small enough for the oracle to finish in
+seconds.  Tolerance: fp32 MFMA accumulation vs fp64 -> max|diff| <= 1e-4 * max|ref|
+(indexing mistakes produce O(1) relative errors)."""
+import numpy as np
+import pytest
+import torch
+
+import casapose_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def dev(a, device, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
+
+
+def close(got: torch.Tensor, ref: np.ndarray, rtol=RTOL):
+    g = got.detach().cpu().numpy().astype(np.float64)
+    assert g.shape == ref.shape, (g.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-6)
+    err = np.abs(g - ref).max()
+    assert err <= rtol * scale, "max|diff| %.3e vs scale %.3e" % (err, scale)
+
+
+@pytest.mark.parametrize(
+    "cin,cout,k,stride,dil,pad,hw",
+    [
+        (32, 64, 3, 1, 1, 1, (20, 28)),
+        (64, 128, 3, 2, 1, 1, (21, 30)),
+        (64, 64, 3, 1, 2, 2, (18, 22)),
+        (128, 160, 3, 1, 4, 4, (16, 24)),
+        (64, 96, 1, 2, 1, 0, (22, 26)),
+        (32, 9, 1, 1, 1, 0, (24, 40)),
+        (96, 27, 1, 1, 1, 0, (9, 11)),
+    ],
+)
+def test_plain_conv(device, cin, cout, k, stride, dil, pad, hw):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = rng.standard_normal((2, hw[0], hw[1], cin))
+    w = rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)
+    ref = O.conv2d(x, w, stride=stride, dilation=dil, pad=pad)
+    raw, _ = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), stride=stride, dilation=dil, pad=pad)
+    close(raw, ref)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_every_tile_shape(device, tile):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(tile)
+    x = rng.standard_normal((3, 19, 23, 64))
+    w = rng.standard_normal((3, 3, 64, 72)) / 24.0
+    ref = O.conv2d(x, w, pad=1)
+    raw, _ = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=tile)
+    close(raw, ref)
+
+
+def test_conv0_c4_source_with_input_affine(device):
+    """conv0 path: 3-channel image padded to 4, bn_data as the operand affine applied BEFORE the
+    zero padding (resnet.py:247-249), 7x7 stride 2 pad 3, bn0+relu epilogue."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-1, 1, (2, 30, 44, 3))
+    w = rng.standard_normal((7, 7, 3, 64)) / 12.0
+    ps, pb = rng.uniform(0.5, 1.5, 3), rng.standard_normal(3) * 0.3
+    es, eb = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.3
+    ref = O.relu(O.conv2d(img * ps + pb, w, stride=2, pad=3) * es + eb)
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    pre = (dev(np.append(ps, 0.0), device), dev(np.append(pb, 0.0), device))
+    _, act = ops.conv2d_fused([img4], w.astype(np.float32), stride=2, pad=3, pre=[pre], real_channels=[3],
+                              scale=dev(es, device), shift=dev(eb, device), act=1, want_raw=False, want_act=True)
+    close(act, ref)
+
+
+def test_two_sources_residual_dual_output(device):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((2, 14, 18, 64))
+    b = rng.standard_normal((2, 14, 18, 32))
+    w = rng.standard_normal((3, 3, 96, 64)) / 30.0
+    res = rng.standard_normal((2, 14, 18, 64))
+    sc, sh = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.2
+    raw_ref = O.conv2d(np.concatenate([a, b], 3), w, pad=1) + res
+    act_ref = O.leaky_as_relu_pair(raw_ref * sc + sh)
+    raw, act = ops.conv2d_fused([dev(a, device), dev(b, device)], w.astype(np.float32), pad=1, residual=dev(res, device),
+                                scale=dev(sc, device), shift=dev(sh, device), act=2, want_raw=True, want_act=True)
+    close(raw, raw_ref)
+    close(act, act_ref)
+
+
+def test_feature_plus_image_source(device):
+    """blocks 5/10: concat[32-channel feature, raw 3-channel image] (pose_models.py:545,607)."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(7)
+    f = rng.standard_normal((2, 16, 20, 32))
+    img = rng.uniform(-1, 1, (2, 16, 20, 3))
+    w = rng.standard_normal((3, 3, 35, 32)) / 18.0
+    ref = O.conv2d(np.concatenate([f, img], 3), w, pad=1)
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    raw, _ = ops.conv2d_fused([dev(f, device), img4], w.astype(np.float32), pad=1, real_channels=[32, 3])
+    close(raw, ref)
+
+
+def _labels(rng, b, h, w, k):
+    lab = np.zeros((b, h, w), dtype=np.int64)
+    for bi in range(b):
+        for o in range(1, k):
+            y0, x0 = rng.integers(0, h - 4), rng.integers(0, w - 4)
+            lab[bi, y0 : y0 + rng.integers(3, h // 2 + 2), x0 : x0 + rng.integers(3, w // 2 + 2)] = o
+    return lab
+
+
+def test_partial_conv_with_clade_epilogue(device):
+    """PartialConvolution + ClassAdaptiveWeightedNormalization + leaky pair
+    (_normalization_layers.py:325-373,119-139; casapose.py:98-105) in ONE launch."""
+    from casapose_amd import ops
+    from casapose_amd.engine import fold_clade
+
+    rng = np.random.default_rng(8)
+    b, h, w, k, cin, cout = 2, 24, 32, 5, 64, 32
+    lab = _labels(rng, b, h, w, k)
+    mask = O.onehot_from_labels(lab, k)
+    x = rng.standard_normal((b, h, w, cin))
+    wt = rng.standard_normal((cin, 3, 3, cout)) / 24.0
+    p = {
+        "c.gamma": rng.uniform(0.5, 1.5, (k, cout)),
+        "c.beta": rng.standard_normal((k, cout)) * 0.2,
+        "c.moving_mean": rng.standard_normal(cout) * 0.1,
+        "c.moving_variance": rng.uniform(0.5, 1.5, cout),
+    }
+    y = O.partial_convolution(x, wt, mask)
+    y = O.clade_weighted(y, mask, p["c.gamma"], p["c.beta"], p["c.moving_mean"], p["c.moving_variance"])
+    ref = O.leaky_as_relu_pair(y)
+    labels, pnorm, _ = ops.label_pyramid(dev(lab, device, torch.uint8))
+    ts, tb = fold_clade(p, "c")
+    _, act = ops.conv2d_fused([dev(x, device)], wt.astype(np.float32), layout=1, pad=1, tap_label=labels[0], row_scale=pnorm[0],
+                              scale=dev(ts, device), shift=dev(tb, device), epi_label=labels[0], act=2, want_raw=False, want_act=True)
+    close(act, ref)
+
+
+def test_partial_conv_all_one_label_is_border_rescaled_conv(device):
+    """KAT: with a single label everywhere the partial conv equals the ordinary
+    SAME conv scaled by 9 / (#in-bounds taps)."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 10, 12, 32))
+    wt = rng.standard_normal((32, 3, 3, 32)) / 17.0
+    lab = np.zeros((1, 10, 12), np.uint8)
+    labels, pnorm, _ = ops.label_pyramid(dev(lab, device, torch.uint8))
+    raw, _ = ops.conv2d_fused([dev(x, device)], wt.astype(np.float32), layout=1, pad=1, tap_label=labels[0], row_scale=pnorm[0])
+    plain = O.conv2d(x, np.transpose(wt, (1, 2, 0, 3)), pad=1)
+    cnt = O.conv2d(np.ones((1, 10, 12, 1)), np.ones((3, 3, 1, 1)), pad=1)
+    close(raw, plain * 9.0 / cnt)
+
+
+def test_fused_guided_and_bilinear_sources(device):
+    """decoder blocks 3-5 / 8-10: the x2 upsampling of the previous block is fused into the operand
+    gather of the consumer (GuidedUpsampling, _normalization_layers.py:507-566; UpSampling2D bilinear,
+    casapose.py:135-140)."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(10)
+    b, h, w, k = 2, 16, 24, 4
+    lab = _labels(rng, b, h, w, k)
+    mask = O.onehot_from_labels(lab, k)
+    mask_lo = O.half_size(mask)
+    low = rng.standard_normal((b, h // 2, w // 2, 64))
+    skip = rng.standard_normal((b, h, w, 32))
+    wt = rng.standard_normal((96, 3, 3, 32)) / 29.0
+    labels, pnorm, sel = ops.label_pyramid(dev(lab, device, torch.uint8))
+    # guided + partial conv
+    up = O.guided_upsampling(low, mask_lo, mask)
+    ref = O.partial_convolution(np.concatenate([up, skip], 3), wt, mask)
+    raw, _ = ops.conv2d_fused([dev(low, device), dev(skip, device)], wt.astype(np.float32), layout=1, pad=1, modes=[1, 0],
+                              sels=[sel[0], None], tap_label=labels[0], row_scale=pnorm[0])
+    close(raw, ref)
+    # stand-alone guided upsampling kernel agrees too
+    close(ops.guided_upsample_x2(dev(low, device), sel[0]), up, rtol=1e-7)
+    # bilinear + plain conv
+    w2 = np.transpose(wt, (1, 2, 0, 3))
+    upb = O.upsample_bilinear_x2(low)
+    ref2 = O.conv2d(np.concatenate([upb, skip], 3), w2, pad=1)
+    raw2, _ = ops.conv2d_fused([dev(low, device), dev(skip, device)], w2.astype(np.float32), pad=1, modes=[2, 0])
+    close(raw2, ref2)
+    close(ops.upsample_bilinear_x2(dev(low, device)), upb, rtol=1e-6)
+
+
+def test_aux_kernels(device):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(11)
+    x = np.maximum(rng.standard_normal((2, 15, 22, 64)), 0)  # post-ReLU like relu0
+    sc, sh = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.2
+    close(ops.maxpool3x3s2(dev(x, device)), O.maxpool_3x3_s2_pad1(x), rtol=1e-7)
+    close(ops.maxpool3x3s2(dev(x, device), dev(sc, device), dev(sh, device), relu=True), O.relu(O.maxpool_3x3_s2_pad1(x) * sc + sh), rtol=1e-6)
+    # negative inputs: the zero padding must win at the border (resnet.py:253)
+    xn = -np.abs(rng.standard_normal((1, 6, 6, 4))) - 1.0
+    close(ops.maxpool3x3s2(dev(xn, device)), O.maxpool_3x3_s2_pad1(xn), rtol=1e-7)
+    logits = rng.standard_normal((2, 12, 16, 12))
+    got = ops.argmax_labels(dev(logits, device), classes=9, offset=0).cpu().numpy()
+    assert (got == logits[..., :9].argmax(-1)).all()
+    lab = _labels(rng, 2, 32, 48, 6)
+    labels, pnorm, sel = ops.label_pyramid(dev(lab, device, torch.uint8))
+    masks = [O.onehot_from_labels(lab, 6)]
+    for _ in range(3):
+        masks.append(O.half_size(masks[-1]))
+    for l in range(4):
+        assert (labels[l].cpu().numpy() == masks[l].argmax(-1)).all()
+        _, norm = O.partial_conv_mask(masks[l])
+        close(pnorm[l], norm[..., 0], rtol=1e-6)
+    for l in range(3):
+        assert (sel[l].cpu().numpy() == O.guided_upsampling_select(masks[l + 1], masks[l])).all()
+
+
+def test_bad_arguments_report_errors(device):
+    from casapose_amd import _lib, ops
+
+    x = torch.zeros(1, 8, 8, 24, device=device)  # 24 channels: neither 4 nor a multiple of 32
+    with pytest.raises((_lib.CasaposeHipError, ValueError)):
+        ops.conv2d_fused([x], np.zeros((3, 3, 24, 8), np.float32), pad=1)
