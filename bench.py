@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the CASAPose hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): 8-object LMO inference, casapose_c_gcu5,
+batch 16, 480x640, fp32 -- one step = network forward (encoder + both decoders, estimated
+mask) + confidence-weighted LS keypoint voting, inputs already resident in HBM.  PnP stays
+on the host in the reference and is outside the timed GPU path.  For N>1 every rank runs
+an independent replica on its own batch (inference shards by image, no data-path
+collective): weak scaling.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1,2> (64x128)", 3: "conv_f32_kernel<2,2,2,1> (128x64)",
+              4: "conv_f32_kernel<4,1,1,1> (128x32)", 5: "conv_f32_kernel<2,2,1,1> (64x64)", 6: "conv_f32_kernel<4,1,2,1> (256x32)"}
+
+
+def cpu_baseline(h, w, seg_dim, ver_dim):
+    """The NumPy oracle (fp32 arithmetic, BLAS threads = all host cores) on ONE image of the same
+    workload: forward + LS voting.  A reported baseline, not the optimisation target; the
+    reference's TF-CPU path cannot run here."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import casapose_oracle as O
+
+    p = O.init_params(seg_dim, ver_dim, seed=1237, dtype=np.float32)
+    img = np.random.default_rng(1237).uniform(-1, 1, (1, h, w, 3)).astype(np.float32)
+    t0 = time.perf_counter()
+    out = O.casapose_c_gcu5(p, img).astype(np.float32)
+    O.ls_voting(out[..., :seg_dim], out[..., seg_dim : seg_dim + 18], out[..., seg_dim + 18 :])
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 image 480x640 forward + LS voting, NumPy oracle in fp32 (%.1f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from casapose_amd import _lib
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, H, W = args.batch, args.height, args.width
+    seg_dim, ver_dim, kp = 9, 27, 9
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None,
+                                             base_model="resnet18", device=dev, seed=1237)
+    # randomised normalisation statistics so no term of the folded affines is trivial
+    rng = np.random.default_rng(1237)
+    params = net.get_parameters()
+    for k, v in params.items():
+        if k.endswith(".gamma") or k.endswith(".moving_variance"):
+            params[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif k.endswith(".beta") or k.endswith(".moving_mean"):
+            params[k] = (0.1 * rng.standard_normal(v.shape)).astype(np.float32)
+    net.set_parameters(params)
+    gen = torch.Generator(device="cpu").manual_seed(1237 + rank)
+    img = (2.0 * torch.rand(B, H, W, 3, generator=gen) - 1.0).to(dev)
+    voter = CoordLSVotingWeighted(name="coords_ls_voting", num_classes=seg_dim, num_points=kp, filter_estimates=False)
+    out_buf = torch.empty(B, H, W, seg_dim + ver_dim, dtype=torch.float32, device=dev)
+
+    def step():
+        out = net._net.forward(img, None, out_buf)
+        s, d, c = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
+        return voter([s, d, c])
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kpts = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(kpts).all()
+
+    result = {
+        "metric": "images/sec at 640x480, 8-object LMO (casapose_c_gcu5 forward + LS keypoint voting)",
+        "value": round(world * B * args.steps / dt, 3),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seed 1237: uniform [-1,1) images, he_uniform weights, randomised BN/CLADE statistics)",
+        "config": {"workload": "config_8.ini inference: casapose_c_gcu5, K=9 classes, ver_dim=27, bs=%d per GPU, %dx%d, fp32, estimated-mask conditioning, LS voting" % (B, H, W),
+                   "images_per_gpu_per_step": B, "parallelism": "replicas x%d (no collective)" % world},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # ---- per-launch durations of the convolution kernels, HIP events on the launch stream ----
+        plan = net._net.plan(B, H, W)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        reps = max(3, min(args.steps, 10))
+        per_tile = {}
+        for conv in plan.convs:
+            tile = lib.cp_conv_selected_tile(conv.desc) if hasattr(lib, "cp_conv_selected_tile") else 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            conv.run(stream)
+            e0.record()
+            for _ in range(reps):
+                conv.run(stream)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            t["ms"] += ms
+            t["flops"] += conv.flops
+            t["launches"] += 1
+        dom = max(per_tile, key=lambda k: per_tile[k]["ms"])
+        d = per_tile[dom]
+        conv_ms = sum(t["ms"] for t in per_tile.values())
+        conv_fl = sum(t["flops"] for t in per_tile.values())
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "launches_per_step": d["launches"],
+            "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+            "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 3), "ms_per_step": round(conv_ms, 3),
+                                 "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs)},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# PyTorch-ROCm ships its own libamdhip64; import it FIRST so that our library's dependency on
+# the same SONAME binds to the runtime that owns torch's device context and streams (two HIP
+# runtimes in one process do not share devices: launches fail with "no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcasapose_hip.so")
 
@@ -75,6 +80,7 @@ SYMBOLS = [
     ("cp_conv_ktot", _i, [_i, _i, _i, C.POINTER(_i)]),
     ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
+    ("cp_conv_selected_tile", _i, [C.POINTER(ConvDesc)]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),
     ("cp_maxpool3x3s2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     ("cp_upsample_bilinear_x2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -179,7 +179,7 @@ __global__ void guided_sel_kernel(const uint8_t* __restrict__ hi, const uint8_t*
 
 extern "C" int cp_pad_channels_3to4(const float* src, float* dst, long long pixels, void* stream) {
     CP_REQUIRE(src && dst && pixels > 0, "cp_pad_channels_3to4: bad arguments");
-    hipLaunchKernelGGL(pad3to4_kernel, dim3(grid_for(pixels)), dim3(THREADS), 0, (hipStream_t)stream, src, dst, pixels);
+    CP_LAUNCH(pad3to4_kernel, dim3(grid_for(pixels)), dim3(THREADS), 0, (hipStream_t)stream, src, dst, pixels);
     return cp::check_launch("cp_pad_channels_3to4");
 }
 
@@ -190,7 +190,7 @@ extern "C" int cp_maxpool3x3s2_f32(const float* src, int batch, int h, int w, in
     CP_REQUIRE((scale == nullptr) == (shift == nullptr), "cp_maxpool3x3s2_f32: scale/shift come together");
     int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     long long total = (long long)batch * ho * wo * (channels / 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, batch, h, w,
+    CP_LAUNCH(maxpool_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, batch, h, w,
                        channels, ho, wo, scale, shift, relu, dst);
     return cp::check_launch("cp_maxpool3x3s2_f32");
 }
@@ -198,7 +198,7 @@ extern "C" int cp_maxpool3x3s2_f32(const float* src, int batch, int h, int w, in
 extern "C" int cp_upsample_bilinear_x2_f32(const float* src, int batch, int h, int w, int channels, float* dst, void* stream) {
     CP_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && channels % 4 == 0, "cp_upsample_bilinear_x2_f32: bad arguments");
     long long total = (long long)batch * 4 * h * w * (channels / 4);
-    hipLaunchKernelGGL(bilinear_x2_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, batch, h, w, channels, dst);
+    CP_LAUNCH(bilinear_x2_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, batch, h, w, channels, dst);
     return cp::check_launch("cp_upsample_bilinear_x2_f32");
 }
 
@@ -206,14 +206,14 @@ extern "C" int cp_guided_upsample_x2_f32(const float* src, const uint8_t* sel, i
                                          float* dst, void* stream) {
     CP_REQUIRE(src && sel && dst && batch > 0 && h > 0 && w > 0 && channels % 4 == 0, "cp_guided_upsample_x2_f32: bad arguments");
     long long total = (long long)batch * 4 * h * w * (channels / 4);
-    hipLaunchKernelGGL(guided_x2_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, sel, batch, h, w, channels, dst);
+    CP_LAUNCH(guided_x2_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, sel, batch, h, w, channels, dst);
     return cp::check_launch("cp_guided_upsample_x2_f32");
 }
 
 extern "C" int cp_argmax_labels(const float* logits, int ld, int classes, long long pixels, uint8_t* labels, void* stream) {
     CP_REQUIRE(logits && labels && pixels > 0, "cp_argmax_labels: bad arguments");
     CP_REQUIRE(classes >= 1 && classes <= 255 && ld >= classes, "cp_argmax_labels: classes must be 1..255 and ld >= classes");
-    hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(pixels)), dim3(THREADS), 0, (hipStream_t)stream, logits, ld, classes, pixels, labels);
+    CP_LAUNCH(argmax_kernel, dim3(grid_for(pixels)), dim3(THREADS), 0, (hipStream_t)stream, logits, ld, classes, pixels, labels);
     return cp::check_launch("cp_argmax_labels");
 }
 
@@ -230,7 +230,7 @@ extern "C" int cp_label_pyramid(const uint8_t* labels0, int batch, int h, int w,
         if (!labels[l]) break;
         CP_REQUIRE(hs[l] > 0 && ws[l] > 0, "cp_label_pyramid: level %d is empty", l);
         long long total = (long long)batch * hs[l] * ws[l];
-        hipLaunchKernelGGL(half_labels_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l - 1], batch, hs[l - 1],
+        CP_LAUNCH(half_labels_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l - 1], batch, hs[l - 1],
                            ws[l - 1], hs[l], ws[l], labels[l]);
         lv[l] = labels[l];
     }
@@ -238,13 +238,13 @@ extern "C" int cp_label_pyramid(const uint8_t* labels0, int batch, int h, int w,
         if (pnorm && pnorm[l]) {
             CP_REQUIRE(lv[l], "cp_label_pyramid: pnorm[%d] requested without labels[%d]", l, l);
             long long total = (long long)batch * hs[l] * ws[l];
-            hipLaunchKernelGGL(pnorm_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l], batch, hs[l], ws[l], pnorm[l]);
+            CP_LAUNCH(pnorm_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l], batch, hs[l], ws[l], pnorm[l]);
         }
         if (l < 3 && sel && sel[l]) {
             CP_REQUIRE(lv[l] && lv[l + 1], "cp_label_pyramid: sel[%d] needs labels[%d] and labels[%d]", l, l, l + 1);
             CP_REQUIRE(hs[l] == 2 * hs[l + 1] && ws[l] == 2 * ws[l + 1], "cp_label_pyramid: level %d size must be even", l);
             long long total = (long long)batch * hs[l] * ws[l];
-            hipLaunchKernelGGL(guided_sel_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l], lv[l + 1], batch, hs[l], ws[l], sel[l]);
+            CP_LAUNCH(guided_sel_kernel, dim3(grid_for(total)), dim3(THREADS), 0, st, lv[l], lv[l + 1], batch, hs[l], ws[l], sel[l]);
         }
     }
     return cp::check_launch("cp_label_pyramid");

@@ -21,6 +21,14 @@ inline int check_launch(const char* what) {
     return CP_OK;
 }
 
+// hipGetLastError() is sticky per thread: clear whatever an earlier (possibly foreign, e.g.
+// PyTorch's device probing) call left behind so check_launch() reports THIS launch only.
+#define CP_LAUNCH(...)               \
+    do {                             \
+        (void)hipGetLastError();     \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define CP_REQUIRE(cond, ...)            \
     do {                                 \
         if (!(cond)) {                   \

@@ -286,7 +286,7 @@ int launch(const ConvK& k, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(kk.tiles_m * kk.tiles_n);
-    hipLaunchKernelGGL((conv_f32_kernel<WGM, WGN, TM, TN>), grid, dim3(256), lds, st, kk);
+    CP_LAUNCH((conv_f32_kernel<WGM, WGN, TM, TN>), grid, dim3(256), lds, st, kk);
     return cp::check_launch("cp_conv2d_fwd_f32");
 }
 
@@ -356,6 +356,11 @@ extern "C" int cp_conv_pack_weights_host(const float* w, int layout, int kh, int
         cbase += Cr;
     }
     return CP_OK;
+}
+
+extern "C" int cp_conv_selected_tile(const cp_conv_desc* d) {
+    if (!d) return CP_ERR_INVALID;
+    return d->tile_hint ? d->tile_hint : pick_tile((long long)d->batch * d->out_h * d->out_w, d->cout);
 }
 
 extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {

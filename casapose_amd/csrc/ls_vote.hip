@@ -192,9 +192,9 @@ extern "C" int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_o
     int strips_x = (w + 63) / 64, strips_y = (h + ROWS - 1) / ROWS;
     int blocks_per_img = (strips_x * strips_y + WAVES - 1) / WAVES;
     size_t lds = sizeof(double) * objects * kp * 5 + sizeof(float) * WAVES * 64 * ld;
-    hipLaunchKernelGGL((ls_accumulate_kernel<MAXKP>), dim3(batch * blocks_per_img), dim3(256), lds, st, field, ld, seg_off,
+    CP_LAUNCH((ls_accumulate_kernel<MAXKP>), dim3(batch * blocks_per_img), dim3(256), lds, st, field, ld, seg_off,
                        dir_off, conf_off, labels, batch, h, w, objects, sums_ws, strips_x, strips_y);
     int total = batch * objects * kp;
-    hipLaunchKernelGGL(ls_solve_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, total, h, keypoints);
+    CP_LAUNCH(ls_solve_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, total, h, keypoints);
     return cp::check_launch("cp_ls_vote_f32");
 }

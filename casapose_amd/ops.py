@@ -116,10 +116,12 @@ def label_pyramid(labels0: torch.Tensor):
     ws = [w, w // 2, w // 4, w // 8]
     labels = [labels0] + [torch.empty(b, hs[l], ws[l], dtype=torch.uint8, device=dev) for l in range(1, 4)]
     pnorm = [torch.empty(b, hs[l], ws[l], dtype=torch.float32, device=dev) for l in range(4)]
-    sel = [torch.empty(b, hs[l], ws[l], dtype=torch.uint8, device=dev) for l in range(3)]
-    lab = (C.c_void_p * 4)(*[t.data_ptr() for t in labels])
-    pn = (C.c_void_p * 4)(*[t.data_ptr() for t in pnorm])
-    sl = (C.c_void_p * 3)(*[t.data_ptr() for t in sel])
+    # guided-upsampling selection maps exist only between levels whose sizes are exactly 2:1
+    sel = [torch.empty(b, hs[l], ws[l], dtype=torch.uint8, device=dev) if (hs[l] == 2 * hs[l + 1] and ws[l] == 2 * ws[l + 1] and hs[l + 1] > 0) else None
+           for l in range(3)]
+    lab = (C.c_void_p * 4)(*[t.data_ptr() if t.numel() else None for t in labels])
+    pn = (C.c_void_p * 4)(*[t.data_ptr() if t.numel() else None for t in pnorm])
+    sl = (C.c_void_p * 3)(*[t.data_ptr() if t is not None else None for t in sel])
     check(_lib.load().cp_label_pyramid(labels0.data_ptr(), b, h, w, lab, pn, sl, _stream(labels0)), "cp_label_pyramid")
     return labels, pnorm, sel
 

@@ -122,6 +122,8 @@ int cp_conv_ktot(int kh, int kw, int num_sources, const int* channels);
 int cp_conv_pack_weights_host(const float* w_host, int layout, int kh, int kw, int cout, int num_sources,
                               const int* channels, const int* real_channels, float* dst_host);
 int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);
+/* which CP_TILE_* instantiation cp_conv2d_fwd_f32 will launch for this descriptor (profiling aid) */
+int cp_conv_selected_tile(const cp_conv_desc* desc);
 
 /* ------------------------------------------------------------------------------------
  * Small streaming kernels around the convolutions
