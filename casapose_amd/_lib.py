@@ -16,7 +16,8 @@ from typing import Optional
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcasapose_hip.so")
+# CASAPOSE_HIP_LIB overrides the library path (kernel-variant experiments only)
+LIB_PATH = os.environ.get("CASAPOSE_HIP_LIB") or os.path.join(_HERE, "libcasapose_hip.so")
 
 
 class CasaposeHipError(RuntimeError):

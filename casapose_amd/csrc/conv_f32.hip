@@ -25,6 +25,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats per tile row (32 + 4 pad)
 constexpr int MAX_TAPS = 64;
+#ifndef CP_CONV_WAVES
+#define CP_CONV_WAVES 2
+#endif
+#ifndef CP_CONV_NBUF
+#define CP_CONV_NBUF 2
+#endif
+constexpr int NBUF = CP_CONV_NBUF;  // LDS stages: 2 = one barrier per K chunk, 1 = two barriers but half the LDS (more blocks per CU)
 
 struct SrcK {
     const float* data;
@@ -32,6 +39,7 @@ struct SrcK {
     const float* pre_scale;
     const float* pre_shift;
     int C, ld, mode, Hs, Ws;
+    unsigned bytes;  // extent of `data` for the buffer descriptor (range-checked loads)
     int c4;       // 1: channels == 4, eight taps per chunk
     int cpt;      // chunks per tap (C/32) when !c4
     int nchunks;  // K chunks contributed by this source
@@ -41,6 +49,7 @@ struct ConvK {
     SrcK s[2];
     const float* W;
     int ktot;
+    unsigned w_bytes, lab_bytes;  // extents of W and of the tap_label / sel maps
     int B, Hin, Win, Ho, Wo, Cout, KH, KW, stride, dil, pad;
     int M;
     const uint8_t* tap_label;
@@ -60,18 +69,29 @@ struct ConvK {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
+// Operand-loader variants (compile-time so that the prefetch path has no data-dependent
+// control flow: every load is issued unconditionally from a clamped, always-valid address
+// and zeroing / affine / interpolation happen when the registers are written to LDS,
+// AFTER the MFMA block -- this is what keeps the loads in flight under the MFMAs).
+enum : int { F_PRE = 1, F_BILINEAR = 2, F_PARTIAL = 4, F_SEL = 8 };
+
+template <int WGM, int WGN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const ConvK p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
     constexpr int RM = BM / 32;  // A rows staged per thread
     constexpr int RN = BN / 32;  // B rows staged per thread
+    constexpr bool PRE = (MODE & F_PRE) != 0;
+    constexpr bool BILINEAR = (MODE & F_BILINEAR) != 0;
+    constexpr bool PARTIAL = (MODE & F_PARTIAL) != 0;
+    constexpr bool SEL = (MODE & F_SEL) != 0;
+    constexpr int NV = BILINEAR ? 4 : 1;
     static_assert(WGM * WGN == 4, "4 waves per block");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_STRIDE]
-    float* Bs = smem + 2 * BM * LDS_STRIDE;      // [2][BN][LDS_STRIDE]
-    int* tapoff = reinterpret_cast<int*>(Bs + 2 * BN * LDS_STRIDE);  // [MAX_TAPS] (dy<<16)|(dx & 0xffff)
+    float* Bs = smem + NBUF * BM * LDS_STRIDE;   // [NBUF][BN][LDS_STRIDE]
+    int* tapoff = reinterpret_cast<int*>(Bs + NBUF * BN * LDS_STRIDE);  // [MAX_TAPS] (dy<<16)|(dx & 0xffff)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,9 +111,23 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
     }
 
     // ---- per-thread staging coordinates -------------------------------------------------
+    // All operand fetches are range-checked raw-buffer loads with 32-bit byte offsets: an
+    // offset of OOB (>= the descriptor's extent) returns zeros, which is exactly the zero
+    // padding / tile-edge behaviour needed, with no branches and one VALU add per row.
+    constexpr unsigned OOB = 0x80000000u;
     const int col4 = tid & 7;   // which float4 of the 32-wide K chunk
     const int rbase = tid >> 3; // 0..31
-    int r_n[RM], r_iy0[RM], r_ix0[RM], r_clab[RM];
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
+                                                                          p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(PARTIAL ? (const void*)p.tap_label : (const void*)p.W), 0,
+                                                                          PARTIAL ? p.lab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
+                                                                          SEL ? p.lab_bytes : 0u, 0x00020000);
+    int r_pix[RM];   // (n*Hin + iy0)*Win + ix0 : pixel index of the tap-(0,0) position (may be "negative")
+    int r_iy0[RM], r_ix0[RM], r_clab[RM];
+    int r_nb[RM];    // SEL / BILINEAR: n * Hs * Ws
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
         int m = m0 + rbase + 32 * i;
@@ -101,91 +135,130 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
             int n = m / (p.Ho * p.Wo);
             int rem = m - n * (p.Ho * p.Wo);
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            r_n[i] = n;
             r_iy0[i] = oy * p.stride - p.pad;
             r_ix0[i] = ox * p.stride - p.pad;
-            r_clab[i] = p.tap_label ? (int)p.tap_label[((size_t)n * p.Hin + oy) * p.Win + ox] : 0;
+            r_pix[i] = (n * p.Hin + r_iy0[i]) * p.Win + r_ix0[i];
+            r_nb[i] = n * p.s[0].Hs * p.s[0].Ws;
+            r_clab[i] = PARTIAL ? (int)p.tap_label[((size_t)n * p.Hin + oy) * p.Win + ox] : 0;
         } else {
-            r_n[i] = 0;
             r_iy0[i] = -0x10000000;  // always out of bounds (also when added to the invalid-tap dy)
             r_ix0[i] = 0;
+            r_pix[i] = 0;
+            r_nb[i] = 0;
             r_clab[i] = -1;
         }
     }
+    unsigned r_wof[RN];  // byte offset of this thread's float4 in weight row co (OOB for co >= Cout)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int co = n0 + rbase + 32 * j;
+        r_wof[j] = (co < p.Cout) ? (unsigned)((co * p.ktot + col4 * 4) * 4) : OOB;
+    }
     __syncthreads();  // tapoff visible
 
-    float4 areg[RM], breg[RN];
+    // ---- staging registers (chunk q+1 while chunk q is multiplied) ------------------------
+    float4 areg[RM][NV], breg[RN];
+    float4 pre_s, pre_b;          // PRE
+    int aflag[RM];                // bit0 in-bounds, bit1 y parity, bit2 x parity
+    int alab[RM];                 // PARTIAL: label byte at the tap position
+    int selreg[RM];               // SEL: neighbour index for the NEXT chunk to be issued
+    int st_si = 0;                // source of the staged chunk (uniform)
+    bool st_pre = false;
 
-    auto load_chunk = [&](int q) {
-        // ---- B: packed weights, always in bounds along K --------------------------------
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            int co = n0 + rbase + 32 * j;
-            breg[j] = (co < p.Cout) ? ld4(p.W + (size_t)co * p.ktot + q * BK + col4 * 4) : make_float4(0, 0, 0, 0);
-        }
-        // ---- A: gather ------------------------------------------------------------------
-        const int si = (q >= p.s[0].nchunks) ? 1 : 0;
-        const SrcK& s = p.s[si];
+    auto ldb4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off, int soff) -> float4 {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, 0));
+    };
+    auto chunk_tap = [&](int q, int& si, int& tap, int& coff) {
+        si = (q >= p.s[0].nchunks) ? 1 : 0;
         const int ql = q - (si ? p.s[0].nchunks : 0);
-        int tap, coff;
-        if (s.c4) {
+        const int c4 = si ? p.s[1].c4 : p.s[0].c4;
+        const int cpt = si ? p.s[1].cpt : p.s[0].cpt;
+        if (c4) {
             tap = ql * 8 + col4;
             coff = 0;
         } else {
-            tap = ql / s.cpt;
-            coff = (ql - tap * s.cpt) * 32 + col4 * 4;
+            tap = ql / cpt;
+            coff = (ql - tap * cpt) * 32 + col4 * 4;
         }
+    };
+    auto tap_delta = [&](int tap, int& dy, int& dx) {
         const int to = tapoff[tap < MAX_TAPS ? tap : MAX_TAPS - 1];
-        const int dy = (tap < ntaps) ? (to >> 16) : 0x20000000;
-        const int dx = (int)(short)(to & 0xffff);
-        float4 ps = make_float4(1, 1, 1, 1), pb = make_float4(0, 0, 0, 0);
-        const bool has_pre = s.pre_scale != nullptr;
-        if (has_pre) {
-            ps = ld4(s.pre_scale + coff);
-            pb = ld4(s.pre_shift + coff);
+        dy = (tap < ntaps) ? (to >> 16) : 0x20000000;
+        dx = (int)(short)(to & 0xffff);
+    };
+
+    // SEL: fetch the neighbour-selection bytes of chunk q (consumed one iteration later)
+    auto load_sel = [&](int q) {
+        if constexpr (SEL) {
+            int si, tap, coff, dy, dx;
+            chunk_tap(q < p.nchunks ? q : p.nchunks - 1, si, tap, coff);
+            tap_delta(tap, dy, dx);
+            const int dpix = dy * p.Win + dx;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int iy = r_iy0[i] + dy, ix = r_ix0[i] + dx;
+                const bool inb = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+                selreg[i] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? (r_pix[i] + dpix) : (int)OOB, 0, 0);
+            }
+        }
+    };
+
+    auto issue_chunk = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < RN; ++j) breg[j] = ldb4(rsw, r_wof[j], q * (BK * 4));
+        int si, tap, coff, dy, dx;
+        chunk_tap(q, si, tap, coff);
+        tap_delta(tap, dy, dx);
+        const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
+        const int sld = si ? p.s[1].ld : p.s[0].ld;
+        const int dpix = dy * p.Win + dx;
+        st_si = si;
+        if constexpr (PRE) {
+            const float* ps = si ? p.s[1].pre_scale : p.s[0].pre_scale;
+            const float* pb = si ? p.s[1].pre_shift : p.s[0].pre_shift;
+            st_pre = ps != nullptr;
+            pre_s = ld4((st_pre ? ps : p.W) + coff);  // clamped to valid memory when unused
+            pre_b = ld4((st_pre ? pb : p.W) + coff);
         }
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
             const int iy = r_iy0[i] + dy, ix = r_ix0[i] + dx;
-            bool inb = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
-            const size_t gpix = ((size_t)r_n[i] * p.Hin + (inb ? iy : 0)) * p.Win + (inb ? ix : 0);
-            if (p.tap_label) {
-                int lab = inb ? (int)p.tap_label[gpix] : -2;
-                inb = inb && (lab == r_clab[i]);
-            }
-            float4 v = make_float4(0, 0, 0, 0);
-            if (inb) {
-                if (s.mode == CP_SRC_DIRECT) {
-                    v = ld4(s.data + gpix * s.ld + coff);
-                } else if (s.mode == CP_SRC_NEAREST_SEL) {
-                    int sl = s.sel[gpix];
-                    int sy = (iy >> 1) + (sl >> 1), sx = (ix >> 1) + (sl & 1);
-                    v = ld4(s.data + (((size_t)r_n[i] * s.Hs + sy) * s.Ws + sx) * s.ld + coff);
-                } else {  // CP_SRC_BILINEAR_X2, half-pixel centres
+            const bool inb = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+            const int gpix = r_pix[i] + dpix;  // valid when inb
+            aflag[i] = (inb ? 1 : 0) | ((iy & 1) << 1) | ((ix & 1) << 2);
+            if constexpr (PARTIAL) alab[i] = __builtin_amdgcn_raw_buffer_load_b8(rsl, inb ? gpix : (int)OOB, 0, 0);
+            if constexpr (BILINEAR) {
+                unsigned o00, o01, o10, o11;
+                if (si == 0) {  // uniform: the x2 source
+                    const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
                     int y0 = (iy >> 1) - ((iy & 1) ? 0 : 1), x0 = (ix >> 1) - ((ix & 1) ? 0 : 1);
-                    float fy = (iy & 1) ? 0.25f : 0.75f, fx = (ix & 1) ? 0.25f : 0.75f;
-                    int y1 = min(y0 + 1, s.Hs - 1), x1 = min(x0 + 1, s.Ws - 1);
+                    int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
                     y0 = max(y0, 0);
                     x0 = max(x0, 0);
-                    const float* base = s.data + (size_t)r_n[i] * s.Hs * s.Ws * s.ld + coff;
-                    float4 v00 = ld4(base + ((size_t)y0 * s.Ws + x0) * s.ld);
-                    float4 v01 = ld4(base + ((size_t)y0 * s.Ws + x1) * s.ld);
-                    float4 v10 = ld4(base + ((size_t)y1 * s.Ws + x0) * s.ld);
-                    float4 v11 = ld4(base + ((size_t)y1 * s.Ws + x1) * s.ld);
-                    float gx = 1.f - fx, gy = 1.f - fy;
-                    v.x = (v00.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
-                    v.y = (v00.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
-                    v.z = (v00.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
-                    v.w = (v00.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
+                    const int c4b = coff * 4;
+                    o00 = inb ? (unsigned)(((r_nb[i] + y0 * Ws + x0) * sld) * 4 + c4b) : OOB;
+                    o01 = inb ? (unsigned)(((r_nb[i] + y0 * Ws + x1) * sld) * 4 + c4b) : OOB;
+                    o10 = inb ? (unsigned)(((r_nb[i] + y1 * Ws + x0) * sld) * 4 + c4b) : OOB;
+                    o11 = inb ? (unsigned)(((r_nb[i] + y1 * Ws + x1) * sld) * 4 + c4b) : OOB;
+                } else {
+                    o00 = o01 = o10 = o11 = inb ? (unsigned)((gpix * sld + coff) * 4) : OOB;
                 }
-                if (has_pre) {
-                    v.x = v.x * ps.x + pb.x;
-                    v.y = v.y * ps.y + pb.y;
-                    v.z = v.z * ps.z + pb.z;
-                    v.w = v.w * ps.w + pb.w;
+                areg[i][0] = ldb4(rs, o00, 0);
+                areg[i][1] = ldb4(rs, o01, 0);
+                areg[i][2] = ldb4(rs, o10, 0);
+                areg[i][3] = ldb4(rs, o11, 0);
+            } else if constexpr (SEL) {
+                unsigned o;
+                if (si == 0) {
+                    const int sl = selreg[i];
+                    o = inb ? (unsigned)(((r_nb[i] + ((iy >> 1) + (sl >> 1)) * p.s[0].Ws + (ix >> 1) + (sl & 1)) * sld + coff) * 4) : OOB;
+                } else {
+                    o = inb ? (unsigned)((gpix * sld + coff) * 4) : OOB;
                 }
+                areg[i][0] = ldb4(rs, o, 0);
+            } else {
+                areg[i][0] = ldb4(rs, inb ? (unsigned)((gpix * sld + coff) * 4) : OOB, 0);
             }
-            areg[i] = v;
         }
     };
 
@@ -193,8 +266,33 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
         float* a = As + buf * BM * LDS_STRIDE;
         float* b = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
-            *reinterpret_cast<float4*>(a + (rbase + 32 * i) * LDS_STRIDE + col4 * 4) = areg[i];
+        for (int i = 0; i < RM; ++i) {
+            float4 v = areg[i][0];
+            if constexpr (BILINEAR) {
+                if (st_si == 0) {
+                    const float fy = (aflag[i] & 2) ? 0.25f : 0.75f, fx = (aflag[i] & 4) ? 0.25f : 0.75f;
+                    const float gy = 1.f - fy, gx = 1.f - fx;
+                    const float4 v01 = areg[i][1], v10 = areg[i][2], v11 = areg[i][3];
+                    v.x = (v.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
+                    v.y = (v.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
+                    v.z = (v.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
+                    v.w = (v.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
+                }
+            }
+            if constexpr (PRE) {
+                // the affine applies to real pixels only: padding stays exactly zero
+                if (st_pre && (aflag[i] & 1)) {
+                    v.x = v.x * pre_s.x + pre_b.x;
+                    v.y = v.y * pre_s.y + pre_b.y;
+                    v.z = v.z * pre_s.z + pre_b.z;
+                    v.w = v.w * pre_s.w + pre_b.w;
+                }
+            }
+            if constexpr (PARTIAL) {
+                if (alab[i] != r_clab[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4*>(a + (rbase + 32 * i) * LDS_STRIDE + col4 * 4) = v;
+        }
 #pragma unroll
         for (int j = 0; j < RN; ++j)
             *reinterpret_cast<float4*>(b + (rbase + 32 * j) * LDS_STRIDE + col4 * 4) = breg[j];
@@ -211,36 +309,68 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
     const int lrow = lane & 31;
     const int khalf = (lane >> 5) * 4;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-
-    for (int q = 0; q < p.nchunks; ++q) {
-        const int buf = q & 1;
-        const bool more = (q + 1) < p.nchunks;
-        if (more) load_chunk(q + 1);
-
-        const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + lrow) * LDS_STRIDE + khalf;
-        const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + lrow) * LDS_STRIDE + khalf;
+    // MFMA fragments, double-buffered across the four 8-deep k steps of a chunk so that the
+    // LDS reads of step k+1 are in flight while step k multiplies.
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int buf, int k8, int slot) {
+        const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + lrow) * LDS_STRIDE + khalf + k8 * 8;
+        const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + lrow) * LDS_STRIDE + khalf + k8 * 8;
 #pragma unroll
-        for (int k8 = 0; k8 < BK / 8; ++k8) {
-            float4 av[TM], bv[TN];
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_STRIDE);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_STRIDE + k8 * 8);
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_STRIDE);
+    };
+    auto mfma_step = [&](int slot) {
+        // element-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_STRIDE + k8 * 8);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+                    const float av = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
+                    const float bv = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                 }
+    };
+
+    load_sel(0);
+    issue_chunk(0);
+    load_sel(1);
+    store_chunk(0);
+    __syncthreads();
+    read_frags(0, 0, 0);
+
+    for (int q = 0; q < p.nchunks; ++q) {
+        const int buf = (NBUF == 2) ? (q & 1) : 0;
+        const bool more = (q + 1) < p.nchunks;
+#ifdef CP_EXPERIMENT_NOSTAGE
+        const bool stage = false;
+#else
+        const bool stage = more;
+#endif
+        if (stage) {
+            issue_chunk(q + 1);  // global loads stay in flight under the MFMAs below
+            load_sel(q + 2);
         }
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
+        read_frags(buf, 1, 1);
+        mfma_step(0);
+        read_frags(buf, 2, 0);
+        mfma_step(1);
+        read_frags(buf, 3, 1);
+        mfma_step(0);
+        if constexpr (NBUF == 2) {
+            if (stage) store_chunk(buf ^ 1);  // LDS writes of the next chunk under the last MFMA group
+            mfma_step(1);
+            __syncthreads();
+            if (more) read_frags(buf ^ 1, 0, 0);
+        } else {
+            mfma_step(1);
+            __syncthreads();  // everyone finished reading the single stage
+            if (stage) store_chunk(0);
+            __syncthreads();
+            if (more) read_frags(0, 0, 0);
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -272,47 +402,47 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const ConvK p) {
     }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int MODE>
 int launch(const ConvK& k, hipStream_t st) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     ConvK kk = k;
     kk.tiles_m = (k.M + BM - 1) / BM;
     kk.tiles_n = (k.Cout + BN - 1) / BN;
-    size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float) + MAX_TAPS * sizeof(int);
+    size_t lds = (size_t)NBUF * (BM + BN) * LDS_STRIDE * sizeof(float) + MAX_TAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<WGM, WGN, TM, TN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<WGM, WGN, TM, TN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(kk.tiles_m * kk.tiles_n);
-    CP_LAUNCH((conv_f32_kernel<WGM, WGN, TM, TN>), grid, dim3(256), lds, st, kk);
+    CP_LAUNCH((conv_f32_kernel<WGM, WGN, TM, TN, MODE>), grid, dim3(256), lds, st, kk);
     return cp::check_launch("cp_conv2d_fwd_f32");
+}
+
+template <int MODE>
+int launch_tile(int tile, const ConvK& k, hipStream_t st) {
+    switch (tile) {
+        case CP_TILE_128x128: return launch<2, 2, 2, 2, MODE>(k, st);
+        case CP_TILE_64x128: return launch<2, 2, 1, 2, MODE>(k, st);
+        case CP_TILE_128x64: return launch<2, 2, 2, 1, MODE>(k, st);
+        case CP_TILE_64x64: return launch<2, 2, 1, 1, MODE>(k, st);
+        case CP_TILE_128x32: return launch<4, 1, 1, 1, MODE>(k, st);
+        case CP_TILE_256x32:
+            if constexpr ((MODE & F_BILINEAR) != 0) return launch<4, 1, 1, 1, MODE>(k, st);  // 8 rows x 4 taps would not fit the VGPR budget
+            else return launch<4, 1, 2, 1, MODE>(k, st);
+        default: cp::set_error("cp_conv2d_fwd_f32: unknown tile_hint %d", tile); return CP_ERR_INVALID;
+    }
 }
 
 int chunks_for(int taps, int C) { return (C == 4) ? (taps + 7) / 8 : taps * (C / 32); }
 
-// Pick the tile that wastes the least MFMA work once padding of N, padding of M and the
-// last partial round over the 256 CUs are accounted for; ties go to the larger tile.
+// Tile choice from the measured sweep on MI355X (profiles/): 64x64 blocks win or tie
+// for every layer with cout >= 64 (3+ blocks per CU hide the staging of each other); the
+// 32-channel full-resolution layers and the 9/27-channel heads want all four waves along M.
 int pick_tile(long long M, int N) {
-    struct T { int id, bm, bn; };
-    static const T tiles[] = {{CP_TILE_128x128, 128, 128}, {CP_TILE_64x128, 64, 128}, {CP_TILE_128x64, 128, 64},
-                              {CP_TILE_64x64, 64, 64},     {CP_TILE_256x32, 256, 32}, {CP_TILE_128x32, 128, 32}};
-    double best = 1e30;
-    int best_id = CP_TILE_128x128;
-    for (const T& t : tiles) {
-        long long tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
-        long long nt = tm * tn;
-        long long rounds = (nt + 255) / 256;
-        double cost = (double)rounds * 256.0 * t.bm * t.bn;  // MFMA work the chip spends
-        // small tiles pay relatively more staging per MFMA: mild penalty
-        cost *= 1.0 + 2.0 / (t.bm < t.bn ? t.bm : t.bn);
-        if (cost < best * 0.999) {
-            best = cost;
-            best_id = t.id;
-        }
-    }
-    return best_id;
+    (void)M;
+    return N <= 32 ? CP_TILE_128x32 : CP_TILE_64x64;
 }
 
 }  // namespace
@@ -404,6 +534,12 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
         o.mode = in.mode;
         o.Hs = (in.mode == CP_SRC_DIRECT) ? d->in_h : d->in_h / 2;
         o.Ws = (in.mode == CP_SRC_DIRECT) ? d->in_w : d->in_w / 2;
+        {
+            const long long px = (long long)d->batch * o.Hs * o.Ws;
+            const long long nbytes = px * in.ld * 4;
+            CP_REQUIRE(nbytes < (1LL << 31), "cp_conv2d_fwd_f32: source %d spans %lld bytes; 32-bit range-checked addressing needs < 2 GiB", s, nbytes);
+            o.bytes = (unsigned)nbytes;
+        }
         o.c4 = in.channels == 4;
         o.cpt = o.c4 ? 1 : in.channels / 32;
         o.nchunks = chunks_for(d->kh * d->kw, in.channels);
@@ -412,6 +548,8 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
     k.W = d->weights;
     k.ktot = cp_conv_ktot(d->kh, d->kw, d->num_sources, chans);
     k.nchunks = k.ktot / BK;
+    k.w_bytes = (unsigned)((size_t)d->cout * k.ktot * 4);
+    k.lab_bytes = (unsigned)((size_t)d->batch * d->in_h * d->in_w);
     k.B = d->batch; k.Hin = d->in_h; k.Win = d->in_w; k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->cout;
     k.KH = d->kh; k.KW = d->kw; k.stride = d->stride; k.dil = d->dilation; k.pad = d->pad;
     k.M = d->batch * d->out_h * d->out_w;
@@ -425,13 +563,21 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int tile = d->tile_hint ? d->tile_hint : pick_tile(k.M, k.Cout);
-    switch (tile) {
-        case CP_TILE_128x128: return launch<2, 2, 2, 2>(k, st);
-        case CP_TILE_64x128: return launch<2, 2, 1, 2>(k, st);
-        case CP_TILE_128x64: return launch<2, 2, 2, 1>(k, st);
-        case CP_TILE_64x64: return launch<2, 2, 1, 1>(k, st);
-        case CP_TILE_128x32: return launch<4, 1, 1, 1>(k, st);
-        case CP_TILE_256x32: return launch<4, 1, 2, 1>(k, st);
-        default: cp::set_error("cp_conv2d_fwd_f32: unknown tile_hint %d", tile); return CP_ERR_INVALID;
+    // operand-loader variant
+    const bool any_pre = k.s[0].pre_scale || (d->num_sources > 1 && k.s[1].pre_scale);
+    const bool bil = k.s[0].mode == CP_SRC_BILINEAR_X2, sel = k.s[0].mode == CP_SRC_NEAREST_SEL;
+    CP_REQUIRE(d->num_sources == 1 || d->src[1].mode == CP_SRC_DIRECT, "cp_conv2d_fwd_f32: only source 0 may use an x2 mode");
+    const int mode = (any_pre ? F_PRE : 0) | (bil ? F_BILINEAR : 0) | (k.tap_label ? F_PARTIAL : 0) | (sel ? F_SEL : 0);
+    switch (mode) {
+        case 0: return launch_tile<0>(tile, k, st);
+        case F_PRE: return launch_tile<F_PRE>(tile, k, st);
+        case F_BILINEAR: return launch_tile<F_BILINEAR>(tile, k, st);
+        case F_PARTIAL: return launch_tile<F_PARTIAL>(tile, k, st);
+        case F_SEL: return launch_tile<F_SEL>(tile, k, st);
+        case F_PARTIAL | F_SEL: return launch_tile<F_PARTIAL | F_SEL>(tile, k, st);
+        default:
+            cp::set_error("cp_conv2d_fwd_f32: unsupported combination of operand modes (pre=%d bilinear=%d partial=%d sel=%d)",
+                          (int)any_pre, (int)bil, (int)(k.tap_label != nullptr), (int)sel);
+            return CP_ERR_INVALID;
     }
 }
