@@ -76,7 +76,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 enum : int { F_PRE = 1, F_BILINEAR = 2, F_PARTIAL = 4, F_SEL = 8 };
 
 template <int WGM, int WGN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const ConvK p) {
+__global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(const ConvK p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
     constexpr int RM = BM / 32;  // A rows staged per thread
@@ -86,17 +86,23 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
     constexpr bool PARTIAL = (MODE & F_PARTIAL) != 0;
     constexpr bool SEL = (MODE & F_SEL) != 0;
     constexpr int NV = BILINEAR ? 4 : 1;
-    static_assert(WGM * WGN == 4, "4 waves per block");
+    static_assert(WGM * WGN == 4, "4 consumer waves per block");
+    static_assert(NBUF == 2, "producer/consumer pipeline uses two LDS stages");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_STRIDE]
     float* Bs = smem + NBUF * BM * LDS_STRIDE;   // [NBUF][BN][LDS_STRIDE]
     int* tapoff = reinterpret_cast<int*>(Bs + NBUF * BN * LDS_STRIDE);  // [MAX_TAPS] (dy<<16)|(dx & 0xffff)
 
-    const int tid = threadIdx.x;
+    // Wave specialisation: waves 0-3 (one per SIMD) only read fragments from LDS and issue
+    // MFMAs; waves 4-7 (their SIMD partners) only gather operands (global -> registers ->
+    // LDS).  The matrix pipe and the VALU/VMEM/LDS pipes are separate, so the hardware
+    // overlaps the two instruction streams without depending on compiler scheduling.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255;  // index within the role
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int wm = (wave & 3) / WGN, wn = (wave & 3) % WGN;
 
     const int logical = cp::xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tile_n = logical % p.tiles_n;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
     const int n0 = tile_n * BN;
 
     const int ntaps = p.KH * p.KW;
-    if (tid < MAX_TAPS) {
+    if (threadIdx.x < MAX_TAPS) {
         int ky = tid / p.KW, kx = tid - ky * p.KW;
         tapoff[tid] = ((ky * p.dil) << 16) | ((kx * p.dil) & 0xffff);
     }
@@ -166,7 +172,11 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
     bool st_pre = false;
 
     auto ldb4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off, int soff) -> float4 {
+#ifdef CP_EXP_NOLOAD
+        return make_float4(__builtin_bit_cast(float, off), 1.f, 2.f, (float)soff);  // timing experiment only
+#else
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, 0));
+#endif
     };
     auto chunk_tap = [&](int q, int& si, int& tap, int& coff) {
         si = (q >= p.s[0].nchunks) ? 1 : 0;
@@ -263,6 +273,9 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
     };
 
     auto store_chunk = [&](int buf) {
+#ifdef CP_EXP_NOSTORE
+        if (p.M >= 0) { asm volatile("" :: "v"(areg[0][0].x), "v"(breg[0].x)); return; }  // timing experiment only
+#endif
         float* a = As + buf * BM * LDS_STRIDE;
         float* b = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
@@ -298,6 +311,35 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
             *reinterpret_cast<float4*>(b + (rbase + 32 * j) * LDS_STRIDE + col4 * 4) = breg[j];
     };
 
+    // raw barrier: LDS traffic must be complete, but the producers' global loads stay in
+    // flight across it (a __syncthreads() would drain vmcnt and serialise the prefetch)
+#define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    if (producer) {
+        load_sel(0);
+        issue_chunk(0);
+        load_sel(1);
+        store_chunk(0);
+        if (p.nchunks > 1) {
+            issue_chunk(1);
+            load_sel(2);
+        }
+        CP_BARRIER();
+        for (int q = 0; q < p.nchunks; ++q) {
+            // stage (q+1)&1 was last read by the consumers in iteration q-1: free since the barrier
+            if (q + 1 < p.nchunks) {
+                store_chunk((q + 1) & 1);
+                if (q + 2 < p.nchunks) {
+                    issue_chunk(q + 2);
+                    load_sel(q + 3);
+                }
+            }
+            CP_BARRIER();
+        }
+        return;
+    }
+
+    // ---------------------------------- consumers ------------------------------------------
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -334,44 +376,53 @@ __global__ __launch_bounds__(256, CP_CONV_WAVES) void conv_f32_kernel(const Conv
                 }
     };
 
-    load_sel(0);
-    issue_chunk(0);
-    load_sel(1);
-    store_chunk(0);
-    __syncthreads();
-    read_frags(0, 0, 0);
-
-    for (int q = 0; q < p.nchunks; ++q) {
-        const int buf = (NBUF == 2) ? (q & 1) : 0;
-        const bool more = (q + 1) < p.nchunks;
-#ifdef CP_EXPERIMENT_NOSTAGE
-        const bool stage = false;
-#else
-        const bool stage = more;
+#ifdef CP_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(CP_EXP_SETPRIO);  // MFMA waves win issue arbitration against their producer partners
 #endif
-        if (stage) {
-            issue_chunk(q + 1);  // global loads stay in flight under the MFMAs below
-            load_sel(q + 2);
-        }
+    CP_BARRIER();  // stage 0 is ready
+#ifndef CP_EXP_LOOP2
+    read_frags(0, 0, 0);
+    for (int q = 0; q < p.nchunks; ++q) {
+        const int buf = q & 1;
         read_frags(buf, 1, 1);
         mfma_step(0);
         read_frags(buf, 2, 0);
         mfma_step(1);
         read_frags(buf, 3, 1);
         mfma_step(0);
-        if constexpr (NBUF == 2) {
-            if (stage) store_chunk(buf ^ 1);  // LDS writes of the next chunk under the last MFMA group
-            mfma_step(1);
-            __syncthreads();
-            if (more) read_frags(buf ^ 1, 0, 0);
-        } else {
-            mfma_step(1);
-            __syncthreads();  // everyone finished reading the single stage
-            if (stage) store_chunk(0);
-            __syncthreads();
-            if (more) read_frags(0, 0, 0);
-        }
+        mfma_step(1);
+        CP_BARRIER();  // stage buf^1 now holds chunk q+1; stage buf may be overwritten
+        if (q + 1 < p.nchunks) read_frags(buf ^ 1, 0, 0);
     }
+#else
+    // every LDS read is issued >= one 4*TM*TN-MFMA step before its first use; the barrier sits
+    // after step 2 (all reads of the current stage complete), so step 3 covers the first read
+    // of the next stage
+    read_frags(0, 0, 0);
+    read_frags(0, 1, 1);
+    for (int q = 0; q < p.nchunks; ++q) {
+        const int buf = q & 1;
+        mfma_step(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(buf, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(buf, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(0);
+        __builtin_amdgcn_sched_barrier(0);
+        CP_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < p.nchunks) read_frags(buf ^ 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < p.nchunks) read_frags(buf ^ 1, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+#undef CP_BARRIER
 
     // ---- epilogue ----------------------------------------------------------------------
     const int hi4 = (lane >> 5) * 4;
@@ -416,7 +467,7 @@ int launch(const ConvK& k, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(kk.tiles_m * kk.tiles_n);
-    CP_LAUNCH((conv_f32_kernel<WGM, WGN, TM, TN, MODE>), grid, dim3(256), lds, st, kk);
+    CP_LAUNCH((conv_f32_kernel<WGM, WGN, TM, TN, MODE>), grid, dim3(512), lds, st, kk);
     return cp::check_launch("cp_conv2d_fwd_f32");
 }
 
