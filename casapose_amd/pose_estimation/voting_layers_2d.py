@@ -16,14 +16,16 @@ def _as_record(seg: torch.Tensor, direct: torch.Tensor, conf: torch.Tensor):
     """If the three inputs are channel slices of ONE [B,H,W,ld] tensor (the usual
     `tf.split(output_net, ...)` of train_casapose.py:539) use it in place; otherwise pack them."""
     ts = (seg, direct, conf)
-    base = seg._base if seg._base is not None else None
-    same = base is not None and all(t._base is base for t in ts) and base.dim() == 4 and base.is_contiguous()
-    if same:
-        ld = base.shape[3]
-        ok = all(t.stride() == (base.stride(0), base.stride(1), base.stride(2), 1) for t in ts)
-        offs = [t.storage_offset() - base.storage_offset() for t in ts]
-        if ok and ld % 4 == 0 and ld <= 64 and all(0 <= o < ld for o in offs):
-            return base, offs
+    b, h, w = seg.shape[:3]
+    ld = seg.stride(2)
+    want = (h * w * ld, w * ld, ld, 1)
+    same_store = all(t.untyped_storage().data_ptr() == seg.untyped_storage().data_ptr() for t in ts)
+    if same_store and all(t.dtype == torch.float32 and t.stride() == want for t in ts) and ld % 4 == 0 and 0 < ld <= 64:
+        first = min(t.storage_offset() for t in ts)
+        offs = [t.storage_offset() - first for t in ts]
+        fits = first + b * h * w * ld <= seg.untyped_storage().nbytes() // 4
+        if fits and all(o + t.shape[3] <= ld for o, t in zip(offs, ts)) and (seg.untyped_storage().data_ptr() + 4 * first) % 16 == 0:
+            return torch.as_strided(seg, (b, h, w, ld), want, storage_offset=first), offs
     k, d, c = seg.shape[3], direct.shape[3], conf.shape[3]
     ld = (k + d + c + 3) // 4 * 4
     rec = torch.zeros(seg.shape[0], seg.shape[1], seg.shape[2], ld, dtype=torch.float32, device=seg.device)

@@ -1,0 +1,129 @@
+"""CPU tests of the host side: the registry/constructor API mirrors the reference, the
+normalisation folding is exact, the config parser keeps the reference's precedence, and the
+product path refuses to run without a GPU instead of falling back."""
+import numpy as np
+import pytest
+import torch
+
+import casapose_oracle as O
+
+
+def test_registry_names_match_reference_and_unknown_name_raises():
+    from casapose_amd.pose_models import model_factory, tfkeras
+    from casapose_amd.pose_models.models_factory import Classifiers
+
+    assert tfkeras.Classifiers is Classifiers and model_factory.Classifiers is Classifiers
+    names = Classifiers.models_names()
+    for n in ("resnet18", "casapose_c", "casapose_c_gu", "casapose_c_gcu3", "casapose_c_gcu4", "casapose_c_gcu5", "pvnet_combined",
+              "casapose_custom", "casapose_c_gcu5_sw5", "casapose_c_gcu4_sw1", "casapose_c_gcu5_sw1", "casapose_c_gcu4_bilat",
+              "casapose_c_gcu4_sw2", "pvnet"):
+        assert n in names
+    assert len(names) == 18  # models_factory.py:9-32
+    with pytest.raises(ValueError, match="No such model"):
+        Classifiers.get("does_not_exist")
+    with pytest.raises(NotImplementedError):
+        Classifiers.get("pvnet")(ver_dim=18, seg_dim=9)
+
+
+def test_no_cpu_fallback():
+    from casapose_amd import _lib
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.CasaposeHipError, match="no CPU fallback"):
+        Classifiers.get("casapose_c_gcu5")(ver_dim=27, seg_dim=9, input_shape=(64, 96, 3))
+    t = torch.zeros(1, 8, 8, 9)
+    with pytest.raises(_lib.CasaposeHipError, match="no CPU fallback"):
+        CoordLSVotingWeighted("v", 9)([t, torch.zeros(1, 8, 8, 18), t])
+
+
+def test_decoder_params_surface():
+    from casapose_amd.pose_models.models.casapose import CASAPOSE_PARAMS, DecoderParams
+
+    assert DecoderParams._fields == ("weighted_clade", "partial_conv", "guided_upsampling", "bilinear_upsampling", "reuse_conv")
+    p = CASAPOSE_PARAMS["clade"]
+    assert len(p) == 5 and [x.guided_upsampling for x in p] == [False, True, True, True, False]
+    assert all(x.weighted_clade and x.partial_conv and not x.bilinear_upsampling and not x.reuse_conv for x in p)
+
+
+def test_bn_and_clade_folding_match_the_oracle():
+    from casapose_amd.engine import fold_bn, fold_clade
+
+    rng = np.random.default_rng(0)
+    c, k = 16, 4
+    p = {"n.gamma": rng.uniform(0.5, 1.5, c), "n.beta": rng.standard_normal(c), "n.moving_mean": rng.standard_normal(c),
+         "n.moving_variance": rng.uniform(0.5, 1.5, c)}
+    x = rng.standard_normal((2, 3, 5, c))
+    s, b = fold_bn(p, "n")
+    assert np.allclose(x * s + b, O.batchnorm_inference(x, p["n.gamma"], p["n.beta"], p["n.moving_mean"], p["n.moving_variance"]), atol=1e-5)
+    q = {"d.beta": p["n.beta"][:3], "d.moving_mean": p["n.moving_mean"][:3], "d.moving_variance": p["n.moving_variance"][:3]}
+    s, b = fold_bn(q, "d", pad_to=4)  # bn_data: no gamma, padded to the 4-channel operand
+    assert s.shape == (4,) and s[3] == 0 and b[3] == 0
+    assert np.allclose(x[..., :3] * s[:3] + b[:3], O.batchnorm_inference(x[..., :3], None, q["d.beta"], q["d.moving_mean"], q["d.moving_variance"]), atol=1e-5)
+    pc = {"c.gamma": rng.uniform(0.5, 1.5, (k, c)), "c.beta": rng.standard_normal((k, c)), "c.moving_mean": p["n.moving_mean"],
+          "c.moving_variance": p["n.moving_variance"]}
+    lab = rng.integers(0, k, (2, 3, 5))
+    ts, tb = fold_clade(pc, "c")
+    ref = O.clade_weighted(x, O.onehot_from_labels(lab, k), pc["c.gamma"], pc["c.beta"], pc["c.moving_mean"], pc["c.moving_variance"])
+    assert np.allclose(x * ts[lab] + tb[lab], ref, atol=1e-5)
+
+
+def test_initial_parameters_cover_the_oracle_parameter_set():
+    from casapose_amd.pose_models.models.model import initial_parameters
+
+    mine = initial_parameters(9, 27, (256, 128, 64, 32, 32), seed=0)
+    ref = O.init_params(9, 27)
+    assert set(mine) == set(ref)
+    for k in mine:
+        assert mine[k].shape == ref[k].shape, k
+    n = sum(v.size for k, v in mine.items() if k.endswith((".kernel", ".weights")))
+    assert n == 11171008 + 3560256  # encoder + decoder conv weights (K=9, ver_dim=27)
+    w = mine["pv_block_6_prepare_conv2d.weights"]
+    assert w.shape == (512, 3, 3, 256) and abs(w).max() <= np.sqrt(6.0 / (9 * 512))  # he_uniform, fan_in 9*Cin
+
+
+def test_config_precedence_and_postprocessing(tmp_path):
+    from casapose_amd.utils.config_parser import parse_config
+
+    opt = parse_config([])
+    assert opt.modelname == "casapose_cond_weighted" and opt.imagesize == (448, 448) and opt.batchsize == 32
+    assert opt.outf == "output/tmp" and opt.evalf == "output/tmp/tmp" and 1 <= opt.manualseed < 10000
+    ini = tmp_path / "c.ini"
+    ini.write_text("[defaults]\nmodelname: casapose_c_gcu5\nimagesize_test: 480, 640\nbatchsize: 4\nestimate_coords: 1\n"
+                   "lr_epochs_steps: 50,75,90\ngpuids: 0,1\nmanualseed: 1237\nobject: obj_000001,obj_000005\n")
+    opt = parse_config(["-c", str(ini)])
+    assert opt.modelname == "casapose_c_gcu5" and opt.imagesize_test == (480, 640) and opt.batchsize == 4
+    assert opt.estimate_coords is True and opt.lr_epochs_steps == [50, 75, 90] and opt.gpuids == [0, 1] and opt.manualseed == 1237
+    opt = parse_config(["-c", str(ini), "--batchsize", "16", "--estimate_coords", "no", "--gpuids", "-1"])
+    assert opt.batchsize == 16 and opt.estimate_coords is False and opt.gpuids == [-1]  # command line wins
+    assert opt.objects_to_copy.tolist() == [[0, 0]] and opt.objects_in_input_network == 0
+    with pytest.raises(SystemExit):
+        parse_config(["--estimate_coords", "maybe"])  # argparse.ArgumentTypeError -> exit, like the reference
+
+
+def test_shipped_configs_parse():
+    import os
+
+    from casapose_amd.utils.config_parser import parse_config
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    o8 = parse_config(["-c", os.path.join(root, "config", "config_8.ini")])
+    o13 = parse_config(["-c", os.path.join(root, "config", "config_13.ini")])
+    assert o8.modelname == o13.modelname == "casapose_c_gcu5"
+    assert len(o8.object.split(",")) == 8 and len(o13.object.split(",")) == 13
+    assert o8.imagesize == (448, 448) and o8.imagesize_test == (480, 640) and o8.train_vectors_with_ground_truth is True
+    assert o8.proxy_loss_weight == 0.015 and o8.keypoint_loss_weight == 0.007 and o8.max_keypoint_pixel_error == 12.5
+    assert o13.filter_test_with_gt is True and o8.filter_test_with_gt is False
+
+
+def test_voting_record_detection():
+    from casapose_amd.pose_estimation.voting_layers_2d import _as_record
+
+    out = torch.arange(2 * 4 * 5 * 36, dtype=torch.float32).reshape(2, 4, 5, 36)
+    s, d, c = torch.split(out, [9, 18, 9], dim=3)
+    rec, offs = _as_record(s, d, c)
+    assert rec.data_ptr() == out.data_ptr() and offs == [0, 9, 27]  # zero-copy
+    rec2, offs2 = _as_record(s.contiguous(), d.contiguous(), c.contiguous())
+    assert rec2.shape[3] == 36 and offs2 == [0, 9, 27] and torch.equal(rec2, out)

@@ -1,0 +1,223 @@
+"""Known-answer tests that pin the oracle's semantics by hand (the reference ships no tests or
+golden vectors and cannot be imported here: SURVEY.md F2/F3 -- parity is otherwise unpinned).
+Each case is small enough to verify on paper; where PyTorch has an independent implementation of
+the same published op (conv, bilinear resize, max-pool) the oracle is cross-checked against it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import casapose_oracle as O
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).numpy()
+
+
+def nchw(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------- plain layers ----------------
+def test_conv_by_hand():
+    x = np.arange(16, dtype=np.float64).reshape(1, 4, 4, 1)
+    w = np.ones((3, 3, 1, 1))
+    out = O.conv2d(x, w, pad=1)
+    assert out[0, 0, 0, 0] == 0 + 1 + 4 + 5            # corner: 4 taps in bounds
+    assert out[0, 1, 1, 0] == sum([0, 1, 2, 4, 5, 6, 8, 9, 10])
+    assert out[0, 3, 3, 0] == 10 + 11 + 14 + 15
+    # no kernel flip: a one-hot kernel at (ky=0,kx=2) picks the upper-right neighbour
+    w2 = np.zeros((3, 3, 1, 1)); w2[0, 2] = 1
+    assert O.conv2d(x, w2, pad=1)[0, 1, 1, 0] == x[0, 0, 2, 0]
+
+
+@pytest.mark.parametrize("k,stride,dil,pad", [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (3, 1, 4, 4), (1, 2, 1, 0), (7, 2, 1, 3)])
+def test_conv_matches_torch(k, stride, dil, pad):
+    rng = np.random.default_rng(k + stride + dil)
+    x = rng.standard_normal((2, 13, 17, 5))
+    w = rng.standard_normal((k, k, 5, 7))
+    ref = F.conv2d(nchw(x), torch.from_numpy(w).permute(3, 2, 0, 1), stride=stride, dilation=dil, padding=pad)
+    assert np.allclose(O.conv2d(x, w, stride, dil, pad), nhwc(ref), atol=1e-10)
+
+
+def test_bilinear_x2_by_hand_and_torch():
+    x = np.array([0.0, 1.0]).reshape(1, 1, 2, 1)
+    up = O.upsample_bilinear_x2(np.repeat(x, 1, axis=1))
+    assert np.allclose(up[0, 0, :, 0], [0.0, 0.25, 0.75, 1.0])  # half-pixel centres, edge clamp
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((2, 5, 7, 3))
+    ref = F.interpolate(nchw(y), scale_factor=2, mode="bilinear", align_corners=False)
+    assert np.allclose(O.upsample_bilinear_x2(y), nhwc(ref), atol=1e-12)
+
+
+def test_maxpool_zero_padding_wins_for_negative_input():
+    x = -np.ones((1, 4, 4, 1))
+    out = O.maxpool_3x3_s2_pad1(x)
+    assert out.shape == (1, 2, 2, 1)
+    assert out[0, 0, 0, 0] == 0.0   # window touches the zero padding (resnet.py:253)
+    assert out[0, 1, 1, 0] == -1.0  # rows/cols 1..3: interior window
+    y = np.abs(np.random.default_rng(1).standard_normal((1, 9, 11, 2)))
+    ref = F.max_pool2d(nchw(y), 3, 2, 1)
+    assert np.allclose(O.maxpool_3x3_s2_pad1(y), nhwc(ref))
+
+
+def test_batchnorm_and_leaky_pair():
+    x = np.array([[-2.0, 3.0]]).reshape(1, 1, 1, 2)
+    y = O.batchnorm_inference(x, np.array([2.0, 0.5]), np.array([1.0, -1.0]), np.array([0.0, 1.0]), np.array([4.0 - 2e-5, 1.0 - 2e-5]))
+    assert np.allclose(y.ravel(), [2.0 * (-2.0 / 2.0) + 1.0, 0.5 * 2.0 - 1.0])
+    assert np.allclose(O.leaky_as_relu_pair(np.array([-10.0, 0.0, 4.0])), [-1.0, 0.0, 4.0])
+
+
+def test_half_size_and_saturated_softmax():
+    m = np.arange(2 * 6 * 8 * 3, dtype=np.float64).reshape(2, 6, 8, 3)
+    assert np.array_equal(O.half_size(m), m[:, ::2, ::2, :])
+    s = O.saturated_softmax(np.array([[0.1, 0.3, 0.2]], dtype=np.float32))
+    assert np.array_equal(s, [[0.0, 1.0, 0.0]])
+
+
+# ---------------------------------------------------------------- class-adaptive layers -------
+def test_partial_conv_single_label_is_border_rescaled_conv():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, 6, 7, 4))
+    w = rng.standard_normal((4, 3, 3, 5))
+    mask = np.zeros((1, 6, 7, 3)); mask[..., 1] = 1.0
+    out = O.partial_convolution(x, w, mask)
+    plain = O.conv2d(x, np.transpose(w, (1, 2, 0, 3)), pad=1)
+    cnt = O.conv2d(np.ones((1, 6, 7, 1)), np.ones((3, 3, 1, 1)), pad=1)
+    assert np.allclose(out, plain * 9.0 / cnt)
+    assert np.allclose(O.partial_convolution(x, w, None), plain)  # one input -> ordinary SAME conv
+
+
+def test_partial_conv_vertical_label_edge_by_hand():
+    """x = 1 everywhere, W = 1: out(p) = norm(p) * #matching taps = 9 wherever at least the centre
+    matches -- the partial conv exactly compensates the dropped taps; with x = label-dependent
+    values the foreign side never leaks in."""
+    lab = np.zeros((1, 5, 6), np.int64); lab[:, :, 3:] = 1
+    mask = O.onehot_from_labels(lab, 2)
+    x = np.ones((1, 5, 6, 1))
+    w = np.ones((1, 3, 3, 1))
+    assert np.allclose(O.partial_convolution(x, w, mask)[0, 1:4, 1:5, 0], 9.0)
+    xv = np.where(lab[..., None] == 1, 100.0, 1.0)
+    out = O.partial_convolution(xv, w, mask)
+    assert np.allclose(out[0, 2, 2, 0], 9.0)      # left of the edge: only label-0 taps (6 of 9) -> 6*1*9/6
+    assert np.allclose(out[0, 2, 3, 0], 900.0)    # right of the edge
+    m, norm = O.partial_conv_mask(mask)
+    assert m[0, 2, 2].tolist() == [1, 1, 0, 1, 1, 0, 1, 1, 0] and norm[0, 2, 2, 0] == 9.0 / 6.0
+    assert norm[0, 0, 0, 0] == 9.0 / 4.0           # image corner: 4 taps in bounds
+
+
+def test_clade_with_one_class_is_affine_bn():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 3, 4, 5))
+    mask = np.ones((1, 3, 4, 1))
+    g, b = rng.uniform(0.5, 1.5, (1, 5)), rng.standard_normal((1, 5))
+    mean, var = rng.standard_normal(5), rng.uniform(0.5, 1.5, 5)
+    assert np.allclose(O.clade_weighted(x, mask, g, b, mean, var), O.batchnorm_inference(x, g[0], b[0], mean, var))
+
+
+def test_guided_upsampling_constant_label_is_nearest():
+    x = np.random.default_rng(4).standard_normal((1, 3, 4, 2))
+    lo = np.zeros((1, 3, 4, 3)); lo[..., 2] = 1
+    hi = np.zeros((1, 6, 8, 3)); hi[..., 2] = 1
+    assert np.array_equal(O.guided_upsampling(x, lo, hi), O.upsample_nearest_x2(x))
+    assert np.allclose(O.guided_bilinear_upsampling(x, lo, hi)[0, 0, 0], x[0, 0, 0])
+
+
+def test_guided_upsampling_edge_by_hand():
+    """low-res 2x2 labels [[A,B],[A,B]]; the hi-res label map moves the edge one hi-res pixel to the
+    left: hi-res column 1 (inside low-res cell x=0, label A) carries label B, so it must take the
+    RIGHT neighbour (y, x+1) -- the first of the 2x2 candidates with a matching label."""
+    lo_lab = np.array([[[0, 1], [0, 1]]])
+    hi_lab = np.array([[[0, 1, 1, 1]] * 4])
+    lo, hi = O.onehot_from_labels(lo_lab, 2), O.onehot_from_labels(hi_lab, 2)
+    x = np.array([[[10.0, 20.0], [30.0, 40.0]]]).reshape(1, 2, 2, 1)
+    up = O.guided_upsampling(x, lo, hi)[0, :, :, 0]
+    assert up.tolist() == [[10, 20, 20, 20], [10, 20, 20, 20], [30, 40, 40, 40], [30, 40, 40, 40]]
+    sel = O.guided_upsampling_select(lo, hi)[0]
+    assert sel[0].tolist() == [0, 1, 0, 0]
+    # a hi-res label that exists nowhere in the 2x2 neighbourhood falls back to (y, x)
+    hi2 = O.onehot_from_labels(np.full((1, 4, 4), 2), 3)
+    lo2 = O.onehot_from_labels(lo_lab, 3)
+    assert np.array_equal(O.guided_upsampling(x, lo2, hi2), O.upsample_nearest_x2(x))
+
+
+def test_guided_bilinear_by_hand():
+    lo = O.onehot_from_labels(np.array([[[0, 1], [0, 1]]]), 2)
+    hi = O.onehot_from_labels(np.array([[[0, 0, 1, 1]] * 4]), 2)
+    x = np.array([[[10.0, 20.0], [30.0, 40.0]]]).reshape(1, 2, 2, 1)
+    up = O.guided_bilinear_upsampling(x, lo, hi)[0, :, :, 0]
+    # sub-pixel (0,1) of cell (0,0): weights (.5,.5,0,0); tap (0,1) has a foreign label and is replaced
+    # by the mean of the matching taps {10, 30} = 20 -> .5*10 + .5*20 = 15
+    assert up[0, 1] == 15.0
+    # sub-pixel (1,1): weights .25 each: taps 10,30 match; 20,40 replaced by mean 20 -> (10+20+30+20)/4
+    assert up[1, 1] == 20.0
+    assert up[0, 0] == 10.0
+
+
+# ---------------------------------------------------------------- voting ----------------------
+def test_ls_voting_exact_field_recovers_keypoints():
+    seg, direct, conf, labels, kps = O.synthetic_voting_inputs(1, 48, 64, num_obj=3, seed=5, noise=0.0)
+    est = O.ls_voting(seg, direct, conf)
+    assert np.abs(est - kps).max() < 1e-3
+    # an object without pixels gives zeros (pinv of the zero matrix)
+    seg2 = np.concatenate([seg, np.full(seg.shape[:3] + (1,), -10.0, np.float32)], -1)
+    assert np.array_equal(O.ls_voting(seg2, direct, conf)[:, 3], np.zeros((1, 9, 2), np.float32))
+
+
+def test_ransac_hypothesis_two_ray_intersection_by_hand():
+    # pixel 0 at (0,0) looks along +x, pixel 1 at (4,3) looks along -y: rays meet at (4,0)
+    coords = np.array([[0.0, 0.0], [4.0, 3.0]], np.float32)
+    direct = np.array([[[1.0, 0.0]], [[0.0, -1.0]]], np.float32)
+    hyp = O.ransac_generate_hypothesis(direct, coords, np.array([[[0, 1]]]))
+    assert np.allclose(hyp[0, 0], [4.0, 0.0])
+    # parallel rays -> |det| <= 1e-6 -> zeros
+    par = np.array([[[1.0, 0.0]], [[1.0, 0.0]]], np.float32)
+    assert np.array_equal(O.ransac_generate_hypothesis(par, coords, np.array([[[0, 1]]]))[0, 0], [0.0, 0.0])
+    inl = O.ransac_vote(direct, coords, np.array([[[4.0, 0.0]]], np.float32), np.float32(0.99))
+    assert inl[0, :, 0].tolist() == [1, 1]
+
+
+def test_ransac_voting_exact_field():
+    seg, direct, conf, labels, kps = O.synthetic_voting_inputs(1, 48, 64, num_obj=2, seed=6, noise=0.0)
+    rng = np.random.default_rng(0)
+    for o in range(2):
+        mask = (labels[0] == o + 1).astype(np.float32)
+        tn = int(mask.sum())
+        idx = [rng.integers(0, tn, (64, 9, 2)) for _ in range(20)]
+        pts, rounds = O.ransac_voting_single(mask, direct[0].reshape(48, 64, 9, 2), idx)
+        assert rounds == 1
+        assert np.abs(pts[:, ::-1] - kps[0, o]).max() < 1e-2   # output is (x,y)
+    empty, r = O.ransac_voting_single(np.zeros((48, 64), np.float32), direct[0].reshape(48, 64, 9, 2), [])
+    assert r == 0 and not empty.any()
+
+
+def test_largest_component_filter():
+    hot = np.zeros((12, 20), np.float32)
+    hot[1:9, 1:9] = 1       # 64 px
+    hot[1:8, 11:19] = 1     # 56 px: second component, dropped
+    hot[10, 0:3] = 1        # 3 px speck
+    keep = O.largest_component_filter(hot)
+    assert keep[1:9, 1:9].all() and keep.sum() == 64
+    # Reference quirk (voting_layers_2d.py:64-76): bins below 50 px are ZEROED, not removed, and
+    # top_k's second entry is then the lowest-index zero bin -- so a lone 25-px component (id 1)
+    # survives, and of two sub-threshold components the one met first in raster order is kept.
+    small = np.zeros((12, 20), np.float32); small[0:5, 0:5] = 1
+    assert O.largest_component_filter(small).sum() == 25
+    two = np.zeros((12, 20), np.float32); two[0:3, 0:3] = 1; two[6:11, 6:12] = 1   # 9 px (id 1), 30 px (id 2)
+    k2 = O.largest_component_filter(two)
+    assert k2[0:3, 0:3].all() and k2.sum() == 9
+    # nothing but background: id 1 does not exist, nothing is kept
+    assert O.largest_component_filter(np.zeros((12, 20), np.float32)).sum() == 0
+    diag = np.zeros((12, 20), np.float32); diag[0, 0] = diag[1, 1] = 1
+    assert O.label_components_4(diag).max() == 2   # 4-connectivity: diagonal neighbours are separate
+
+
+def test_full_forward_shapes_and_mask_conditioning():
+    p = O.init_params(3, 27, seed=1, dtype=np.float64)
+    img = np.random.default_rng(0).uniform(-1, 1, (1, 32, 48, 3))
+    out = O.casapose_c_gcu5(p, img)
+    assert out.shape == (1, 32, 48, 30) and np.isfinite(out).all()
+    lab = np.zeros((1, 32, 48), np.int64); lab[:, 8:24, 8:40] = 2
+    out2 = O.casapose_c_gcu5(p, img, seg_input=O.onehot_from_labels(lab, 3))
+    assert np.allclose(out2[..., :3], out[..., :3])          # decoder 1 does not see the mask
+    assert not np.allclose(out2[..., 3:], out[..., 3:])      # decoder 2 does
