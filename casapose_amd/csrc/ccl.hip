@@ -1,7 +1,165 @@
-// placeholder -- implemented after the first end-to-end forward runs on the GPU
+// Largest-connected-component filter of CoordLSVotingWeighted (filter_estimates=True):
+// casapose/pose_estimation/voting_layers_2d.py:43-79, where the reference calls
+// tfa.image.connected_components once per (image, object) map.
+//
+// Here ONE union-find pass labels the multi-class map (two 4-neighbours are connected iff they
+// carry the same non-zero label), which yields every object's components at once.  Roots are
+// the minimum linear index of a component, so "component id order" of the reference (raster
+// order of the first pixel) is the order of the roots.
+//
+// Selection rule restated from :64-76 (including its quirks): per (image, object) build the
+// histogram {bin 0 = all pixels not in the object, bin i = i-th component}, zero every bin below
+// `min_size`, sort by (count desc, index asc) and keep the SECOND entry.  So: the largest
+// component survives when the rest of the image is larger than it; if every component is below
+// the threshold the first one in raster order survives; an object larger than the rest of the
+// image is dropped.
 #include "common.h"
-extern "C" size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects) { return (size_t)batch * h * w * sizeof(int) * 2; }
-extern "C" int cp_ccl_filter_labels(const uint8_t*, int, int, int, int, int, void*, uint8_t*, void*) {
-    cp::set_error("cp_ccl_filter_labels: not implemented yet");
-    return CP_ERR_INVALID;
+
+namespace {
+
+constexpr int THREADS = 256;
+
+inline int grid_for(long long n) {
+    long long b = (n + THREADS - 1) / THREADS;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+__device__ __forceinline__ int find_root(const int* parent, int x) {
+    int p = parent[x];
+    while (p != x) {
+        x = p;
+        p = parent[x];
+    }
+    return x;
+}
+
+__device__ __forceinline__ void unite(int* parent, int a, int b) {
+    while (true) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }  // a > b: hang the larger root under the smaller
+        int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void ccl_init(const uint8_t* __restrict__ lab, int* __restrict__ parent, int* __restrict__ count, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        parent[i] = lab[i] ? (int)i : -1;
+        count[i] = 0;
+    }
+}
+
+__global__ void ccl_merge(const uint8_t* __restrict__ lab, int* __restrict__ parent, int H, int W, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = lab[i];
+        if (!l) continue;
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        if (x > 0 && lab[i - 1] == l) unite(parent, (int)i, (int)i - 1);
+        if (y > 0 && lab[i - W] == l) unite(parent, (int)i, (int)i - W);
+    }
+}
+
+__global__ void ccl_flatten_count(const uint8_t* __restrict__ lab, int* __restrict__ parent, int* __restrict__ count, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (!lab[i]) continue;
+        const int r = find_root(parent, (int)i);
+        parent[i] = r;
+        atomicAdd(&count[r], 1);
+    }
+}
+
+// per (image, object): [0] foreground pixels, [1] best key, [2] second-best key
+__global__ void ccl_zero_stats(unsigned long long* __restrict__ stats, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stats[i] = 0ull;
+}
+
+__global__ void ccl_fg_count(const uint8_t* __restrict__ lab, const int* __restrict__ parent, const int* __restrict__ count,
+                             unsigned long long* __restrict__ stats, int objects, long long hw, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = lab[i];
+        if (l && parent[i] == (int)i) atomicAdd(&stats[((i / hw) * objects + (l - 1)) * 3 + 0], (unsigned long long)count[i]);
+    }
+}
+
+// key: (thresholded count << 32) | tie-break, larger key = earlier in the reference's top_k order.
+// bin 0 gets tie-break 0xFFFFFFFF (index 0 wins ties), component with root r gets 0xFFFFFFFE - local r.
+__device__ __forceinline__ unsigned long long comp_key(int cnt, int min_size, unsigned tie) {
+    const unsigned c = cnt < min_size ? 0u : (unsigned)cnt;
+    return ((unsigned long long)c << 32) | tie;
+}
+
+__global__ void ccl_best(const uint8_t* __restrict__ lab, const int* __restrict__ parent, const int* __restrict__ count,
+                         unsigned long long* __restrict__ stats, int objects, long long hw, long long total, int min_size, int pass) {
+    const long long nstat = (total / hw) * objects;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total + nstat; i += (long long)gridDim.x * blockDim.x) {
+        unsigned long long key;
+        long long s;
+        if (i < total) {
+            const int l = lab[i];
+            if (!l || parent[i] != (int)i) continue;
+            s = (i / hw) * objects + (l - 1);
+            key = comp_key(count[i], min_size, 0xFFFFFFFEu - (unsigned)(i % hw));
+        } else {  // bin 0 of (image, object) s
+            s = i - total;
+            const long long bg = hw - (long long)stats[s * 3 + 0];
+            key = comp_key((int)bg, min_size, 0xFFFFFFFFu);
+        }
+        if (pass == 0) atomicMax(&stats[s * 3 + 1], key);
+        else if (key < stats[s * 3 + 1]) atomicMax(&stats[s * 3 + 2], key);
+    }
+}
+
+__global__ void ccl_write(const uint8_t* __restrict__ lab, const int* __restrict__ parent, const unsigned long long* __restrict__ stats,
+                          int objects, long long hw, long long total, uint8_t* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = lab[i];
+        uint8_t o = 0;
+        if (l) {
+            const unsigned long long second = stats[((i / hw) * objects + (l - 1)) * 3 + 2];
+            const unsigned tie = (unsigned)(second & 0xFFFFFFFFull);
+            // `second` is 0 when the histogram had a single bin (never for l > 0: its own component exists);
+            // tie 0xFFFFFFFF = bin 0 was second -> nothing of this object is kept
+            if (second != 0ull && tie != 0xFFFFFFFFu) {
+                const long long root_local = (long long)(0xFFFFFFFEu - tie);
+                if ((long long)parent[i] == (i / hw) * hw + root_local) o = (uint8_t)l;
+            }
+        }
+        out[i] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects) {
+    size_t px = (size_t)batch * h * w;
+    return px * sizeof(int) * 2 + (size_t)batch * objects * 3 * sizeof(unsigned long long) + 64;
+}
+
+extern "C" int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size, void* ws,
+                                    uint8_t* labels_out, void* stream) {
+    CP_REQUIRE(labels_in && labels_out && ws, "cp_ccl_filter_labels: null pointer");
+    CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ccl_filter_labels: bad sizes");
+    const long long hw = (long long)h * w, total = hw * batch;
+    CP_REQUIRE(total < (1LL << 31) && hw < 0xFFFFFFF0LL, "cp_ccl_filter_labels: too many pixels for 32-bit component ids");
+    hipStream_t st = (hipStream_t)stream;
+    int* parent = reinterpret_cast<int*>(ws);
+    int* count = parent + total;
+    uintptr_t sp = (reinterpret_cast<uintptr_t>(count + total) + 63) & ~(uintptr_t)63;
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(sp);
+    const int nstat = batch * objects;
+    const int g = grid_for(total);
+    CP_LAUNCH(ccl_init, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, total);
+    CP_LAUNCH(ccl_zero_stats, dim3((nstat * 3 + THREADS - 1) / THREADS), dim3(THREADS), 0, st, stats, nstat * 3);
+    CP_LAUNCH(ccl_merge, dim3(g), dim3(THREADS), 0, st, labels_in, parent, h, w, total);
+    CP_LAUNCH(ccl_flatten_count, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, total);
+    CP_LAUNCH(ccl_fg_count, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, stats, objects, hw, total);
+    CP_LAUNCH(ccl_best, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, stats, objects, hw, total, min_size, 0);
+    CP_LAUNCH(ccl_best, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, stats, objects, hw, total, min_size, 1);
+    CP_LAUNCH(ccl_write, dim3(g), dim3(THREADS), 0, st, labels_in, parent, stats, objects, hw, total, labels_out);
+    return cp::check_launch("cp_ccl_filter_labels");
 }

@@ -1,8 +1,412 @@
-// placeholder -- implemented after the first end-to-end forward runs on the GPU
+// PVNet-style RANSAC keypoint voting for all (image, object) pairs of a batch:
+// ransac_voting_layer_all_masks -> ransac_voting_batch
+// (casapose/pose_estimation/ransac_voting.py:276-368,447-484; hypothesis generation :197-227,
+// inlier test :230-249).
+//
+// The reference serialises B x objects calls under tf.map_fn and materialises a
+// [hyp, tn, kp] tensor per round.  Here:
+//   1. the object's pixels are compacted in RASTER order (same order as tf.where, so injected
+//      pixel-pair indices mean the same pixels) with a row-count scan + wave ballots;
+//   2. hypotheses = two-ray intersections of the drawn pixel pairs;
+//   3. voting: a lane owns one pixel (coalesced gather of its 18 direction floats), the
+//      hypotheses of the block are broadcast from LDS, and every (hypothesis, keypoint) count
+//      is the popcount of the wave's inlier ballot -- no per-pixel x hypothesis tensor exists;
+//   4. per round: arg-max per keypoint, best-so-far update, the reference's stopping rule
+//      1-(1-r_min^2)^hyps > confidence, evaluated on the device (finished objects skip the
+//      remaining rounds);
+//   5. refinement: fp64 normal-equation sums over the winners' inliers, 2x2 solve, with the
+//      reference's "all keypoints invertible, cond < 1e6, else return the winners" rule.
+// Random numbers: the caller supplies 31-bit uniform draws (tests inject them; the Python wrapper
+// generates them with torch); a draw d selects pixel d % tn.
 #include "common.h"
-extern "C" size_t cp_ransac_workspace_bytes(int, int, int, int, int, int) { return 0; }
-extern "C" int cp_ransac_vote_f32(const uint8_t*, const float*, int, int, int, int, int, int, int, const int32_t*, int, float,
-                                  float, int, int, int, void*, float*, int32_t*, void*) {
-    cp::set_error("cp_ransac_vote_f32: not implemented yet");
-    return CP_ERR_INVALID;
+
+namespace {
+
+constexpr int KP = 9;
+constexpr int HB = 16;  // hypotheses per voting block
+
+struct ObjState {        // one per (image, object)
+    int tn;              // pixels (after min_num gate: 0 if skipped)
+    int done;            // stopping rule reached
+    int rounds;
+    float hyp_num;
+    float win_ratio[KP];
+    float win_pts[KP][2];
+};
+
+// ---- 1. compaction -------------------------------------------------------------------------
+__global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int objects, int* __restrict__ rowcnt) {
+    // one wave per (image,row); rowcnt[(img*objects+o)*H + y]
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * H) return;
+    const int img = row / H, y = row % H;
+    const uint8_t* p = lab + (size_t)row * W;
+    for (int o = 1 + 0; o <= objects; ++o) {
+        int c = 0;
+        for (int x0 = 0; x0 < W; x0 += 64) {
+            int x = x0 + lane;
+            bool m = x < W && p[x] == o;
+            c += __popcll(__ballot(m));
+        }
+        if (lane == 0) rowcnt[((size_t)img * objects + (o - 1)) * H + y] = c;
+    }
+}
+
+__global__ void rowscan_kernel(int* __restrict__ rowcnt, int H, int n_obj_total, int min_num, ObjState* __restrict__ st) {
+    // one thread per (image, object): exclusive scan over rows, in place
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_obj_total) return;
+    int* r = rowcnt + (size_t)i * H;
+    int run = 0;
+    for (int y = 0; y < H; ++y) {
+        int c = r[y];
+        r[y] = run;
+        run += c;
+    }
+    ObjState s;
+    s.tn = (run < min_num) ? 0 : run;  // ransac_voting.py:290-292
+    s.done = s.tn == 0;
+    s.rounds = 0;
+    s.hyp_num = 0.f;
+    for (int v = 0; v < KP; ++v) {
+        s.win_ratio[v] = 0.f;
+        s.win_pts[v][0] = s.win_pts[v][1] = 0.f;
+    }
+    st[i] = s;
+}
+
+__global__ void compact_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int objects, const int* __restrict__ rowstart,
+                               int* __restrict__ pixlist, int list_stride) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * H) return;
+    const int img = row / H, y = row % H;
+    const uint8_t* p = lab + (size_t)row * W;
+    for (int o = 1; o <= objects; ++o) {
+        const size_t io = (size_t)img * objects + (o - 1);
+        int base = rowstart[io * H + y];
+        for (int x0 = 0; x0 < W; x0 += 64) {
+            int x = x0 + lane;
+            bool m = x < W && p[x] == o;
+            unsigned long long bal = __ballot(m);
+            if (m) {
+                int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                pixlist[io * list_stride + base + rank] = y * W + x;
+            }
+            base += __popcll(bal);
+        }
+    }
+}
+
+// ---- 2. hypotheses ----------------------------------------------------------------------------
+__device__ __forceinline__ void pixel_record(const float* __restrict__ vertex, int ld, int dir_off, int img, int H, int W, int pix, int v,
+                                             float& cx, float& cy, float& dx, float& dy) {
+    const int y = pix / W, x = pix - y * W;
+    cx = (float)x + 0.5f;  // coords are (x, y) + 0.5 (:303-306)
+    cy = (float)y + 0.5f;
+    const float* p = vertex + ((size_t)img * H * W + pix) * ld + dir_off + 2 * v;
+    dy = p[0];  // the field stores (dy, dx); the voter works in (dx, dy) (:308)
+    dx = p[1];
+}
+
+__global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects, const int* __restrict__ pixlist,
+                              int list_stride, const int32_t* __restrict__ draws, int hyp, const ObjState* __restrict__ st,
+                              float* __restrict__ hyp_pts, int n_obj_total) {
+    // one thread per (image*object, h, v)
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long per = (long long)hyp * KP;
+    if (i >= per * n_obj_total) return;
+    const int io = (int)(i / per);
+    const int hv = (int)(i % per);
+    const ObjState& s = st[io];
+    if (s.done) return;
+    const int img = io / objects;
+    const int v = hv % KP;
+    const int32_t* d = draws + ((size_t)io * per + hv) * 2;
+    const int* pl = pixlist + (size_t)io * list_stride;
+    const int p0 = pl[(unsigned)d[0] % (unsigned)s.tn], p1 = pl[(unsigned)d[1] % (unsigned)s.tn];
+    float c0x, c0y, d0x, d0y, c1x, c1y, d1x, d1y;
+    pixel_record(vertex, ld, dir_off, img, H, W, p0, v, c0x, c0y, d0x, d0y);
+    pixel_record(vertex, ld, dir_off, img, H, W, p1, v, c1x, c1y, d1x, d1y);
+    // generate_hypothesis (:219-226)
+    const float det = d1x * d0y - d1y * d0x;
+    const float u = ((c1y - c0y) * d1x - (c1x - c0x) * d1y) / det;
+    float hx = c0x + d0x * u, hy = c0y + d0y * u;
+    if (!(fabsf(det) > 1e-6f)) hx = hy = 0.f;
+    hyp_pts[((size_t)io * per + hv) * 2 + 0] = hx;
+    hyp_pts[((size_t)io * per + hv) * 2 + 1] = hy;
+}
+
+// ---- 3. voting --------------------------------------------------------------------------------
+__device__ __forceinline__ bool inlier_test(float dx, float dy, float nd, float cx, float cy, float hx, float hy, float thresh) {
+    // voting_for_hypothesis (:236-247)
+    const float ex = hx - cx, ey = hy - cy;
+    const float nh = sqrtf(ex * ex + ey * ey);
+    const bool valid = nd > 1e-6f && nh > 1e-6f && fabsf(hx + hy) > 1e-6f;
+    const float ang = (dx * ex + dy * ey) / (nd * nh);
+    return valid && ang > thresh;
+}
+
+__global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects,
+                                                   const int* __restrict__ pixlist, int list_stride, const float* __restrict__ hyp_pts,
+                                                   int hyp, const ObjState* __restrict__ st, int* __restrict__ counts, float thresh,
+                                                   int px_chunks) {
+    // grid: (hyp / HB, px_chunks, image*object).  A block votes HB hypotheses x 9 keypoints over one chunk of pixels.
+    __shared__ float hp[HB * KP * 2];
+    __shared__ int cnt[HB * KP];
+    const int io = blockIdx.z;
+    const ObjState& s = st[io];
+    if (s.done) return;
+    const int img = io / objects;
+    const int h0 = blockIdx.x * HB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < HB * KP * 2; i += blockDim.x) hp[i] = hyp_pts[((size_t)io * hyp + h0) * KP * 2 + i];
+    for (int i = tid; i < HB * KP; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int* pl = pixlist + (size_t)io * list_stride;
+    const int per_chunk = (s.tn + px_chunks - 1) / px_chunks;
+    const int t_begin = blockIdx.y * per_chunk, t_end = min(s.tn, t_begin + per_chunk);
+    int local[(HB * KP + 63) / 64 + 1];  // lane j keeps the count of pair j + 64*r
+#pragma unroll
+    for (int r = 0; r < (HB * KP + 63) / 64; ++r) local[r] = 0;
+    for (int t0 = t_begin + (tid & ~63); t0 < t_end; t0 += blockDim.x) {
+        const int t = t0 + lane;
+        const bool act = t < t_end;
+        float cx = 0.f, cy = 0.f, dxv[KP], dyv[KP], ndv[KP];
+        if (act) {
+            const int pix = pl[t];
+            const int y = pix / W, x = pix - y * W;
+            cx = (float)x + 0.5f;
+            cy = (float)y + 0.5f;
+            const float* p = vertex + ((size_t)img * H * W + pix) * ld + dir_off;
+#pragma unroll
+            for (int v = 0; v < KP; ++v) {
+                dyv[v] = p[2 * v];
+                dxv[v] = p[2 * v + 1];
+                ndv[v] = sqrtf(dxv[v] * dxv[v] + dyv[v] * dyv[v]);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < KP; ++v) dxv[v] = dyv[v] = ndv[v] = 0.f;
+        }
+#pragma unroll
+        for (int hh = 0; hh < HB; ++hh) {
+#pragma unroll
+            for (int v = 0; v < KP; ++v) {
+                const int pair = hh * KP + v;
+                const bool in = act && inlier_test(dxv[v], dyv[v], ndv[v], cx, cy, hp[pair * 2], hp[pair * 2 + 1], thresh);
+                const int c = __popcll(__ballot(in));  // wave-uniform
+                if (lane == (pair & 63)) local[pair >> 6] += c;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < (HB * KP + 63) / 64; ++r) {
+        const int pair = r * 64 + lane;
+        if (pair < HB * KP && local[r]) atomicAdd(&cnt[pair], local[r]);
+    }
+    __syncthreads();
+    for (int i = tid; i < HB * KP; i += blockDim.x)
+        if (cnt[i]) atomicAdd(&counts[((size_t)io * hyp + h0) * KP + i], cnt[i]);
+}
+
+// ---- 4. round update --------------------------------------------------------------------------
+__global__ void update_kernel(const int* __restrict__ counts, const float* __restrict__ hyp_pts, int hyp, ObjState* __restrict__ st,
+                              int n_obj_total, float confidence, int max_iter) {
+    // one wave per (image, object); lane-parallel arg-max over hypotheses for each keypoint
+    const int io = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (io >= n_obj_total) return;
+    ObjState s = st[io];
+    if (s.done) return;
+    float min_ratio = 1e30f;
+    for (int v = 0; v < KP; ++v) {
+        int best = -1, besth = 0x7fffffff;
+        for (int h = lane; h < hyp; h += 64) {
+            int c = counts[((size_t)io * hyp + h) * KP + v];
+            if (c > best) { best = c; besth = h; }  // first maximum within the lane's stride
+        }
+        for (int off = 32; off; off >>= 1) {
+            int ob = __shfl_xor(best, off), oh = __shfl_xor(besth, off);
+            if (ob > best || (ob == best && oh < besth)) { best = ob; besth = oh; }  // tf.argmax: lowest index on ties
+        }
+        const float ratio = (float)best / (float)s.tn;  // :333
+        if (s.win_ratio[v] < ratio) {                     // :336-338
+            s.win_ratio[v] = ratio;
+            s.win_pts[v][0] = hyp_pts[(((size_t)io * hyp + besth) * KP + v) * 2 + 0];
+            s.win_pts[v][1] = hyp_pts[(((size_t)io * hyp + besth) * KP + v) * 2 + 1];
+        }
+        min_ratio = fminf(min_ratio, s.win_ratio[v]);
+    }
+    s.hyp_num += (float)hyp;
+    s.rounds += 1;
+    const float conf = 1.f - powf(1.f - min_ratio * min_ratio, s.hyp_num);  // :344-346
+    if (conf > confidence || s.rounds >= max_iter) s.done = 1;
+    if (lane == 0) st[io] = s;
+}
+
+__global__ void zero_int_kernel(int* __restrict__ p, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+// ---- 5. refinement ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_accumulate_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects,
+                                                                const int* __restrict__ pixlist, int list_stride,
+                                                                const ObjState* __restrict__ st, double* __restrict__ sums, float thresh,
+                                                                int px_chunks) {
+    // grid (px_chunks, image*object); sums[io][v][5] = {a00, a01, a11, b0, b1}
+    __shared__ double acc[KP * 5];
+    const int io = blockIdx.y;
+    const ObjState& s = st[io];
+    if (s.tn == 0) return;
+    const int img = io / objects;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP * 5; i += blockDim.x) acc[i] = 0.0;
+    __syncthreads();
+    const int* pl = pixlist + (size_t)io * list_stride;
+    const int per_chunk = (s.tn + px_chunks - 1) / px_chunks;
+    const int t_begin = blockIdx.x * per_chunk, t_end = min(s.tn, t_begin + per_chunk);
+    double a[KP][5];
+#pragma unroll
+    for (int v = 0; v < KP; ++v)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a[v][c] = 0.0;
+    for (int t = t_begin + tid; t < t_end; t += blockDim.x) {
+        const int pix = pl[t];
+        const int y = pix / W, x = pix - y * W;
+        const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+        const float* p = vertex + ((size_t)img * H * W + pix) * ld + dir_off;
+#pragma unroll
+        for (int v = 0; v < KP; ++v) {
+            const float dy = p[2 * v], dx = p[2 * v + 1];
+            const float nd = sqrtf(dx * dx + dy * dy);
+            if (inlier_test(dx, dy, nd, cx, cy, s.win_pts[v][0], s.win_pts[v][1], thresh)) {
+                const float nx = -dy, ny = dx;           // normal = reverse(direct * (1,-1)) (:349)
+                const float b = nx * cx + ny * cy;       // (:359)
+                a[v][0] += (double)(nx * nx);
+                a[v][1] += (double)(nx * ny);
+                a[v][2] += (double)(ny * ny);
+                a[v][3] += (double)(nx * b);
+                a[v][4] += (double)(ny * b);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < KP; ++v)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            double x = a[v][c];
+            for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off);
+            if ((tid & 63) == 0 && x != 0.0) atomicAdd(&acc[v * 5 + c], x);
+        }
+    __syncthreads();
+    for (int i = tid; i < KP * 5; i += blockDim.x)
+        if (acc[i] != 0.0) atomicAdd(&sums[(size_t)io * KP * 5 + i], acc[i]);
+}
+
+__global__ void refine_solve_kernel(const double* __restrict__ sums, const ObjState* __restrict__ st, int n_obj_total, float* __restrict__ out,
+                                    int32_t* __restrict__ rounds_out) {
+    const int io = blockIdx.x * blockDim.x + threadIdx.x;
+    if (io >= n_obj_total) return;
+    const ObjState& s = st[io];
+    float* o = out + (size_t)io * KP * 2;
+    if (rounds_out) rounds_out[io] = s.rounds;
+    if (s.tn == 0) {
+        for (int i = 0; i < KP * 2; ++i) o[i] = 0.f;
+        return;
+    }
+    bool all_ok = true;
+    double sol[KP][2];
+    for (int v = 0; v < KP; ++v) {
+        const double* q = sums + ((size_t)io * KP + v) * 5;
+        // the reference forms ATA in fp32 (:361); singular values of the symmetric PSD 2x2
+        const double a = (double)(float)q[0], b = (double)(float)q[1], c = (double)(float)q[2];
+        const double ht = 0.5 * (a + c), hd = 0.5 * (a - c), rad = sqrt(hd * hd + b * b);
+        const double l1 = fabs(ht + rad), l2 = fabs(ht - rad);
+        const double smax = fmax(l1, l2), smin = fmin(l1, l2);
+        const double cond = smax / smin;  // inf / nan when singular
+        if (!(isfinite(cond) && cond < 1e6)) all_ok = false;  // is_invertible (:267-272), reduce_min over keypoints (:364)
+        const double det = a * c - b * b;
+        const double t0 = (double)(float)q[3], t1 = (double)(float)q[4];
+        sol[v][0] = (c * t0 - b * t1) / det;
+        sol[v][1] = (a * t1 - b * t0) / det;
+    }
+    for (int v = 0; v < KP; ++v) {
+        o[2 * v + 0] = all_ok ? (float)sol[v][0] : s.win_pts[v][0];
+        o[2 * v + 1] = all_ok ? (float)sol[v][1] : s.win_pts[v][1];
+    }
+}
+
+struct Workspace {
+    int* rowcnt;
+    int* pixlist;
+    ObjState* st;
+    float* hyp_pts;
+    int* counts;
+    double* sums;
+    size_t bytes;
+};
+
+Workspace carve(void* base, int batch, int h, int w, int objects, int hyp) {
+    Workspace ws{};
+    uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    auto take = [&](size_t n) {
+        p = (p + 255) & ~(uintptr_t)255;
+        uintptr_t r = p;
+        p += n;
+        return r;
+    };
+    const size_t no = (size_t)batch * objects;
+    ws.rowcnt = reinterpret_cast<int*>(take(no * h * sizeof(int)));
+    ws.pixlist = reinterpret_cast<int*>(take((size_t)batch * objects * h * w * sizeof(int)));
+    ws.st = reinterpret_cast<ObjState*>(take(no * sizeof(ObjState)));
+    ws.hyp_pts = reinterpret_cast<float*>(take(no * hyp * KP * 2 * sizeof(float)));
+    ws.counts = reinterpret_cast<int*>(take(no * hyp * KP * sizeof(int)));
+    ws.sums = reinterpret_cast<double*>(take(no * KP * 5 * sizeof(double)));
+    ws.bytes = p - reinterpret_cast<uintptr_t>(base) + 256;
+    return ws;
+}
+
+}  // namespace
+
+extern "C" size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp) {
+    (void)kp;
+    return carve(nullptr, batch, h, w, objects, hyp).bytes;
+}
+
+extern "C" int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h, int w, int objects,
+                                  int kp, const int32_t* idx, int hyp, float inlier_thresh, float confidence, int max_iter, int min_num,
+                                  int max_num, void* wsp, float* out, int32_t* rounds_out, void* stream) {
+    CP_REQUIRE(labels && vertex && idx && wsp && out, "cp_ransac_vote_f32: null pointer");
+    CP_REQUIRE(kp == KP, "cp_ransac_vote_f32: built for %d keypoints (got %d)", KP, kp);
+    CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ransac_vote_f32: bad sizes");
+    CP_REQUIRE(hyp > 0 && hyp % HB == 0, "cp_ransac_vote_f32: hypotheses per round must be a multiple of %d", HB);
+    CP_REQUIRE(max_iter >= 1 && dir_off >= 0 && dir_off + 2 * kp <= ld, "cp_ransac_vote_f32: bad max_iter / channel offsets");
+    CP_REQUIRE((long long)h * w < (1LL << 31), "cp_ransac_vote_f32: image too large");
+    (void)max_num;  // sub-sampling above max_num (:295-301) is random in the reference: the caller applies it to `labels`
+    hipStream_t st = (hipStream_t)stream;
+    Workspace ws = carve(wsp, batch, h, w, objects, hyp);
+    const int no = batch * objects;
+    const int list_stride = h * w;
+    const int rows = batch * h;
+    (void)hipMemsetAsync(ws.sums, 0, (size_t)no * KP * 5 * sizeof(double), st);
+    CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt);
+    CP_LAUNCH(rowscan_kernel, dim3((no + 63) / 64), dim3(64), 0, st, ws.rowcnt, h, no, min_num, ws.st);
+    CP_LAUNCH(compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, ws.pixlist, list_stride);
+    const int px_chunks = 8;
+    const long long nhyp = (long long)no * hyp * KP;
+    for (int r = 0; r < max_iter; ++r) {
+        const int32_t* draws = idx + (size_t)r * nhyp * 2;
+        CP_LAUNCH(zero_int_kernel, dim3((int)((nhyp + 255) / 256 > 4096 ? 4096 : (nhyp + 255) / 256)), dim3(256), 0, st, ws.counts, nhyp);
+        CP_LAUNCH(hypgen_kernel, dim3((unsigned)((nhyp + 255) / 256)), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist,
+                  list_stride, draws, hyp, ws.st, ws.hyp_pts, no);
+        CP_LAUNCH(vote_kernel, dim3(hyp / HB, px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
+                  ws.hyp_pts, hyp, ws.st, ws.counts, inlier_thresh, px_chunks);
+        CP_LAUNCH(update_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.counts, ws.hyp_pts, hyp, ws.st, no, confidence, max_iter);
+    }
+    CP_LAUNCH(refine_accumulate_kernel, dim3(px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
+              ws.st, ws.sums, inlier_thresh, px_chunks);
+    CP_LAUNCH(refine_solve_kernel, dim3((no + 63) / 64), dim3(64), 0, st, ws.sums, ws.st, no, out, rounds_out);
+    return cp::check_launch("cp_ransac_vote_f32");
 }

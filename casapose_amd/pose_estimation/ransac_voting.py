@@ -1,0 +1,52 @@
+"""ransac_voting_layer_all_masks with the reference's signature
+(casapose/pose_estimation/ransac_voting.py:446-484), computed by cp_ransac_vote_f32.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from .._lib import check
+
+
+def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, round_hyp_num: int, inlier_thresh: float = 0.99,
+                                  confidence: float = 0.99, max_iter: int = 20, min_num: int = 5, max_num: int = 30000,
+                                  draws: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                                  return_rounds: bool = False):
+    """mask [b,h,w,oc] one-hot object masks (no background channel), vertex [b,h,w,vn,2] or
+    [b,h,w,vn*2] in (dy,dx) order.  Returns [b,oc,vn,2] keypoints in (x,y).
+
+    `draws` (int32 [max_iter,b,oc,round_hyp_num,vn,2], values in [0,2^31)) replaces the random
+    pixel-pair draws of :319-321 -- tests inject them; by default they come from torch.randint
+    on the device (`generator` makes them reproducible)."""
+    if not mask.is_cuda:
+        raise _lib.CasaposeHipError("ransac_voting_layer_all_masks needs CUDA (ROCm) tensors; there is no CPU fallback")
+    lib = _lib.load()
+    b, h, w, oc = mask.shape
+    vert = vertex.reshape(b, h, w, -1).to(torch.float32).contiguous()
+    vn = vert.shape[3] // 2
+    fg = mask > 0.5
+    labels = (fg.to(torch.uint8) * torch.arange(1, oc + 1, device=mask.device, dtype=torch.uint8)).amax(dim=3).contiguous()
+    counts = fg.reshape(b, h * w, oc).sum(dim=1)  # [b,oc]
+    if bool((counts > max_num).any()):
+        # random down-sampling of large masks (:295-301): keep a pixel with probability max_num / count
+        keep_p = (max_num / counts.clamp(min=1).to(torch.float32)).clamp(max=1.0)  # [b,oc]
+        u = torch.rand(b, h, w, device=mask.device, generator=generator)
+        lab_l = labels.long()
+        p_pix = torch.cat([torch.ones(b, 1, device=mask.device), keep_p], dim=1).gather(1, lab_l.reshape(b, -1)).reshape(b, h, w)
+        labels = torch.where(u < p_pix, labels, torch.zeros_like(labels)).contiguous()
+    if draws is None:
+        draws = torch.randint(0, 2**31 - 1, (max_iter, b, oc, round_hyp_num, vn, 2), device=mask.device, dtype=torch.int32, generator=generator)
+    if tuple(draws.shape) != (max_iter, b, oc, round_hyp_num, vn, 2) or draws.dtype != torch.int32:
+        raise ValueError("draws must be int32 with shape [max_iter,b,oc,hyp,vn,2]")
+    draws = draws.contiguous()
+    ws = torch.empty(lib.cp_ransac_workspace_bytes(b, h, w, oc, vn, round_hyp_num), dtype=torch.uint8, device=mask.device)
+    out = torch.empty(b, oc, vn, 2, dtype=torch.float32, device=mask.device)
+    rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
+    stream = torch.cuda.current_stream(mask.device).cuda_stream
+    check(lib.cp_ransac_vote_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, draws.data_ptr(), round_hyp_num,
+                                 float(inlier_thresh), float(confidence), int(max_iter), int(min_num), int(max_num), ws.data_ptr(),
+                                 out.data_ptr(), rounds.data_ptr(), stream), "cp_ransac_vote_f32")
+    return (out, rounds) if return_rounds else out

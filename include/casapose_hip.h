@@ -194,11 +194,14 @@ size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects);
 /* ransac_voting_layer_all_masks (casapose/pose_estimation/ransac_voting.py:276-368,447-484).
  * One call votes all (image, object) pairs.  labels: uint8 [n,h,w] hard object map
  * (arg-max one-hot of pose_evaluation.py:37-38); vertex: [n,h,w,ld] with (dy,dx)*kp at
- * dir_off.  idx: int32 [max_iter][n][objects][hyp][kp][2] uniform random numbers in
+ * dir_off.  idx: int32 [max_iter][n][objects][hyp][kp][2] uniform random draws in
  * [0, 2^31) supplied by the caller (the reference draws tf.random.uniform per round,
- * :319-321); the kernel maps them to pixel indices by `idx % tn`.  Objects with fewer
- * than min_num pixels give zeros (:290-292).  Objects with more than max_num pixels are
- * rejected with CP_ERR_INVALID unless the caller sub-sampled the label map (:295-301).
+ * :319-321; tests inject them); a draw d selects the (d % tn)-th pixel of the object in
+ * raster order (the order of tf.where, :303-305).  Objects with fewer than min_num pixels
+ * give zeros (:290-292).  The random sub-sampling of objects above max_num pixels
+ * (:295-301) is the caller's job (apply it to `labels`); max_num is accepted for signature
+ * parity only.  Rounds stop per object when 1-(1-r_min^2)^hyps > confidence or after
+ * max_iter rounds (:340-347), decided on the device.  hyp must be a multiple of 16.
  * out: fp32 [n][objects][kp][2] in (x,y); rounds_out (optional) int32 [n][objects].
  * ws: workspace of cp_ransac_workspace_bytes. */
 int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h,
