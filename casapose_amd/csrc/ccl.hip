@@ -64,11 +64,26 @@ __global__ void ccl_merge(const uint8_t* __restrict__ lab, int* __restrict__ par
 }
 
 __global__ void ccl_flatten_count(const uint8_t* __restrict__ lab, int* __restrict__ parent, int* __restrict__ count, long long total) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        if (!lab[i]) continue;
-        const int r = find_root(parent, (int)i);
-        parent[i] = r;
-        atomicAdd(&count[r], 1);
+    // Sizes: one atomic per (wave, distinct root) instead of one per pixel -- a large component
+    // would otherwise serialise hundreds of thousands of atomics on one address.
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_iter = (total + stride - 1) / stride;
+    const int lane = threadIdx.x & 63;
+    for (long long it = 0; it < n_iter; ++it) {
+        const long long i = it * stride + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+        int r = -1;
+        if (i < total && lab[i]) {
+            r = find_root(parent, (int)i);
+            parent[i] = r;
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int r0 = __shfl(r, leader);
+            const unsigned long long same = __ballot(r == r0);
+            if (lane == leader) atomicAdd(&count[r0], (int)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
