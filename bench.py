@@ -63,12 +63,9 @@ def main():
     from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
     from casapose_amd.pose_models.tfkeras import Classifiers
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from casapose_amd import parallel
+
+    rank, local, world = parallel.init_from_env("nccl")  # RCCL over xGMI on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -99,9 +96,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        parallel.barrier_sync(dev)
 
     barrier()
     t0 = time.perf_counter()
@@ -109,10 +104,7 @@ def main():
         kpts = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, dev)
     assert torch.isfinite(kpts).all()
 
     result = {

@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm,
+"gloo" on CPU for tests).  Inference and voting shard by IMAGE with no exchange on the data
+path: ranks are independent replicas; the only collectives are the benchmark's
+barrier and its max-over-ranks clock.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE (torchrun contract); returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) slice of `total` images for `rank`; sizes differ by at most one and
+    the union over ranks is exactly range(total) (ragged tails included)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world: %d/%d" % (rank, world))
+    base, extra = divmod(total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def barrier_sync(device=None) -> None:
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
