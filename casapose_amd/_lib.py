@@ -52,6 +52,7 @@ class ConvDesc(C.Structure):
         ("num_sources", C.c_int),
         ("src", ConvSource * 2),
         ("weights", C.c_void_p),
+        ("weights_halo", C.c_void_p),
         ("tap_label", C.c_void_p),
         ("row_scale", C.c_void_p),
         ("residual", C.c_void_p),
@@ -70,7 +71,7 @@ class ConvDesc(C.Structure):
 
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
-TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32 = range(7)
+TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO = range(8)
 
 # every symbol include/casapose_hip.h declares: (name, restype, argtypes)
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -80,6 +81,8 @@ SYMBOLS = [
     ("cp_device_count", _i, []),
     ("cp_conv_ktot", _i, [_i, _i, _i, C.POINTER(_i)]),
     ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    ("cp_conv_halo_weight_floats", _i, [_i, _i, C.POINTER(_i)]),
+    ("cp_conv_pack_weights_halo_host", _i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
     ("cp_conv_selected_tile", _i, [C.POINTER(ConvDesc)]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),

@@ -18,6 +18,13 @@
 // Reference call sites replaced: see include/casapose_hip.h (cp_conv2d_fwd_f32).
 #include "common.h"
 
+namespace cp {
+int halo_weight_floats(int cout, int num_sources, const int* channels);
+int halo_pack_weights(const float* w, int layout, int cout, int num_sources, const int* channels, const int* real_channels, float* dst);
+bool halo_applicable(const cp_conv_desc* d);
+int launch_halo_conv(const cp_conv_desc* d, hipStream_t st);
+}  // namespace cp
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -541,7 +548,24 @@ extern "C" int cp_conv_pack_weights_host(const float* w, int layout, int kh, int
 
 extern "C" int cp_conv_selected_tile(const cp_conv_desc* d) {
     if (!d) return CP_ERR_INVALID;
-    return d->tile_hint ? d->tile_hint : pick_tile((long long)d->batch * d->out_h * d->out_w, d->cout);
+    if (d->tile_hint) return d->tile_hint;
+    if (cp::halo_applicable(d)) return CP_TILE_HALO;
+    return pick_tile((long long)d->batch * d->out_h * d->out_w, d->cout);
+}
+
+extern "C" int cp_conv_halo_weight_floats(int cout, int num_sources, const int* channels) {
+    if (!channels || num_sources < 1 || num_sources > 2 || cout < 1 || cout > 64) return CP_ERR_INVALID;
+    return cp::halo_weight_floats(cout, num_sources, channels);
+}
+
+extern "C" int cp_conv_pack_weights_halo_host(const float* w, int layout, int cout, int num_sources, const int* channels,
+                                              const int* real_channels, float* dst) {
+    CP_REQUIRE(w && dst && channels && real_channels, "cp_conv_pack_weights_halo_host: null pointer");
+    CP_REQUIRE(cout >= 1 && cout <= 64 && (num_sources == 1 || num_sources == 2), "cp_conv_pack_weights_halo_host: cout must be <= 64, 1-2 sources");
+    for (int s = 0; s < num_sources; ++s)
+        CP_REQUIRE((channels[s] == 4 && s == num_sources - 1 && s > 0) || (channels[s] > 0 && channels[s] % 32 == 0),
+                   "cp_conv_pack_weights_halo_host: source channels must be multiples of 32 (a 4-channel source only as the last of two)");
+    return cp::halo_pack_weights(w, layout, cout, num_sources, channels, real_channels, dst);
 }
 
 extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
@@ -613,6 +637,10 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
     CP_REQUIRE(!d->residual || d->residual_ld >= d->cout, "cp_conv2d_fwd_f32: residual_ld < cout");
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->tile_hint == CP_TILE_HALO || (d->tile_hint == 0 && cp::halo_applicable(d))) {
+        CP_REQUIRE(cp::halo_applicable(d), "cp_conv2d_fwd_f32: CP_TILE_HALO requested but the layer does not qualify (3x3/s1/p1, cout<=64, weights_halo)");
+        return cp::launch_halo_conv(d, st);
+    }
     int tile = d->tile_hint ? d->tile_hint : pick_tile(k.M, k.Cout);
     // operand-loader variant
     const bool any_pre = k.s[0].pre_scale || (d->num_sources > 1 && k.s[1].pre_scale);

@@ -85,6 +85,15 @@ class FusedConv:
         check(lib.cp_conv_pack_weights_host(w.ctypes.data, layout, kh, kw, cout, ns, chans, real, packed.ctypes.data),
               "cp_conv_pack_weights_host(%s)" % name)
         self.wp = torch.from_numpy(packed).to(device)
+        # second packing for the LDS-resident halo-tile kernel (3x3, cout <= 64, 32-multiple sources [+ image])
+        self.wp_halo = None
+        halo_ok = kh == 3 and kw == 3 and cout <= 64 and sources[0][0] % 32 == 0 and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 32 == 0)
+        if halo_ok:
+            nfl = lib.cp_conv_halo_weight_floats(cout, ns, chans)
+            ph = np.empty(nfl, dtype=np.float32)
+            check(lib.cp_conv_pack_weights_halo_host(w.ctypes.data, layout, cout, ns, chans, real, ph.ctypes.data),
+                  "cp_conv_pack_weights_halo_host(%s)" % name)
+            self.wp_halo = torch.from_numpy(ph).to(device)
         self.desc = ConvDesc()
         self._keep: List[torch.Tensor] = []
 
@@ -114,6 +123,7 @@ class FusedConv:
             cs.pre_shift = _ptr(pre[1]) if pre else None
             keep += [s["data"], s.get("sel")] + (list(pre) if pre else [])
         d.weights = _ptr(self.wp)
+        d.weights_halo = _ptr(self.wp_halo)
         d.tap_label = _ptr(tap_label)
         d.row_scale = _ptr(row_scale)
         d.residual = _ptr(residual)

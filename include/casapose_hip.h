@@ -93,6 +93,8 @@ typedef struct cp_conv_desc {
     int num_sources;            /* 1 or 2 (channel concatenation, source 0 first)            */
     cp_conv_source src[2];
     const float* weights;       /* packed [cout][ktot]                                        */
+    const float* weights_halo;  /* optional second packing (cp_conv_pack_weights_halo_host): lets 3x3/s1/p1   */
+                                /* layers with cout <= 64 run on the LDS-resident halo-tile kernel            */
     const uint8_t* tap_label;   /* optional [n,in_h,in_w] -> partial-conv tap mask            */
     /* epilogue */
     const float* row_scale;     /* optional [n,out_h,out_w]                                   */
@@ -110,7 +112,7 @@ typedef struct cp_conv_desc {
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
-       CP_TILE_64x64 = 5, CP_TILE_256x32 = 6 };
+       CP_TILE_64x64 = 5, CP_TILE_256x32 = 6, CP_TILE_HALO = 7 /* halo-tile kernel (needs weights_halo) */ };
 
 /* K extent (multiple of 32) of the packed weight rows for a conv with the given sources */
 int cp_conv_ktot(int kh, int kw, int num_sources, const int* channels);
@@ -121,6 +123,10 @@ int cp_conv_ktot(int kh, int kw, int num_sources, const int* channels);
  * dst has cout*ktot floats.  All pointers are host memory. */
 int cp_conv_pack_weights_host(const float* w_host, int layout, int kh, int kw, int cout, int num_sources,
                               const int* channels, const int* real_channels, float* dst_host);
+/* halo-kernel weight layout [chunk][tap][32 or 64][kc]: float count and HOST packing (3x3 kernels only) */
+int cp_conv_halo_weight_floats(int cout, int num_sources, const int* channels);
+int cp_conv_pack_weights_halo_host(const float* w_host, int layout, int cout, int num_sources, const int* channels,
+                                   const int* real_channels, float* dst_host);
 int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);
 /* which CP_TILE_* instantiation cp_conv2d_fwd_f32 will launch for this descriptor (profiling aid) */
 int cp_conv_selected_tile(const cp_conv_desc* desc);
