@@ -17,6 +17,9 @@
 //
 // Reference call sites replaced: see include/casapose_hip.h (cp_conv2d_fwd_f32).
 #include "common.h"
+#include "epilogue.h"
+
+#include <algorithm>
 
 namespace cp {
 int halo_weight_floats(int cout, int num_sources, const int* channels);
@@ -431,32 +434,20 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
 #endif
 #undef CP_BARRIER
 
-    // ---- epilogue ----------------------------------------------------------------------
+    // ---- epilogue (epilogue.h: batched, branch-free) ---------------------------------------
     const int hi4 = (lane >> 5) * 4;
+    cp::EpiArgs ea;
+    ea.row_scale = p.row_scale; ea.label = p.epi_label; ea.residual = p.residual; ea.scale = p.scale; ea.shift = p.shift;
+    ea.out_raw = p.out_raw; ea.out_act = p.out_act; ea.res_ld = p.res_ld; ea.raw_ld = p.raw_ld; ea.act_ld = p.act_ld;
+    ea.cout = p.Cout; ea.act = p.act; ea.npix = (unsigned)p.M;
+    const cp::EpiRsrc er = cp::epi_make(ea, p.W);
+    int cos[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cos[j] = n0 + (wn * TN + j) * 32 + lrow;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + hi4;
-            if (m >= p.M) continue;
-            const float rs = p.row_scale ? p.row_scale[m] : 1.f;
-            const int lab = p.epi_label ? (int)p.epi_label[m] : 0;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n0 + (wn * TN + j) * 32 + lrow;
-                if (co >= p.Cout) continue;
-                float v = acc[i][j][r] * rs;
-                if (p.residual) v += p.residual[(size_t)m * p.res_ld + co];
-                if (p.out_raw) p.out_raw[(size_t)m * p.raw_ld + co] = v;
-                if (p.out_act) {
-                    float t = v;
-                    if (p.scale) t = t * p.scale[lab * p.Cout + co] + p.shift[lab * p.Cout + co];
-                    if (p.act == CP_ACT_RELU) t = fmaxf(t, 0.f);
-                    else if (p.act == CP_ACT_LEAKY01) t = fmaxf(t, 0.f) - fmaxf(-0.1f * t, 0.f);
-                    p.out_act[(size_t)m * p.act_ld + co] = t;
-                }
-            }
-        }
+        const int mb = m0 + (wm * TM + i) * 32 + hi4;
+        cp::epilogue_block<TN, (TM * TN == 1) ? 4 : ((TN == 1) ? 8 : 4)>(acc[i], cos, ea, er, [&](int r) { const int m = mb + (r & 3) + 8 * (r >> 2); return m < p.M ? m : -1; }, nullptr);
     }
 }
 
@@ -635,6 +626,11 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
     CP_REQUIRE(!d->out_raw || d->out_raw_ld >= d->cout, "cp_conv2d_fwd_f32: out_raw_ld < cout");
     CP_REQUIRE(!d->out_act || d->out_act_ld >= d->cout, "cp_conv2d_fwd_f32: out_act_ld < cout");
     CP_REQUIRE(!d->residual || d->residual_ld >= d->cout, "cp_conv2d_fwd_f32: residual_ld < cout");
+    {
+        const long long npx = (long long)d->batch * d->out_h * d->out_w;
+        const long long ldmax = std::max(std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0), d->residual ? d->residual_ld : 0);
+        CP_REQUIRE(npx * ldmax * 4 < (1LL << 31), "cp_conv2d_fwd_f32: output/residual tensor spans >= 2 GiB; split the batch (32-bit range-checked addressing)");
+    }
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->tile_hint == CP_TILE_HALO || (d->tile_hint == 0 && cp::halo_applicable(d))) {
