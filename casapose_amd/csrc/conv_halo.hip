@@ -55,52 +55,63 @@ struct HaloK {
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// Per tile the consumers run   nwide x 9 "tap steps" (16*TN MFMAs each, one 32-channel slice of one tap)
-//                            + 1 "image step" (20*TN MFMAs: the 9 taps x 4 image channels as K = 40)
-// with one barrier per step.  The producers run the same step sequence and keep three streams ahead
-// of it -- weights (3-step register ring), halo fills of the NEXT 32-channel slice (2-step ring, 7
-// elements per thread per slice), the image halo of the next tile -- using only incremental integer
-// state (no divisions in the steady state; a step is only ~1000 MFMA cycles long).
+// Structure (v3).  Per tile the consumers run, for every 32-channel slice ("wide chunk"), 9 taps x 4
+// k8-steps of 4*TMW*TN MFMAs straight out of the LDS-resident halo, then (if the layer has the image
+// source) 5 more k8-steps on the image halo (K = 9 taps x 4 channels, padded to 40).  The WEIGHT
+// fragments do not go through LDS at all: they are tiny, shared by every tile and every wave, so each
+// consumer lane fetches its 16 bytes per k8-step directly from L1/L2 with a 3-step register prefetch
+// ring (the weight layout makes every such wave access one contiguous 1 KiB).  That leaves ONE
+// barrier per wide chunk (halo stage flip); an earlier version staged weights per tap through LDS
+// and its 10-18 barriers + producer bookkeeping per tile cost more than the MFMAs of a 32-channel
+// layer.  The producers only refill the other halo stage once per chunk.
 template <int TMW, int TN, int MODE>
 __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel(const HaloK p) {
     constexpr int TH = 4 * TMW;             // output rows per tile
     constexpr int HR = TH + 2;              // halo rows
     constexpr int HP = HR * HW_COLS;        // halo pixels
     constexpr int BN = 32 * TN;
-    constexpr int AS = 36;                  // wide halo pixel stride / weight row stride (floats)
+    constexpr int AS = 36;                  // halo pixel stride (floats)
     constexpr bool BILINEAR = (MODE & H_BILINEAR) != 0;
     constexpr bool PARTIAL = (MODE & H_PARTIAL) != 0;
     constexpr bool SEL = (MODE & H_SEL) != 0;
     constexpr int NV = BILINEAR ? 4 : 1;
     constexpr int NIT = (HP * 8 + 255) / 256;   // wide halo float4 elements per producer thread
-    constexpr int NB = TN + 1;                  // float4 of weights per producer thread per step (image step: BN*40/4 = 320*TN)
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(NIT <= 7, "halo elements are issued at taps 0..6, the image element at tap 7");
     static_assert(HP <= 256, "one image-halo element per producer thread");
 
     const bool has_img = p.img != nullptr;
-    const int BS = has_img ? 44 : 36;       // weight-stage row stride: the image step has 40-wide rows (+4 pad)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                        // [2][HP][AS]
-    float* bst = halo + 2 * HP * AS;           // [2][BN][BS]
-    float* imgh = bst + 2 * BN * BS;           // [2][HP][4]
+    float* imgh = halo + 2 * HP * AS;          // [2][HP][4]
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool producer = wave >= 4;
     const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
-    const int spt = 9 * p.nwide + (has_img ? 1 : 0);  // steps per tile
 
     const int bid = cp::xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halo rows) on one XCD
     const int my_tiles = (p.ntiles - bid + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total_steps = my_tiles * spt;
-    auto tile_origin = [&](int k, int& n, int& y0, int& x0) {  // divisions: once per tile only
-        int t = bid + k * (int)gridDim.x;
-        const int tx = t % p.tiles_x;
+    const int total_chunks = my_tiles * p.nwide;
+    // Tile coordinates advance by the constant stride gridDim.x: mixed-radix increments, no divisions later
+    struct TilePos { int tx, ty, n; };
+    TilePos first;
+    {
+        int t = bid;
+        first.tx = t % p.tiles_x;
         t /= p.tiles_x;
-        x0 = tx * 32;
-        y0 = (t % p.tiles_y) * TH;
-        n = t / p.tiles_y;
+        first.ty = t % p.tiles_y;
+        first.n = t / p.tiles_y;
+    }
+    const int g = (int)gridDim.x;
+    const int d_tx = g % p.tiles_x, d_ty = (g / p.tiles_x) % p.tiles_y, d_n = g / (p.tiles_x * p.tiles_y);
+    auto next_tile = [&](TilePos& t) {
+        t.tx += d_tx;
+        int cy = 0;
+        if (t.tx >= p.tiles_x) { t.tx -= p.tiles_x; cy = 1; }
+        t.ty += d_ty + cy;
+        int cn = 0;
+        if (t.ty >= p.tiles_y) { t.ty -= p.tiles_y; cn = 1; }
+        t.n += d_n + cn;
     };
 
     if (producer) {
@@ -110,7 +121,6 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                                                                               p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(has_img ? p.img : p.s[0].data), 0,
                                                                               has_img ? p.img_bytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
                                                                               SEL ? p.lab_bytes : 0u, 0x00020000);
         auto ldb4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> float4 {
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
             return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 #endif
         };
-        // per-thread constants: wide element `it` is halo pixel it*32 + tid/8, float4 slot tid%8
+        // wide element `it` of a thread is halo pixel it*32 + tid/8, float4 slot tid%8
         const int f4 = tid & 7;
         const int hp0 = tid >> 3;
         int e_hy[NIT], e_hx[NIT];
@@ -132,222 +142,116 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
         }
         const int i_hy = tid < HP ? tid / HW_COLS : 0x4000, i_hx = tid % HW_COLS;
 
-        // rings (slot = step % 3, compile-time because the step loop is unrolled by 3)
-        float4 hreg[3][NV];
-        int hdst[3];   // LDS float offset incl. stage, -1 = empty; bit 30 set = image element
-        int hflag[3];
-        float4 bring[3][NB];
-        int selc[NIT], seln[NIT];
-
-        // ---- stream state ---------------------------------------------------------------------
-        int ft = 0, fc = 0;          // fill stream: tile, wide chunk in tile, next element
-        int fn, fy0, fx0;                     // its tile origin
-        int fgc = 0;                          // global wide-chunk counter of the fill (stage = fgc & 1)
-        int bt = 0, bstep = 0;                // weight stream: tile, step in tile
-        int ct = 0, cstep = 0, ctap = 0;      // consumer position: tile, step in tile, tap within the wide chunk
-        int cgc = 0;                          // consumers' global wide-chunk counter
-        int it_tile = 1;                      // image stream: next tile whose image halo is still to be fetched
-        tile_origin(0, fn, fy0, fx0);
-
-        auto load_sel_tile = [&](int k, int (&dst)[NIT]) {
-            if constexpr (SEL) {
-                int n, y0, x0;
-                if (k >= my_tiles) return;
-                tile_origin(k, n, y0, x0);
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
-                    const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                    dst[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? ((n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
-                }
-            }
-        };
-        // issue element `it` of wide chunk `c` of the tile at (n,y0,x0) into ring slot
-        auto issue_wide = [&](int slot, int n, int y0, int x0, int c, int it, int stage, int selbyte) {
+        // fill the halo stage of wide chunk `c` of tile `tp` (elements [it0, it1)) -- issue all, then store all
+        auto fill_wide = [&](const TilePos& tp, int c, int stage, int it0, int it1) {
+            const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
             const int si = c >= p.nwide0 ? 1 : 0;
             const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
             const int sld = si ? p.s[1].ld : p.s[0].ld;
             const int cb = ((c - (si ? p.nwide0 : 0)) * 32 + f4 * 4) * 4;
-            const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
-            const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-            hdst[slot] = e_hy[it] < 0x4000 ? (stage * HP * AS + (it * 32 + hp0) * AS + f4 * 4) : -1;
-            hflag[slot] = ((y & 1) << 1) | ((x & 1) << 2) | (si << 3);
-            if constexpr (BILINEAR) {
-                unsigned o00, o01, o10, o11;
-                if (si == 0) {
-                    const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
-                    int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
-                    int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
-                    ys = max(ys, 0);
-                    xs = max(xs, 0);
-                    const int nb = n * Hs * Ws;
-                    o00 = inb ? (unsigned)(((nb + ys * Ws + xs) * sld) * 4 + cb) : OOB;
-                    o01 = inb ? (unsigned)(((nb + ys * Ws + x1) * sld) * 4 + cb) : OOB;
-                    o10 = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld) * 4 + cb) : OOB;
-                    o11 = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld) * 4 + cb) : OOB;
-                } else {
-                    o00 = o01 = o10 = o11 = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
-                }
-                hreg[slot][0] = ldb4(rs, o00);
-                hreg[slot][1] = ldb4(rs, o01);
-                hreg[slot][2] = ldb4(rs, o10);
-                hreg[slot][3] = ldb4(rs, o11);
-            } else if constexpr (SEL) {
-                unsigned o;
-                if (si == 0) {
-                    const int sl = selbyte;
-                    o = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * sld) * 4 + cb) : OOB;
-                } else {
-                    o = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
-                }
-                hreg[slot][0] = ldb4(rs, o);
-            } else {
-                hreg[slot][0] = ldb4(rs, inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB);
-            }
-        };
-        auto issue_img = [&](int slot, int k) {  // image halo element of tile k -> image stage k&1
-            int n, y0, x0;
-            tile_origin(k, n, y0, x0);
-            const int y = y0 - 1 + i_hy, x = x0 - 1 + i_hx;
-            const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-            hdst[slot] = i_hy < 0x4000 ? (0x40000000 | ((k & 1) * HP * 4 + tid * 4)) : -1;
-            hflag[slot] = 8;  // no interpolation
-            hreg[slot][0] = ldb4(rsi, inb ? (unsigned)(((n * p.H + y) * p.Wd + x) * 16) : OOB);
-        };
-        auto store_elem = [&](int slot) {
-            const int d = hdst[slot];
-            if (d < 0) return;
-            float4 v = hreg[slot][0];
-            if constexpr (BILINEAR) {
-                if (!(hflag[slot] & 8)) {
-                    const float fy = (hflag[slot] & 2) ? 0.25f : 0.75f, fx = (hflag[slot] & 4) ? 0.25f : 0.75f;
-                    const float gy = 1.f - fy, gx = 1.f - fx;
-                    const float4 v01 = hreg[slot][1], v10 = hreg[slot][2], v11 = hreg[slot][3];
-                    v.x = (v.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
-                    v.y = (v.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
-                    v.z = (v.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
-                    v.w = (v.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
-                }
-            }
-            float* dst = (d & 0x40000000) ? (imgh + (d & 0x3fffffff)) : (halo + d);
-            *reinterpret_cast<float4*>(dst) = v;
-            hdst[slot] = -1;
-        };
-        // weights of step `st` of a tile: wide step st = c*9+tap -> block of BN*32 floats; image step -> BN*40 floats
-        auto issue_b = [&](int slot, int st, bool valid) {
-            const bool wide = st < 9 * p.nwide;
-            const unsigned base = (unsigned)(wide ? st * BN * 32 : 9 * p.nwide * BN * 32) * 4u;
-            const int nf4 = wide ? BN * 8 : BN * 10;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = j * 256 + tid;
-                bring[slot][j] = ldb4(rsw, (valid && e < nf4) ? base + (unsigned)e * 16u : OOB);
-            }
-        };
-        auto store_b = [&](int slot, int st, int stage) {
-            const bool wide = st < 9 * p.nwide;
-            float* b = bst + stage * BN * BS;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = j * 256 + tid;
-                if (wide) {
-                    if (e < BN * 8) *reinterpret_cast<float4*>(b + (e >> 3) * AS + (e & 7) * 4) = bring[slot][j];
-                } else {
-                    if (e < BN * 10) *reinterpret_cast<float4*>(b + (e / 10) * BS + (e % 10) * 4) = bring[slot][j];
-                }
-            }
-        };
-
-        // ---- prologue ---------------------------------------------------------------------------
-        if constexpr (SEL) {
-            load_sel_tile(0, selc);
-            load_sel_tile(1, seln);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {  // fill 0: wide chunk 0 of tile 0 -> stage 0
-            issue_wide(it % 3, fn, fy0, fx0, 0, it, 0, SEL ? selc[it] : 0);
-            store_elem(it % 3);
-        }
-        if (has_img) {
-            issue_img(0, 0);
-            store_elem(0);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) hdst[q] = -1;
-        // advance the fill stream to the next wide chunk
-        fgc = 1;
-        fc = 1;
-        if (fc == p.nwide) {
-            fc = 0;
-            ft = 1;
-            if (ft < my_tiles) tile_origin(ft, fn, fy0, fx0);
+            float4 v[NIT][NV];
+            int par[NIT];
+            int selb[NIT];
             if constexpr (SEL) {
+                if (si == 0) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) selc[it] = seln[it];
-                load_sel_tile(2, seln);
-            }
-        }
-        // weights: step 0 straight to LDS, steps 1 and 2 into ring slots 1 and 2
-        issue_b(0, 0, total_steps > 0);
-        store_b(0, 0, 0);
-        issue_b(1, 1 % spt, total_steps > 1);
-        issue_b(2, 2 % spt, total_steps > 2);
-        bstep = 3 % spt;  // next step (within a tile) whose weights are to be issued
-        bt = 3 / spt;
-        CP_BARRIER();
-
-        // ---- steady state: one iteration per consumer step, ring slots static ---------------------
-        auto do_step = [&](int cur, int gs) {
-            // (1) weights of step gs+1 -> LDS stage (gs+1)&1 ; weights of step gs+3 -> ring slot cur
-            {
-                int st1 = cstep + 1;
-                if (st1 == spt) st1 = 0;
-                if (gs + 1 < total_steps) store_b((cur + 1) % 3, st1, (gs + 1) & 1);
-                issue_b(cur, bstep, bt < my_tiles);
-                if (++bstep == spt) { bstep = 0; ++bt; }
-            }
-            // (2) element issued two steps ago -> LDS
-            store_elem((cur + 1) % 3);
-            // (3) issue one element: halo fill of the next wide chunk at taps 0..NIT-1, image halo at tap 7
-            const bool in_wide = cstep < 9 * p.nwide;
-            if (in_wide && ctap < NIT) {
-                if (fgc == cgc + 1 && ft < my_tiles) issue_wide(cur, fn, fy0, fx0, fc, ctap, fgc & 1, SEL ? selc[ctap] : 0);
-            } else if (in_wide && ctap == 7 && has_img) {
-                // the image stage of tile ct+1 is free once tile ct-1's image step is done: issue it in the LAST wide chunk
-                if (cstep >= 9 * (p.nwide - 1) && it_tile == ct + 1 && it_tile < my_tiles) {
-                    issue_img(cur, it_tile);
-                    ++it_tile;
-                }
-            }
-            CP_BARRIER();
-            // (4) advance the consumer position; at a wide-chunk boundary the fill stream moves on
-            ++cstep;
-            if (in_wide) {
-                if (++ctap == 9) {
-                    ctap = 0;
-                    ++cgc;
-                    ++fgc;
-                    if (++fc == p.nwide) {
-                        fc = 0;
-                        ++ft;
-                        if (ft < my_tiles) tile_origin(ft, fn, fy0, fx0);
-                        if constexpr (SEL) {
-#pragma unroll
-                            for (int it = 0; it < NIT; ++it) selc[it] = seln[it];
-                            load_sel_tile(ft + 1, seln);
-                        }
+                    for (int it = 0; it < NIT; ++it) {
+                        if (it < it0 || it >= it1) continue;
+                        const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
+                        const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                        selb[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? ((n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
                     }
                 }
             }
-            if (cstep == spt) {
-                cstep = 0;
-                ++ct;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it < it0 || it >= it1) continue;
+                const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
+                const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                par[it] = ((y & 1) << 1) | ((x & 1) << 2);
+                if constexpr (BILINEAR) {
+                    unsigned o00, o01, o10, o11;
+                    if (si == 0) {
+                        const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
+                        int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
+                        int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
+                        ys = max(ys, 0);
+                        xs = max(xs, 0);
+                        const int nb = n * Hs * Ws;
+                        o00 = inb ? (unsigned)(((nb + ys * Ws + xs) * sld) * 4 + cb) : OOB;
+                        o01 = inb ? (unsigned)(((nb + ys * Ws + x1) * sld) * 4 + cb) : OOB;
+                        o10 = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld) * 4 + cb) : OOB;
+                        o11 = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld) * 4 + cb) : OOB;
+                    } else {
+                        o00 = o01 = o10 = o11 = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
+                    }
+                    v[it][0] = ldb4(rs, o00);
+                    v[it][1] = ldb4(rs, o01);
+                    v[it][2] = ldb4(rs, o10);
+                    v[it][3] = ldb4(rs, o11);
+                } else if constexpr (SEL) {
+                    unsigned o;
+                    if (si == 0) {
+                        const int sl = selb[it];
+                        o = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * sld) * 4 + cb) : OOB;
+                    } else {
+                        o = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
+                    }
+                    v[it][0] = ldb4(rs, o);
+                } else {
+                    v[it][0] = ldb4(rs, inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB);
+                }
+            }
+            float* h = halo + stage * HP * AS;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it < it0 || it >= it1) continue;
+                if (e_hy[it] >= 0x4000) continue;
+                float4 r = v[it][0];
+                if constexpr (BILINEAR) {
+                    if (si == 0) {
+                        const float fy = (par[it] & 2) ? 0.25f : 0.75f, fx = (par[it] & 4) ? 0.25f : 0.75f;
+                        const float gy = 1.f - fy, gx = 1.f - fx;
+                        const float4 v01 = v[it][1], v10 = v[it][2], v11 = v[it][3];
+                        r.x = (r.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
+                        r.y = (r.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
+                        r.z = (r.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
+                        r.w = (r.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
+                    }
+                }
+                *reinterpret_cast<float4*>(h + (it * 32 + hp0) * AS + f4 * 4) = r;
             }
         };
-        for (int gs = 0; gs < total_steps; gs += 3) {
-            do_step(0, gs);
-            if (gs + 1 < total_steps) do_step(1, gs + 1);
-            if (gs + 2 < total_steps) do_step(2, gs + 2);
+        auto fill = [&](const TilePos& tp, int c, int stage) {
+            if constexpr (BILINEAR) {  // 4 taps per element: two batches keep the register footprint down
+                fill_wide(tp, c, stage, 0, (NIT + 1) / 2);
+                fill_wide(tp, c, stage, (NIT + 1) / 2, NIT);
+            } else {
+                fill_wide(tp, c, stage, 0, NIT);
+            }
+        };
+        auto fill_img = [&](const TilePos& tp, int stage) {
+            const int n = tp.n, y = tp.ty * TH - 1 + i_hy, x = tp.tx * 32 - 1 + i_hx;
+            const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+            const float4 v = ldb4(rsi, inb ? (unsigned)(((n * p.H + y) * p.Wd + x) * 16) : OOB);
+            if (i_hy < 0x4000) *reinterpret_cast<float4*>(imgh + stage * HP * 4 + tid * 4) = v;
+        };
+
+        TilePos ftile = first;  // tile of the NEXT chunk to fill
+        int fk = 0, fc = 0;     // its tile counter / wide chunk index
+        fill(ftile, 0, 0);
+        if (has_img) fill_img(ftile, 0);
+        CP_BARRIER();
+        for (int gc = 0; gc < total_chunks; ++gc) {
+            // consumers work on chunk gc (stage gc&1); refill the other stage with chunk gc+1
+            if (++fc == p.nwide) {
+                fc = 0;
+                ++fk;
+                next_tile(ftile);
+                if (has_img && fk < my_tiles) fill_img(ftile, fk & 1);  // image stage fk&1 was last read in tile fk-2
+            }
+            if (gc + 1 < total_chunks) fill(ftile, fc, (gc + 1) & 1);
+            CP_BARRIER();
         }
         return;
     }
@@ -359,8 +263,6 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
     const int hi4 = (lane >> 5) * 4;
     const int half = lane >> 5;
     f32x16 acc[TMW][TN];
-    float4 fa[2][TMW], fb[2][TN];
-    int gs = 0, gwc = 0;  // global step / global wide-chunk counters
     cp::EpiArgs ea;
     ea.row_scale = nullptr; ea.label = p.clade ? p.label : nullptr; ea.residual = p.residual; ea.scale = p.scale; ea.shift = p.shift;
     ea.out_raw = p.out_raw; ea.out_act = p.out_act; ea.res_ld = p.res_ld; ea.raw_ld = p.raw_ld; ea.act_ld = p.act_ld;
@@ -368,10 +270,29 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
     const cp::EpiRsrc er = cp::epi_make(ea, p.W);
     const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(PARTIAL ? (const void*)p.label : (const void*)p.W), 0,
                                                                           PARTIAL ? p.lab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+    // weight fragment of k8-step u of wide chunk c: 16 B at ((c*36 + u)*2 + half)*BN + co  (x16 B); image block after the wide part
+    const unsigned wlane = (unsigned)((half * BN + lrow) * 16);
+    auto ldw = [&](unsigned step_bytes, int j) -> float4 {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(step_bytes + wlane + (unsigned)j * 512u), 0, 0));
+    };
+    constexpr unsigned STEP_BYTES = 2u * BN * 16u;      // one k8-step of weights
+    constexpr unsigned CHUNK_BYTES = 36u * STEP_BYTES;
+    const unsigned img_w_off = (unsigned)p.nwide * CHUNK_BYTES;
+    float4 fb[4][TN];  // ring: the fragment of step u lives in slot u%4 and is fetched 3 steps ahead
+    float4 fa[2][TMW];
+    // prime the ring with steps 0..2 of chunk 0
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[u][j] = ldw(u * STEP_BYTES, j);
+
+    int gwc = 0;  // global wide-chunk counter
+    TilePos ctile = first;
     CP_BARRIER();  // prologue data is in LDS
     for (int k = 0; k < my_tiles; ++k) {
-        int n, y0, x0;
-        tile_origin(k, n, y0, x0);
+        const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        next_tile(ctile);
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -398,10 +319,10 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 pmask[i] = (lb[4] & 0xff00) ? 0 : m;
             }
         }
-        auto mfma4 = [&](int slot, int tap_lo, int tap_hi) {
+        auto mfma4 = [&](int aslot, int bslot, int tap_lo, int tap_hi) {
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
-                float4 av = fa[slot][i];
+                float4 av = fa[aslot][i];
                 if constexpr (PARTIAL) {
                     const int tp = half ? tap_hi : tap_lo;
                     if (!((pmask[i] >> tp) & 1)) av = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -409,46 +330,45 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
 #ifdef HX_NOMFMA
-                    acc[i][j][0] += av.x * fb[slot][j].x + av.y * fb[slot][j].y + av.z * fb[slot][j].z + av.w * fb[slot][j].w;  // timing experiment
+                    acc[i][j][0] += av.x * fb[bslot][j].x + av.y * fb[bslot][j].y + av.z * fb[bslot][j].z + av.w * fb[bslot][j].w;  // timing experiment
 #else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, fb[slot][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, fb[slot][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, fb[slot][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, fb[slot][j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, fb[bslot][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, fb[bslot][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, fb[bslot][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, fb[bslot][j].w, acc[i][j], 0, 0, 0);
 #endif
                 }
             }
         };
-        // ---- wide chunks: 9 taps x 4 k8-steps, one barrier per tap ----------------------------------
+        // ---- wide chunks: 36 k8-steps each, no barrier inside --------------------------------------
         for (int c = 0; c < p.nwide; ++c, ++gwc) {
             const float* hb = halo + (gwc & 1) * HP * AS + ((wy * TMW) * HW_COLS + lrow) * AS + khalf;
-            auto read_wide = [&](int tap, int k8, int slot, int bstage) {
-                const int ky = tap / 3, kx = tap - ky * 3;  // tap is a compile-time constant after unrolling
+            const bool last = (c + 1 == p.nwide);
+            // where the weight stream continues after this chunk: next chunk, the image block, or chunk 0 of the next tile
+            const unsigned wcur = (unsigned)c * CHUNK_BYTES;
+            const unsigned wnext = last ? (has_img ? img_w_off : 0u) : wcur + CHUNK_BYTES;
+            auto read_a = [&](int u, int slot) {
+                const int tap = u >> 2, k8 = u & 3;  // compile-time after unrolling
+                const int ky = tap / 3, kx = tap - ky * 3;
                 const float* a = hb + (ky * HW_COLS + kx) * AS + k8 * 8;
-                const float* b = bst + bstage * BN * BS + lrow * AS + k8 * 8 + khalf;
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(a + i * HW_COLS * AS);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(b + j * 32 * AS);
             };
-            read_wide(0, 0, 0, gs & 1);
+            read_a(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap, ++gs) {
-                read_wide(tap, 1, 1, gs & 1);
-                mfma4(0, tap, tap);
-                read_wide(tap, 2, 0, gs & 1);
-                mfma4(1, tap, tap);
-                read_wide(tap, 3, 1, gs & 1);
-                mfma4(0, tap, tap);
-                CP_BARRIER();  // all reads of weight stage gs&1 are complete; stage (gs+1)&1 is ready
-                if (tap < 8) read_wide(tap + 1, 0, 0, (gs + 1) & 1);
-                mfma4(1, tap, tap);
+            for (int u = 0; u < 36; ++u) {
+                // prefetch the weights of step u+3 (possibly in the next block of the stream) and the halo fragment of step u+1
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[(u + 3) & 3][j] = (u + 3 < 36) ? ldw(wcur + (unsigned)(u + 3) * STEP_BYTES, j) : ldw(wnext + (unsigned)(u + 3 - 36) * STEP_BYTES, j);
+                if (u + 1 < 36) read_a(u + 1, (u + 1) & 1);
+                mfma4(u & 1, u & 3, u >> 2, u >> 2);
             }
+            if (!(last && has_img)) CP_BARRIER();  // halo stage consumed; the other stage is ready
         }
         // ---- image step: K = 9 taps x 4 channels (+4 zero) = 5 k8-steps; half-wave h handles tap 2s+h ----
         if (has_img) {
             const float* ib = imgh + (k & 1) * HP * 4 + ((wy * TMW) * HW_COLS + lrow) * 4;
-            const float* b0 = bst + (gs & 1) * BN * BS + lrow * BS + khalf;
 #pragma unroll
             for (int s5 = 0; s5 < 5; ++s5) {
                 const int tl = 2 * s5, th = (2 * s5 + 1 < 9) ? 2 * s5 + 1 : 8;  // tap 9 does not exist: its weights are zero
@@ -456,12 +376,22 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 const float* a = ib + (half ? offh : offl);
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) fa[s5 & 1][i] = *reinterpret_cast<const float4*>(a + i * HW_COLS * 4);
+                // the ring continues from the wide part (36 % 4 == 0): image step s5 sits in slot s5 % 4
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[s5 & 1][j] = *reinterpret_cast<const float4*>(b0 + j * 32 * BS + s5 * 8);
-                if (s5 == 4) CP_BARRIER();  // reads of this weight stage / image stage are complete
-                mfma4(s5 & 1, tl, th);
+                for (int j = 0; j < TN; ++j) {
+                    const int nu = s5 + 3;  // next fragments: image steps 3,4, then steps 0..2 of the next tile's chunk 0
+                    fb[nu & 3][j] = (nu < 5) ? ldw(img_w_off + (unsigned)nu * STEP_BYTES, j) : ldw((unsigned)(nu - 5) * STEP_BYTES, j);
+                }
+                mfma4(s5 & 1, s5 & 3, tl, th);
             }
-            ++gs;
+            // the ring is now one step out of phase (5 % 4 == 1): realign slots 1,2,3 -> 0,1,2
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fb[0][j] = fb[1][j];
+                fb[1][j] = fb[2][j];
+                fb[2][j] = fb[3][j];
+            }
+            CP_BARRIER();
         }
         // ---- epilogue (epilogue.h) ------------------------------------------------------------
         int cos[TN];
@@ -496,8 +426,9 @@ int launch_halo(HaloK k, hipStream_t st) {
     k.tiles_x = (k.Wd + 31) / 32;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
     const bool img = k.img != nullptr;
-    const size_t lds = (size_t)(2 * HP * 36 + 2 * BN * (img ? 44 : 36) + (img ? 2 * HP * 4 : 0)) * sizeof(float);
-    const size_t lds_max = (size_t)(2 * HP * 36 + 2 * BN * 44 + 2 * HP * 4) * sizeof(float);
+    const size_t lds = (size_t)(2 * HP * 36 + (img ? 2 * HP * 4 : 0)) * sizeof(float);
+    const size_t lds_max = (size_t)(2 * HP * 36 + 2 * HP * 4) * sizeof(float);
+    (void)BN;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<TMW, TN, MODE>),
@@ -523,8 +454,10 @@ int halo_weight_floats(int cout, int num_sources, const int* channels) {
     return n;
 }
 
-// layout: for every 32-channel slice (sources in order): [tap][cout_pad][32]; then, for a trailing 4-channel image
-// source, one block [cout_pad][40] with k = tap*4 + channel (36 real values + 4 zeros)
+// Fragment-major layout (what one consumer wave loads per k8-step is one contiguous 1 KiB per 32 output channels):
+//   every 32-channel slice (sources in order): [tap (9)][k8 (4)][half (2)][cout_pad][4]  = W[co][slice*32 + k8*8 + half*4 + e] at `tap`
+//   a trailing 4-channel image source:         [s5 (5)][half (2)][cout_pad][4]           = W[co][image channel e] at tap 2*s5+half
+//   (tap 9 and the 4th image channel do not exist: zeros)
 int halo_pack_weights(const float* w, int layout, int cout, int num_sources, const int* channels, const int* real_channels, float* dst) {
     const int bn = cout <= 32 ? 32 : 64;
     int cin = 0;
@@ -540,18 +473,26 @@ int halo_pack_weights(const float* w, int layout, int cout, int num_sources, con
     for (int s = 0; s < num_sources; ++s) {
         const int C = channels[s], Cr = real_channels[s];
         if (C == 4) {
-            for (int co = 0; co < cout; ++co)
-                for (int t = 0; t < 9; ++t)
-                    for (int c = 0; c < Cr; ++c) dst[base + (size_t)co * 40 + t * 4 + c] = w[src_index(cbase + c, t, co)];
+            for (int s5 = 0; s5 < 5; ++s5)
+                for (int half = 0; half < 2; ++half) {
+                    const int t = 2 * s5 + half;
+                    if (t >= 9) continue;
+                    for (int co = 0; co < cout; ++co)
+                        for (int e = 0; e < Cr; ++e)
+                            dst[base + (((size_t)s5 * 2 + half) * bn + co) * 4 + e] = w[src_index(cbase + e, t, co)];
+                }
             base += (size_t)bn * 40;
         } else {
             for (int ch = 0; ch < C / 32; ++ch)
                 for (int t = 0; t < 9; ++t)
-                    for (int co = 0; co < cout; ++co)
-                        for (int kk = 0; kk < 32; ++kk) {
-                            const int c = ch * 32 + kk;
-                            if (c < Cr) dst[base + ((size_t)(ch * 9 + t) * bn + co) * 32 + kk] = w[src_index(cbase + c, t, co)];
-                        }
+                    for (int k8 = 0; k8 < 4; ++k8)
+                        for (int half = 0; half < 2; ++half)
+                            for (int co = 0; co < cout; ++co)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int c = ch * 32 + k8 * 8 + half * 4 + e;
+                                    if (c < Cr)
+                                        dst[base + (((((size_t)ch * 9 + t) * 4 + k8) * 2 + half) * bn + co) * 4 + e] = w[src_index(cbase + c, t, co)];
+                                }
             base += (size_t)(C / 32) * 9 * bn * 32;
         }
         cbase += Cr;
