@@ -2,7 +2,7 @@
 // casapose/pose_estimation/voting_layers_2d.py:43-79, where the reference calls
 // tfa.image.connected_components once per (image, object) map.
 //
-// Here ONE union-find pass labels the multi-class map (two 4-neighbours are connected iff they
+// Here ONE union-find (tile-local in LDS, then stitched along tile borders) labels the multi-class map (two 4-neighbours are connected iff they
 // carry the same non-zero label), which yields every object's components at once.  Roots are
 // the minimum linear index of a component, so "component id order" of the reference (raster
 // order of the first pixel) is the order of the roots.
@@ -45,21 +45,59 @@ __device__ __forceinline__ void unite(int* parent, int a, int b) {
     }
 }
 
-__global__ void ccl_init(const uint8_t* __restrict__ lab, int* __restrict__ parent, int* __restrict__ count, long long total) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        parent[i] = lab[i] ? (int)i : -1;
-        count[i] = 0;
+__global__ void ccl_init(int* __restrict__ count, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) count[i] = 0;
+}
+
+// Pass 1: union-find inside a 64x16 tile held in LDS (LDS atomics are ~10x cheaper than the global
+// ones and never contend across blocks), then one global parent per pixel = its tile-local root.
+constexpr int TW = 64, TH = 16;
+__global__ __launch_bounds__(256) void ccl_local(const uint8_t* __restrict__ lab, int* __restrict__ parent, int H, int W, int tiles_x,
+                                                 int tiles_y) {
+    __shared__ uint8_t sl[TH][TW];
+    __shared__ int sp[TH * TW];
+    const int t = blockIdx.x;
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const size_t img = (size_t)n * H * W;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ly = i / TW, lx = i % TW;
+        const int y = y0 + ly, x = x0 + lx;
+        const uint8_t l = (y < H && x < W) ? lab[img + (size_t)y * W + x] : 0;
+        sl[ly][lx] = l;
+        sp[i] = l ? i : -1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ly = i / TW, lx = i % TW;
+        const uint8_t l = sl[ly][lx];
+        if (!l) continue;
+        if (lx > 0 && sl[ly][lx - 1] == l) unite(sp, i, i - 1);
+        if (ly > 0 && sl[ly - 1][lx] == l) unite(sp, i, i - TW);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ly = i / TW, lx = i % TW;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        int r = -1;
+        if (sl[ly][lx]) {
+            const int lr = find_root(sp, i);
+            r = (int)(img + (size_t)(y0 + lr / TW) * W + x0 + lr % TW);
+        }
+        parent[img + (size_t)y * W + x] = r;
     }
 }
 
-__global__ void ccl_merge(const uint8_t* __restrict__ lab, int* __restrict__ parent, int H, int W, long long total) {
+// Pass 2: stitch the tiles along their borders (global union-find, ~8 % of the pixels)
+__global__ void ccl_border(const uint8_t* __restrict__ lab, int* __restrict__ parent, int H, int W, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int l = lab[i];
         if (!l) continue;
         const int x = (int)(i % W);
         const int y = (int)((i / W) % H);
-        if (x > 0 && lab[i - 1] == l) unite(parent, (int)i, (int)i - 1);
-        if (y > 0 && lab[i - W] == l) unite(parent, (int)i, (int)i - W);
+        if (x > 0 && (x % TW) == 0 && lab[i - 1] == l) unite(parent, (int)i, (int)i - 1);
+        if (y > 0 && (y % TH) == 0 && lab[i - W] == l) unite(parent, (int)i, (int)i - W);
     }
 }
 
@@ -168,9 +206,11 @@ extern "C" int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, 
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(sp);
     const int nstat = batch * objects;
     const int g = grid_for(total);
-    CP_LAUNCH(ccl_init, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, total);
+    CP_LAUNCH(ccl_init, dim3(g), dim3(THREADS), 0, st, count, total);
     CP_LAUNCH(ccl_zero_stats, dim3((nstat * 3 + THREADS - 1) / THREADS), dim3(THREADS), 0, st, stats, nstat * 3);
-    CP_LAUNCH(ccl_merge, dim3(g), dim3(THREADS), 0, st, labels_in, parent, h, w, total);
+    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+    CP_LAUNCH(ccl_local, dim3(batch * tiles_x * tiles_y), dim3(256), 0, st, labels_in, parent, h, w, tiles_x, tiles_y);
+    CP_LAUNCH(ccl_border, dim3(g), dim3(THREADS), 0, st, labels_in, parent, h, w, total);
     CP_LAUNCH(ccl_flatten_count, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, total);
     CP_LAUNCH(ccl_fg_count, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, stats, objects, hw, total);
     CP_LAUNCH(ccl_best, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, stats, objects, hw, total, min_size, 0);

@@ -22,6 +22,25 @@ from ._lib import ConvDesc, check
 
 BN_EPS = 2e-5  # resnet.py:44; _normalization_layers.py:108
 
+# Hard label maps the forward already computed (arg-max of its own logits), keyed by the storage
+# address of the network output: the voting layer receives `torch.split` views of that output and
+# can reuse the map instead of re-reading 708 MB of logits.  Entries hold a weak reference to the
+# output tensor and are refreshed by every forward that writes into the same buffer.
+import weakref
+
+_LABEL_CACHE: Dict[int, Tuple["weakref.ReferenceType", torch.Tensor]] = {}
+
+
+def cached_labels(storage_ptr: int, shape: Tuple[int, int, int]) -> Optional[torch.Tensor]:
+    hit = _LABEL_CACHE.get(storage_ptr)
+    if hit is None:
+        return None
+    ref, labels = hit
+    if ref() is None or tuple(labels.shape) != tuple(shape):
+        _LABEL_CACHE.pop(storage_ptr, None)
+        return None
+    return labels
+
 STAGE_FILTERS = (64, 128, 256, 512)
 STAGE_STRIDE = (1, 2, 1, 1)  # resnet.py:262-290 (output_stride 8)
 STAGE_DILATION = (1, 1, 2, 4)
@@ -359,6 +378,12 @@ class ForwardPlan:
         check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
         for step in self.steps:
             step(stream)
+        if seg_input is None:  # labels[0] is the arg-max of THIS output's logits
+            if len(_LABEL_CACHE) > 8:
+                _LABEL_CACHE.clear()
+            _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), self.labels[0])
+        else:
+            _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
         return out
 
 

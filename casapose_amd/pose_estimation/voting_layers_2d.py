@@ -58,7 +58,13 @@ class CoordLSVotingWeighted:
         if self.filter_estimates:
             lib = _lib.load()
             b, h, w, _ = rec.shape
-            lab0 = ops.argmax_labels(rec, classes=objects + 1, offset=so)
+            from ..engine import cached_labels
+
+            lab0 = None
+            if so == 0 and rec.storage_offset() == 0:
+                lab0 = cached_labels(rec.untyped_storage().data_ptr(), (b, h, w))  # the forward's own arg-max map
+            if lab0 is None:
+                lab0 = ops.argmax_labels(rec, classes=objects + 1, offset=so)
             ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objects), dtype=torch.uint8, device=rec.device)
             labels = torch.empty_like(lab0)
             check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, objects, self.min_component, ws.data_ptr(),
