@@ -66,6 +66,10 @@ class ConvDesc(C.Structure):
         ("out_act", C.c_void_p),
         ("out_act_ld", C.c_int),
         ("tile_hint", C.c_int),
+        ("head_weights", C.c_void_p),
+        ("head_out", C.c_void_p),
+        ("head_cout", C.c_int),
+        ("head_out_ld", C.c_int),
     ]
 
 
@@ -83,6 +87,7 @@ SYMBOLS = [
     ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     ("cp_conv_halo_weight_floats", _i, [_i, _i, C.POINTER(_i)]),
     ("cp_conv_pack_weights_halo_host", _i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    ("cp_conv_pack_head_weights_host", _i, [_vp, _i, _vp]),
     ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
     ("cp_conv_selected_tile", _i, [C.POINTER(ConvDesc)]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),

@@ -447,7 +447,8 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mb = m0 + (wm * TM + i) * 32 + hi4;
-        cp::epilogue_block<TN, (TM * TN == 1) ? 4 : ((TN == 1) ? 8 : 4)>(acc[i], cos, ea, er, [&](int r) { const int m = mb + (r & 3) + 8 * (r >> 2); return m < p.M ? m : -1; }, nullptr);
+        float unused_keep[16][TN];
+        cp::epilogue_block<TN, (TM * TN == 1) ? 4 : ((TN == 1) ? 8 : 4)>(acc[i], cos, ea, er, [&](int r) { const int m = mb + (r & 3) + 8 * (r >> 2); return m < p.M ? m : -1; }, nullptr, unused_keep);
     }
 }
 
@@ -544,6 +545,17 @@ extern "C" int cp_conv_selected_tile(const cp_conv_desc* d) {
     return pick_tile((long long)d->batch * d->out_h * d->out_w, d->cout);
 }
 
+extern "C" int cp_conv_pack_head_weights_host(const float* w, int head_cout, float* dst) {
+    CP_REQUIRE(w && dst && head_cout >= 1 && head_cout <= 32, "cp_conv_pack_head_weights_host: bad arguments");
+    // fragment-major like the halo weights: [k8 (4)][half (2)][q (32)][4] = Wh[c = k8*8 + half*4 + e][q]
+    for (int i = 0; i < 1024; ++i) dst[i] = 0.f;
+    for (int k8 = 0; k8 < 4; ++k8)
+        for (int half = 0; half < 2; ++half)
+            for (int q = 0; q < head_cout; ++q)
+                for (int e = 0; e < 4; ++e) dst[((k8 * 2 + half) * 32 + q) * 4 + e] = w[(k8 * 8 + half * 4 + e) * head_cout + q];
+    return CP_OK;
+}
+
 extern "C" int cp_conv_halo_weight_floats(int cout, int num_sources, const int* channels) {
     if (!channels || num_sources < 1 || num_sources > 2 || cout < 1 || cout > 64) return CP_ERR_INVALID;
     return cp::halo_weight_floats(cout, num_sources, channels);
@@ -570,7 +582,12 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
                "cp_conv2d_fwd_f32: out size %dx%d inconsistent with input %dx%d k%d s%d d%d p%d", d->out_h, d->out_w,
                d->in_h, d->in_w, d->kh, d->stride, d->dilation, d->pad);
     CP_REQUIRE(d->weights, "cp_conv2d_fwd_f32: null weights");
-    CP_REQUIRE(d->out_raw || d->out_act, "cp_conv2d_fwd_f32: no output requested");
+    CP_REQUIRE(d->out_raw || d->out_act || d->head_out, "cp_conv2d_fwd_f32: no output requested");
+    if (d->head_out) {
+        CP_REQUIRE(d->head_weights && d->head_cout >= 1 && d->head_cout <= 32 && d->head_out_ld >= d->head_cout && d->cout == 32,
+                   "cp_conv2d_fwd_f32: fused head needs head_weights, 1 <= head_cout <= 32 <= ... and cout == 32");
+        CP_REQUIRE(cp::halo_applicable(d) && (d->tile_hint == 0 || d->tile_hint == CP_TILE_HALO), "cp_conv2d_fwd_f32: the fused head is implemented by the halo-tile kernel only (3x3/s1/p1, weights_halo)");
+    }
     CP_REQUIRE(!d->tap_label || d->stride == 1, "cp_conv2d_fwd_f32: tap_label needs stride 1");
     CP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "cp_conv2d_fwd_f32: scale and shift come together");
     CP_REQUIRE(!d->epi_label || d->scale, "cp_conv2d_fwd_f32: epi_label needs a scale/shift table");

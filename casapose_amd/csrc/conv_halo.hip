@@ -51,6 +51,9 @@ struct HaloK {
     int raw_ld;
     float* out_act;
     int act_ld;
+    const float* head_w;   // fused 1x1 head [4][2][32][4] (cout == 32 only)
+    float* head_out;
+    int head_cout, head_ld;
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 if (has_img && fk < my_tiles) fill_img(ftile, fk & 1);  // image stage fk&1 was last read in tile fk-2
             }
             if (gc + 1 < total_chunks) fill(ftile, fc, (gc + 1) & 1);
+            if ((TN == 1) && p.head_out != nullptr && fc == 0) CP_BARRIER();  // chunk gc closes a tile: head-scratch barrier
             CP_BARRIER();
         }
         return;
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
         for (int j = 0; j < TN; ++j) fb[u][j] = ldw(u * STEP_BYTES, j);
 
     int gwc = 0;  // global wide-chunk counter
+    int hstage_last = 0;
     TilePos ctile = first;
     CP_BARRIER();  // prologue data is in LDS
     for (int k = 0; k < my_tiles; ++k) {
@@ -364,7 +369,8 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 if (u + 1 < 36) read_a(u + 1, (u + 1) & 1);
                 mfma4(u & 1, u & 3, u >> 2, u >> 2);
             }
-            if (!(last && has_img)) CP_BARRIER();  // halo stage consumed; the other stage is ready
+            hstage_last = gwc;
+            if (!last) CP_BARRIER();  // halo stage consumed; the other stage is ready (the tile's last barrier follows the epilogue)
         }
         // ---- image step: K = 9 taps x 4 channels (+4 zero) = 5 k8-steps; half-wave h handles tap 2s+h ----
         if (has_img) {
@@ -391,12 +397,13 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 fb[1][j] = fb[2][j];
                 fb[2][j] = fb[3][j];
             }
-            CP_BARRIER();
         }
         // ---- epilogue (epilogue.h) ------------------------------------------------------------
+        if ((TN == 1) && p.head_out != nullptr) CP_BARRIER();  // every wave is done with the halo stage that now becomes head scratch
         int cos[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) cos[j] = j * 32 + lrow;
+        const bool head = (TN == 1) && p.head_out != nullptr;
 #pragma unroll
         for (int i = 0; i < TMW; ++i) {
             const int y = y0 + wy * TMW + i;
@@ -409,13 +416,53 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 }
             }
             const int rowbase = (n * p.H + y) * p.Wd + x0 + hi4;
+            auto rowpix = [&](int r) { const int xr = (r & 3) + 8 * (r >> 2); return (y < p.H && x0 + hi4 + xr < p.Wd) ? rowbase + xr : -1; };
+            float keep[16][TN];
 #ifdef HX_NOEPI
             if (p.B < 0)  // timing experiment: never true, keeps the accumulators alive
 #endif
-            cp::epilogue_block<TN, (TN == 1) ? 8 : 4>(acc[i], cos, ea, er,
-                                   [&](int r) { const int xr = (r & 3) + 8 * (r >> 2); return (y < p.H && x0 + hi4 + xr < p.Wd) ? rowbase + xr : -1; },
-                                   PARTIAL ? rsp : nullptr);
+            cp::epilogue_block<TN, (TN == 1) ? 8 : 4>(acc[i], cos, ea, er, rowpix, PARTIAL ? rsp : nullptr, keep);
+            if constexpr (TN == 1) {
+                if (head) {
+                    // Fused 1x1 head: the activated 32(px) x 32(ch) tile goes through this wave's private corner of the halo
+                    // stage it has just finished reading (the stage is not refilled before the tile's closing barrier) to
+                    // become an MFMA A operand; B = head weights straight from L1/L2; 16 more MFMAs; store head_cout columns.
+                    float* scr = halo + (hstage_last & 1) * HP * AS + (wy * TMW + i) * 32 * AS;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + hi4) * AS + lrow] = keep[r][0];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    f32x16 a2;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+                    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 4096u, 0x00020000);
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) {
+                        const float4 av = *reinterpret_cast<const float4*>(scr + lrow * AS + k8 * 8 + khalf);
+                        const float4 bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsh, (int)(((k8 * 2 + half) * 32 + lrow) * 16), 0, 0));
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, a2, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, a2, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, a2, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, a2, 0, 0, 0);
+                    }
+                    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_out, 0, ea.npix * (unsigned)p.head_ld * 4u, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = rowpix(r);
+                        const bool ok = px >= 0 && lrow < p.head_cout;
+#if defined(HX_DBG_KEEP)
+                        a2[r] = keep[r][0];
+#elif defined(HX_DBG_SCR)
+                        a2[r] = scr[((r & 3) + 8 * (r >> 2) + hi4) * AS + lrow];
+#endif
+                        const float hv = a2[r];  // (bit_cast directly on a vector element reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), rso,
+                                                              (int)(ok ? ((unsigned)px * (unsigned)p.head_ld + (unsigned)lrow) * 4u : 0x80000000u), 0, 0);
+                    }
+                }
+            }
         }
+        CP_BARRIER();  // tile done: the consumed halo stage (and, above, its use as head scratch) may be refilled
     }
 }
 
@@ -553,6 +600,7 @@ int launch_halo_conv(const cp_conv_desc* d, hipStream_t st) {
     k.residual = d->residual; k.res_ld = d->residual_ld;
     k.scale = d->scale; k.shift = d->shift; k.clade = d->epi_label != nullptr; k.act = d->act;
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
+    k.head_w = d->head_out ? d->head_weights : nullptr; k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     const bool partial = d->tap_label != nullptr;
     const bool bil = d->src[0].mode == CP_SRC_BILINEAR_X2, sel = d->src[0].mode == CP_SRC_NEAREST_SEL;
     const int tn = d->cout <= 32 ? 1 : 2;

@@ -53,10 +53,11 @@ __device__ __forceinline__ EpiRsrc epi_make(const EpiArgs& e, const void* any_va
 // One 32x32 accumulator block per j (TN blocks side by side along channels).  `rowpix(r)` maps
 // accumulator row r (0..15 of this lane) to the output pixel index, or -1 if the row is outside
 // the tensor.  `co[j]` is this lane's output channel in block j.  `rs_pre[r]` is an extra per-row
-// factor computed by the caller (partial-conv 9/count) -- pass nullptr when unused.
+// factor computed by the caller (partial-conv 9/count) -- pass nullptr when unused.  `keep` receives the
+// activated values [16 rows][TN] of this lane (0 for rows/channels outside the tensor).
 template <int TN, int RB, typename RowPix>
 __device__ __forceinline__ void epilogue_block(const f32x16_t (&acc)[TN], const int (&co)[TN], const EpiArgs& e, const EpiRsrc& rr,
-                                               RowPix rowpix, const float* rs_pre) {
+                                               RowPix rowpix, const float* rs_pre, float (&keep)[16][TN]) {
     constexpr unsigned OOB = 0x80000000u;
     static_assert(16 % RB == 0, "rows per batch must divide 16");  // RB trades registers for memory round trips
     unsigned coff[TN];                       // OOB when this lane's channel does not exist
@@ -120,6 +121,7 @@ __device__ __forceinline__ void epilogue_block(const f32x16_t (&acc)[TN], const 
                 else if (e.act == CP_ACT_LEAKY01) t = fmaxf(t, 0.f) - fmaxf(-0.1f * t, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rr.actb,
                                                       (int)(ok ? (po * (unsigned)e.act_ld + coff[j]) * 4u : OOB), 0, 0);
+                keep[r0 + q][j] = ok ? t : 0.f;  // for a fused 1x1 head: the caller may multiply the activated tile again
             }
         }
     }

@@ -115,10 +115,23 @@ class FusedConv:
             self.wp_halo = torch.from_numpy(ph).to(device)
         self.desc = ConvDesc()
         self._keep: List[torch.Tensor] = []
+        self.head_w: Optional[torch.Tensor] = None
+        self.head_cout = 0
+
+    def attach_head(self, kernel_1x1: np.ndarray):
+        """Fuse a following 1x1 convolution (HWIO [1,1,32,q], no bias / activation) into this layer's epilogue."""
+        lib = _lib.load()
+        w = np.ascontiguousarray(kernel_1x1, dtype=np.float32).reshape(32, -1)
+        if self.cout != 32 or self.wp_halo is None or not (1 <= w.shape[1] <= 32):
+            raise ValueError("%s: a fused head needs a 3x3 halo-kernel layer with 32 output channels" % self.name)
+        packed = np.empty(1024, dtype=np.float32)
+        check(lib.cp_conv_pack_head_weights_host(w.ctypes.data, w.shape[1], packed.ctypes.data), "cp_conv_pack_head_weights_host")
+        self.head_w = torch.from_numpy(packed).to(self.wp.device)
+        self.head_cout = int(w.shape[1])
 
     def bind(self, *, batch, in_h, in_w, stride=1, dilation=1, pad=0, srcs, tap_label=None, row_scale=None,
              residual=None, scale=None, shift=None, epi_label=None, act=0, out_raw=None, out_raw_ld=None,
-             out_act=None, out_act_ld=None, tile_hint=0):
+             out_act=None, out_act_ld=None, tile_hint=0, head_out=None, head_out_ld=0):
         """srcs: list of dicts(data=tensor, ld=int, mode=int, sel=tensor|None, pre=(scale,shift)|None)."""
         d = self.desc
         eh = (self.kh - 1) * dilation + 1
@@ -155,6 +168,10 @@ class FusedConv:
         d.out_act = _ptr(out_act)
         d.out_act_ld = out_act_ld if out_act_ld is not None else self.cout
         d.tile_hint = tile_hint
+        d.head_weights = _ptr(self.head_w) if head_out is not None else None
+        d.head_out = _ptr(head_out)
+        d.head_cout = self.head_cout if head_out is not None else 0
+        d.head_out_ld = head_out_ld
         keep += [tap_label, row_scale, residual, scale, shift, epi_label, out_raw, out_act]
         self._keep = [k for k in keep if k is not None]
         return d.out_h, d.out_w
@@ -166,17 +183,19 @@ class FusedConv:
     def flops(self) -> float:
         d = self.desc
         cin = sum(s[1] for s in self.sources)
-        return 2.0 * d.batch * d.out_h * d.out_w * self.kh * self.kw * cin * self.cout
+        head = 2.0 * d.batch * d.out_h * d.out_w * 32 * d.head_cout if d.head_out else 0.0
+        return 2.0 * d.batch * d.out_h * d.out_w * self.kh * self.kw * cin * self.cout + head
 
 
 class ForwardPlan:
     """All buffers, descriptors and the launch order for one (batch, H, W) input shape."""
 
-    def __init__(self, net: "CasaposeNet", batch: int, h: int, w: int, fuse_upsample: bool = True):
+    def __init__(self, net: "CasaposeNet", batch: int, h: int, w: int, fuse_upsample: bool = True, fuse_heads: bool = True):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         self.net, self.batch, self.h, self.w = net, batch, h, w
         self.fuse_upsample = fuse_upsample
+        self.fuse_heads = fuse_heads and net.decoder_dims[4] == 32
         dev = net.device
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -198,7 +217,7 @@ class ForwardPlan:
         self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
         self.pnorm = [new(B, hs[l], ws[l]) for l in range(4)]
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
-        self._out_bound: List[Tuple[FusedConv, int]] = []  # convs writing into the per-call output
+        self._out_bound: List[Tuple[FusedConv, int, str]] = []  # (conv, channel offset, descriptor field) writing into the per-call output
         self._bufs: List[torch.Tensor] = []
 
         def conv(layer: FusedConv, **kw):
@@ -283,13 +302,21 @@ class ForwardPlan:
                         self._bufs.append(big)
                         src0 = big
                 srcs = [dict(data=src0, ld=prev_c, mode=mode), dict(data=skips[i][0], ld=skips[i][1])]
-            conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1],
-                 act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+            fused = self.fuse_heads and i == 4
+            if fused:  # blocks 5 + pv_final_conv_segmentation in one launch; the 32-channel tensor is never stored
+                L[name].attach_head(net.params["pv_final_conv_segmentation.kernel"])
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1], act=_lib.ACT_LEAKY01,
+                     head_out=self.img4, head_out_ld=self.out_ld)
+                self._out_bound.append((L[name], 0, "head_out"))
+            else:
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1],
+                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
             self._bufs.append(o)
             prev, prev_c = o, dims[i]
-        seg_head = L["pv_final_conv_segmentation"]
-        conv(seg_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
-        self._out_bound.append((seg_head, 0))
+        if not self.fuse_heads:
+            seg_head = L["pv_final_conv_segmentation"]
+            conv(seg_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
+            self._out_bound.append((seg_head, 0, "out_raw"))
 
         # ---- hard label map + pyramid (pose_models.py:547-559) -----------------------------
         self.seg_input_ptr = None  # set per call when the model has a data_segmentation input
@@ -328,14 +355,23 @@ class ForwardPlan:
                         self._bufs.append(big)
                         src0 = big
                 srcs = [dict(data=src0, ld=prev_c, mode=mode, sel=sel), dict(data=skips[i][0], ld=skips[i][1])]
-            conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
-                 scale=tab[0], shift=tab[1], epi_label=self.labels[l],
-                 act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+            fused = self.fuse_heads and i == 4
+            if fused:  # block 10 + pv_final_conv_vertex in one launch
+                L[name].attach_head(net.params["pv_final_conv_vertex.kernel"])
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
+                     scale=tab[0], shift=tab[1], epi_label=self.labels[l], act=_lib.ACT_LEAKY01, head_out=self.img4,
+                     head_out_ld=self.out_ld)
+                self._out_bound.append((L[name], K, "head_out"))
+            else:
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
+                     scale=tab[0], shift=tab[1], epi_label=self.labels[l],
+                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
             self._bufs.append(o)
             prev, prev_c = o, dims[i]
-        ver_head = L["pv_final_conv_vertex"]
-        conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
-        self._out_bound.append((ver_head, K))
+        if not self.fuse_heads:
+            ver_head = L["pv_final_conv_vertex"]
+            conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
+            self._out_bound.append((ver_head, K, "out_raw"))
 
     def _bilinear_step(self, src, dst, sh, sw, c):
         lib = _lib.load()
@@ -367,8 +403,8 @@ class ForwardPlan:
         if out is None:
             out = torch.empty(B, h, w, self.out_ld, dtype=torch.float32, device=img.device)
         self.out = out
-        for layer, off in self._out_bound:
-            layer.desc.out_raw = out.data_ptr() + 4 * off
+        for layer, off, field in self._out_bound:
+            setattr(layer.desc, field, out.data_ptr() + 4 * off)
         if seg_input is not None:
             if tuple(seg_input.shape) != (B, h, w, self.net.seg_dim) or seg_input.dtype != torch.float32 or not seg_input.is_contiguous():
                 raise ValueError("segmentation input must be a contiguous float32 [%d,%d,%d,%d] tensor" % (B, h, w, self.net.seg_dim))
@@ -391,7 +427,7 @@ class CasaposeNet:
     """Parameters + launch plans of casapose_c_gcu5 on one GPU."""
 
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
-                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True):
+                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -399,6 +435,7 @@ class CasaposeNet:
         self.seg_dim, self.ver_dim = seg_dim, ver_dim
         self.decoder_dims = tuple(decoder_dims)
         self.fuse_upsample = fuse_upsample
+        self.fuse_heads = fuse_heads
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self.set_params(params)
 
@@ -455,7 +492,7 @@ class CasaposeNet:
         if key not in self.plans:
             # descriptors live inside the FusedConv objects, so one plan is active at a time
             self.plans.clear()
-            self.plans[key] = ForwardPlan(self, batch, h, w, self.fuse_upsample)
+            self.plans[key] = ForwardPlan(self, batch, h, w, self.fuse_upsample, self.fuse_heads)
         return self.plans[key]
 
     def forward(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):

@@ -89,7 +89,7 @@ class Layer:
 class CasaposeModel:
     def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
-                 fuse_upsample: bool = True):
+                 fuse_upsample: bool = True, fuse_heads: bool = True):
         if output_lablemap:
             raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
         self.name = name
@@ -106,7 +106,7 @@ class CasaposeModel:
                           "no network here -- using he_uniform initialisation; call load_weights() for real weights")
             weights = None
         self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed)
-        self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample)
+        self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads)
         if isinstance(weights, str):
             self.load_weights(weights)
         self._layers = self._build_layers()

@@ -18,4 +18,4 @@ def CASAPoseConditional5(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim
     return CasaposeModel("casapose_c_gcu5", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
-                         fuse_upsample=kwargs.get("fuse_upsample", True))
+                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True))

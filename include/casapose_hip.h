@@ -109,6 +109,12 @@ typedef struct cp_conv_desc {
     float* out_act;             /* optional, pixel stride out_act_ld                          */
     int out_act_ld;
     int tile_hint;              /* 0 = auto; otherwise a CP_TILE_* value (benchmark / tests) */
+    /* optional fused 1x1 head (halo-tile kernel only, cout == 32): head_out[n,y,x,0..head_cout) = sum_c out_act[..,c] *
+     * Wh[c][q]; replaces pv_final_conv_segmentation / pv_final_conv_vertex (pose_models.py:546,616).  head_weights from
+     * cp_conv_pack_head_weights_host.  With a head, out_act/out_raw may both be NULL (the 32-channel tensor is not stored). */
+    const float* head_weights;
+    float* head_out;
+    int head_cout, head_out_ld;
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
@@ -127,6 +133,8 @@ int cp_conv_pack_weights_host(const float* w_host, int layout, int kh, int kw, i
 int cp_conv_halo_weight_floats(int cout, int num_sources, const int* channels);
 int cp_conv_pack_weights_halo_host(const float* w_host, int layout, int cout, int num_sources, const int* channels,
                                    const int* real_channels, float* dst_host);
+/* HOST: pack a [1][1][32][head_cout] (HWIO) 1x1 kernel for the fused head: 1024 floats */
+int cp_conv_pack_head_weights_host(const float* w_host, int head_cout, float* dst_host);
 int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);
 /* which CP_TILE_* instantiation cp_conv2d_fwd_f32 will launch for this descriptor (profiling aid) */
 int cp_conv_selected_tile(const cp_conv_desc* desc);

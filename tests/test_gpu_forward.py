@@ -31,7 +31,7 @@ def test_forward_with_given_mask(device, fuse):
     """Decoder 2 conditioned on a supplied one-hot mask (training default, config_8.ini:71;
     pose_models.py:550-554): every output value is compared."""
     b, h, w, k, v = 2, 64, 96, 5, 27
-    net, p64 = build(device, k, v, h, w, seg_input=True, fuse_upsample=fuse)
+    net, p64 = build(device, k, v, h, w, seg_input=True, fuse_upsample=fuse, fuse_heads=fuse)
     rng = np.random.default_rng(3)
     img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
     lab = np.zeros((b, h, w), np.int64)
