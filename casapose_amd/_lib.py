@@ -73,7 +73,7 @@ class ConvDesc(C.Structure):
     ]
 
 
-SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2 = 0, 1, 2
+SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO = range(8)
 
@@ -102,6 +102,21 @@ SYMBOLS = [
     ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
     ("cp_ransac_vote_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("cp_ransac_workspace_bytes", C.c_size_t, [_i, _i, _i, _i, _i, _i]),
+    # ---- training path ----
+    ("cp_conv2d_wgrad_f32", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
+    ("cp_bn_stats_f32", _i, [_vp, _ll, _i, _i, _vp, _vp]),
+    ("cp_affine_act_f32", _i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    ("cp_bn_act_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("cp_bn_act_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, _vp, _vp, _i, _i, _vp]),
+    ("cp_maxpool3x3s2_bwd_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    ("cp_upsample_bilinear_x2_bwd_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    ("cp_guided_upsample_x2_bwd_f32", _i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cp_gather_f32", _i, [_vp, _vp, _ll, _vp, _vp]),
+    ("cp_scatter_f32", _i, [_vp, _vp, _ll, _vp, _i, _vp]),
+    ("cp_axpby_f32", _i, [_vp, _f, _vp, _f, _ll, _vp, _vp]),
+    ("cp_adam_step_f32", _i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),
+    ("cp_pose_loss_workspace_bytes", C.c_size_t, [_i, _i, _i]),
+    ("cp_pose_loss_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
         }
     };
 
+    const bool zins = p.s[0].mode == CP_SRC_ZERO_INSERT_X2;
     auto issue_chunk = [&](int q) {
 #pragma unroll
         for (int j = 0; j < RN; ++j) breg[j] = ldb4(rsw, r_wof[j], q * (BK * 4));
@@ -277,7 +278,10 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
                 }
                 areg[i][0] = ldb4(rs, o, 0);
             } else {
-                areg[i][0] = ldb4(rs, inb ? (unsigned)((gpix * sld + coff) * 4) : OOB, 0);
+                unsigned o = inb ? (unsigned)((gpix * sld + coff) * 4) : OOB;
+                if (zins && si == 0)  // zero-insertion x2 (transposed convolution): only even positions carry data
+                    o = (inb && !((iy | ix) & 1)) ? (unsigned)(((r_nb[i] + (iy >> 1) * p.s[0].Ws + (ix >> 1)) * sld + coff) * 4) : OOB;
+                areg[i][0] = ldb4(rs, o, 0);
             }
         }
     };
@@ -602,7 +606,8 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
                    "cp_conv2d_fwd_f32: source %d channels must be 4 or a multiple of 32 (got %d)", s, in.channels);
         CP_REQUIRE(in.ld >= in.channels && in.ld % 4 == 0, "cp_conv2d_fwd_f32: source %d ld must be >= channels and a multiple of 4", s);
         CP_REQUIRE(((uintptr_t)in.data & 15) == 0, "cp_conv2d_fwd_f32: source %d not 16-byte aligned", s);
-        CP_REQUIRE(in.mode >= 0 && in.mode <= 2, "cp_conv2d_fwd_f32: source %d bad mode", s);
+        CP_REQUIRE(in.mode >= 0 && in.mode <= 3, "cp_conv2d_fwd_f32: source %d bad mode", s);
+        CP_REQUIRE(in.mode != CP_SRC_ZERO_INSERT_X2 || (s == 0 && !in.pre_scale && !d->tap_label), "cp_conv2d_fwd_f32: zero-insertion applies to source 0 only, without pre-affine / tap mask");
         CP_REQUIRE(in.mode != CP_SRC_NEAREST_SEL || in.sel, "cp_conv2d_fwd_f32: source %d needs a sel map", s);
         CP_REQUIRE(in.mode == CP_SRC_DIRECT || (d->in_h % 2 == 0 && d->in_w % 2 == 0),
                    "cp_conv2d_fwd_f32: x2 source modes need even in_h/in_w");

@@ -1,0 +1,451 @@
+// Streaming kernels of the TRAINING path: batch-norm statistics, normalise + activate, their
+// backward, the adjoint of the resampling layers, weight re-packing and Adam.
+//
+// Reference call sites: (Sync)BatchNormalization with training=True (resnet.py:78,100,247,250,303;
+// casapose.py:77; _normalization_layers.py:108 -- batch statistics over (N,H,W), biased variance,
+// SURVEY B5), ClassAdaptiveWeightedNormalization.calc (_normalization_layers.py:119-139), ReLU and the
+// leaky pair (casapose.py:98-107), MaxPooling2D / UpSampling2D(bilinear) / GuidedUpsampling gradients
+// (the reference gets them from tf.GradientTape, train_casapose.py:594), Keras Adam
+// (train_casapose.py:334-347, eps 1e-7).  All of them are HBM-bound: 16 B per lane per access,
+// grid-stride over a capped grid, fp64 accumulation for the statistics.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+inline int grid_for(long long n) {
+    long long b = (n + THREADS - 1) / THREADS;
+    return (int)(b < 1 ? 1 : (b > 256 * 8 ? 256 * 8 : b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics: sums[c] += sum x, sums[C + c] += sum x^2
+// A block walks rows (pixels) with stride gridDim; thread t owns channel group (t % C4) and row lane
+// (t / C4): per-thread fp32 partials over <= 64 rows, then fp64, LDS reduce, one fp64 atomic per value.
+__global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restrict__ x, long long pixels, int C, int ld,
+                                                           double* __restrict__ sums) {
+    extern __shared__ double sred[];  // [2][C]
+    const int c4n = C >> 2;
+    const int lanes_per_row = c4n;              // threads covering one pixel
+    const int rows_per_pass = THREADS / lanes_per_row;  // C <= 1024
+    const int c4 = threadIdx.x % lanes_per_row;
+    const int rl = threadIdx.x / lanes_per_row;
+    for (int i = threadIdx.x; i < 2 * C; i += THREADS) sred[i] = 0.0;
+    __syncthreads();
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < rows_per_pass) {
+        for (long long r0 = (long long)blockIdx.x * rows_per_pass; r0 < pixels; r0 += (long long)gridDim.x * rows_per_pass) {
+            const long long r = r0 + rl;
+            if (r < pixels) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c4 * 4);
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+                q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sred[c4 * 4 + e], s[e]);
+            atomicAdd(&sred[C + c4 * 4 + e], q[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += THREADS) atomicAdd(&sums[i], sred[i]);
+}
+
+__device__ __forceinline__ float act_fwd(float t, int act) {
+    if (act == CP_ACT_RELU) return fmaxf(t, 0.f);
+    if (act == CP_ACT_LEAKY01) return fmaxf(t, 0.f) - fmaxf(-0.1f * t, 0.f);
+    return t;
+}
+__device__ __forceinline__ float act_grad(float t, int act) {  // derivative wrt the pre-activation t
+    if (act == CP_ACT_RELU) return t > 0.f ? 1.f : 0.f;
+    if (act == CP_ACT_LEAKY01) return t > 0.f ? 1.f : (t < 0.f ? 0.1f : 0.f);
+    return 1.f;
+}
+
+// y = act(x*scale[l][c] + shift[l][c]) (+ add), l = labels ? labels[pixel] : 0
+__global__ void affine_act_kernel(const float* __restrict__ x, long long pixels, int C, int ld_x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const uint8_t* __restrict__ labels, int act,
+                                  float* __restrict__ y, int ld_y) {
+    const int c4n = C >> 2;
+    const long long total = pixels * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long long r = i / c4n;
+        const int l = labels ? labels[r] : 0;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
+        const float4 s = *reinterpret_cast<const float4*>(scale + (size_t)l * C + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(shift + (size_t)l * C + c4 * 4);
+        float4 o;
+        o.x = act_fwd(v.x * s.x + b.x, act); o.y = act_fwd(v.y * s.y + b.y, act);
+        o.z = act_fwd(v.z * s.z + b.z, act); o.w = act_fwd(v.w * s.w + b.w, act);
+        *reinterpret_cast<float4*>(y + r * ld_y + c4 * 4) = o;
+    }
+}
+
+// backward of y = act(t), t = gamma[l][c]*xhat + beta[l][c], xhat = (x - mean[c]) * rstd[c]
+// reduce pass: red[(l*C + c)*2 + {0,1}] += {g, g*xhat} (g = dy*act'(t))   -> dbeta[l][c], dgamma[l][c]
+//              chan[c*2 + {0,1}]       += {g*gamma, g*gamma*xhat}           -> the two means of the BN backward
+__global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
+                                                                    long long pixels, int C, int classes, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const uint8_t* __restrict__ labels,
+                                                                    int act, double* __restrict__ red, double* __restrict__ chan) {
+    extern __shared__ double sred[];  // [classes*C*2] + [C*2]
+    const int nred = classes * C * 2, nch = C * 2;
+    for (int i = threadIdx.x; i < nred + nch; i += THREADS) sred[i] = 0.0;
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int rows_per_pass = THREADS / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    if (rl < rows_per_pass) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + c4 * 4);
+        int cur = -1;
+        double a[4][4];  // per channel: g, g*xhat, g*gamma, g*gamma*xhat for the current label
+        float4 gm = make_float4(1, 1, 1, 1), bt = make_float4(0, 0, 0, 0);
+        auto flush = [&]() {
+            if (cur < 0) return;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c4 * 4 + e;
+                atomicAdd(&sred[((size_t)cur * C + c) * 2 + 0], a[e][0]);
+                atomicAdd(&sred[((size_t)cur * C + c) * 2 + 1], a[e][1]);
+                atomicAdd(&sred[nred + c * 2 + 0], a[e][2]);
+                atomicAdd(&sred[nred + c * 2 + 1], a[e][3]);
+            }
+        };
+        for (long long r0 = (long long)blockIdx.x * rows_per_pass; r0 < pixels; r0 += (long long)gridDim.x * rows_per_pass) {
+            const long long r = r0 + rl;
+            if (r >= pixels) continue;
+            const int l = labels ? labels[r] : 0;
+            if (l != cur) {
+                flush();
+                cur = l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e][0] = a[e][1] = a[e][2] = a[e][3] = 0.0;
+                gm = gamma ? *reinterpret_cast<const float4*>(gamma + (size_t)l * C + c4 * 4) : make_float4(1, 1, 1, 1);
+                bt = beta ? *reinterpret_cast<const float4*>(beta + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
+            const float4 dv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c4 * 4);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
+            const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xs[e] - mus[e]) * rss[e];
+                const float g = ds[e] * act_grad(gms[e] * xh + bts[e], act);
+                a[e][0] += g;
+                a[e][1] += (double)g * xh;
+                a[e][2] += (double)g * gms[e];
+                a[e][3] += (double)g * gms[e] * xh;
+            }
+        }
+        flush();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nred; i += THREADS)
+        if (sred[i] != 0.0) atomicAdd(&red[i], sred[i]);
+    for (int i = threadIdx.x; i < nch; i += THREADS)
+        if (sred[nred + i] != 0.0) atomicAdd(&chan[i], sred[nred + i]);
+}
+
+// apply pass: dx = rstd * (g*gamma - m1[c] - xhat*m2[c]), m1 = chan[c][0]/N, m2 = chan[c][1]/N  (N = GLOBAL pixel count)
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy, long long pixels, int C,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const uint8_t* __restrict__ labels, int act,
+                                        const double* __restrict__ chan, double inv_n, const float* __restrict__ row_scale,
+                                        float* __restrict__ dx, int ld_dx, int accumulate) {
+    const int c4n = C >> 2;
+    const long long total = pixels * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long long r = i / c4n;
+        const int l = labels ? labels[r] : 0;
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c4 * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + c4 * 4);
+        const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + (size_t)l * C + c4 * 4) : make_float4(1, 1, 1, 1);
+        const float4 bt = beta ? *reinterpret_cast<const float4*>(beta + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+        float o[4];
+        const float rsc = row_scale ? row_scale[r] : 1.f;  // partial convolution: the normalised tensor was rowscale * conv
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - mus[e]) * rss[e];
+            const float g = ds[e] * act_grad(gms[e] * xh + bts[e], act) * gms[e];
+            const float m1 = (float)(chan[(c4 * 4 + e) * 2 + 0] * inv_n), m2 = (float)(chan[(c4 * 4 + e) * 2 + 1] * inv_n);
+            o[e] = rss[e] * (g - m1 - xh * m2) * rsc;
+        }
+        float4* dst = reinterpret_cast<float4*>(dx + r * ld_dx + c4 * 4);
+        if (accumulate) { const float4 old = *dst; o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoints of the resampling layers (gather form: no atomics, deterministic)
+// max-pool 3x3/s2 zero-pad-1: dx(iy,ix) = sum over the <=4 windows containing it where x(iy,ix) is the
+// window's FIRST maximum in raster order (the tie rule of the forward arg-max; post-ReLU inputs: the zero
+// padding can tie with zeros, in which case the padded tap wins only if it comes first)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
+                                   float* __restrict__ dx, int accumulate) {
+    const int c4n = C >> 2;
+    const long long total = (long long)B * H * W * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long pix = i / c4n;
+        const int ix = (int)(pix % W);
+        long long t = pix / W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)pix * C + c4 * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4] = {0, 0, 0, 0};
+        for (int oy = (iy + 1) / 2 - 1; oy <= (iy + 1) / 2; ++oy) {
+            if (oy < 0 || oy >= Ho || iy < 2 * oy - 1 || iy > 2 * oy + 1) continue;
+            for (int ox = (ix + 1) / 2 - 1; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo || ix < 2 * ox - 1 || ix > 2 * ox + 1) continue;
+                // arg-max of window (oy,ox) per channel
+                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bidx[4] = {-1, -1, -1, -1};
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = 2 * oy - 1 + ky, xx = 2 * ox - 1 + kx;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                            v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + yy) * W + xx) * C + c4 * 4);
+                        const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (vs[e] > best[e]) { best[e] = vs[e]; bidx[e] = ky * 3 + kx; }
+                    }
+                const int mine = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+                const float4 g = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4);
+                const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (bidx[e] == mine && xs[e] == best[e]) o[e] += gs[e];
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(dx + (size_t)pix * C + c4 * 4);
+        if (accumulate) { const float4 old = *dst; o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// bilinear x2 (half-pixel centres): dx(y,x) = sum of dy over the <=16 hi-res pixels that sample (y,x)
+__global__ void bilinear_x2_bwd_kernel(const float* __restrict__ dy, int ld_dy, int B, int H, int W, int C, float* __restrict__ dx) {
+    const int c4n = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)B * H * W * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long pix = i / c4n;
+        const int x = (int)(pix % W);
+        long long t = pix / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float o[4] = {0, 0, 0, 0};
+        for (int oy = 2 * y - 2; oy <= 2 * y + 3; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            int y0 = (oy >> 1) - ((oy & 1) ? 0 : 1);
+            const float fy = (oy & 1) ? 0.25f : 0.75f;
+            const int y1 = min(y0 + 1, H - 1);
+            y0 = max(y0, 0);
+            const float wy = (y0 == y ? 1.f - fy : 0.f) + (y1 == y ? fy : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 2 * x - 2; ox <= 2 * x + 3; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                int x0 = (ox >> 1) - ((ox & 1) ? 0 : 1);
+                const float fx = (ox & 1) ? 0.25f : 0.75f;
+                const int x1 = min(x0 + 1, W - 1);
+                x0 = max(x0, 0);
+                const float wx = (x0 == x ? 1.f - fx : 0.f) + (x1 == x ? fx : 0.f);
+                if (wx == 0.f) continue;
+                const float4 g = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * ld_dy + c4 * 4);
+                const float ww = wy * wx;
+                o[0] += ww * g.x; o[1] += ww * g.y; o[2] += ww * g.z; o[3] += ww * g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)pix * C + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// guided nearest x2: dx(y,x) = sum of dy over the hi-res pixels whose selection points at (y,x):
+// candidates live in the low-res cells (y,x) [sel 0], (y,x-1) [sel 1], (y-1,x) [sel 2], (y-1,x-1) [sel 3]
+__global__ void guided_x2_bwd_kernel(const float* __restrict__ dy, int ld_dy, const uint8_t* __restrict__ sel, int B, int H, int W, int C,
+                                     float* __restrict__ dx) {
+    const int c4n = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)B * H * W * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long pix = i / c4n;
+        const int x = (int)(pix % W);
+        long long t = pix / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cy = y - (s >> 1), cx = x - (s & 1);  // low-res cell whose sub-pixels may select (y,x) with index s
+            if (cy < 0 || cx < 0) continue;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int oy = 2 * cy + (sub >> 1), ox = 2 * cx + (sub & 1);
+                const size_t hp = ((size_t)n * Ho + oy) * Wo + ox;
+                if (sel[hp] == s) {
+                    const float4 g = *reinterpret_cast<const float4*>(dy + hp * ld_dy + c4 * 4);
+                    o[0] += g.x; o[1] += g.y; o[2] += g.z; o[3] += g.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)pix * C + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0            (re-pack master weights into a kernel layout)
+__global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long n, float* __restrict__ dst) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        dst[i] = j >= 0 ? src[j] : 0.f;
+    }
+}
+// dst[idx[i]] (+)= src[i] for idx[i] >= 0              (packed weight gradient -> master layout; idx is injective)
+__global__ void scatter_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long n, float* __restrict__ dst, int accumulate) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        if (j >= 0) dst[j] = accumulate ? dst[j] + src[i] : src[i];
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b, float beta, long long n, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// Keras Adam (tf.keras.optimizers.Adam, eps 1e-7): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t * m / (sqrt(v) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float lr_t, float b1, float b2, float eps, float grad_scale) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_bn_stats_f32(const float* x, long long pixels, int channels, int ld, double* sums, void* stream) {
+    CP_REQUIRE(x && sums && pixels > 0, "cp_bn_stats_f32: bad arguments");
+    CP_REQUIRE(channels % 4 == 0 && channels >= 4 && channels <= 1024 && ld >= channels && ld % 4 == 0, "cp_bn_stats_f32: channels must be a multiple of 4 (<= 1024), ld >= channels");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, st) != hipSuccess) return cp::check_launch("cp_bn_stats_f32 memset");
+    const int rows_per_pass = THREADS / (channels / 4);
+    long long blocks = (pixels + rows_per_pass * 16 - 1) / (rows_per_pass * 16);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    CP_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(THREADS), sizeof(double) * 2 * channels, st, x, pixels, channels, ld, sums);
+    return cp::check_launch("cp_bn_stats_f32");
+}
+
+extern "C" int cp_affine_act_f32(const float* x, long long pixels, int channels, int ld_x, const float* scale, const float* shift,
+                                 const uint8_t* labels, int act, float* y, int ld_y, void* stream) {
+    CP_REQUIRE(x && y && scale && shift && pixels > 0 && channels % 4 == 0 && ld_x >= channels && ld_y >= channels, "cp_affine_act_f32: bad arguments");
+    CP_LAUNCH(affine_act_kernel, dim3(grid_for(pixels * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, pixels, channels, ld_x, scale,
+              shift, labels, act, y, ld_y);
+    return cp::check_launch("cp_affine_act_f32");
+}
+
+extern "C" int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, int classes,
+                                        const float* mean, const float* rstd, const float* gamma, const float* beta, const uint8_t* labels,
+                                        int act, double* red, double* chan, void* stream) {
+    CP_REQUIRE(x && dy && mean && rstd && red && chan && pixels > 0, "cp_bn_act_bwd_reduce_f32: null pointer");
+    CP_REQUIRE(channels % 4 == 0 && channels <= 1024 && classes >= 1 && classes <= 64, "cp_bn_act_bwd_reduce_f32: channels %% 4, classes <= 64");
+    CP_REQUIRE(classes == 1 || labels, "cp_bn_act_bwd_reduce_f32: class-adaptive form needs labels");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nred = (size_t)classes * channels * 2, nch = (size_t)channels * 2;
+    const size_t lds = (nred + nch) * sizeof(double);
+    CP_REQUIRE(lds <= 150 * 1024, "cp_bn_act_bwd_reduce_f32: classes*channels too large for the LDS reduction (%zu bytes)", lds);
+    if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+    if (hipMemsetAsync(chan, 0, nch * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr = true;
+    }
+    const int rows_per_pass = THREADS / (channels / 4);
+    long long blocks = (pixels + rows_per_pass * 32 - 1) / (rows_per_pass * 32);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    CP_LAUNCH(bn_act_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, x, ld_x, dy, ld_dy, pixels, channels, classes, mean, rstd,
+              gamma, beta, labels, act, red, chan);
+    return cp::check_launch("cp_bn_act_bwd_reduce_f32");
+}
+
+extern "C" int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, const uint8_t* labels, int act,
+                                       const double* chan, double global_pixels, const float* row_scale, float* dx, int ld_dx, int accumulate, void* stream) {
+    CP_REQUIRE(x && dy && mean && rstd && chan && dx && pixels > 0 && channels % 4 == 0 && global_pixels > 0, "cp_bn_act_bwd_apply_f32: bad arguments");
+    CP_LAUNCH(bn_act_bwd_apply_kernel, dim3(grid_for(pixels * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, ld_x, dy, ld_dy, pixels,
+              channels, mean, rstd, gamma, beta, labels, act, chan, 1.0 / global_pixels, row_scale, dx, ld_dx, accumulate);
+    return cp::check_launch("cp_bn_act_bwd_apply_f32");
+}
+
+extern "C" int cp_maxpool3x3s2_bwd_f32(const float* x, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate, void* stream) {
+    CP_REQUIRE(x && dy && dx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0, "cp_maxpool3x3s2_bwd_f32: bad arguments");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    CP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long long)batch * h * w * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, dy, batch, h, w,
+              channels, ho, wo, dx, accumulate);
+    return cp::check_launch("cp_maxpool3x3s2_bwd_f32");
+}
+
+extern "C" int cp_upsample_bilinear_x2_bwd_f32(const float* dy, int ld_dy, int batch, int h, int w, int channels, float* dx, void* stream) {
+    CP_REQUIRE(dy && dx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0 && ld_dy >= channels, "cp_upsample_bilinear_x2_bwd_f32: bad arguments");
+    CP_LAUNCH(bilinear_x2_bwd_kernel, dim3(grid_for((long long)batch * h * w * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, dy, ld_dy, batch,
+              h, w, channels, dx);
+    return cp::check_launch("cp_upsample_bilinear_x2_bwd_f32");
+}
+
+extern "C" int cp_guided_upsample_x2_bwd_f32(const float* dy, int ld_dy, const uint8_t* sel, int batch, int h, int w, int channels, float* dx,
+                                             void* stream) {
+    CP_REQUIRE(dy && sel && dx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0 && ld_dy >= channels, "cp_guided_upsample_x2_bwd_f32: bad arguments");
+    CP_LAUNCH(guided_x2_bwd_kernel, dim3(grid_for((long long)batch * h * w * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, dy, ld_dy, sel,
+              batch, h, w, channels, dx);
+    return cp::check_launch("cp_guided_upsample_x2_bwd_f32");
+}
+
+extern "C" int cp_gather_f32(const float* src, const int32_t* idx, long long n, float* dst, void* stream) {
+    CP_REQUIRE(src && idx && dst && n > 0, "cp_gather_f32: bad arguments");
+    CP_LAUNCH(gather_kernel, dim3(grid_for(n)), dim3(THREADS), 0, (hipStream_t)stream, src, idx, n, dst);
+    return cp::check_launch("cp_gather_f32");
+}
+
+extern "C" int cp_scatter_f32(const float* src, const int32_t* idx, long long n, float* dst, int accumulate, void* stream) {
+    CP_REQUIRE(src && idx && dst && n > 0, "cp_scatter_f32: bad arguments");
+    CP_LAUNCH(scatter_kernel, dim3(grid_for(n)), dim3(THREADS), 0, (hipStream_t)stream, src, idx, n, dst, accumulate);
+    return cp::check_launch("cp_scatter_f32");
+}
+
+extern "C" int cp_axpby_f32(const float* a, float alpha, const float* b, float beta, long long n, float* out, void* stream) {
+    CP_REQUIRE(a && out && n > 0, "cp_axpby_f32: bad arguments");
+    CP_LAUNCH(axpby_kernel, dim3(grid_for(n)), dim3(THREADS), 0, (hipStream_t)stream, a, alpha, b, beta, n, out);
+    return cp::check_launch("cp_axpby_f32");
+}
+
+extern "C" int cp_adam_step_f32(float* params, const float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                int step, float grad_scale, void* stream) {
+    CP_REQUIRE(params && grads && m && v && n > 0 && step >= 1, "cp_adam_step_f32: bad arguments");
+    const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
+    const float lr_t = (float)(lr * sqrt(c2) / c1);
+    CP_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(THREADS), 0, (hipStream_t)stream, params, grads, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    return cp::check_launch("cp_adam_step_f32");
+}

@@ -1,0 +1,678 @@
+"""Training step of casapose_c_gcu5 on MI355X: forward with batch statistics, losses, hand-written
+backward, Adam -- the path of train_casapose.py:494-611 (runnetwork/train_step) -- issued as a static
+launch plan over libcasapose_hip.so.
+
+Design
+  * one flat fp32 MASTER parameter buffer (Keras layout per variable, names of SURVEY Appendix A) with a
+    flat gradient and the two Adam moments beside it: one Adam launch and one all-reduce per step;
+  * every kernel layout of a convolution (forward K order, halo fragment order, the flipped/transposed
+    data-gradient packs) is a device GATHER of the master buffer through an index map built once by pushing
+    an index ramp through the same host packers the inference engine uses; the packed weight gradient of
+    cp_conv2d_wgrad_f32 goes back through the same map (scatter);
+  * the plan is a tape: a list of ops with forward()/backward(); tensors with several consumers
+    accumulate gradients in place (first writer overwrites, later writers add -- for convolution
+    data-gradients through the kernel's fused residual input);
+  * SyncBatchNormalization: the fp64 sum tables of cp_bn_stats_f32 / cp_bn_act_bwd_reduce_f32 are
+    all-reduced across replicas when a process group is given (parallel.py), nothing else is exchanged in
+    the forward/backward; the flat gradient is SUM-all-reduced before Adam (MirroredStrategy semantics,
+    train_casapose.py:641-643).
+
+The decoder-2 conditioning is the hard label map (arg-max of the logits or, with
+train_vectors_with_ground_truth, the ground-truth segmentation: train_casapose.py:522-524) and is a constant
+of the gradient, exactly like the saturated softmax of the reference (pose_models.py:547-552) whose
+derivative vanishes in fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+from .engine import BN_EPS, DECODER_DIMS_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
+
+BN_MOMENTUM = 0.99  # resnet.py:43 (Keras default elsewhere)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters
+# ------------------------------------------------------------------------------------------------
+class ParamStore:
+    """Flat master parameters / gradients / Adam moments with named views."""
+
+    def __init__(self, params: Dict[str, np.ndarray], device: torch.device):
+        self.device = device
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.state: Dict[str, torch.Tensor] = {}  # non-trainable: moving statistics
+        chunks, off = [], 0
+        for name, v in params.items():
+            a = np.asarray(v, dtype=np.float32)
+            if name.endswith(".moving_mean") or name.endswith(".moving_variance"):
+                self.state[name] = torch.from_numpy(a.copy()).to(device)
+                continue
+            n = a.size
+            self.offsets[name] = (off, tuple(a.shape))
+            chunks.append(a.reshape(-1))
+            pad = (-n) % 4  # keep every variable 16-byte aligned
+            if pad:
+                chunks.append(np.zeros(pad, np.float32))
+            off += n + pad
+        self.size = off
+        self.theta = torch.from_numpy(np.concatenate(chunks)).to(device)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.step_count = 0
+
+    def view(self, name: str, of: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shape = self.offsets[name]
+        n = int(np.prod(shape))
+        return (self.theta if of is None else of)[off:off + n].view(shape)
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        return self.view(name, self.grad)
+
+    def export(self) -> Dict[str, np.ndarray]:
+        out = {k: self.view(k).detach().cpu().numpy().copy() for k in self.offsets}
+        out.update({k: v.detach().cpu().numpy().copy() for k, v in self.state.items()})
+        return out
+
+    def adam_step(self, lr: float, stream: int, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        self.step_count += 1
+        check(_lib.load().cp_adam_step_f32(self.theta.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.size,
+                                           lr, beta1, beta2, eps, self.step_count, grad_scale, stream), "cp_adam_step_f32")
+
+
+class TT:
+    """Activation tensor [B,H,W,C] (contiguous) with an optional gradient buffer."""
+
+    __slots__ = ("data", "grad", "has_grad", "needs_grad", "name")
+
+    def __init__(self, data: torch.Tensor, needs_grad: bool = True, name: str = ""):
+        self.data = data
+        self.needs_grad = needs_grad
+        self.grad = torch.empty_like(data) if needs_grad else None
+        self.has_grad = False
+        self.name = name
+
+    @property
+    def c(self):
+        return self.data.shape[-1]
+
+    @property
+    def pixels(self):
+        return self.data.numel() // self.data.shape[-1]
+
+
+def _index_map(pack: Callable[[np.ndarray, np.ndarray], None], ramp_hwio: np.ndarray, n_out: int) -> np.ndarray:
+    """Run a host packer over (index+1) stored as fp32 and recover the int32 gather map (-1 = zero fill)."""
+    assert ramp_hwio.max() < (1 << 24)
+    src = np.ascontiguousarray(ramp_hwio + 1, dtype=np.float32)
+    dst = np.empty(n_out, dtype=np.float32)
+    pack(src, dst)
+    return (dst.astype(np.int64) - 1).astype(np.int32)
+
+
+class TrainConv:
+    """One convolution layer of the training plan: packs, descriptors, forward / wgrad / dgrad launches."""
+
+    def __init__(self, store: ParamStore, key: str, layout: int, k: int, cout: int, sources: Sequence[Tuple[int, int]],
+                 grad_sources: Sequence[bool]):
+        lib = _lib.load()
+        dev = store.device
+        self.store, self.key, self.k, self.cout = store, key, k, cout
+        self.sources = list(sources)
+        self.name = key.rsplit(".", 1)[0]
+        off, shape = store.offsets[key]
+        n = int(np.prod(shape))
+        self.master = store.theta[off:off + n]
+        self.master_grad = store.grad[off:off + n]
+        ramp = np.arange(n, dtype=np.int64).reshape(shape)
+        hwio = ramp if layout == 0 else ramp.transpose(1, 2, 0, 3)  # [kh,kw,cin,cout] view of the master indices
+        ns = len(sources)
+        chans = (C.c_int * 2)(*([s[0] for s in sources] + [0] * (2 - ns)))
+        real = (C.c_int * 2)(*([s[1] for s in sources] + [0] * (2 - ns)))
+        self.ktot = lib.cp_conv_ktot(k, k, ns, chans)
+
+        def pack_fwd(src, dst):
+            check(lib.cp_conv_pack_weights_host(src.ctypes.data, 0, k, k, cout, ns, chans, real, dst.ctypes.data), "pack " + key)
+
+        self.idx_fwd = torch.from_numpy(_index_map(pack_fwd, hwio, cout * self.ktot)).to(dev)
+        self.wp = torch.empty(cout * self.ktot, dtype=torch.float32, device=dev)
+        self.dwp = torch.empty(cout * self.ktot, dtype=torch.float32, device=dev)
+        self.idx_halo = self.wp_halo = None
+        if k == 3 and cout <= 64 and sources[0][0] % 32 == 0 and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 32 == 0):
+            nfl = lib.cp_conv_halo_weight_floats(cout, ns, chans)
+
+            def pack_halo(src, dst):
+                check(lib.cp_conv_pack_weights_halo_host(src.ctypes.data, 0, cout, ns, chans, real, dst.ctypes.data), "pack halo " + key)
+
+            self.idx_halo = torch.from_numpy(_index_map(pack_halo, hwio, nfl)).to(dev)
+            self.wp_halo = torch.empty(nfl, dtype=torch.float32, device=dev)
+        # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
+        self.dgrad: List[Optional[dict]] = []
+        cpad = (cout + 31) // 32 * 32
+        c0 = 0
+        for s, (cs, cr) in enumerate(sources):
+            if not grad_sources[s]:
+                self.dgrad.append(None)
+                c0 += cr
+                continue
+            sub = hwio[::-1, ::-1, c0:c0 + cr, :].transpose(0, 1, 3, 2)  # [kh,kw,cout,cr]: taps flipped, in/out swapped
+            dch = (C.c_int * 2)(cpad, 0)
+            dre = (C.c_int * 2)(cout, 0)
+            kt = lib.cp_conv_ktot(k, k, 1, dch)
+
+            def pack_d(src, dst, dch=dch, dre=dre, cr=cr):
+                check(lib.cp_conv_pack_weights_host(src.ctypes.data, 0, k, k, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad " + key)
+
+            ent = dict(idx=torch.from_numpy(_index_map(pack_d, np.ascontiguousarray(sub), cr * kt)).to(dev),
+                       w=torch.empty(cr * kt, dtype=torch.float32, device=dev), cout=cr, cin=cpad, idx_halo=None, w_halo=None,
+                       desc=ConvDesc())
+            if k == 3 and cr <= 64:
+                nfl = lib.cp_conv_halo_weight_floats(cr, 1, dch)
+
+                def pack_dh(src, dst, dch=dch, dre=dre, cr=cr):
+                    check(lib.cp_conv_pack_weights_halo_host(src.ctypes.data, 0, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad halo " + key)
+
+                ent["idx_halo"] = torch.from_numpy(_index_map(pack_dh, np.ascontiguousarray(sub), nfl)).to(dev)
+                ent["w_halo"] = torch.empty(nfl, dtype=torch.float32, device=dev)
+            self.dgrad.append(ent)
+            c0 += cr
+        self.desc = ConvDesc()
+        self._keep: List = []
+
+    def refresh(self, stream: int):
+        """Re-pack the kernel layouts from the master weights (after an optimizer step / at start)."""
+        lib = _lib.load()
+        m = self.master.data_ptr()
+        check(lib.cp_gather_f32(m, self.idx_fwd.data_ptr(), self.idx_fwd.numel(), self.wp.data_ptr(), stream), "cp_gather_f32")
+        if self.idx_halo is not None:
+            check(lib.cp_gather_f32(m, self.idx_halo.data_ptr(), self.idx_halo.numel(), self.wp_halo.data_ptr(), stream), "cp_gather_f32")
+        for ent in self.dgrad:
+            if ent is None:
+                continue
+            check(lib.cp_gather_f32(m, ent["idx"].data_ptr(), ent["idx"].numel(), ent["w"].data_ptr(), stream), "cp_gather_f32")
+            if ent["idx_halo"] is not None:
+                check(lib.cp_gather_f32(m, ent["idx_halo"].data_ptr(), ent["idx_halo"].numel(), ent["w_halo"].data_ptr(), stream), "cp_gather_f32")
+
+
+class ConvOp:
+    """raw = conv(sources) [* row_scale] [+ residual]; backward: wgrad + per-source dgrad."""
+
+    def __init__(self, layer: TrainConv, srcs: Sequence[Tuple[TT, int]], out_ptr_ld: Tuple[torch.Tensor, int, int], batch: int, in_h: int,
+                 in_w: int, stride=1, dilation=1, pad=0, tap_label=None, row_scale=None, residual: Optional[TT] = None,
+                 out: Optional[TT] = None, dy_ptr_ld: Optional[Tuple[torch.Tensor, int, int]] = None):
+        """srcs: (tensor, ld).  out_ptr_ld = (storage tensor, float offset, ld) of the raw output.  dy_ptr_ld: where the
+        gradient of the output lives (default: out.grad)."""
+        self.layer, self.srcs, self.out, self.residual = layer, list(srcs), out, residual
+        self.tap_label, self.row_scale = tap_label, row_scale
+        self.stride, self.dil, self.pad = stride, dilation, pad
+        self.batch, self.in_h, self.in_w = batch, in_h, in_w
+        k = layer.k
+        eff = (k - 1) * dilation + 1
+        self.out_h = (in_h + 2 * pad - eff) // stride + 1
+        self.out_w = (in_w + 2 * pad - eff) // stride + 1
+        d = layer.desc
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w = batch, in_h, in_w, self.out_h, self.out_w
+        d.cout, d.kh, d.kw, d.stride, d.dilation, d.pad = layer.cout, k, k, stride, dilation, pad
+        d.num_sources = len(srcs)
+        for i, (t, ld) in enumerate(srcs):
+            cs = d.src[i]
+            cs.data, cs.channels, cs.ld, cs.mode = t.data.data_ptr(), layer.sources[i][0], ld, _lib.SRC_DIRECT
+            cs.sel = cs.pre_scale = cs.pre_shift = None
+        d.weights = layer.wp.data_ptr()
+        d.weights_halo = _ptr(layer.wp_halo)
+        d.tap_label, d.row_scale = _ptr(tap_label), _ptr(row_scale)
+        d.residual = residual.data.data_ptr() if residual is not None else None
+        d.residual_ld = layer.cout
+        d.scale = d.shift = d.epi_label = None
+        d.act = 0
+        st, off, ld = out_ptr_ld
+        d.out_raw, d.out_raw_ld = st.data_ptr() + 4 * off, ld
+        d.out_act, d.out_act_ld = None, layer.cout
+        d.tile_hint = 0
+        d.head_weights = d.head_out = None
+        d.head_cout = d.head_out_ld = 0
+        self.dy_ptr_ld = dy_ptr_ld
+        # data-gradient descriptors
+        for s, ent in enumerate(layer.dgrad):
+            if ent is None:
+                continue
+            t, ld = srcs[s]
+            assert t.needs_grad and ld == t.c
+            g = ent["desc"]
+            g.batch = batch
+            g.in_h, g.in_w = (in_h + 2 * pad - (eff - 1), in_w + 2 * pad - (eff - 1)) if stride == 2 else (self.out_h, self.out_w)
+            if stride == 2:
+                assert dilation == 1 and g.in_h == 2 * self.out_h and g.in_w == 2 * self.out_w, "stride-2 data gradient expects even geometry"
+            g.out_h, g.out_w = in_h, in_w
+            g.cout, g.kh, g.kw, g.stride, g.dilation, g.pad = ent["cout"], k, k, 1, dilation, dilation * (k - 1) - pad
+            g.num_sources = 1
+            g.src[0].channels = ent["cin"]
+            g.src[0].mode = _lib.SRC_ZERO_INSERT_X2 if stride == 2 else _lib.SRC_DIRECT
+            g.src[0].sel = g.src[0].pre_scale = g.src[0].pre_shift = None
+            g.weights, g.weights_halo = ent["w"].data_ptr(), _ptr(ent["w_halo"])
+            g.tap_label, g.row_scale = _ptr(tap_label), None
+            g.residual_ld = ent["cout"]
+            g.scale = g.shift = g.epi_label = None
+            g.act = 0
+            g.out_raw, g.out_raw_ld = t.grad.data_ptr(), t.c
+            g.out_act, g.out_act_ld = None, t.c
+            g.tile_hint = 0
+            g.head_weights = g.head_out = None
+            g.head_cout = g.head_out_ld = 0
+
+    def forward(self, stream: int):
+        check(_lib.load().cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
+
+    def _dy(self):
+        if self.dy_ptr_ld is not None:
+            st, off, ld = self.dy_ptr_ld
+            return st.data_ptr() + 4 * off, ld
+        assert self.out.has_grad, "gradient of %s not produced" % self.layer.name
+        return self.out.grad.data_ptr(), self.out.c
+
+    def backward(self, stream: int):
+        lib = _lib.load()
+        L = self.layer
+        dy, dy_ld = self._dy()
+        d = L.desc  # one op per layer: filled by this op's constructor
+        check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
+        check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 0, stream), "cp_scatter_f32")
+        for s, ent in enumerate(L.dgrad):
+            if ent is None:
+                continue
+            t, _ = self.srcs[s]
+            g = ent["desc"]
+            g.src[0].data, g.src[0].ld = dy, dy_ld
+            g.residual = t.grad.data_ptr() if t.has_grad else None
+            check(lib.cp_conv2d_fwd_f32(C.byref(g), stream), "dgrad(%s)" % L.name)
+            t.has_grad = True
+        if self.residual is not None:
+            add_grad(self.residual, dy, self.out.pixels * self.out.c, stream)
+
+
+def add_grad(t: TT, src_ptr: int, n: int, stream: int):
+    lib = _lib.load()
+    if t.has_grad:
+        check(lib.cp_axpby_f32(t.grad.data_ptr(), 1.0, src_ptr, 1.0, n, t.grad.data_ptr(), stream), "cp_axpby_f32")
+    else:
+        check(lib.cp_axpby_f32(src_ptr, 1.0, None, 0.0, n, t.grad.data_ptr(), stream), "cp_axpby_f32")
+        t.has_grad = True
+
+
+class BnActOp:
+    """y = act(gamma[l]*(x-mean)*rstd + beta[l]) with batch statistics (optionally all-reduced across replicas)."""
+
+    def __init__(self, plan: "TrainPlan", name: str, x: TT, y: TT, act: int, gamma: Optional[str], beta: Optional[str],
+                 labels: Optional[torch.Tensor] = None, classes: int = 1, row_scale: Optional[torch.Tensor] = None,
+                 pad_one: bool = False):
+        self.plan, self.name, self.x, self.y, self.act = plan, name, x, y, act
+        self.gamma_key, self.beta_key, self.labels, self.classes = gamma, beta, labels, classes
+        self.row_scale = row_scale  # partial convolution: x = row_scale * conv, so d conv = row_scale * dx
+        self.pad_one = pad_one      # bn_data: channel 3 is padding; its output is the constant 1 (see TrainPlan)
+        C_ = x.c
+        dev = x.data.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(2 * C_, **f64)
+        self.mean = torch.zeros(C_, **f32)
+        self.rstd = torch.zeros(C_, **f32)
+        self.scale = torch.zeros(classes, C_, **f32)
+        self.shift = torch.zeros(classes, C_, **f32)
+        self.red = torch.zeros(classes * C_ * 2, **f64)
+        self.chan = torch.zeros(C_ * 2, **f64)
+        st = plan.store
+        self.real_c = st.offsets[beta][1][-1] if beta else C_
+        self.gamma_full = torch.ones(classes, C_, **f32) if (gamma or self.real_c != C_) else None
+        self.beta_full = torch.zeros(classes, C_, **f32)
+
+    def forward(self, stream: int):
+        lib = _lib.load()
+        x, p = self.x, self.plan
+        C_ = x.c
+        check(lib.cp_bn_stats_f32(x.data.data_ptr(), x.pixels, C_, C_, self.sums.data_ptr(), stream), "cp_bn_stats_f32(%s)" % self.name)
+        n = p.all_reduce_stats(self.sums, x.pixels)
+        mean = self.sums[:C_] / n
+        var = torch.clamp(self.sums[C_:] / n - mean * mean, min=0.0)
+        rstd = torch.rsqrt(var + BN_EPS)
+        self.mean.copy_(mean)
+        self.rstd.copy_(rstd)
+        st = p.store
+        rc = self.real_c
+        if self.gamma_key:
+            self.gamma_full[:, :rc].copy_(st.view(self.gamma_key).reshape(self.classes, rc))
+        if self.beta_key:
+            self.beta_full[:, :rc].copy_(st.view(self.beta_key).reshape(self.classes, rc))
+        g64 = self.gamma_full.double() if self.gamma_full is not None else None
+        scale = rstd[None, :] * (g64 if g64 is not None else 1.0)
+        shift = self.beta_full.double() - mean[None, :] * scale
+        if self.pad_one:
+            scale[:, rc:] = 0.0
+            shift[:, rc:] = 1.0
+        self.scale.copy_(scale.expand(self.classes, C_))
+        self.shift.copy_(shift.expand(self.classes, C_))
+        check(lib.cp_affine_act_f32(x.data.data_ptr(), x.pixels, C_, C_, self.scale.data_ptr(), self.shift.data_ptr(), _ptr(self.labels), self.act,
+                                    self.y.data.data_ptr(), C_, stream), "cp_affine_act_f32(%s)" % self.name)
+        # moving statistics (Keras: moving = moving*momentum + batch*(1-momentum), biased variance)
+        mm, mv = st.state.get(self.name + ".moving_mean"), st.state.get(self.name + ".moving_variance")
+        if mm is not None and p.update_moving:
+            mm.mul_(BN_MOMENTUM).add_(mean[:rc].float(), alpha=1.0 - BN_MOMENTUM)
+            mv.mul_(BN_MOMENTUM).add_(var[:rc].float(), alpha=1.0 - BN_MOMENTUM)
+
+    def backward(self, stream: int):
+        lib = _lib.load()
+        x, y, p = self.x, self.y, self.plan
+        C_ = x.c
+        if not y.needs_grad:
+            return  # bn_data: its beta gradient comes from conv0's weight gradient (TrainPlan.backward)
+        assert y.has_grad, "gradient of %s output not produced" % self.name
+        gam = _ptr(self.gamma_full)
+        bet = self.beta_full.data_ptr()
+        check(lib.cp_bn_act_bwd_reduce_f32(x.data.data_ptr(), C_, y.grad.data_ptr(), C_, x.pixels, C_, self.classes, self.mean.data_ptr(),
+                                           self.rstd.data_ptr(), gam, bet, _ptr(self.labels), self.act, self.red.data_ptr(), self.chan.data_ptr(),
+                                           stream), "cp_bn_act_bwd_reduce_f32(%s)" % self.name)
+        n = p.all_reduce_stats(self.chan, x.pixels)
+        if x.needs_grad:
+            check(lib.cp_bn_act_bwd_apply_f32(x.data.data_ptr(), C_, y.grad.data_ptr(), C_, x.pixels, C_, self.mean.data_ptr(), self.rstd.data_ptr(),
+                                              gam, bet, _ptr(self.labels), self.act, self.chan.data_ptr(), float(n), _ptr(self.row_scale),
+                                              x.grad.data_ptr(), C_, 1 if x.has_grad else 0, stream), "cp_bn_act_bwd_apply_f32(%s)" % self.name)
+            x.has_grad = True
+        red = self.red.view(self.classes, C_, 2)
+        st, rc = p.store, self.real_c
+        if self.beta_key:
+            st.grad_view(self.beta_key).copy_(red[:, :rc, 0].reshape(st.offsets[self.beta_key][1]))
+        if self.gamma_key:
+            st.grad_view(self.gamma_key).copy_(red[:, :rc, 1].reshape(st.offsets[self.gamma_key][1]))
+
+
+class FnOp:
+    def __init__(self, fwd, bwd):
+        self.forward, self.backward = fwd, bwd
+
+
+# ------------------------------------------------------------------------------------------------
+# plan
+# ------------------------------------------------------------------------------------------------
+class TrainPlan:
+    """Buffers + tape for one (batch, H, W); `group` = torch.distributed process group for SyncBN / DP (or None)."""
+
+    GRAD_LD = 64   # loss gradient rows: [0,32) logits (seg_dim real), [32,64) vertex (ver_dim real)
+    VERT_OFF = 32
+
+    def __init__(self, store: ParamStore, seg_dim: int, ver_dim: int, batch: int, h: int, w: int,
+                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1):
+        if h % 8 or w % 8:
+            raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
+        if seg_dim > 32 or ver_dim > 32:
+            raise ValueError("the training plan supports up to 32 classes / 32 vertex channels")
+        lib = _lib.load()
+        self.store, self.seg_dim, self.ver_dim = store, seg_dim, ver_dim
+        self.batch, self.h, self.w = batch, h, w
+        self.group, self.world_size = group, world_size
+        self.update_moving = True
+        dev = store.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        B, K, V = batch, seg_dim, ver_dim
+        self.out_ld = K + V
+        hs = [h, h // 2, h // 4, h // 8]
+        ws = [w, w // 2, w // 4, w // 8]
+        self.ops: List = []
+        self.convs: List[TrainConv] = []
+        dims = tuple(decoder_dims)
+
+        def new(hh, ww, c, grad=True, name=""):
+            return TT(torch.empty(B, hh, ww, c, **f32), grad, name)
+
+        self.img4 = new(h, w, 4, False, "img4")        # raw image, channel 3 = 0 (decoder skip)
+        self.x0 = new(h, w, 4, False, "bn_data")        # bn_data(image), channel 3 = 1 (see below)
+        self.out = torch.empty(B, h, w, self.out_ld, **f32)
+        self.dout = torch.zeros(B, h, w, self.GRAD_LD, **f32)
+        self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
+        self.pnorm = [torch.empty(B, hs[l], ws[l], **f32) for l in range(4)]
+        self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
+        self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
+
+        def layer(key, layout, k, cout, sources, grad_sources):
+            L = TrainConv(store, key, layout, k, cout, sources, grad_sources)
+            self.convs.append(L)
+            return L
+
+        def conv(L, srcs, o: TT, in_h, in_w, **kw):
+            op = ConvOp(L, srcs, (o.data, 0, o.c), B, in_h, in_w, out=o, **kw)
+            self.ops.append(op)
+            return op
+
+        def bn(name, x, y, act, gamma=True, labels=None, classes=1, row_scale=None, pad_one=False, clade=False):
+            gk = (name + ".gamma") if gamma else None
+            self.ops.append(BnActOp(self, name, x, y, act, gk, name + ".beta", labels, classes, row_scale, pad_one))
+
+        RELU, LEAKY, NONE = _lib.ACT_RELU, _lib.ACT_LEAKY01, _lib.ACT_NONE
+        # ---- encoder --------------------------------------------------------------------------------
+        # bn_data has no gamma; its padding channel is forced to the constant 1 so that conv0's weight gradient
+        # for that (zero-weight) channel is G[t][o] = sum of dy over the positions where tap t is inside the image:
+        # d beta_data[c] = sum_{t,o} W0[t,c,o] * G[t][o] without a 7x7 transposed convolution for three numbers.
+        bn("bn_data", self.img4, self.x0, NONE, gamma=False, pad_one=True)
+        self.bn_data_op = self.ops[-1]
+        c0 = layer("conv0.kernel", 0, 7, 64, [(4, 3)], [False])
+        self.conv0 = c0
+        x = new(hs[1], ws[1], 64)
+        conv(c0, [(self.x0, 4)], x, h, w, stride=2, pad=3)
+        x2s = new(hs[1], ws[1], 64, name="x2s")
+        bn("bn0", x, x2s, RELU)
+        pooled = new(hs[2], ws[2], 64, name="pool")
+
+        def pool_f(stream, src=x2s, dst=pooled):
+            check(lib.cp_maxpool3x3s2_f32(src.data.data_ptr(), B, hs[1], ws[1], 64, None, None, 0, dst.data.data_ptr(), stream), "cp_maxpool3x3s2_f32")
+
+        def pool_b(stream, src=x2s, dst=pooled):
+            assert dst.has_grad
+            check(lib.cp_maxpool3x3s2_bwd_f32(src.data.data_ptr(), dst.grad.data_ptr(), B, hs[1], ws[1], 64, src.grad.data_ptr(),
+                                              1 if src.has_grad else 0, stream), "cp_maxpool3x3s2_bwd_f32")
+            src.has_grad = True
+
+        self.ops.append(FnOp(pool_f, pool_b))
+        xr, cur_h, cur_w, cin = pooled, hs[2], ws[2], 64
+        taps: Dict[str, TT] = {"x2s": x2s}
+        tap_names = ["x4s", "x8s", "x16s", "x32s"]
+        for s, f in enumerate(STAGE_FILTERS):
+            dl = STAGE_DILATION[s]
+            for u in range(2):
+                base = "stage%d_unit%d_" % (s + 1, u + 1)
+                stride = STAGE_STRIDE[s] if u == 0 else 1
+                oh, ow = (cur_h - 1) // stride + 1, (cur_w - 1) // stride + 1
+                a = new(cur_h, cur_w, cin, name=base + "a")
+                bn(base + "bn1", xr, a, RELU)
+                if u == 0:
+                    if s > 0:
+                        taps[tap_names[s - 1]] = a
+                    sc = new(oh, ow, f, name=base + "sc")
+                    conv(layer(base + "sc.kernel", 0, 1, f, [(cin, cin)], [True]), [(a, cin)], sc, cur_h, cur_w, stride=stride)
+                    shortcut = sc
+                else:
+                    shortcut = xr
+                t = new(oh, ow, f)
+                conv(layer(base + "conv1.kernel", 0, 3, f, [(cin, cin)], [True]), [(a, cin)], t, cur_h, cur_w, stride=stride, dilation=dl, pad=dl)
+                t2 = new(oh, ow, f)
+                bn(base + "bn2", t, t2, RELU)
+                xn = new(oh, ow, f, name=base + "out")
+                conv(layer(base + "conv2.kernel", 0, 3, f, [(f, f)], [True]), [(t2, f)], xn, oh, ow, dilation=dl, pad=dl, residual=shortcut)
+                xr, cur_h, cur_w, cin = xn, oh, ow, f
+        x32s = new(cur_h, cur_w, 512, name="x32s")
+        bn("bn1", xr, x32s, RELU)
+        taps["x32s"] = x32s
+        self.taps = taps
+        skips = [None, taps["x8s"], taps["x4s"], taps["x2s"], self.img4]
+        skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
+        lvl = [3, 3, 2, 1, 0]
+
+        def upsample(prev: TT, l: int, guided: bool) -> TT:
+            big = new(hs[l], ws[l], prev.c)
+            sh, sw, c = hs[l] // 2, ws[l] // 2, prev.c
+
+            def f(stream):
+                if guided:
+                    check(lib.cp_guided_upsample_x2_f32(prev.data.data_ptr(), self.sel[l].data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_guided_upsample_x2_f32")
+                else:
+                    check(lib.cp_upsample_bilinear_x2_f32(prev.data.data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_upsample_bilinear_x2_f32")
+
+            def b(stream):
+                assert big.has_grad and not prev.has_grad
+                if guided:
+                    check(lib.cp_guided_upsample_x2_bwd_f32(big.grad.data_ptr(), c, self.sel[l].data_ptr(), B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_guided_upsample_x2_bwd_f32")
+                else:
+                    check(lib.cp_upsample_bilinear_x2_bwd_f32(big.grad.data_ptr(), c, B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_upsample_bilinear_x2_bwd_f32")
+                prev.has_grad = True
+
+            self.ops.append(FnOp(f, b))
+            return big
+
+        def decoder(first: int, partial: bool):
+            prev = None
+            for i in range(5):
+                l = lvl[i]
+                idx = first + i
+                if partial:
+                    key, layout = "pv_block_%d_prepare_conv2d.weights" % idx, 1
+                else:
+                    key, layout = "pv_block_%d_conv2d.kernel" % idx, 0
+                if i == 0:
+                    srcs, tts, gs = [(512, 512)], [(x32s, 512)], [True]
+                else:
+                    src0 = upsample(prev, l, partial) if i >= 2 else prev
+                    srcs = [(dims[i - 1], dims[i - 1]), skip_c[i]]
+                    tts = [(src0, dims[i - 1]), (skips[i], skips[i].c)]
+                    gs = [True, skips[i].needs_grad]
+                L = layer(key, layout, 3, dims[i], srcs, gs)
+                raw = new(hs[l], ws[l], dims[i])
+                act = new(hs[l], ws[l], dims[i])
+                act_kind = RELU if i == 0 else LEAKY
+                if partial:
+                    conv(L, tts, raw, hs[l], ws[l], pad=1, tap_label=self.labels[l], row_scale=self.pnorm[l])
+                    bn("pv_block_%d_clade" % idx, raw, act, act_kind, labels=self.labels[l], classes=K, row_scale=self.pnorm[l])
+                else:
+                    conv(L, tts, raw, hs[l], ws[l], pad=1)
+                    bn("pv_block_%d_bn" % idx, raw, act, act_kind)
+                prev = act
+            return prev
+
+        feat1 = decoder(1, False)
+        seg_head = layer("pv_final_conv_segmentation.kernel", 0, 1, K, [(dims[4], dims[4])], [True])
+        self.ops.append(ConvOp(seg_head, [(feat1, dims[4])], (self.out, 0, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, 0, self.GRAD_LD)))
+        self.cond_labels: Optional[torch.Tensor] = None  # ground-truth conditioning (train_vectors_with_ground_truth)
+
+        def label_f(stream):
+            if self.cond_labels is not None:
+                self.labels[0].copy_(self.cond_labels)
+            else:
+                check(lib.cp_argmax_labels(self.out.data_ptr(), self.out_ld, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
+            lab = (C.c_void_p * 4)(*[t.data_ptr() for t in self.labels])
+            pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
+            sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])
+            check(lib.cp_label_pyramid(self.labels[0].data_ptr(), B, h, w, lab, pn, sl, stream), "cp_label_pyramid")
+
+        self.ops.append(FnOp(label_f, lambda stream: None))
+        feat2 = decoder(6, True)
+        ver_head = layer("pv_final_conv_vertex.kernel", 0, 1, V, [(dims[4], dims[4])], [True])
+        self.ops.append(ConvOp(ver_head, [(feat2, dims[4])], (self.out, K, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, self.VERT_OFF, self.GRAD_LD)))
+        self.tensors = [o for o in self._all_tensors()]
+        # gather map of conv0's packed weight-gradient entries that belong to the padding channel (c = 3)
+        ramp = np.zeros((7, 7, 3, 64), np.int64)  # unused values; only the layout matters
+        k0 = np.full((64, c0.ktot), -1, np.int64)
+        for t in range(49):
+            k0[:, t * 4 + 3] = np.arange(64) * c0.ktot + t * 4 + 3
+        self.g_idx = torch.from_numpy(k0[:, [t * 4 + 3 for t in range(49)]].T.copy()).to(dev)  # [49 taps][64 cout] -> flat index into dwp
+        del ramp
+
+    def _all_tensors(self):
+        seen = {}
+        for op in self.ops:
+            for attr in ("x", "y", "out", "residual"):
+                t = getattr(op, attr, None)
+                if isinstance(t, TT):
+                    seen[id(t)] = t
+            for t, _ in getattr(op, "srcs", []):
+                seen[id(t)] = t
+        for t in self.taps.values():
+            seen[id(t)] = t
+        return list(seen.values())
+
+    # ---- distributed hooks ---------------------------------------------------------------------------
+    def all_reduce_stats(self, table: torch.Tensor, local_pixels: int) -> int:
+        """SUM the fp64 statistic table over the replicas; returns the global pixel count."""
+        if self.group is not None and self.world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)
+            return local_pixels * self.world_size
+        return local_pixels
+
+    # ---- one step ------------------------------------------------------------------------------------
+    def refresh_weights(self, stream: int):
+        for L in self.convs:
+            L.refresh(stream)
+
+    def forward(self, img: torch.Tensor, cond_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+        lib = _lib.load()
+        B, h, w = self.batch, self.h, self.w
+        if tuple(img.shape) != (B, h, w, 3) or img.dtype != torch.float32 or not img.is_contiguous():
+            raise ValueError("image must be a contiguous float32 [%d,%d,%d,3] tensor" % (B, h, w))
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        self.cond_labels = cond_labels
+        check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
+        for op in self.ops:
+            op.forward(stream)
+        return self.out
+
+    def loss_and_grad(self, labels_ce: torch.Tensor, labels_fg: torch.Tensor, keypoints_yx: torch.Tensor, mask_w=1.0, vertex_w=1.0, proxy_w=1.0,
+                      filter_with_segmentation=True, kp: int = 9) -> torch.Tensor:
+        """Losses of compute_loss on the last forward's output and d loss / d output into self.dout. Returns fp64 [mask, vertex, proxy]."""
+        lib = _lib.load()
+        B, h, w = self.batch, self.h, self.w
+        stream = torch.cuda.current_stream(self.out.device).cuda_stream
+        assert labels_ce.dtype == torch.uint8 and labels_fg.dtype == torch.uint8 and keypoints_yx.dtype == torch.float32
+        assert tuple(keypoints_yx.shape) == (B, self.seg_dim - 1, kp, 2) and keypoints_yx.is_contiguous()
+        check(lib.cp_pose_loss_f32(self.out.data_ptr(), self.out_ld, self.seg_dim, kp, labels_ce.data_ptr(), labels_fg.data_ptr(), keypoints_yx.data_ptr(),
+                                   self.seg_dim - 1, B, h, w, 1 if filter_with_segmentation else 0, mask_w, vertex_w, proxy_w, self.loss_ws.data_ptr(),
+                                   self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(), stream), "cp_pose_loss_f32")
+        return self.loss_sums
+
+    def backward(self):
+        """Back-propagate self.dout through the tape into store.grad."""
+        stream = torch.cuda.current_stream(self.out.device).cuda_stream
+        for t in self.tensors:
+            t.has_grad = False
+        for op in reversed(self.ops):
+            op.backward(stream)
+        # d beta of bn_data from the padding-channel entries of conv0's weight gradient (see __init__)
+        G = self.conv0.dwp[self.g_idx.reshape(-1)].view(49, 64)            # [tap][cout]
+        W0 = self.store.view("conv0.kernel").reshape(49, 3, 64)               # [tap][c][cout]
+        dbeta = torch.einsum("tco,to->c", W0.double(), G.double())
+        self.store.grad_view("bn_data.beta").copy_(dbeta)
+
+    def all_reduce_grads(self):
+        if self.group is not None and self.world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.store.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def train_step(self, img, labels_ce, labels_fg, keypoints_yx, lr: float, cond_labels=None, weights=(1.0, 1.0, 1.0),
+                   filter_with_segmentation=True):
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        self.forward(img, cond_labels)
+        sums = self.loss_and_grad(labels_ce, labels_fg, keypoints_yx, *weights, filter_with_segmentation=filter_with_segmentation)
+        self.backward()
+        self.all_reduce_grads()
+        self.store.adam_step(lr, stream)
+        self.refresh_weights(stream)
+        return sums

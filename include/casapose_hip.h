@@ -72,7 +72,9 @@ int cp_device_count(void);
  *  (K order: source 0 chunks, then source 1 chunks; see cp_conv_ktot).
  * ---------------------------------------------------------------------------------- */
 
-enum { CP_SRC_DIRECT = 0, CP_SRC_NEAREST_SEL = 1, CP_SRC_BILINEAR_X2 = 2 };
+enum { CP_SRC_DIRECT = 0, CP_SRC_NEAREST_SEL = 1, CP_SRC_BILINEAR_X2 = 2,
+       CP_SRC_ZERO_INSERT_X2 = 3 /* the source holds the EVEN positions of the in_h x in_w grid, the rest is zero:
+                                    the data-gradient of a stride-2 convolution (transposed convolution) */ };
 enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY01 = 2 };
 
 typedef struct cp_conv_source {
@@ -223,6 +225,94 @@ int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int d
                        float confidence, int max_iter, int min_num, int max_num, void* ws, float* out,
                        int32_t* rounds_out, void* stream);
 size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp);
+
+/* ====================================================================================
+ * TRAINING PATH (train_casapose.py:494-611: forward with training=True, compute_loss,
+ * tf.GradientTape gradients, Adam).  The reference gets every gradient below from
+ * TensorFlow's autodiff of the layers cited at the forward entry points; the kernels here
+ * are the adjoints of those layers, written out.
+ * ==================================================================================== */
+
+/* Weight gradient of cp_conv2d_fwd_f32 (Conv2DBackpropFilter of resnet.py:85-103,249; casapose.py:71-74;
+ * PartialConvolution, _normalization_layers.py:325-373):
+ *   dw_packed[co][k] (+)= sum_m dy[m][co] * A[m][k]
+ * with A the forward's implicit im2col matrix (same descriptor: geometry, sources, tap_label; weights, outputs
+ * and epilogue fields are ignored -- for a partial convolution dy is the gradient of the un-normalised sum,
+ * i.e. already multiplied by row_scale, see cp_bn_act_bwd_apply_f32) and k in the packed K order, so dw_packed has the layout
+ * of cp_conv_pack_weights_host.  Sources must be CP_SRC_DIRECT without pre-affine.  Split over pixels
+ * with fp32 atomics: the summation order is not fixed (results reproducible to fp32 rounding only). */
+int cp_conv2d_wgrad_f32(const cp_conv_desc* desc, const float* dy, int dy_ld, float* dw_packed, int accumulate, void* stream);
+
+/* The DATA gradient needs no entry point of its own: it is cp_conv2d_fwd_f32 over dy with the kernel
+ * flipped and transposed (host-side repack), pad' = dilation*(k-1) - pad, the same dilation, and, for a
+ * stride-2 forward, source mode CP_SRC_ZERO_INSERT_X2.  A partial convolution keeps its tap_label (the mask
+ * is symmetric) and takes row_scale-multiplied dy (see cp_bn_act_bwd_apply_f32). */
+
+/* Batch statistics of (Sync)BatchNormalization in training mode (resnet.py:78,100,247,250,303;
+ * casapose.py:77; _normalization_layers.py:108): sums[c] = sum_p x[p][c], sums[C+c] = sum_p x[p][c]^2 in
+ * fp64 (zeroed by the call).  The caller all-reduces `sums` across replicas (SyncBN) and derives
+ * mean / biased variance.  channels % 4 == 0, <= 1024. */
+int cp_bn_stats_f32(const float* x, long long pixels, int channels, int ld, double* sums, void* stream);
+
+/* y[p][c] = act(x[p][c]*scale[l][c] + shift[l][c]), l = labels ? labels[p] : 0 -- the normalise(+CLADE
+ * modulation, _normalization_layers.py:119-139)+activation (casapose.py:98-107) step with the batch
+ * statistics folded into scale/shift by the caller. */
+int cp_affine_act_f32(const float* x, long long pixels, int channels, int ld_x, const float* scale, const float* shift,
+                      const uint8_t* labels, int act, float* y, int ld_y, void* stream);
+
+/* Backward of y = act(gamma[l][c]*xhat + beta[l][c]), xhat = (x-mean[c])*rstd[c] (batch statistics), pass 1:
+ *   red[(l*C+c)*2 + {0,1}] = sum_p {g, g*xhat}           (g = dy*act')  -> d beta[l][c], d gamma[l][c]
+ *   chan[c*2 + {0,1}]      = sum_p {g*gamma, g*gamma*xhat}                -> the two batch means of pass 2
+ * (fp64, zeroed by the call; gamma/beta may be null = 1/0; classes = 1 without labels).  The caller
+ * all-reduces `chan` across replicas for SyncBN. */
+int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, int classes,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, const uint8_t* labels,
+                             int act, double* red, double* chan, void* stream);
+/* pass 2: dx = rstd*(g*gamma - chan[c][0]/N - xhat*chan[c][1]/N) * (row_scale ? row_scale[p] : 1),
+ * N = global_pixels (all replicas); accumulate != 0 adds to dx (a tensor with several consumers). */
+int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, const uint8_t* labels, int act,
+                            const double* chan, double global_pixels, const float* row_scale, float* dx, int ld_dx, int accumulate,
+                            void* stream);
+
+/* Adjoints of MaxPooling2D(3, strides 2) after ZeroPadding2D(1) (resnet.py:252-253), UpSampling2D(bilinear)
+ * (casapose.py:135-140) and the GuidedUpsampling gather (_normalization_layers.py:554-558).  Gather form
+ * (every input pixel sums the output gradients that reference it): deterministic, no atomics.
+ * h, w are the LOW-resolution (input) sizes for the two upsampling adjoints. */
+int cp_maxpool3x3s2_bwd_f32(const float* x, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate,
+                            void* stream);
+int cp_upsample_bilinear_x2_bwd_f32(const float* dy, int ld_dy, int batch, int h, int w, int channels, float* dx, void* stream);
+int cp_guided_upsample_x2_bwd_f32(const float* dy, int ld_dy, const uint8_t* sel, int batch, int h, int w, int channels, float* dx,
+                                  void* stream);
+
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- re-pack the master (Keras-layout) weights into a kernel layout after
+ * an optimizer step; cp_scatter_f32 is the inverse (packed weight gradient -> master layout; idx injective on
+ * its non-negative entries). */
+int cp_gather_f32(const float* src, const int32_t* idx, long long n, float* dst, void* stream);
+int cp_scatter_f32(const float* src, const int32_t* idx, long long n, float* dst, int accumulate, void* stream);
+/* out = alpha*a + beta*b (b may be null) */
+int cp_axpby_f32(const float* a, float alpha, const float* b, float beta, long long n, float* out, void* stream);
+
+/* tf.keras.optimizers.Adam.apply_gradients (train_casapose.py:334-347,611; epsilon 1e-7):
+ *   g = grads*grad_scale; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2;
+ *   params -= lr*sqrt(1-b2^step)/(1-b1^step) * m/(sqrt(v)+eps)          (step counts from 1) */
+int cp_adam_step_f32(float* params, const float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, int step, float grad_scale, void* stream);
+
+/* compute_loss for the merged-output models (train_casapose.py:40-145), value AND gradient:
+ *   loss_sums[0] mask   = mean softmax cross-entropy(labels_ce)                         (:59-60)
+ *   loss_sums[1] vertex = smooth_l1_loss(dirs, unit vectors to the keypoints, fg)        (loss_functions.py:14-44)
+ *   loss_sums[2] proxy  = proxy_voting_loss_v2(loss_per_object=False)                    (loss_functions.py:132-203)
+ * out: network output [batch,h,w,ld] = [seg_dim logits | 2*kp directions (dy,dx) | ...]; labels_ce / labels_fg:
+ * uint8 [batch,h,w] (target_seg / filtered_seg as class indices); keypoints_yx: fp32 [batch][objects][kp][2].
+ * With filter_with_segmentation the foreground keeps only pixels whose arg-max prediction equals labels_fg
+ * (:64-69).  dout [batch*h*w][dld] receives d(mask_w*mask + vertex_w*vertex + proxy_w*proxy)/d out with the
+ * logit gradients in columns [0,seg_dim) and the direction gradients in [vert_off, vert_off+2kp); every other
+ * column is zeroed.  ws: cp_pose_loss_workspace_bytes. */
+size_t cp_pose_loss_workspace_bytes(int batch, int h, int w);
+int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, const uint8_t* labels_ce, const uint8_t* labels_fg,
+                     const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation, float mask_w,
+                     float vertex_w, float proxy_w, void* ws, float* dout, int dld, int vert_off, double* loss_sums, void* stream);
 
 #ifdef __cplusplus
 }

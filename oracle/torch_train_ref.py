@@ -1,0 +1,243 @@
+"""Gradient oracle for the training path (TEST INFRASTRUCTURE ONLY).
+
+A PyTorch-CPU (fp64) restatement of casapose_c_gcu5 in TRAINING mode and of the losses, written
+with differentiable torch ops so that autograd provides reference gradients for the HIP backward
+kernels.  Same status as casapose_oracle.py: parity with the TensorFlow reference is UNPINNED (it
+cannot be imported here); the forward of this file is cross-checked against the NumPy oracle in
+tests/test_train_oracle.py, and every function cites the reference lines it restates.
+
+Only tests/ and smoke checks may import this module.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 2e-5
+BN_MOMENTUM = 0.99  # resnet.py:43 -- moving = 0.99*moving + 0.01*batch
+
+STAGE_FILTERS = (64, 128, 256, 512)
+STAGE_STRIDE = (1, 2, 1, 1)
+STAGE_DILATION = (1, 1, 2, 4)
+
+
+def to_torch(params: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=True) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in params.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        trainable = not k.endswith(("moving_mean", "moving_variance"))
+        out[k] = t.requires_grad_(requires_grad and trainable)
+    return out
+
+
+def conv_nhwc(x, w_hwio, stride=1, dilation=1, pad=0):
+    """layers.Conv2D (valid after explicit zero padding), NHWC / HWIO."""
+    y = F.conv2d(x.permute(0, 3, 1, 2), w_hwio.permute(3, 2, 0, 1), stride=stride, dilation=dilation, padding=pad)
+    return y.permute(0, 2, 3, 1)
+
+
+def batchnorm_train(x, gamma, beta, stats_out: Optional[dict] = None, name: str = ""):
+    """(Sync)BatchNormalization, training=True: normalise with the BIASED batch variance over
+    (N,H,W); the moving statistics are updated with the same biased variance."""
+    mean = x.mean(dim=(0, 1, 2))
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    if stats_out is not None:
+        stats_out[name] = (mean.detach(), var.detach())
+    y = (x - mean) / torch.sqrt(var + BN_EPS)
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    return y
+
+
+def leaky_pair(x):
+    return F.relu(x) - F.relu(-0.1 * x)  # casapose.py:98-105
+
+
+def maxpool_zero_pad(x):
+    xp = F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1))  # zero padding (resnet.py:253)
+    return F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1)
+
+
+def bilinear_x2(x):
+    return F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+
+def labels_pyramid(labels: torch.Tensor) -> List[torch.Tensor]:
+    out = [labels]
+    for _ in range(3):
+        out.append(out[-1][:, ::2, ::2])
+    return out
+
+
+def partial_conv(x, w_ihwo, labels):
+    """PartialConvolution with a hard label map: m(p,n) = [label(p+n) == label(p)] inside the image
+    (_normalization_layers.py:333-371)."""
+    b, h, w, c = x.shape
+    w_hwio = w_ihwo.permute(1, 2, 0, 3)
+    lab = labels.to(torch.int64)
+    lp = F.pad(lab + 1, (1, 1, 1, 1))  # 0 = outside
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    out = torch.zeros(b, h, w, w_ihwo.shape[3], dtype=x.dtype)
+    cnt = torch.zeros(b, h, w, dtype=x.dtype)
+    for ky in range(3):
+        for kx in range(3):
+            m = (lp[:, ky : ky + h, kx : kx + w] == (lab + 1)).to(x.dtype)
+            cnt = cnt + m
+            out = out + (xp[:, ky : ky + h, kx : kx + w, :] * m[..., None]) @ w_hwio[ky, kx]
+    return out * (9.0 / cnt)[..., None]
+
+
+def clade_train(x, labels, gamma_kc, beta_kc, stats_out=None, name=""):
+    """ClassAdaptiveWeightedNormalization, training=True, hard labels (_normalization_layers.py:119-139)."""
+    xn = batchnorm_train(x, None, None, stats_out, name)
+    lab = labels.to(torch.int64)
+    return gamma_kc[lab] * xn + beta_kc[lab]
+
+
+def guided_select(lab_lo: torch.Tensor, lab_hi: torch.Tensor) -> torch.Tensor:
+    """neighbour index 0..3 per hi-res pixel (_normalization_layers.py:534-551); labels are int maps."""
+    b, h2, w2 = lab_lo.shape
+    lp = F.pad(lab_lo + 1, (0, 1, 0, 1))  # bottom/right zero pad (label 0 never matches label+1 >= 1)
+    cands = torch.stack([lp[:, :h2, :w2], lp[:, :h2, 1:], lp[:, 1:, :w2], lp[:, 1:, 1:]], dim=-1)
+    cu = cands.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    eq = cu == (lab_hi + 1)[..., None]
+    score = eq.to(torch.int64) * torch.tensor([4, 3, 2, 1])
+    return torch.argmax(score, dim=-1)  # all-zero -> 0
+
+
+def guided_upsample(x, lab_lo, lab_hi):
+    b, h2, w2, c = x.shape
+    sel = guided_select(lab_lo.to(torch.int64), lab_hi.to(torch.int64))
+    yy, xx = torch.meshgrid(torch.arange(2 * h2), torch.arange(2 * w2), indexing="ij")
+    sy = torch.clamp(yy[None] // 2 + sel // 2, max=h2 - 1)
+    sx = torch.clamp(xx[None] // 2 + sel % 2, max=w2 - 1)
+    bi = torch.arange(b)[:, None, None]
+    return x[bi, sy, sx, :]
+
+
+def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None):
+    """casapose_c_gcu5 with training=True and decoder 2 conditioned on the given hard label map (the
+    `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
+
+    def bn(name, x):
+        return batchnorm_train(x, p.get(name + ".gamma"), p.get(name + ".beta"), stats_out, name)
+
+    x = bn("bn_data", img)
+    x = conv_nhwc(x, p["conv0.kernel"], stride=2, pad=3)
+    x2s = F.relu(bn("bn0", x))
+    x = maxpool_zero_pad(x2s)
+    taps = []
+    for s in range(4):
+        d = STAGE_DILATION[s]
+        for u in range(2):
+            base = "stage%d_unit%d_" % (s + 1, u + 1)
+            stride = STAGE_STRIDE[s] if u == 0 else 1
+            a = F.relu(bn(base + "bn1", x))
+            shortcut = conv_nhwc(a, p[base + "sc.kernel"], stride=stride) if u == 0 else x
+            y = conv_nhwc(a, p[base + "conv1.kernel"], stride=stride, dilation=d, pad=d)
+            y = F.relu(bn(base + "bn2", y))
+            y = conv_nhwc(y, p[base + "conv2.kernel"], dilation=d, pad=d)
+            x = y + shortcut
+            if u == 0 and s > 0:
+                taps.append(a)
+    x32s = F.relu(bn("bn1", x))
+    x4s, x8s, _x16s = taps
+    skips = [None, x8s, x4s, x2s, img]
+    d1 = None
+    for i in range(5):
+        n = "pv_block_%d" % (i + 1)
+        inp = x32s if i == 0 else torch.cat([d1, skips[i]], dim=3)
+        y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
+        y = bn(n + "_bn", y)
+        y = F.relu(y) if i == 0 else leaky_pair(y)
+        if 0 < i < 4:
+            y = bilinear_x2(y)
+        d1 = y
+    logits = conv_nhwc(d1, p["pv_final_conv_segmentation.kernel"])
+    labs = labels_pyramid(labels)
+    lvl = [3, 3, 2, 1, 0]
+    d2 = None
+    for i in range(5):
+        n = "pv_block_%d" % (i + 6)
+        inp = x32s if i == 0 else torch.cat([d2, skips[i]], dim=3)
+        lab = labs[lvl[i]]
+        y = partial_conv(inp, p[n + "_prepare_conv2d.weights"], lab)
+        y = clade_train(y, lab, p[n + "_clade.gamma"], p[n + "_clade.beta"], stats_out, n + "_clade")
+        y = F.relu(y) if i == 0 else leaky_pair(y)
+        if 0 < i < 4:
+            y = guided_upsample(y, lab, labs[lvl[i] - 1])
+        d2 = y
+    vertex = conv_nhwc(d2, p["pv_final_conv_vertex.kernel"])
+    return torch.cat([logits, vertex], dim=3)
+
+
+# --------------------------------------------------------------------------------------
+#  targets and losses (train_casapose.py:40-145; utils/loss_functions.py; utils/image_utils.py)
+# --------------------------------------------------------------------------------------
+
+
+def target_vector_field(labels: torch.Tensor, keypoints_yx: torch.Tensor) -> torch.Tensor:
+    """compute_vertex_hcoords_batch_v3 for one instance per object (image_utils.py:17-63):
+    unit vectors from each foreground pixel centre to its object's keypoints, (dy,dx) pairs, zero on
+    background.  labels [B,H,W] int, keypoints [B,oc,kp,2] in (y,x)."""
+    b, h, w = labels.shape
+    kp = keypoints_yx.shape[2]
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=keypoints_yx.dtype) + 0.5, torch.arange(w, dtype=keypoints_yx.dtype) + 0.5, indexing="ij")
+    grid = torch.stack([yy, xx], dim=-1)[None, :, :, None, :]  # [1,h,w,1,2]
+    kpz = torch.cat([torch.zeros(b, 1, kp, 2, dtype=keypoints_yx.dtype), keypoints_yx], dim=1)  # prepend background
+    bi = torch.arange(b)[:, None, None]
+    tgt = kpz[bi, labels.to(torch.int64)]  # [b,h,w,kp,2]
+    d = (tgt - grid) * (labels != 0)[..., None, None].to(keypoints_yx.dtype)
+    nrm = torch.sqrt((d * d).sum(-1, keepdim=True))
+    d = d / torch.clamp(nrm, min=1e-12)  # tf.math.l2_normalize
+    return d.reshape(b, h, w, kp * 2)
+
+
+def smooth_l1(e):
+    return torch.where(e < 1.0, 0.5 * e * e, e - 0.5)
+
+
+def losses(output: torch.Tensor, labels: torch.Tensor, keypoints_yx: torch.Tensor, seg_dim: int, kp: int = 9,
+           filter_vertex_with_segmentation: bool = True):
+    """mask / vertex / proxy losses of compute_loss (train_casapose.py:40-145) for the merged-output
+    models (not `pvnet`): returns (mask_loss, vertex_loss, proxy_loss).
+      mask   : mean softmax cross-entropy (:59-60)
+      vertex : smooth_l1_loss(pred, target field, fg weights, normalised per image by ver_dim*sum(w)+1e-3), mean over images
+               (loss_functions.py:14-44, ver_dim = 2*kp)
+      proxy  : proxy_voting_loss_v2(loss_per_object=False) (:132-203)
+    With filter_vertex_with_segmentation the foreground is restricted to pixels whose predicted label
+    equals the ground truth (:62-69); the filtered target is a constant (stop_gradient, :95)."""
+    b, h, w, _ = output.shape
+    logits = output[..., :seg_dim]
+    dirs = output[..., seg_dim : seg_dim + 2 * kp]
+    lab = labels.to(torch.int64)
+    mask_loss = F.cross_entropy(logits.reshape(-1, seg_dim), lab.reshape(-1), reduction="mean")
+    fg_lab = lab.clone()
+    if filter_vertex_with_segmentation:
+        pred = torch.argmax(logits.detach(), dim=-1)
+        fg_lab = torch.where(pred == lab, lab, torch.zeros_like(lab))
+    wgt = (fg_lab != 0).to(output.dtype)  # [b,h,w]
+    target = target_vector_field(labels, keypoints_yx)
+    # vertex loss
+    e = torch.abs(wgt[..., None] * (dirs - target))
+    per_img = smooth_l1(e).reshape(b, -1).sum(1) / (2 * kp * wgt.reshape(b, -1).sum(1) + 1e-3)
+    vertex_loss = per_img.mean()
+    # proxy voting loss: distance between the GT keypoint and the line through the pixel along the predicted direction
+    v = dirs.reshape(b, h, w, kp, 2)
+    vy, vx = v[..., 0], v[..., 1]
+    bi = torch.arange(b)[:, None, None]
+    obj = torch.clamp(fg_lab - 1, min=0)  # argmax over target_seg[...,1:] (background pixels have weight 0 anyway)
+    k = keypoints_yx[bi, obj]  # [b,h,w,kp,2] (y,x)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=output.dtype) + 0.5, torch.arange(w, dtype=output.dtype) + 0.5, indexing="ij")
+    num = torch.abs(vy * (k[..., 1] - xx[None, :, :, None]) - vx * (k[..., 0] - yy[None, :, :, None]))
+    nrm = torch.sqrt(vy * vy + vx * vx)
+    dist = torch.where(nrm > 0, num / torch.where(nrm > 0, nrm, torch.ones_like(nrm)), torch.zeros_like(num))  # divide_no_nan
+    dist = torch.abs(wgt[..., None] * dist)
+    per_img = smooth_l1(dist).reshape(b, -1).sum(1) / (2 * kp * wgt.reshape(b, -1).sum(1) + 1e-3)
+    proxy_loss = per_img.mean()
+    return mask_loss, vertex_loss, proxy_loss

@@ -1,0 +1,372 @@
+"""GPU parity of the TRAINING path (forward with batch statistics, losses, hand-written backward, Adam)
+against the fp64 PyTorch-autograd restatement in oracle/torch_train_ref.py, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import casapose_oracle as O
+import torch_train_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+
+
+def rel_l2(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+
+
+def blob_labels(b, h, w, k, seed):
+    rng = np.random.default_rng(seed)
+    lab = np.zeros((b, h, w), np.uint8)
+    for n in range(b):
+        for c in range(1, k):
+            y0, x0 = rng.integers(0, h - h // 3), rng.integers(0, w - w // 3)
+            lab[n, y0:y0 + rng.integers(h // 4, h // 2), x0:x0 + rng.integers(w // 4, w // 2)] = c
+    return lab
+
+
+# --------------------------------------------------------------------------------------------------
+# single-layer checks: weight and data gradient of every convolution flavour on the path
+# --------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name, k, stride, dil, pad, sources [(padded, real)], cout, partial, (h, w)
+    ("3x3", 3, 1, 1, 1, [(64, 64)], 64, False, (12, 20)),
+    ("3x3_two_sources", 3, 1, 1, 1, [(64, 64), (32, 32)], 32, False, (10, 12)),
+    ("3x3_image_skip", 3, 1, 1, 1, [(32, 32), (4, 3)], 32, False, (16, 16)),
+    ("3x3_dil2", 3, 1, 2, 2, [(32, 32)], 96, False, (9, 11)),
+    ("3x3_dil4_wide", 3, 1, 4, 4, [(128, 128)], 160, False, (8, 8)),
+    ("3x3_stride2", 3, 2, 1, 1, [(64, 64)], 128, False, (12, 16)),
+    ("1x1_stride2", 1, 2, 1, 0, [(64, 64)], 128, False, (12, 16)),
+    ("1x1_head", 1, 1, 1, 0, [(32, 32)], 9, False, (10, 14)),
+    ("7x7_stride2_image", 7, 2, 1, 3, [(4, 3)], 64, False, (16, 24)),
+    ("3x3_partial", 3, 1, 1, 1, [(64, 64)], 32, True, (12, 16)),
+    ("3x3_partial_image", 3, 1, 1, 1, [(32, 32), (4, 3)], 32, True, (16, 16)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_wgrad_dgrad(device, case):
+    from casapose_amd import _lib
+    from casapose_amd.train_engine import ConvOp, ParamStore, TrainConv, TT
+
+    name, k, stride, dil, pad, sources, cout, partial, (h, w) = case
+    b = 2
+    rng = np.random.default_rng(sum(name.encode()))
+    cin = sum(s[1] for s in sources)
+    wk = rng.standard_normal((k, k, cin, cout)).astype(np.float32) * 0.1
+    store = ParamStore({"L.kernel": wk}, device)
+    needs = [s[0] != 4 for s in sources]
+    layer = TrainConv(store, "L.kernel", 0, k, cout, sources, needs)
+    xs = []
+    for (cp, cr), ng in zip(sources, needs):
+        x = np.zeros((b, h, w, cp), np.float32)
+        x[..., :cr] = rng.standard_normal((b, h, w, cr))
+        xs.append(x)
+    tts = [TT(torch.from_numpy(x).to(device), ng) for x, ng in zip(xs, needs)]
+    eff = (k - 1) * dil + 1
+    oh, ow = (h + 2 * pad - eff) // stride + 1, (w + 2 * pad - eff) // stride + 1
+    ldo = (cout + 31) // 32 * 32
+    out = TT(torch.zeros(b, oh, ow, ldo, device=device), True)
+    lab_t = pn_t = None
+    lab = None
+    if partial:
+        lab = blob_labels(b, h, w, 4, 5)
+        lab_t = torch.from_numpy(lab).to(device)
+        cnt = np.zeros((b, h, w))
+        lp = np.pad(lab.astype(np.int64) + 1, ((0, 0), (1, 1), (1, 1)))
+        for ky in range(3):
+            for kx in range(3):
+                cnt += lp[:, ky:ky + h, kx:kx + w] == (lab + 1)
+        pn = (9.0 / cnt).astype(np.float32)
+        pn_t = torch.from_numpy(pn).to(device)
+    op = ConvOp(layer, [(t, t.c) for t in tts], (out.data, 0, ldo), b, h, w, stride=stride, dilation=dil, pad=pad, tap_label=lab_t, row_scale=pn_t,
+                out=out, dy_ptr_ld=(out.grad, 0, ldo))
+    stream = torch.cuda.current_stream(device).cuda_stream
+    layer.refresh(stream)
+    op.forward(stream)
+    # reference (fp64 autograd)
+    xr = [torch.tensor(x[..., :cr].astype(np.float64), requires_grad=True) for x, (cp, cr) in zip(xs, sources)]
+    wr = torch.tensor(wk.astype(np.float64), requires_grad=True)
+    xin = torch.cat(xr, dim=3)
+    if partial:
+        yr = R.partial_conv(xin, wr.permute(2, 0, 1, 3), torch.from_numpy(lab.astype(np.int64)))
+    else:
+        yr = R.conv_nhwc(xin, wr, stride=stride, dilation=dil, pad=pad)
+    got = out.data.cpu().numpy()[..., :cout]
+    assert rel(got, yr.detach().numpy()) < 2e-5
+    dy = rng.standard_normal((b, oh, ow, cout))
+    yr.backward(torch.from_numpy(dy))
+    dyp = np.zeros((b, oh, ow, ldo), np.float32)
+    dyp[..., :cout] = dy
+    if partial:  # the gradient of the un-normalised sum, as the normalisation backward hands it over
+        dyp *= pn[..., None]
+    out.grad.copy_(torch.from_numpy(dyp))
+    out.has_grad = True
+    op.backward(stream)
+    torch.cuda.synchronize()
+    gw = store.grad_view("L.kernel").cpu().numpy()
+    assert rel(gw, wr.grad.numpy()) < 3e-5, "weight gradient"
+    for t, x64, ng in zip(tts, xr, needs):
+        if ng:
+            assert rel(t.grad.cpu().numpy(), x64.grad.numpy()) < 3e-5, "data gradient"
+    # accumulation into an existing gradient (tensor with several consumers)
+    for t in tts:
+        if t.needs_grad:
+            t.grad.fill_(1.0)
+            t.has_grad = True
+    op.backward(stream)
+    torch.cuda.synchronize()
+    for t, x64, ng in zip(tts, xr, needs):
+        if ng:
+            assert rel(t.grad.cpu().numpy(), x64.grad.numpy() + 1.0) < 3e-5, "accumulated data gradient"
+
+
+# --------------------------------------------------------------------------------------------------
+# normalisation + activation, resampling adjoints, loss, Adam
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("classes,act,c", [(1, 1, 64), (1, 2, 32), (5, 2, 32), (9, 1, 256), (1, 0, 4)])
+def test_bn_act_forward_backward(device, hip_lib, classes, act, c):
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(c + classes)
+    b, h, w = 2, 12, 10
+    n = b * h * w
+    x = (rng.standard_normal((n, c)) * 2 + 0.5).astype(np.float32)
+    lab = rng.integers(0, classes, n).astype(np.uint8)
+    gamma = (1 + 0.3 * rng.standard_normal((classes, c))).astype(np.float32)
+    beta = (0.2 * rng.standard_normal((classes, c))).astype(np.float32)
+    dy = rng.standard_normal((n, c)).astype(np.float32)
+    rs = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    st = torch.cuda.current_stream(device).cuda_stream
+    keep = []
+
+    def d(a):
+        keep.append(torch.from_numpy(np.ascontiguousarray(a)).to(device))  # stays alive for the whole test
+        return keep[-1]
+
+    xd, labd, dyd = d(x), d(lab), d(dy)
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=device)
+    check(lib.cp_bn_stats_f32(xd.data_ptr(), n, c, c, sums.data_ptr(), st))
+    s = sums.cpu().numpy()
+    x64 = x.astype(np.float64)
+    assert rel(s[:c], x64.sum(0)) < 1e-12 and rel(s[c:], (x64 ** 2).sum(0)) < 1e-12
+    # reference
+    xt = torch.tensor(x64, requires_grad=True)
+    gt, bt = torch.tensor(gamma.astype(np.float64), requires_grad=True), torch.tensor(beta.astype(np.float64), requires_grad=True)
+    mean = xt.mean(0)
+    var = ((xt - mean) ** 2).mean(0)
+    xh = (xt - mean) / torch.sqrt(var + R.BN_EPS)
+    li = torch.from_numpy(lab.astype(np.int64))
+    t = gt[li] * xh + bt[li]
+    yr = t if act == 0 else (F.relu(t) if act == 1 else R.leaky_pair(t))
+    yr.backward(torch.from_numpy(dy.astype(np.float64)))
+    # device forward
+    meanv = (s[:c] / n)
+    varv = s[c:] / n - meanv ** 2
+    rstd = 1.0 / np.sqrt(varv + R.BN_EPS)
+    scale = (gamma * rstd[None]).astype(np.float32)
+    shift = (beta - gamma * (meanv * rstd)[None]).astype(np.float32)
+    y = torch.empty(n, c, device=device)
+    check(lib.cp_affine_act_f32(xd.data_ptr(), n, c, c, d(scale).data_ptr(), d(shift).data_ptr(), labd.data_ptr() if classes > 1 else None, act,
+                                y.data_ptr(), c, st))
+    assert rel(y.cpu().numpy(), yr.detach().numpy()) < 2e-5
+    # device backward
+    red = torch.zeros(classes * c * 2, dtype=torch.float64, device=device)
+    chan = torch.zeros(c * 2, dtype=torch.float64, device=device)
+    md, rd, gd, bd = d(meanv.astype(np.float32)), d(rstd.astype(np.float32)), d(gamma), d(beta)
+    lp = labd.data_ptr() if classes > 1 else None
+    check(lib.cp_bn_act_bwd_reduce_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, classes, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                       red.data_ptr(), chan.data_ptr(), st))
+    dx = torch.full((n, c), 7.0, device=device)
+    check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                      chan.data_ptr(), float(n), None, dx.data_ptr(), c, 0, st))
+    r = red.cpu().numpy().reshape(classes, c, 2)
+    assert rel(r[..., 0], bt.grad.numpy()) < 2e-5, "d beta"
+    assert rel(r[..., 1], gt.grad.numpy()) < 2e-5, "d gamma"
+    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 5e-5, "dx"
+    # row scale + accumulate
+    check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                      chan.data_ptr(), float(n), d(rs).data_ptr(), dx.data_ptr(), c, 1, st))
+    assert rel(dx.cpu().numpy(), xt.grad.numpy() * (1 + rs[:, None])) < 5e-5
+
+
+def test_resampling_adjoints(device, hip_lib):
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(0)
+    b, h, w, c = 2, 10, 14, 32
+    st = torch.cuda.current_stream(device).cuda_stream
+    keep = []
+
+    def d(a):
+        keep.append(torch.from_numpy(np.ascontiguousarray(a)).to(device))
+        return keep[-1]
+
+    # max pool (post-ReLU input, like the reference graph)
+    x = np.maximum(rng.standard_normal((b, h, w, c)), 0).astype(np.float32)
+    xt = torch.tensor(x.astype(np.float64), requires_grad=True)
+    yr = R.maxpool_zero_pad(xt)
+    dy = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    (yr * torch.from_numpy(dy.astype(np.float64))).sum().backward()
+    dx = torch.empty(b, h, w, c, device=device)
+    check(lib.cp_maxpool3x3s2_bwd_f32(d(x).data_ptr(), d(dy).data_ptr(), b, h, w, c, dx.data_ptr(), 0, st))
+    got = dx.cpu().numpy()
+    pos = x > 0  # at exact zeros the following ReLU blocks the gradient; ties there are immaterial
+    assert rel(got[pos], xt.grad.numpy()[pos]) < 1e-6
+    # bilinear x2
+    x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    xt = torch.tensor(x.astype(np.float64), requires_grad=True)
+    yr = R.bilinear_x2(xt)
+    dy = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    (yr * torch.from_numpy(dy.astype(np.float64))).sum().backward()
+    check(lib.cp_upsample_bilinear_x2_bwd_f32(d(dy).data_ptr(), c, b, h, w, c, dx.data_ptr(), st))
+    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 1e-5
+    # guided nearest x2
+    lab_hi = blob_labels(b, 2 * h, 2 * w, 4, 3)
+    lab_lo = lab_hi[:, ::2, ::2]
+    sel = R.guided_select(torch.from_numpy(lab_lo.astype(np.int64)), torch.from_numpy(lab_hi.astype(np.int64))).numpy().astype(np.uint8)
+    xt = torch.tensor(x.astype(np.float64), requires_grad=True)
+    yr = R.guided_upsample(xt, torch.from_numpy(lab_lo.astype(np.int64)), torch.from_numpy(lab_hi.astype(np.int64)))
+    (yr * torch.from_numpy(dy.astype(np.float64))).sum().backward()
+    check(lib.cp_guided_upsample_x2_bwd_f32(d(dy).data_ptr(), c, d(sel).data_ptr(), b, h, w, c, dx.data_ptr(), st))
+    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("filt", [True, False])
+def test_pose_loss_value_and_gradient(device, hip_lib, filt):
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(11)
+    b, h, w, k, kp = 2, 24, 32, 5, 9
+    ld = k + 3 * kp
+    out = rng.standard_normal((b, h, w, ld)).astype(np.float32)
+    lab = blob_labels(b, h, w, k, 2)
+    out[..., :k] += 3.0 * np.eye(k, dtype=np.float32)[lab] * (rng.uniform(size=(b, h, w, 1)) < 0.7)  # mostly-correct prediction
+    out[..., k:k + 2 * kp] *= np.where(rng.uniform(size=(b, h, w, 1)) < 0.5, 0.3, 3.0)  # both smooth-L1 branches
+    kpts = rng.uniform(-10, 40, (b, k - 1, kp, 2)).astype(np.float32)
+    ot = torch.tensor(out.astype(np.float64), requires_grad=True)
+    ml, vl, pl = R.losses(ot, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, kp, filt)
+    wts = (1.0, 0.5, 0.015)
+    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
+    st = torch.cuda.current_stream(device).cuda_stream
+    d = lambda a: torch.from_numpy(a).to(device)
+    od, labd, kd = d(out), d(lab), d(kpts)
+    ws = torch.empty(lib.cp_pose_loss_workspace_bytes(b, h, w), dtype=torch.uint8, device=device)
+    dout = torch.full((b, h, w, 64), 5.0, device=device)
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
+    check(lib.cp_pose_loss_f32(od.data_ptr(), ld, k, kp, labd.data_ptr(), labd.data_ptr(), kd.data_ptr(), k - 1, b, h, w, int(filt), *wts, ws.data_ptr(),
+                               dout.data_ptr(), 64, 32, sums.data_ptr(), st))
+    s = sums.cpu().numpy()
+    assert abs(s[0] - ml.item()) < 1e-5 * abs(ml.item())
+    assert abs(s[1] - vl.item()) < 1e-5 * abs(vl.item())
+    assert abs(s[2] - pl.item()) < 1e-5 * abs(pl.item())
+    g = dout.cpu().numpy()
+    gr = ot.grad.numpy()
+    assert rel(g[..., :k], gr[..., :k]) < 2e-5
+    assert rel(g[..., 32:32 + 2 * kp], gr[..., k:k + 2 * kp]) < 2e-5
+    assert np.all(g[..., k:32] == 0) and np.all(g[..., 32 + 2 * kp:] == 0)
+
+
+def test_adam_matches_keras_formula(device, hip_lib):
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(5)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    m, v = np.zeros(n), np.zeros(n)
+    pr = p.astype(np.float64)
+    pd, md, vd = torch.from_numpy(p).to(device), torch.zeros(n, device=device), torch.zeros(n, device=device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-7
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        gd = torch.from_numpy(g).to(device)
+        check(lib.cp_adam_step_f32(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr, b1, b2, eps, step, 1.0, st))
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g.astype(np.float64) ** 2
+        pr -= lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step) * m / (np.sqrt(v) + eps)
+    assert rel(pd.cpu().numpy(), pr) < 1e-6
+
+
+# --------------------------------------------------------------------------------------------------
+# whole network
+# --------------------------------------------------------------------------------------------------
+def _setup(device, b, h, w, k, seed=1237):
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    v = 27
+    params = O.init_params(k, v, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    for name in params:  # non-trivial normalisation parameters
+        if name.endswith(".gamma"):
+            params[name] = (1 + 0.2 * rng.standard_normal(params[name].shape)).astype(np.float32)
+        if name.endswith(".beta"):
+            params[name] = (0.1 * rng.standard_normal(params[name].shape)).astype(np.float32)
+    store = ParamStore(params, device)
+    plan = TrainPlan(store, k, v, b, h, w)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    lab = blob_labels(b, h, w, k, seed + 1)
+    kpts = rng.uniform(0, min(h, w), (b, k - 1, 9, 2)).astype(np.float32)
+    return params, store, plan, img, lab, kpts
+
+
+def test_train_forward_backward_matches_autograd(device):
+    b, h, w, k = 2, 32, 48, 4
+    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    plan.refresh_weights(stream)
+    labd = torch.from_numpy(lab).to(device)
+    out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd)
+    p64 = R.to_torch(params)
+    stats = {}
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats)
+    got = out.cpu().numpy()
+    assert rel(got[..., :k], ref.detach().numpy()[..., :k]) < 1e-3
+    assert rel(got[..., k:], ref.detach().numpy()[..., k:]) < 1e-3
+    wts = (1.0, 0.5, 0.015)
+    sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(device), *wts, filter_with_segmentation=False)
+    ml, vl, pl = R.losses(ref, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, 9, False)
+    s = sums.cpu().numpy()
+    assert abs(s[0] - ml.item()) < 1e-3 * abs(ml.item()) and abs(s[1] - vl.item()) < 1e-3 * abs(vl.item()) and abs(s[2] - pl.item()) < 1e-3 * abs(pl.item())
+    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
+    plan.backward()
+    torch.cuda.synchronize()
+    worst = {}
+    for name in store.offsets:
+        g = store.grad_view(name).cpu().numpy()
+        gr = p64[name].grad.numpy()
+        worst[name] = rel_l2(g, gr)
+    bad = {n: e for n, e in worst.items() if e > 2e-2}
+    assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
+    # moving statistics were updated with the batch statistics
+    mm = store.state["bn0.moving_mean"].cpu().numpy()
+    exp = 0.99 * params["bn0.moving_mean"] + 0.01 * stats["bn0"][0].numpy()
+    assert rel(mm, exp) < 1e-4
+
+
+def test_train_steps_reduce_the_loss(device):
+    b, h, w, k = 2, 32, 32, 3
+    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, seed=99)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    plan.refresh_weights(stream)
+    imgd, labd, kd = torch.from_numpy(img).to(device), torch.from_numpy(lab).to(device), torch.from_numpy(kpts).to(device)
+    hist = []
+    for it in range(12):
+        s = plan.train_step(imgd, labd, labd, kd, lr=1e-3, cond_labels=labd, weights=(1.0, 0.5, 0.015))
+        hist.append(s.cpu().numpy().copy())
+    hist = np.array(hist)
+    total = hist[:, 0] + 0.5 * hist[:, 1] + 0.015 * hist[:, 2]
+    assert np.all(np.isfinite(hist))
+    assert total[-1] < 0.8 * total[0], "loss did not go down: %s" % total
