@@ -105,6 +105,8 @@ SYMBOLS = [
     # ---- training path ----
     ("cp_conv2d_wgrad_f32", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     ("cp_bn_stats_f32", _i, [_vp, _ll, _i, _i, _vp, _vp]),
+    ("cp_bn_finalize_f32", _i, [_vp, C.c_double, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("cp_bn_param_grads_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_affine_act_f32", _i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     ("cp_bn_act_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("cp_bn_act_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, _vp, _vp, _i, _i, _vp]),
@@ -116,6 +118,9 @@ SYMBOLS = [
     ("cp_axpby_f32", _i, [_vp, _f, _vp, _f, _ll, _vp, _vp]),
     ("cp_adam_step_f32", _i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),
     ("cp_pose_loss_workspace_bytes", C.c_size_t, [_i, _i, _i]),
+    ("cp_ls_vote_bwd_f32", _i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    ("cp_kp_stats_f32", _i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_kp_reproj_loss_f32", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     ("cp_pose_loss_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
 ]
 

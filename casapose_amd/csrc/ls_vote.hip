@@ -171,6 +171,187 @@ __global__ void ls_solve_kernel(const double* __restrict__ sums, int total, int 
     out[2 * i + 1] = (float)p1 * (float)H;
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward of the voter (the reference differentiates CoordLSVotingWeighted with tf.GradientTape,
+// train_casapose.py:555-579,594): with A = sum R, b = sum R c, p = A^-1 b and g = dL/dp,
+//   u = A^-1 g,  dL/dR_i = u (c_i - p)^T  for every pixel i of the object, R_i = w_i (I - n_i n_i^T):
+//   dL/dw_i = u.e - (u.n)(n.e)                 e = c_i - p
+//   dL/dn_i = -w_i (u (e.n) + e (u.n))
+//   dL/dd_i = (dL/dn - n (n.dL/dn)) / |d|      n = d/|d|
+//   dL/dconf_i = dL/dw_i * sigmoid(conf_i)      w = softplus(conf)
+// No reduction: one pass over the pixels given the per-keypoint pair (p, u).
+__global__ void ls_bwd_prepare_kernel(const double* __restrict__ sums, const float* __restrict__ dkp, int total, int H, float* __restrict__ pu) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double* s = sums + (size_t)i * 5;
+    const double a = s[0], b = s[1], c = s[2], t0 = s[3], t1 = s[4];
+    const double g0 = (double)dkp[2 * i] * H, g1 = (double)dkp[2 * i + 1] * H;  // keypoints = p * H
+    const double det = a * c - b * b;
+    const double tr = a + c;
+    double p0 = 0, p1 = 0, u0 = 0, u1 = 0;
+    if (tr > 0.0 && fabs(det) > 1e-12 * tr * tr) {  // regular system; a degenerate one passes no gradient
+        p0 = (c * t0 - b * t1) / det;
+        p1 = (a * t1 - b * t0) / det;
+        u0 = (c * g0 - b * g1) / det;
+        u1 = (a * g1 - b * g0) / det;
+    }
+    pu[4 * i] = (float)p0; pu[4 * i + 1] = (float)p1; pu[4 * i + 2] = (float)u0; pu[4 * i + 3] = (float)u1;
+}
+
+template <int KP>
+__global__ void ls_bwd_kernel(const float* __restrict__ field, int ld, int dir_off, int conf_off, const uint8_t* __restrict__ labels, int B, int H,
+                              int W, int objects, const float* __restrict__ pu, const uint8_t* __restrict__ reg_labels,
+                              const float* __restrict__ conf_coef, float* __restrict__ dfield, int dld, int ddir_off, int dconf_off,
+                              int accumulate) {
+    const long long total = (long long)B * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lab = labels[i];
+        const int rlab = reg_labels ? reg_labels[i] : 0;
+        float* g = dfield + i * dld;
+        if (lab == 0 && rlab == 0) {
+            if (!accumulate) {
+                for (int j = 0; j < 2 * KP; ++j) g[ddir_off + j] = 0.f;
+                for (int j = 0; j < KP; ++j) g[dconf_off + j] = 0.f;
+            }
+            continue;
+        }
+        const int x = (int)(i % W);
+        const long long t = i / W;
+        const int y = (int)(t % H), b = (int)(t / H);
+        const float cy = ((float)y + 0.5f) / (float)H, cx = ((float)x + 0.5f) / (float)H;
+        const float* px = field + i * ld;
+        const float* tab = pu + ((size_t)b * objects + (lab > 0 ? lab - 1 : 0)) * KP * 4;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const float cf = px[conf_off + j];
+            const float sg = 1.f / (1.f + __expf(-cf));
+            float gdy = 0.f, gdx = 0.f, gcf = 0.f;
+            if (lab > 0) {
+                const float dy = px[dir_off + 2 * j], dx = px[dir_off + 2 * j + 1];
+                const float w = fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf)));
+                const float nrm = sqrtf(dy * dy + dx * dx);
+                const float p0 = tab[4 * j], p1 = tab[4 * j + 1], u0 = tab[4 * j + 2], u1 = tab[4 * j + 3];
+                const float e0 = cy - p0, e1 = cx - p1;
+                if (nrm > 0.f) {
+                    const float inr = 1.f / nrm;
+                    const float ny = dy * inr, nx = dx * inr;
+                    const float un = u0 * ny + u1 * nx, en = e0 * ny + e1 * nx, ue = u0 * e0 + u1 * e1;
+                    gcf = (ue - un * en) * sg;
+                    const float ln0 = -w * (u0 * en + e0 * un), ln1 = -w * (u1 * en + e1 * un);
+                    const float nl = ny * ln0 + nx * ln1;
+                    gdy = (ln0 - ny * nl) * inr;
+                    gdx = (ln1 - nx * nl) * inr;
+                } else {
+                    gcf = (u0 * e0 + u1 * e1) * sg;  // n = 0: R = w I
+                }
+            }
+            if (rlab > 0 && conf_coef) gcf += conf_coef[b * KP + j] * sg;
+            if (accumulate) {
+                g[ddir_off + 2 * j] += gdy;
+                g[ddir_off + 2 * j + 1] += gdx;
+                g[dconf_off + j] += gcf;
+            } else {
+                g[ddir_off + 2 * j] = gdy;
+                g[ddir_off + 2 * j + 1] = gdx;
+                g[dconf_off + j] = gcf;
+            }
+        }
+    }
+}
+
+// per image: counts of every class in two label maps and, over the foreground of `labels`, the sums of softplus(conf_j)
+// (objects_available and the confidence regulariser of keypoint_reprojection_loss, loss_functions.py:236-262)
+template <int KP>
+__global__ __launch_bounds__(256) void kp_stats_kernel(const float* __restrict__ field, int ld, int conf_off, const uint8_t* __restrict__ labels,
+                                                       const uint8_t* __restrict__ labels_est, int pix_per_img, int classes,
+                                                       int* __restrict__ counts, double* __restrict__ conf_sums) {
+    extern __shared__ int scount[];  // [2][classes]
+    __shared__ double ssum[KP];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * classes; i += blockDim.x) scount[i] = 0;
+    if (threadIdx.x < KP) ssum[threadIdx.x] = 0.0;
+    __syncthreads();
+    double cs[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) cs[j] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pix_per_img; i += gridDim.x * blockDim.x) {
+        const size_t p = (size_t)b * pix_per_img + i;
+        const int l = labels[p];
+        atomicAdd(&scount[l < classes ? l : 0], 1);
+        if (labels_est) {
+            const int le = labels_est[p];
+            atomicAdd(&scount[classes + (le < classes ? le : 0)], 1);
+        }
+        if (l > 0) {
+            const float* px = field + p * ld + conf_off;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const float cf = px[j];
+                cs[j] += (double)(fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf))));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        double v = cs[j];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&ssum[j], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * classes; i += blockDim.x)
+        if (scount[i]) atomicAdd(&counts[((size_t)(i / classes) * gridDim.y + b) * classes + (i % classes)], scount[i]);
+    if (threadIdx.x < KP && ssum[threadIdx.x] != 0.0) atomicAdd(&conf_sums[b * KP + threadIdx.x], ssum[threadIdx.x]);
+}
+
+// keypoint_reprojection_loss without BPnP (loss_functions.py:207-344): crop pixels -> original image through the per-image
+// affine (transform_points_back_tf_batch, ransac_voting.py:124-158), distance to the projected ground-truth keypoints,
+// smooth L1, soft cap at max_err, mean over keypoints, sum over available objects / their number.  One block.
+__global__ void kp_reproj_loss_kernel(const float* __restrict__ coords_yx, const float* __restrict__ gt_xy, const float* __restrict__ affine,
+                                      const float* __restrict__ avail, int batch, int objects, int kp, float max_err, float weight,
+                                      float* __restrict__ g_yx, double* __restrict__ loss_out) {
+    __shared__ double red[256];
+    __shared__ double navail;
+    const int N = batch * objects;
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int n = 0; n < N; ++n) s += avail[n];
+        navail = s;
+    }
+    __syncthreads();
+    const double na = navail;
+    double local = 0.0;
+    for (int i = threadIdx.x; i < N * kp; i += blockDim.x) {
+        const int n = i / kp;
+        const int b = n / objects;
+        const float av = avail[n];
+        const float* A = affine + b * 6;
+        const float y = coords_yx[2 * i], x = coords_yx[2 * i + 1];
+        const float X = A[0] * x + A[1] * y + A[2], Y = A[3] * x + A[4] * y + A[5];
+        const float dx = (gt_xy[2 * i] - X) * av, dy = (gt_xy[2 * i + 1] - Y) * av;
+        const float e = sqrtf(dx * dx + dy * dy);
+        float l = e < 1.f ? 0.5f * e * e : e - 0.5f;
+        float slope = e < 1.f ? e : 1.f;
+        if (l > max_err) { l = max_err + (l - max_err) * 0.01f; slope *= 0.01f; }
+        local += (double)(l * av);
+        float gx = 0.f, gy = 0.f;
+        if (e > 0.f && na > 0.0) {
+            const float c = weight * slope * av * av / (e * (float)kp * (float)na);  // d loss / d (X,Y) = -c*(dx,dy)
+            const float gX = -c * dx, gY = -c * dy;
+            gx = gX * A[0] + gY * A[3];
+            gy = gX * A[1] + gY * A[4];
+        }
+        g_yx[2 * i] = gy;
+        g_yx[2 * i + 1] = gx;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = na > 0.0 ? red[0] / ((double)kp * na) : 0.0;
+}
+
 }  // namespace
 
 extern "C" size_t cp_ls_vote_workspace_bytes(int batch, int objects, int kp) {
@@ -197,4 +378,50 @@ extern "C" int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_o
     int total = batch * objects * kp;
     CP_LAUNCH(ls_solve_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, total, h, keypoints);
     return cp::check_launch("cp_ls_vote_f32");
+}
+
+
+extern "C" int cp_ls_vote_bwd_f32(const float* field, int ld, int dir_off, int conf_off, const uint8_t* labels, int batch, int h, int w,
+                                  int objects, int kp, const double* sums_ws, const float* dkeypoints, float* pu_ws,
+                                  const uint8_t* reg_labels, const float* conf_coef, float* dfield, int dld, int ddir_off, int dconf_off,
+                                  int accumulate, void* stream) {
+    CP_REQUIRE(field && labels && sums_ws && dkeypoints && pu_ws && dfield, "cp_ls_vote_bwd_f32: null pointer");
+    CP_REQUIRE(kp == MAXKP, "cp_ls_vote_bwd_f32: built for %d keypoints (got %d)", MAXKP, kp);
+    CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ls_vote_bwd_f32: bad sizes");
+    CP_REQUIRE(dir_off >= 0 && dir_off + 2 * kp <= ld && conf_off >= 0 && conf_off + kp <= ld, "cp_ls_vote_bwd_f32: channel offsets outside the pixel record");
+    CP_REQUIRE(ddir_off >= 0 && ddir_off + 2 * kp <= dld && dconf_off >= 0 && dconf_off + kp <= dld, "cp_ls_vote_bwd_f32: gradient offsets outside the row");
+    CP_REQUIRE((reg_labels == nullptr) == (conf_coef == nullptr), "cp_ls_vote_bwd_f32: reg_labels and conf_coef come together");
+    hipStream_t st = (hipStream_t)stream;
+    const int total = batch * objects * kp;
+    CP_LAUNCH(ls_bwd_prepare_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, dkeypoints, total, h, pu_ws);
+    if (cp::check_launch("cp_ls_vote_bwd_f32 prepare") != CP_OK) return CP_ERR_LAUNCH;
+    const long long px = (long long)batch * h * w;
+    long long blocks = (px + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    CP_LAUNCH((ls_bwd_kernel<MAXKP>), dim3((unsigned)blocks), dim3(256), 0, st, field, ld, dir_off, conf_off, labels, batch, h, w, objects, pu_ws, reg_labels,
+              conf_coef, dfield, dld, ddir_off, dconf_off, accumulate);
+    return cp::check_launch("cp_ls_vote_bwd_f32");
+}
+
+extern "C" int cp_kp_stats_f32(const float* field, int ld, int conf_off, const uint8_t* labels, const uint8_t* labels_est, int batch, int h, int w,
+                               int classes, int kp, int32_t* counts, double* conf_sums, void* stream) {
+    CP_REQUIRE(field && labels && counts && conf_sums, "cp_kp_stats_f32: null pointer");
+    CP_REQUIRE(kp == MAXKP && classes >= 2 && classes <= 256 && conf_off >= 0 && conf_off + kp <= ld, "cp_kp_stats_f32: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * batch * classes, st) != hipSuccess) return cp::check_launch("cp_kp_stats_f32 memset");
+    if (hipMemsetAsync(conf_sums, 0, sizeof(double) * batch * kp, st) != hipSuccess) return cp::check_launch("cp_kp_stats_f32 memset");
+    const int ppi = h * w;
+    int gx = (ppi + 255) / 256;
+    if (gx > 256) gx = 256;
+    CP_LAUNCH((kp_stats_kernel<MAXKP>), dim3(gx, batch), dim3(256), sizeof(int) * 2 * classes, st, field, ld, conf_off, labels, labels_est, ppi, classes, counts,
+              conf_sums);
+    return cp::check_launch("cp_kp_stats_f32");
+}
+
+extern "C" int cp_kp_reproj_loss_f32(const float* coords_yx, const float* gt_xy, const float* affine, const float* avail, int batch, int objects,
+                                     int kp, float max_pixel_error, float weight, float* g_yx, double* loss_out, void* stream) {
+    CP_REQUIRE(coords_yx && gt_xy && affine && avail && g_yx && loss_out && batch > 0 && objects > 0 && kp > 0, "cp_kp_reproj_loss_f32: bad arguments");
+    CP_LAUNCH(kp_reproj_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, coords_yx, gt_xy, affine, avail, batch, objects, kp, max_pixel_error, weight,
+              g_yx, loss_out);
+    return cp::check_launch("cp_kp_reproj_loss_f32");
 }

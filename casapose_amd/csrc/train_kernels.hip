@@ -342,6 +342,48 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// batch statistics -> normalisation constants, folded affine tables and moving-average update, one launch
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double inv_n, int C, int real_c, int classes, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, int pad_one, float momentum, float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                   float* __restrict__ gamma_full, float* __restrict__ beta_full, float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= classes * C) return;
+    const int l = i / C, c = i - l * C;
+    const double mean = sums[c] * inv_n;
+    double var = sums[C + c] * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const bool real = c < real_c;
+    const double g = (gamma && real) ? (double)gamma[l * real_c + c] : 1.0;
+    const double b = (beta && real) ? (double)beta[l * real_c + c] : 0.0;
+    double sc = rstd * g, sh = b - mean * sc;
+    if (pad_one && !real) { sc = 0.0; sh = 1.0; }
+    scale[i] = (float)sc;
+    shift[i] = (float)sh;
+    gamma_full[i] = (float)g;
+    beta_full[i] = (float)b;
+    if (l == 0) {
+        mean_out[c] = (float)mean;
+        rstd_out[c] = (float)rstd;
+        if (moving_mean && real) {
+            moving_mean[c] = moving_mean[c] * momentum + (float)mean * (1.f - momentum);
+            moving_var[c] = moving_var[c] * momentum + (float)var * (1.f - momentum);
+        }
+    }
+}
+
+// red[(l*C+c)*2 + {0,1}] (fp64) -> d beta[l][c], d gamma[l][c] (fp32, real channels only)
+__global__ void bn_param_grads_kernel(const double* __restrict__ red, int C, int real_c, int classes, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= classes * real_c) return;
+    const int l = i / real_c, c = i - l * real_c;
+    const double* r = red + ((size_t)l * C + c) * 2;
+    if (dbeta) dbeta[i] = (float)r[0];
+    if (dgamma) dgamma[i] = (float)r[1];
+}
+
 }  // namespace
 
 extern "C" int cp_bn_stats_f32(const float* x, long long pixels, int channels, int ld, double* sums, void* stream) {
@@ -355,6 +397,25 @@ extern "C" int cp_bn_stats_f32(const float* x, long long pixels, int channels, i
     if (blocks < 1) blocks = 1;
     CP_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(THREADS), sizeof(double) * 2 * channels, st, x, pixels, channels, ld, sums);
     return cp::check_launch("cp_bn_stats_f32");
+}
+
+extern "C" int cp_bn_finalize_f32(const double* sums, double pixels, int channels, int real_channels, int classes, const float* gamma,
+                                  const float* beta, float eps, int pad_one, float momentum, float* moving_mean, float* moving_var, float* mean,
+                                  float* rstd, float* gamma_full, float* beta_full, float* scale, float* shift, void* stream) {
+    CP_REQUIRE(sums && mean && rstd && gamma_full && beta_full && scale && shift && pixels > 0, "cp_bn_finalize_f32: null pointer");
+    CP_REQUIRE(channels > 0 && real_channels > 0 && real_channels <= channels && classes >= 1, "cp_bn_finalize_f32: bad sizes");
+    CP_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "cp_bn_finalize_f32: moving_mean/moving_var come together");
+    const int n = classes * channels;
+    CP_LAUNCH(bn_finalize_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, (hipStream_t)stream, sums, 1.0 / pixels, channels, real_channels,
+              classes, gamma, beta, eps, pad_one, momentum, moving_mean, moving_var, mean, rstd, gamma_full, beta_full, scale, shift);
+    return cp::check_launch("cp_bn_finalize_f32");
+}
+
+extern "C" int cp_bn_param_grads_f32(const double* red, int channels, int real_channels, int classes, float* dgamma, float* dbeta, void* stream) {
+    CP_REQUIRE(red && (dgamma || dbeta) && channels > 0 && real_channels > 0 && real_channels <= channels && classes >= 1, "cp_bn_param_grads_f32: bad arguments");
+    const int n = classes * real_channels;
+    CP_LAUNCH(bn_param_grads_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, (hipStream_t)stream, red, channels, real_channels, classes, dgamma, dbeta);
+    return cp::check_launch("cp_bn_param_grads_f32");
 }
 
 extern "C" int cp_affine_act_f32(const float* x, long long pixels, int channels, int ld_x, const float* scale, const float* shift,

@@ -328,12 +328,18 @@ class BnActOp:
         self.rstd = torch.zeros(C_, **f32)
         self.scale = torch.zeros(classes, C_, **f32)
         self.shift = torch.zeros(classes, C_, **f32)
+        self.gamma_full = torch.ones(classes, C_, **f32)
+        self.beta_full = torch.zeros(classes, C_, **f32)
         self.red = torch.zeros(classes * C_ * 2, **f64)
         self.chan = torch.zeros(C_ * 2, **f64)
         st = plan.store
         self.real_c = st.offsets[beta][1][-1] if beta else C_
-        self.gamma_full = torch.ones(classes, C_, **f32) if (gamma or self.real_c != C_) else None
-        self.beta_full = torch.zeros(classes, C_, **f32)
+        self.gamma_p = st.view(gamma) if gamma else None
+        self.beta_p = st.view(beta) if beta else None
+        self.dgamma_p = st.grad_view(gamma) if gamma else None
+        self.dbeta_p = st.grad_view(beta) if beta else None
+        self.mm = st.state.get(name + ".moving_mean")
+        self.mv = st.state.get(name + ".moving_variance")
 
     def forward(self, stream: int):
         lib = _lib.load()
@@ -341,32 +347,13 @@ class BnActOp:
         C_ = x.c
         check(lib.cp_bn_stats_f32(x.data.data_ptr(), x.pixels, C_, C_, self.sums.data_ptr(), stream), "cp_bn_stats_f32(%s)" % self.name)
         n = p.all_reduce_stats(self.sums, x.pixels)
-        mean = self.sums[:C_] / n
-        var = torch.clamp(self.sums[C_:] / n - mean * mean, min=0.0)
-        rstd = torch.rsqrt(var + BN_EPS)
-        self.mean.copy_(mean)
-        self.rstd.copy_(rstd)
-        st = p.store
-        rc = self.real_c
-        if self.gamma_key:
-            self.gamma_full[:, :rc].copy_(st.view(self.gamma_key).reshape(self.classes, rc))
-        if self.beta_key:
-            self.beta_full[:, :rc].copy_(st.view(self.beta_key).reshape(self.classes, rc))
-        g64 = self.gamma_full.double() if self.gamma_full is not None else None
-        scale = rstd[None, :] * (g64 if g64 is not None else 1.0)
-        shift = self.beta_full.double() - mean[None, :] * scale
-        if self.pad_one:
-            scale[:, rc:] = 0.0
-            shift[:, rc:] = 1.0
-        self.scale.copy_(scale.expand(self.classes, C_))
-        self.shift.copy_(shift.expand(self.classes, C_))
+        upd = p.update_moving and self.mm is not None
+        check(lib.cp_bn_finalize_f32(self.sums.data_ptr(), float(n), C_, self.real_c, self.classes, _ptr(self.gamma_p), _ptr(self.beta_p), BN_EPS,
+                                     1 if self.pad_one else 0, BN_MOMENTUM, _ptr(self.mm) if upd else None, _ptr(self.mv) if upd else None,
+                                     self.mean.data_ptr(), self.rstd.data_ptr(), self.gamma_full.data_ptr(), self.beta_full.data_ptr(),
+                                     self.scale.data_ptr(), self.shift.data_ptr(), stream), "cp_bn_finalize_f32(%s)" % self.name)
         check(lib.cp_affine_act_f32(x.data.data_ptr(), x.pixels, C_, C_, self.scale.data_ptr(), self.shift.data_ptr(), _ptr(self.labels), self.act,
                                     self.y.data.data_ptr(), C_, stream), "cp_affine_act_f32(%s)" % self.name)
-        # moving statistics (Keras: moving = moving*momentum + batch*(1-momentum), biased variance)
-        mm, mv = st.state.get(self.name + ".moving_mean"), st.state.get(self.name + ".moving_variance")
-        if mm is not None and p.update_moving:
-            mm.mul_(BN_MOMENTUM).add_(mean[:rc].float(), alpha=1.0 - BN_MOMENTUM)
-            mv.mul_(BN_MOMENTUM).add_(var[:rc].float(), alpha=1.0 - BN_MOMENTUM)
 
     def backward(self, stream: int):
         lib = _lib.load()
@@ -375,8 +362,7 @@ class BnActOp:
         if not y.needs_grad:
             return  # bn_data: its beta gradient comes from conv0's weight gradient (TrainPlan.backward)
         assert y.has_grad, "gradient of %s output not produced" % self.name
-        gam = _ptr(self.gamma_full)
-        bet = self.beta_full.data_ptr()
+        gam, bet = self.gamma_full.data_ptr(), self.beta_full.data_ptr()
         check(lib.cp_bn_act_bwd_reduce_f32(x.data.data_ptr(), C_, y.grad.data_ptr(), C_, x.pixels, C_, self.classes, self.mean.data_ptr(),
                                            self.rstd.data_ptr(), gam, bet, _ptr(self.labels), self.act, self.red.data_ptr(), self.chan.data_ptr(),
                                            stream), "cp_bn_act_bwd_reduce_f32(%s)" % self.name)
@@ -386,12 +372,9 @@ class BnActOp:
                                               gam, bet, _ptr(self.labels), self.act, self.chan.data_ptr(), float(n), _ptr(self.row_scale),
                                               x.grad.data_ptr(), C_, 1 if x.has_grad else 0, stream), "cp_bn_act_bwd_apply_f32(%s)" % self.name)
             x.has_grad = True
-        red = self.red.view(self.classes, C_, 2)
-        st, rc = p.store, self.real_c
-        if self.beta_key:
-            st.grad_view(self.beta_key).copy_(red[:, :rc, 0].reshape(st.offsets[self.beta_key][1]))
-        if self.gamma_key:
-            st.grad_view(self.gamma_key).copy_(red[:, :rc, 1].reshape(st.offsets[self.gamma_key][1]))
+        if self.dgamma_p is not None or self.dbeta_p is not None:
+            check(lib.cp_bn_param_grads_f32(self.red.data_ptr(), C_, self.real_c, self.classes, _ptr(self.dgamma_p), _ptr(self.dbeta_p), stream),
+                  "cp_bn_param_grads_f32(%s)" % self.name)
 
 
 class FnOp:
@@ -442,6 +425,16 @@ class TrainPlan:
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
+        # keypoint-reprojection loss (LS voter forward/backward)
+        oc, kp = K - 1, 9
+        self.est_labels = torch.empty(B, h, w, **u8)
+        self.kp_counts = torch.zeros(2, B, K, dtype=torch.int32, device=dev)
+        self.kp_conf_sums = torch.zeros(B, kp, dtype=torch.float64, device=dev)
+        self.ls_sums = torch.zeros(B * oc * kp * 5, dtype=torch.float64, device=dev)
+        self.ls_pu = torch.zeros(B * oc * kp * 4, **f32)
+        self.ls_coords = torch.zeros(B, oc, kp, 2, **f32)
+        self.ls_g = torch.zeros(B, oc, kp, 2, **f32)
+        self.kp_loss_val = torch.zeros(1, dtype=torch.float64, device=dev)
 
         def layer(key, layout, k, cout, sources, grad_sources):
             L = TrainConv(store, key, layout, k, cout, sources, grad_sources)
@@ -647,6 +640,42 @@ class TrainPlan:
                                    self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(), stream), "cp_pose_loss_f32")
         return self.loss_sums
 
+    def kp_loss_and_grad(self, labels_gt: torch.Tensor, gt_xy: torch.Tensor, affine: torch.Tensor, kp_w: float, max_pixel_error: float = 25.0,
+                         min_num: int = 50, confidence_regularization: bool = False, vote_with_gt: bool = True, kp: int = 9) -> torch.Tensor:
+        """keypoint_reprojection_loss (loss_functions.py:207-344, use_bpnp_reprojection_loss=False) on the last forward's
+        output; ADDS kp_w * d loss / d output to self.dout (call after loss_and_grad).  gt_xy [B,oc,kp,2]: projected
+        ground-truth keypoints in image pixels; affine [B,6]: crop->image map (crop_to_image_affine).  Returns the
+        fp64 loss value (device scalar)."""
+        lib = _lib.load()
+        B, h, w, K = self.batch, self.h, self.w, self.seg_dim
+        oc = K - 1
+        out = self.out
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        conf_off = K + 2 * kp
+        check(lib.cp_argmax_labels(out.data_ptr(), self.out_ld, K, B * h * w, self.est_labels.data_ptr(), stream), "cp_argmax_labels")
+        check(lib.cp_kp_stats_f32(out.data_ptr(), self.out_ld, conf_off, labels_gt.data_ptr(), self.est_labels.data_ptr(), B, h, w, K, kp,
+                                  self.kp_counts.data_ptr(), self.kp_conf_sums.data_ptr(), stream), "cp_kp_stats_f32")
+        vote_labels = labels_gt if vote_with_gt else self.est_labels
+        check(lib.cp_ls_vote_f32(out.data_ptr(), self.out_ld, 0, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
+                                 self.ls_coords.data_ptr(), stream), "cp_ls_vote_f32")
+        # objects_available (loss_functions.py:236-252): > min_num pixels in the estimated AND the ground-truth mask
+        avail = ((self.kp_counts[1, :, 1:] > min_num) & (self.kp_counts[0, :, 1:] > min_num)).to(torch.float32).contiguous()
+        check(lib.cp_kp_reproj_loss_f32(self.ls_coords.data_ptr(), gt_xy.data_ptr(), affine.data_ptr(), avail.data_ptr(), B, oc, kp, max_pixel_error,
+                                        kp_w, self.ls_g.data_ptr(), self.kp_loss_val.data_ptr(), stream), "cp_kp_reproj_loss_f32")
+        loss = self.kp_loss_val[0]
+        coef = None
+        if confidence_regularization:
+            cnt = self.kp_counts[0, :, 1:].sum(dim=1, keepdim=True).double()       # foreground pixels of the target mask
+            safe = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
+            cl = torch.where(cnt > 0, self.kp_conf_sums / safe, torch.zeros_like(self.kp_conf_sums))
+            loss = loss + torch.abs(cl - 0.7).mean()
+            coef = (kp_w * torch.sign(cl - 0.7) / (B * kp) / safe * (cnt > 0)).to(torch.float32).contiguous()
+        check(lib.cp_ls_vote_bwd_f32(out.data_ptr(), self.out_ld, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
+                                     self.ls_g.data_ptr(), self.ls_pu.data_ptr(), labels_gt.data_ptr() if coef is not None else None, _ptr(coef),
+                                     self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.VERT_OFF + 2 * kp, 1, stream), "cp_ls_vote_bwd_f32")
+        self._keep_coef = coef
+        return loss
+
     def backward(self):
         """Back-propagate self.dout through the tape into store.grad."""
         stream = torch.cuda.current_stream(self.out.device).cuda_stream
@@ -667,12 +696,39 @@ class TrainPlan:
             dist.all_reduce(self.store.grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def train_step(self, img, labels_ce, labels_fg, keypoints_yx, lr: float, cond_labels=None, weights=(1.0, 1.0, 1.0),
-                   filter_with_segmentation=True):
+                   filter_with_segmentation=True, kp_args: Optional[dict] = None):
+        """One optimisation step.  kp_args (optional): keyword arguments of kp_loss_and_grad.  Returns the fp64 device
+        vector [mask, vertex, proxy] (and, with kp_args, the keypoint loss as a second value)."""
         stream = torch.cuda.current_stream(img.device).cuda_stream
         self.forward(img, cond_labels)
         sums = self.loss_and_grad(labels_ce, labels_fg, keypoints_yx, *weights, filter_with_segmentation=filter_with_segmentation)
+        kp_loss = self.kp_loss_and_grad(**kp_args) if kp_args is not None else None
         self.backward()
         self.all_reduce_grads()
         self.store.adam_step(lr, stream)
         self.refresh_weights(stream)
-        return sums
+        return sums if kp_loss is None else (sums, kp_loss)
+
+
+def crop_to_image_affine(offsets: np.ndarray) -> np.ndarray:
+    """[B,6] row-major 2x3 matrices mapping crop pixels (x,y) back to the original image, the composition applied by
+    transform_points_back_tf_batch (ransac_voting.py:124-158) with the offsets layout used at its call site
+    (loss_functions.py:276-285): [h_crop, w_crop, -, -, dx, dy, angle_deg, scale, sx, sy]."""
+    o = np.asarray(offsets, np.float64)
+    hc, wc, dx, dy, ang, sc, sx, sy = o[:, 0], o[:, 1], o[:, 4], o[:, 5], o[:, 6], o[:, 7], o[:, 8], o[:, 9]
+    ar = -ang * (np.pi / 180.0)
+    a, b = np.cos(ar), np.sin(ar)
+    c = (1.0 - a) * sx / 2.0 - b * sy / 2.0
+    d = b * sx / 2.0 + (1.0 - a) * sy / 2.0
+    A = np.stack([a / sc, b / sc, a * (wc - dx) + b * (hc - dy) + c, -b / sc, a / sc, -b * (wc - dx) + a * (hc - dy) + d], axis=1)
+    return A.astype(np.float32)
+
+
+def project_keypoints(points_3d: np.ndarray, cam: np.ndarray, poses: np.ndarray) -> np.ndarray:
+    """project_tf_batch (ransac_voting.py:185-194): points_3d [...,kp,3], cam [3,3], poses [...,3,4] -> [...,kp,2] (x,y)."""
+    p = np.asarray(points_3d, np.float64)
+    rt = np.asarray(poses, np.float64)
+    camp = p @ np.swapaxes(rt[..., :3], -1, -2) + np.swapaxes(rt[..., 3:], -1, -2)
+    pix = camp @ np.asarray(cam, np.float64).T
+    z = pix[..., 2:]
+    return np.where(z != 0, pix[..., :2] / np.where(z != 0, z, 1.0), 0.0).astype(np.float32)

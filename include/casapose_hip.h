@@ -254,6 +254,17 @@ int cp_conv2d_wgrad_f32(const cp_conv_desc* desc, const float* dy, int dy_ld, fl
  * mean / biased variance.  channels % 4 == 0, <= 1024. */
 int cp_bn_stats_f32(const float* x, long long pixels, int channels, int ld, double* sums, void* stream);
 
+/* Turn the (all-reduced) statistic sums into everything the normalisation needs, in one launch:
+ * mean[c], rstd[c] = 1/sqrt(biased var + eps); gamma_full/beta_full [classes][channels] (gamma [classes][real_channels]
+ * or null = 1, beta likewise = 0; padding channels get 1/0); scale = gamma*rstd, shift = beta - mean*scale (pad_one: padding
+ * channels get scale 0, shift 1); moving = moving*momentum + batch*(1-momentum) when moving_mean/moving_var are given
+ * (Keras BatchNormalization update with the biased batch variance).  pixels = GLOBAL sample count. */
+int cp_bn_finalize_f32(const double* sums, double pixels, int channels, int real_channels, int classes, const float* gamma,
+                       const float* beta, float eps, int pad_one, float momentum, float* moving_mean, float* moving_var, float* mean,
+                       float* rstd, float* gamma_full, float* beta_full, float* scale, float* shift, void* stream);
+/* d beta[l][c] = red[(l*C+c)*2], d gamma[l][c] = red[(l*C+c)*2+1] as fp32 over the real channels (either output may be null) */
+int cp_bn_param_grads_f32(const double* red, int channels, int real_channels, int classes, float* dgamma, float* dbeta, void* stream);
+
 /* y[p][c] = act(x[p][c]*scale[l][c] + shift[l][c]), l = labels ? labels[p] : 0 -- the normalise(+CLADE
  * modulation, _normalization_layers.py:119-139)+activation (casapose.py:98-107) step with the batch
  * statistics folded into scale/shift by the caller. */
@@ -313,6 +324,28 @@ size_t cp_pose_loss_workspace_bytes(int batch, int h, int w);
 int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, const uint8_t* labels_ce, const uint8_t* labels_fg,
                      const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation, float mask_w,
                      float vertex_w, float proxy_w, void* ws, float* dout, int dld, int vert_off, double* loss_sums, void* stream);
+
+/* Backward of cp_ls_vote_f32 (the reference differentiates CoordLSVotingWeighted with tf.GradientTape,
+ * train_casapose.py:555-579): dkeypoints = d loss / d keypoints [batch][objects][kp][2] (y,x px); sums_ws = the workspace
+ * the forward left behind; pu_ws: float [batch*objects*kp*4] scratch.  Writes (accumulate: adds) d loss / d directions
+ * into dfield[pix][ddir_off + 2j..] and d loss / d confidence logits into dfield[pix][dconf_off + j] for the pixels of
+ * each object (zero elsewhere).  Optionally adds conf_coef[b][j]*sigmoid(conf) on the pixels with reg_labels != 0 (the
+ * confidence regulariser of keypoint_reprojection_loss, loss_functions.py:254-262).  `labels` is required. */
+int cp_ls_vote_bwd_f32(const float* field, int ld, int dir_off, int conf_off, const uint8_t* labels, int batch, int h, int w,
+                       int objects, int kp, const double* sums_ws, const float* dkeypoints, float* pu_ws,
+                       const uint8_t* reg_labels, const float* conf_coef, float* dfield, int dld, int ddir_off, int dconf_off,
+                       int accumulate, void* stream);
+/* counts[0][b][c] / counts[1][b][c] = pixels of class c in labels / labels_est (may be null) of image b; conf_sums[b][j] =
+ * sum over labels != 0 of softplus(conf_j) (fp64) -- objects_available and the confidence regulariser
+ * (loss_functions.py:236-262).  Zeroed by the call. */
+int cp_kp_stats_f32(const float* field, int ld, int conf_off, const uint8_t* labels, const uint8_t* labels_est, int batch, int h, int w,
+                    int classes, int kp, int32_t* counts, double* conf_sums, void* stream);
+/* keypoint_reprojection_loss without BPnP (loss_functions.py:207-344): coords_yx [batch*objects][kp][2] voted keypoints
+ * (crop pixels), affine [batch][6] row-major 2x3 crop->image map of transform_points_back_tf_batch, gt_xy the projected
+ * ground-truth keypoints (image pixels), avail [batch*objects] in {0,1}.  loss = sum_n avail*mean_j cap(smoothL1(|gt - T(p)|))
+ * / sum(avail); g_yx = weight * d loss / d coords_yx. */
+int cp_kp_reproj_loss_f32(const float* coords_yx, const float* gt_xy, const float* affine, const float* avail, int batch, int objects,
+                          int kp, float max_pixel_error, float weight, float* g_yx, double* loss_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -241,3 +241,82 @@ def losses(output: torch.Tensor, labels: torch.Tensor, keypoints_yx: torch.Tenso
     per_img = smooth_l1(dist).reshape(b, -1).sum(1) / (2 * kp * wgt.reshape(b, -1).sum(1) + 1e-3)
     proxy_loss = per_img.mean()
     return mask_loss, vertex_loss, proxy_loss
+
+
+# --------------------------------------------------------------------------------------
+#  keypoint reprojection loss (utils/loss_functions.py:207-344) through the LS voter
+# --------------------------------------------------------------------------------------
+def ls_voting(labels: torch.Tensor, dirs: torch.Tensor, conf: torch.Tensor, objects: int) -> torch.Tensor:
+    """CoordLSVotingWeighted.calc (voting_layers_2d.py:83-122) with a hard label map, differentiable in
+    dirs/conf.  labels [B,H,W] int, dirs [B,H,W,2*kp] (dy,dx), conf [B,H,W,kp] -> [B,objects,kp,2] (y,x) px."""
+    b, h, w, kp = conf.shape
+    dt = dirs.dtype
+    wgt = F.softplus(conf)                                            # :35
+    d = dirs.reshape(b, h, w, kp, 2)
+    s2 = (d * d).sum(-1, keepdim=True)
+    pos = s2 > 0
+    nrm = torch.sqrt(torch.where(pos, s2, torch.ones_like(s2)))        # keeps autograd finite at d = 0
+    n = torch.where(pos, d / nrm, torch.zeros_like(d))                 # divide_no_nan :90
+    eye = torch.eye(2, dtype=dt)
+    R = (eye - n[..., :, None] * n[..., None, :]) * wgt[..., None, None]   # [b,h,w,kp,2,2]
+    yy, xx = torch.meshgrid((torch.arange(h, dtype=dt) + 0.5) / h, (torch.arange(w, dtype=dt) + 0.5) / h, indexing="ij")
+    c = torch.stack([yy, xx], dim=-1)[None, :, :, None, :, None]       # (y,x)/H :99-101
+    q = (R @ c)[..., 0]                                                # [b,h,w,kp,2]
+    out = []
+    for o in range(objects):
+        m = (labels == o + 1).to(dt)[..., None, None]
+        A = (R * m[..., None]).sum(dim=(1, 2))                         # [b,kp,2,2]
+        t = (q * m).sum(dim=(1, 2))                                    # [b,kp,2]
+        out.append((torch.linalg.pinv(A) @ t[..., None])[..., 0] * h)
+    return torch.stack(out, dim=1)
+
+
+def crop_to_image_affine(offsets: np.ndarray) -> np.ndarray:
+    """2x3 matrices of transform_points_back_tf_batch (ransac_voting.py:124-158) acting on crop pixels (x,y);
+    offsets [B,10] = [h_crop, w_crop, ?, ?, dx, dy, angle_deg, scale, sx, sy] (loss_functions.py:276-285)."""
+    o = np.asarray(offsets, np.float64)
+    hc, wc, dx, dy, ang, sc, sx, sy = o[:, 0], o[:, 1], o[:, 4], o[:, 5], o[:, 6], o[:, 7], o[:, 8], o[:, 9]
+    ar = -ang * (np.pi / 180.0)
+    a, b = np.cos(ar), np.sin(ar)
+    cx, cy = sx / 2.0, sy / 2.0
+    c = (1.0 - a) * cx - b * cy
+    d = b * cx + (1.0 - a) * cy
+    A = np.zeros((o.shape[0], 2, 3))
+    A[:, 0, 0], A[:, 0, 1], A[:, 0, 2] = a / sc, b / sc, a * (wc - dx) + b * (hc - dy) + c
+    A[:, 1, 0], A[:, 1, 1], A[:, 1, 2] = -b / sc, a / sc, -b * (wc - dx) + a * (hc - dy) + d
+    return A
+
+
+def project_points(xyz: np.ndarray, K: np.ndarray, RT: np.ndarray) -> np.ndarray:
+    """project_tf_batch (ransac_voting.py:185-194): xyz [N,kp,3], K [3,3], RT [N,3,4] -> [N,kp,2] (x,y)."""
+    cam = xyz @ np.transpose(RT[:, :, :3], (0, 2, 1)) + np.transpose(RT[:, :, 3:], (0, 2, 1))
+    pix = cam @ K.T
+    z = pix[..., 2:]
+    return np.where(z != 0, pix[..., :2] / np.where(z != 0, z, 1.0), 0.0)
+
+
+def keypoint_reprojection_loss(coords_yx: torch.Tensor, gt_xy: torch.Tensor, affine: torch.Tensor, avail: torch.Tensor,
+                               conf: torch.Tensor, labels_gt: torch.Tensor, max_pixel_error: float = 25.0,
+                               confidence_regularization: bool = False) -> torch.Tensor:
+    """keypoint_reprojection_loss without BPnP (loss_functions.py:207-344).  coords_yx [B,oc,kp,2] from the voter,
+    gt_xy [B,oc,kp,2] projected GT keypoints (image px), affine [B,2,3], avail [B,oc] in {0,1}."""
+    b, oc, kp, _ = coords_yx.shape
+    xy = coords_yx.flip(-1)                                             # tf.reverse :229
+    X = affine[:, None, None, 0, 0] * xy[..., 0] + affine[:, None, None, 0, 1] * xy[..., 1] + affine[:, None, None, 0, 2]
+    Y = affine[:, None, None, 1, 0] * xy[..., 0] + affine[:, None, None, 1, 1] * xy[..., 1] + affine[:, None, None, 1, 2]
+    pts = torch.stack([X, Y], dim=-1) * avail[..., None, None]
+    gt = gt_xy * avail[..., None, None]
+    s2 = ((gt - pts) ** 2).sum(-1)
+    e = torch.where(s2 > 0, torch.sqrt(torch.where(s2 > 0, s2, torch.ones_like(s2))), torch.zeros_like(s2))
+    l = torch.where(e < 1.0, 0.5 * e * e, e - 0.5)
+    l = torch.where(l > max_pixel_error, max_pixel_error + (l - max_pixel_error) * 0.01, l)
+    l = (l * avail[..., None]).mean(dim=2)                              # mean over keypoints
+    na = avail.sum()
+    loss = torch.where(na > 0, l.sum() / torch.where(na > 0, na, torch.ones_like(na)), torch.zeros_like(na))
+    if confidence_regularization:
+        fg = (labels_gt != 0).to(conf.dtype)[..., None]
+        cs = (F.softplus(conf) * fg).sum(dim=(1, 2))                    # [b,kp]
+        ms = fg.sum(dim=(1, 2))                                         # [b,1]
+        cl = torch.where(ms > 0, cs / torch.where(ms > 0, ms, torch.ones_like(ms)), torch.zeros_like(cs))
+        loss = loss + torch.abs(cl - 0.7).mean()
+    return loss

@@ -370,3 +370,70 @@ def test_train_steps_reduce_the_loss(device):
     total = hist[:, 0] + 0.5 * hist[:, 1] + 0.015 * hist[:, 2]
     assert np.all(np.isfinite(hist))
     assert total[-1] < 0.8 * total[0], "loss did not go down: %s" % total
+
+
+# --------------------------------------------------------------------------------------------------
+# keypoint reprojection loss through the LS voter
+# --------------------------------------------------------------------------------------------------
+def _kp_case(seed, b, h, w, k):
+    rng = np.random.default_rng(seed)
+    kp = 9
+    lab = blob_labels(b, h, w, k, seed + 3)
+    kpts = rng.uniform(0.1 * h, 0.9 * h, (b, k - 1, kp, 2))
+    yy, xx = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+    dirs = np.zeros((b, h, w, kp, 2))
+    for n in range(b):
+        for o in range(1, k):
+            m = lab[n] == o
+            d = kpts[n, o - 1][None, None] - np.stack([yy, xx], -1)[:, :, None, :]
+            d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+            dirs[n][m] = d[m]
+    ang = rng.normal(0, 0.15, (b, h, w, kp))
+    ca, sa = np.cos(ang), np.sin(ang)
+    dirs = np.stack([ca * dirs[..., 0] - sa * dirs[..., 1], sa * dirs[..., 0] + ca * dirs[..., 1]], -1) * rng.uniform(0.5, 1.5, (b, h, w, kp, 1))
+    conf = rng.normal(0, 1, (b, h, w, kp))
+    logits = rng.normal(0, 1, (b, h, w, k)) + 4.0 * np.eye(k)[lab]
+    out = np.concatenate([logits, dirs.reshape(b, h, w, 2 * kp), conf], -1).astype(np.float32)
+    offsets = np.stack([rng.uniform(0, 30, b), rng.uniform(0, 60, b), np.zeros(b), np.zeros(b), rng.uniform(-5, 5, b), rng.uniform(-5, 5, b),
+                        rng.uniform(-20, 20, b), rng.uniform(0.8, 1.2, b), np.full(b, 640.0), np.full(b, 480.0)], 1)
+    A = R.crop_to_image_affine(offsets)
+    # ground-truth image keypoints: the true crop keypoints mapped to the image, plus a few pixels of "pose error"
+    xy = kpts[..., ::-1]
+    gt = np.stack([A[:, None, None, 0, 0] * xy[..., 0] + A[:, None, None, 0, 1] * xy[..., 1] + A[:, None, None, 0, 2],
+                   A[:, None, None, 1, 0] * xy[..., 0] + A[:, None, None, 1, 1] * xy[..., 1] + A[:, None, None, 1, 2]], -1)
+    gt += rng.normal(0, 3.0, gt.shape)
+    gt[0, 0] += 40.0  # one object beyond the soft cap
+    return lab, out, offsets, A, gt
+
+
+@pytest.mark.parametrize("conf_reg", [False, True])
+def test_keypoint_loss_and_voter_backward(device, conf_reg):
+    from casapose_amd.train_engine import ParamStore, TrainPlan, crop_to_image_affine
+
+    b, h, w, k, kp = 2, 64, 64, 5, 9  # record length k + 27 = 32 floats (the voter wants a multiple of 4)
+    lab, out, offsets, A, gt = _kp_case(21, b, h, w, k)
+    # reference
+    ot = torch.tensor(out.astype(np.float64), requires_grad=True)
+    labt = torch.from_numpy(lab.astype(np.int64))
+    coords = R.ls_voting(labt, ot[..., k:k + 2 * kp], ot[..., k + 2 * kp:], k - 1)
+    est = torch.argmax(ot[..., :k].detach(), -1)
+    avail = torch.stack([((est == o).sum((1, 2)) > 50) & ((labt == o).sum((1, 2)) > 50) for o in range(1, k)], 1).double()
+    loss = R.keypoint_reprojection_loss(coords, torch.from_numpy(gt), torch.from_numpy(A), avail, ot[..., k + 2 * kp:], labt, 12.5, conf_reg)
+    kp_w = 0.007
+    (kp_w * loss).backward()
+    # device
+    params = O.init_params(k, 27, seed=5, dtype=np.float32)
+    plan = TrainPlan(ParamStore(params, device), k, 27, b, h, w)
+    plan.out.copy_(torch.from_numpy(out))
+    plan.dout.zero_()
+    Ad = torch.from_numpy(crop_to_image_affine(offsets)).to(device)
+    assert rel(Ad.cpu().numpy().reshape(b, 2, 3), A) < 1e-6
+    val = plan.kp_loss_and_grad(torch.from_numpy(lab).to(device), torch.from_numpy(gt.astype(np.float32)).to(device), Ad, kp_w, max_pixel_error=12.5,
+                                min_num=50, confidence_regularization=conf_reg, vote_with_gt=True)
+    assert rel(plan.ls_coords.cpu().numpy(), coords.detach().numpy()) < 1e-4
+    assert abs(val.item() - loss.item()) < 1e-4 * abs(loss.item())
+    g = plan.dout.cpu().numpy()
+    gr = ot.grad.numpy()
+    assert rel(g[..., 32:32 + 2 * kp], gr[..., k:k + 2 * kp]) < 2e-3
+    assert rel(g[..., 32 + 2 * kp:32 + 3 * kp], gr[..., k + 2 * kp:]) < 2e-3
+    assert np.all(g[..., :32] == 0)
