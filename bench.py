@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1,2> (64x128)", 3: "conv_f32_kernel<2,2,2,1> (128x64)",
-              4: "conv_f32_kernel<4,1,1,1> (128x32)", 5: "conv_f32_kernel<2,2,1,1> (64x64)", 6: "conv_f32_kernel<4,1,2,1> (256x32)"}
+              4: "conv_f32_kernel<4,1,1,1> (128x32)", 5: "conv_f32_kernel<2,2,1,1> (64x64)", 6: "conv_f32_kernel<4,1,2,1> (256x32)",
+              7: "conv_halo_kernel (LDS-resident 4-row halo tile, cout <= 64)"}
 
 
 def cpu_baseline(h, w, seg_dim, ver_dim):
@@ -43,8 +44,84 @@ def cpu_baseline(h, w, seg_dim, ver_dim):
             "sample": "1 image 480x640 forward + LS voting, NumPy oracle in fp32 (%.1f s)" % dt}
 
 
+def bench_train(args):
+    """Secondary workload (BASELINE.json configs[2]/[3]): one data-parallel TRAINING step of casapose_c_gcu5 --
+    forward with batch statistics (SyncBN all-reduced across ranks), mask/vertex/proxy/keypoint losses, hand-written
+    backward, SUM all-reduce of the flat gradient over RCCL, Adam, weight re-pack -- at 448x448, K=9, fp32."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from casapose_amd import parallel
+    from casapose_amd.pose_models.tfkeras import Classifiers
+    from casapose_amd.train_engine import crop_to_image_affine, project_keypoints
+
+    rank, local, world = parallel.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, H, W = args.batch, args.height, args.width
+    seg_dim, ver_dim, kp = 9, 27, 9
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), input_segmentation_shape=(H, W, seg_dim),
+                                             weights=None, base_model="resnet18", device=dev, seed=1237)
+    group = dist.group.WORLD if world > 1 else None
+    plan, _ = net.training_plan(B, H, W, group, world)
+    rng = np.random.default_rng(1237 + rank)
+    gen = torch.Generator(device="cpu").manual_seed(1237 + rank)
+    img = (2.0 * torch.rand(B, H, W, 3, generator=gen) - 1.0).to(dev)
+    # ground truth: 8 axis-aligned ellipses, one per class (SURVEY 8d), keypoints inside their bounding boxes
+    lab = np.zeros((B, H, W), np.uint8)
+    kpts = np.zeros((B, seg_dim - 1, kp, 2), np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for o in range(seg_dim - 1):
+        cy, cx = H * (0.25 + 0.5 * (o // 4)), W * (0.125 + 0.25 * (o % 4))
+        ry, rx = H * 0.11, W * 0.09
+        lab[:, ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = o + 1
+        kpts[:, o, 0] = (cy, cx)
+        kpts[:, o, 1:, 0] = rng.uniform(cy - ry, cy + ry, (B, kp - 1))
+        kpts[:, o, 1:, 1] = rng.uniform(cx - rx, cx + rx, (B, kp - 1))
+    labd = torch.from_numpy(lab).to(dev)
+    kd = torch.from_numpy(kpts).to(dev)
+    offsets = np.tile(np.array([[16.0, 96.0, 0, 0, 0, 0, 0, 1, 640, 480]]), (B, 1))
+    aff = torch.from_numpy(crop_to_image_affine(offsets)).to(dev)
+    gt_xy = torch.from_numpy((kpts[..., ::-1] + np.array([96.0, 16.0], np.float32) + rng.normal(0, 2.0, kpts.shape)).astype(np.float32)).to(dev).contiguous()
+    wts = (1.0, 0.5, 0.015)
+    kp_args = dict(labels_gt=labd, gt_xy=gt_xy, affine=aff, kp_w=0.007, max_pixel_error=12.5, min_num=50, confidence_regularization=True, vote_with_gt=True)
+
+    def step():
+        return plan.train_step(img, labd, labd, kd, 1e-3, cond_labels=labd, weights=wts, filter_with_segmentation=True, kp_args=kp_args)
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums, kpl = step()
+    parallel.barrier_sync(dev)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(sums).all() and torch.isfinite(kpl)
+    fwd_flops = sum(2.0 * c.desc.batch * c.desc.out_h * c.desc.out_w * c.k * c.k * sum(s[1] for s in c.sources) * c.cout for c in plan.convs)
+    result = {
+        "metric": "training images/sec at 448x448, 8-object (casapose_c_gcu5 forward + losses + backward + Adam)",
+        "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seed 1237: uniform images, 8 elliptical objects, he_uniform weights)",
+        "config": {"workload": "config_8.ini training step: casapose_c_gcu5, K=9, ver_dim=27, bs=%d per GPU, %dx%d, fp32, GT-mask conditioning, "
+                               "mask+vertex+proxy+keypoint losses, SyncBN, Adam" % (B, H, W),
+                   "images_per_gpu_per_step": B, "global_batch": B * world, "parallelism": "dp%d (RCCL all-reduce of BN statistics + flat gradient)" % world},
+        "roofline": {"bound": "mfma", "achieved": round(3.0 * fwd_flops * args.steps / dt / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(3.0 * fwd_flops * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "whole step (3 x forward conv FLOPs / step time; conv_f32 / conv_halo / conv_wgrad kernels)"},
+        "losses": {"mask": float(sums[0]), "vertex": float(sums[1]), "proxy": float(sums[2]), "keypoint": float(kpl)},
+    }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer", help="infer = the headline metric (default); train = one DP training step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -54,6 +131,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.mode == "train":
+        if args.batch == 16 and args.height == 480 and args.width == 640:  # training defaults (config_8.ini:18, BASELINE configs[2])
+            args.batch, args.height, args.width = 32, 448, 448
+        return bench_train(args)
 
     import numpy as np
     import torch

@@ -127,3 +127,46 @@ def test_voting_record_detection():
     assert rec.data_ptr() == out.data_ptr() and offs == [0, 9, 27]  # zero-copy
     rec2, offs2 = _as_record(s.contiguous(), d.contiguous(), c.contiguous())
     assert rec2.shape[3] == 36 and offs2 == [0, 9, 27] and torch.equal(rec2, out)
+
+
+# ---- training-side host logic ---------------------------------------------------------------------
+def test_learning_rate_schedules_and_loss_weights():
+    from casapose_amd.utils.learning_rate_schedules import ExponentialDecayLateStart, LossWeightHandler, PiecewiseConstantDecay
+
+    # train_casapose.py:334-337: boundaries = epochs*batches - 1, values = lr * decay^i
+    batches = 10
+    boundaries = (np.array([5, 7]) * batches - 1).tolist()
+    values = (np.power(0.5, np.arange(3)) * 1e-3).tolist()
+    s = PiecewiseConstantDecay(boundaries, values)
+    assert [s(i) for i in (0, 49, 50, 69, 70, 1000)] == [1e-3, 1e-3, 5e-4, 5e-4, 2.5e-4, 2.5e-4]
+    with pytest.raises(ValueError):
+        PiecewiseConstantDecay([1, 2], [1.0, 2.0])
+    e = ExponentialDecayLateStart(1e-3, decay_steps=10, decay_steps_start=20, decay_rate=0.5, staircase=True)
+    assert [e(i) for i in (0, 19, 20, 29, 30)] == [1e-3, 1e-3, 5e-4, 5e-4, 2.5e-4]
+    e0 = ExponentialDecayLateStart(1e-3, decay_steps=10, decay_steps_start=0, decay_rate=0.5, staircase=False)
+    assert abs(e0(5) - 1e-3 * 0.5 ** 0.5) < 1e-12
+    h = LossWeightHandler(mask_loss_weight=1.0, vertex_loss_weight=0.5, proxy_loss_weight=0.015, kp_loss_weight=0.007, proxy_loss_factor=2.0,
+                          kp_loss_factor=0.5)
+    h.update()
+    assert (h.mask_loss_weight, h.vertex_loss_weight, h.proxy_loss_weight, h.kp_loss_weight) == (1.0, 0.5, 0.025, 0.0035)
+
+
+def test_crop_affine_and_projection_match_oracle():
+    import torch_train_ref as R
+    from casapose_amd.train_engine import crop_to_image_affine, project_keypoints
+
+    rng = np.random.default_rng(0)
+    b = 5
+    offsets = np.stack([rng.uniform(0, 30, b), rng.uniform(0, 60, b), np.zeros(b), np.zeros(b), rng.uniform(-5, 5, b), rng.uniform(-5, 5, b),
+                        rng.uniform(-30, 30, b), rng.uniform(0.7, 1.3, b), np.full(b, 640.0), np.full(b, 480.0)], 1)
+    A = crop_to_image_affine(offsets).reshape(b, 2, 3)
+    assert np.allclose(A, R.crop_to_image_affine(offsets), rtol=1e-6, atol=1e-4)
+    # no augmentation: crop pixel + crop origin
+    ident = np.array([[16.0, 96.0, 0, 0, 0, 0, 0, 1, 640, 480]])
+    A0 = crop_to_image_affine(ident).reshape(2, 3)
+    assert np.allclose(A0, [[1, 0, 96], [0, 1, 16]], atol=1e-5)
+    K = np.array([[572.4, 0, 325.3], [0, 573.6, 242.0], [0, 0, 1]])
+    xyz = rng.uniform(-50, 50, (b, 9, 3))
+    RT = np.concatenate([np.tile(np.eye(3), (b, 1, 1)), np.tile(np.array([[0.0], [0.0], [800.0]]), (b, 1, 1))], axis=2)
+    got = project_keypoints(xyz, K, RT)
+    assert np.allclose(got, R.project_points(xyz, K, RT), rtol=1e-5, atol=1e-3)
