@@ -55,3 +55,12 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None, world_size: int = 1) -> torch.Tensor:
+    """In-place SUM all-reduce (RCCL on GPU tensors, gloo on CPU tensors); no-op for a single replica.  The training
+    step uses it for (a) the fp64 SyncBN statistic tables -- forward sums and the two backward means -- and (b) the
+    flat fp32 gradient before Adam (MirroredStrategy's SUM reduction, train_casapose.py:641-643)."""
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

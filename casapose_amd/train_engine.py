@@ -30,7 +30,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from ._lib import ConvDesc, check
 from .engine import BN_EPS, DECODER_DIMS_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
 
@@ -603,12 +603,8 @@ class TrainPlan:
     # ---- distributed hooks ---------------------------------------------------------------------------
     def all_reduce_stats(self, table: torch.Tensor, local_pixels: int) -> int:
         """SUM the fp64 statistic table over the replicas; returns the global pixel count."""
-        if self.group is not None and self.world_size > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)
-            return local_pixels * self.world_size
-        return local_pixels
+        parallel.all_reduce_sum_(table, self.group, self.world_size)
+        return local_pixels * self.world_size
 
     # ---- one step ------------------------------------------------------------------------------------
     def refresh_weights(self, stream: int):
@@ -690,10 +686,7 @@ class TrainPlan:
         self.store.grad_view("bn_data.beta").copy_(dbeta)
 
     def all_reduce_grads(self):
-        if self.group is not None and self.world_size > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.store.grad, op=dist.ReduceOp.SUM, group=self.group)
+        parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
 
     def train_step(self, img, labels_ce, labels_fg, keypoints_yx, lr: float, cond_labels=None, weights=(1.0, 1.0, 1.0),
                    filter_with_segmentation=True, kp_args: Optional[dict] = None):

@@ -59,3 +59,67 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def _syncbn_worker(rank, world, port, q):
+    """The SyncBN protocol of the training step on CPU tensors: every rank holds half of the batch, all-reduces
+    the fp64 statistic tables exactly as TrainPlan does, and must reproduce the whole-batch normalisation and its
+    gradient (compared with the autograd oracle on the full batch)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+
+    from casapose_amd import parallel
+
+    parallel.init_from_env("gloo")
+    rng = np.random.default_rng(0)                      # same data on both ranks; each takes its shard
+    n, c = 64, 8
+    x = torch.from_numpy(rng.standard_normal((n, c)) * 2 + 1)
+    dy = torch.from_numpy(rng.standard_normal((n, c)))
+    gamma = torch.from_numpy(1 + 0.1 * rng.standard_normal(c))
+    b, e = parallel.shard_range(n, rank, world)
+    xl, dyl = x[b:e], dy[b:e]
+    eps = 2e-5
+    sums = torch.cat([xl.sum(0), (xl * xl).sum(0)])    # cp_bn_stats_f32
+    parallel.all_reduce_sum_(sums, None, world)
+    N = (e - b) * world
+    mean = sums[:c] / N
+    var = sums[c:] / N - mean * mean
+    rstd = torch.rsqrt(var + eps)
+    xh = (xl - mean) * rstd
+    g = dyl * gamma
+    chan = torch.cat([g.sum(0), (g * xh).sum(0)])       # cp_bn_act_bwd_reduce_f32 (chan table)
+    parallel.all_reduce_sum_(chan, None, world)
+    dx = rstd * (g - chan[:c] / N - xh * chan[c:] / N)  # cp_bn_act_bwd_apply_f32
+    grad = torch.cat([(dyl * xh).sum(0)])               # d gamma, local part
+    parallel.all_reduce_sum_(grad, None, world)         # the flat-gradient all-reduce
+    q.put((rank, b, e, mean.numpy(), var.numpy(), dx.numpy(), grad.numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_syncbn_protocol_matches_whole_batch():
+    import numpy as np
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    n, c = 64, 8
+    x = torch.tensor(rng.standard_normal((n, c)) * 2 + 1, requires_grad=True)
+    dy = torch.from_numpy(rng.standard_normal((n, c)))
+    gamma = torch.tensor(1 + 0.1 * rng.standard_normal(c), requires_grad=True)
+    mean = x.mean(0)
+    var = ((x - mean) ** 2).mean(0)
+    y = (x - mean) / torch.sqrt(var + 2e-5) * gamma
+    y.backward(dy)
+    dx = np.concatenate([r[5] for r in res])
+    assert np.allclose(res[0][3], mean.detach().numpy(), atol=1e-12) and np.allclose(res[1][4], var.detach().numpy(), atol=1e-10)
+    assert np.allclose(dx, x.grad.numpy(), atol=1e-10)
+    assert np.allclose(res[0][6], gamma.grad.numpy(), atol=1e-10) and np.allclose(res[1][6], gamma.grad.numpy(), atol=1e-10)
