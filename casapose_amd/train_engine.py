@@ -637,11 +637,14 @@ class TrainPlan:
         return self.loss_sums
 
     def kp_loss_and_grad(self, labels_gt: torch.Tensor, gt_xy: torch.Tensor, affine: torch.Tensor, kp_w: float, max_pixel_error: float = 25.0,
-                         min_num: int = 50, confidence_regularization: bool = False, vote_with_gt: bool = True, kp: int = 9) -> torch.Tensor:
+                         min_num: int = 50, confidence_regularization: bool = False, vote_with_gt: bool = True, kp: int = 9,
+                         min_num_gt: Optional[int] = None, filter_with_gt: bool = True, coords: Optional[torch.Tensor] = None,
+                         backward: bool = True) -> torch.Tensor:
         """keypoint_reprojection_loss (loss_functions.py:207-344, use_bpnp_reprojection_loss=False) on the last forward's
         output; ADDS kp_w * d loss / d output to self.dout (call after loss_and_grad).  gt_xy [B,oc,kp,2]: projected
         ground-truth keypoints in image pixels; affine [B,6]: crop->image map (crop_to_image_affine).  Returns the
-        fp64 loss value (device scalar)."""
+        fp64 loss value (device scalar).  `coords` (optional, [B,oc,kp,2] (y,x)) replaces the internal vote (evaluation with the
+        component-filtered voter; implies backward=False); min_num_gt / filter_with_gt as in loss_functions.py:221-222,246-252."""
         lib = _lib.load()
         B, h, w, K = self.batch, self.h, self.w, self.seg_dim
         oc = K - 1
@@ -652,10 +655,18 @@ class TrainPlan:
         check(lib.cp_kp_stats_f32(out.data_ptr(), self.out_ld, conf_off, labels_gt.data_ptr(), self.est_labels.data_ptr(), B, h, w, K, kp,
                                   self.kp_counts.data_ptr(), self.kp_conf_sums.data_ptr(), stream), "cp_kp_stats_f32")
         vote_labels = labels_gt if vote_with_gt else self.est_labels
-        check(lib.cp_ls_vote_f32(out.data_ptr(), self.out_ld, 0, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
-                                 self.ls_coords.data_ptr(), stream), "cp_ls_vote_f32")
-        # objects_available (loss_functions.py:236-252): > min_num pixels in the estimated AND the ground-truth mask
-        avail = ((self.kp_counts[1, :, 1:] > min_num) & (self.kp_counts[0, :, 1:] > min_num)).to(torch.float32).contiguous()
+        if coords is None:
+            check(lib.cp_ls_vote_f32(out.data_ptr(), self.out_ld, 0, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
+                                     self.ls_coords.data_ptr(), stream), "cp_ls_vote_f32")
+        else:
+            self.ls_coords.copy_(coords.reshape(B, oc, kp, 2))
+            backward = False
+        # objects_available (loss_functions.py:236-252): > min_num pixels in the estimated AND (filter_with_gt) the ground-truth mask
+        avail = self.kp_counts[1, :, 1:] > min_num
+        if filter_with_gt:
+            avail = avail & (self.kp_counts[0, :, 1:] > (min_num if min_num_gt is None or min_num_gt < 0 else min_num_gt))
+        avail = avail.to(torch.float32).contiguous()
+        self.objects_available = avail
         check(lib.cp_kp_reproj_loss_f32(self.ls_coords.data_ptr(), gt_xy.data_ptr(), affine.data_ptr(), avail.data_ptr(), B, oc, kp, max_pixel_error,
                                         kp_w, self.ls_g.data_ptr(), self.kp_loss_val.data_ptr(), stream), "cp_kp_reproj_loss_f32")
         loss = self.kp_loss_val[0]
@@ -666,9 +677,10 @@ class TrainPlan:
             cl = torch.where(cnt > 0, self.kp_conf_sums / safe, torch.zeros_like(self.kp_conf_sums))
             loss = loss + torch.abs(cl - 0.7).mean()
             coef = (kp_w * torch.sign(cl - 0.7) / (B * kp) / safe * (cnt > 0)).to(torch.float32).contiguous()
-        check(lib.cp_ls_vote_bwd_f32(out.data_ptr(), self.out_ld, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
-                                     self.ls_g.data_ptr(), self.ls_pu.data_ptr(), labels_gt.data_ptr() if coef is not None else None, _ptr(coef),
-                                     self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.VERT_OFF + 2 * kp, 1, stream), "cp_ls_vote_bwd_f32")
+        if backward:
+            check(lib.cp_ls_vote_bwd_f32(out.data_ptr(), self.out_ld, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
+                                         self.ls_g.data_ptr(), self.ls_pu.data_ptr(), labels_gt.data_ptr() if coef is not None else None, _ptr(coef),
+                                         self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.VERT_OFF + 2 * kp, 1, stream), "cp_ls_vote_bwd_f32")
         self._keep_coef = coef
         return loss
 

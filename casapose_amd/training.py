@@ -12,7 +12,7 @@ reference's batch tuple and option names onto it.  Data parallelism
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional, Sequence, Union
+from typing import Callable, Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -50,44 +50,64 @@ def labels_from_onehot(seg: torch.Tensor) -> torch.Tensor:
     return seg.to(torch.uint8).contiguous()
 
 
-def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Adam, opt, group=None, world_size: int = 1,
-               train: bool = True):
+def _host(x, dtype=np.float64):
+    return np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype)
+
+
+def _kp_targets(batch, B, oc, dev):
+    cam = _host(batch["cam_mat"])
+    cam = cam[0] if cam.ndim == 3 else cam  # the reference uses camera_data[0] for the whole batch (loss_functions.py:322)
+    p3d = _host(batch["keypoints3d"]).reshape(B, oc, -1, 3)
+    poses = _host(batch["poses_gt"]).reshape(B, oc, 3, 4)
+    gt_xy = torch.from_numpy(TE.project_keypoints(p3d, cam, poses)).to(dev).contiguous()
+    aff = torch.from_numpy(TE.crop_to_image_affine(_host(batch["offsets"]))).to(dev).contiguous()
+    return gt_xy, aff, cam, p3d
+
+
+def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Optional[Adam], opt, group=None, world_size: int = 1,
+               train: bool = True, coords: Optional[torch.Tensor] = None, min_num: int = 50, min_num_gt: Optional[int] = None,
+               filter_with_gt: bool = True):
     """One step on a batch dict with the reference's tuple fields (train_casapose.py:496-507):
        img [B,H,W,3]; target_seg [B,H,W,K] one-hot (or a uint8 label map); keypoints3d [B,oc,1,kp,3]; target_vert
        [B,oc,1,kp,2] 2-D keypoints (y,x) in crop pixels; cam_mat [B,3,3] or [3,3]; offsets [B,10]; filtered_seg
        (optional label map); poses_gt [B,oc,1,3,4].
     `opt` carries the config flags (train_vectors_with_ground_truth, estimate_coords, max_keypoint_pixel_error,
-    confidence_regularization, use_bpnp_reprojection_loss).  Returns python floats
-    [loss, mask_loss, vertex_loss, proxy_loss, kp_loss] (compute_loss, train_casapose.py:137-145)."""
+    confidence_regularization, use_bpnp_reprojection_loss).  train=True: forward with batch statistics, backward, Adam.
+    train=False: the network runs in inference mode (moving statistics, net(net_input, training=False),
+    train_casapose.py:596) and only the loss values are computed; filtered_seg is ignored like in the reference's
+    evaluation branch (:637-648).  Returns python floats [loss, mask_loss, vertex_loss, proxy_loss, kp_loss]
+    (compute_loss, train_casapose.py:137-145)."""
     if getattr(opt, "use_bpnp_reprojection_loss", False):
-        raise NotImplementedError("use_bpnp_reprojection_loss (BPnP backward, bpnp_layers.py:138-212) is not built yet")
+        raise NotImplementedError("use_bpnp_reprojection_loss in the training loss (BPnP inside keypoint_reprojection_loss) is not wired yet; "
+                                  "the BPnP gradient itself is casapose_amd.pose_estimation.pnp.bpnp_backward")
     if getattr(loss_factors, "filter_high_proxy_errors", False):
         raise NotImplementedError("filter_high_proxy_errors (train_casapose.py:71-93) is not built yet")
     plan, dev = net.training_plan(batch["img"].shape[0], batch["img"].shape[1], batch["img"].shape[2], group, world_size)
     img = batch["img"].to(device=dev, dtype=torch.float32).contiguous()
-    labels = labels_from_onehot(batch["target_seg"].to(dev))
-    fg = labels_from_onehot(batch["filtered_seg"].to(dev)) if batch.get("filtered_seg") is not None else labels
+    seg_in = batch["target_seg"].to(dev)
+    labels = labels_from_onehot(seg_in)
+    fg = labels_from_onehot(batch["filtered_seg"].to(dev)) if (train and batch.get("filtered_seg") is not None) else labels
     kpts = batch["target_vert"].to(device=dev, dtype=torch.float32)
     B, oc = kpts.shape[0], kpts.shape[1]
     kpts = kpts.reshape(B, oc, -1, 2).contiguous()
-    cond = labels if getattr(opt, "train_vectors_with_ground_truth", False) else None
-    plan.update_moving = train
-    plan.forward(img, cond)
+    with_gt = bool(getattr(opt, "train_vectors_with_ground_truth", False))
+    if train:
+        plan.update_moving = True
+        plan.forward(img, labels if with_gt else None)
+    else:
+        if with_gt and seg_in.dim() != 4:
+            seg_in = torch.nn.functional.one_hot(labels.long(), net.seg_dim)
+        out = net([img, seg_in.to(torch.float32)] if with_gt else [img], training=False)
+        plan.out.copy_(out)
     wts = (float(loss_factors.mask_loss_weight), float(loss_factors.vertex_loss_weight), float(loss_factors.proxy_loss_weight))
     sums = plan.loss_and_grad(labels, fg, kpts, *wts, filter_with_segmentation=bool(loss_factors.filter_vertex_with_segmentation))
     kp_w = float(getattr(loss_factors, "kp_loss_weight", 0.0))
     kp_loss = None
     if getattr(opt, "estimate_coords", False):
-        cam = np.asarray(batch["cam_mat"].cpu() if torch.is_tensor(batch["cam_mat"]) else batch["cam_mat"], np.float64)
-        cam = cam[0] if cam.ndim == 3 else cam  # the reference uses camera_data[0] for the whole batch (loss_functions.py:322)
-        p3d = np.asarray(batch["keypoints3d"].cpu() if torch.is_tensor(batch["keypoints3d"]) else batch["keypoints3d"], np.float64).reshape(B, oc, -1, 3)
-        poses = np.asarray(batch["poses_gt"].cpu() if torch.is_tensor(batch["poses_gt"]) else batch["poses_gt"], np.float64).reshape(B, oc, 3, 4)
-        offs = np.asarray(batch["offsets"].cpu() if torch.is_tensor(batch["offsets"]) else batch["offsets"], np.float64)
-        gt_xy = torch.from_numpy(TE.project_keypoints(p3d, cam, poses)).to(dev).contiguous()
-        aff = torch.from_numpy(TE.crop_to_image_affine(offs)).to(dev).contiguous()
-        kp_loss = plan.kp_loss_and_grad(labels, gt_xy, aff, kp_w, max_pixel_error=float(getattr(opt, "max_keypoint_pixel_error", 25.0)), min_num=50,
+        gt_xy, aff, _, _ = _kp_targets(batch, B, oc, dev)
+        kp_loss = plan.kp_loss_and_grad(labels, gt_xy, aff, kp_w, max_pixel_error=float(getattr(opt, "max_keypoint_pixel_error", 25.0)), min_num=min_num,
                                         confidence_regularization=bool(getattr(opt, "confidence_regularization", False)) and train,
-                                        vote_with_gt=bool(getattr(opt, "train_vectors_with_ground_truth", False)))
+                                        vote_with_gt=with_gt, min_num_gt=min_num_gt, filter_with_gt=filter_with_gt, coords=coords, backward=train)
     if train:
         stream = torch.cuda.current_stream(dev).cuda_stream
         plan.backward()
@@ -99,3 +119,74 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Ada
     kpv = float(kp_loss.item()) if kp_loss is not None else 0.0
     total = wts[0] * s[0] + wts[1] * s[1] + wts[2] * s[2] + kp_w * kpv
     return [float(total), float(s[0]), float(s[1]), float(s[2]), kpv]
+
+
+def poses_from_coords(coords_yx, objects_available, batch, rng=None) -> Tuple[np.ndarray, np.ndarray]:
+    """The pose branch of keypoint_reprojection_loss (loss_functions.py:229,264-315): voted keypoints (y,x) in crop
+    pixels -> (x,y) -> original image pixels (transform_points_back) -> host PnP -> pose negated if t_z < 0 -> zeroed for
+    unavailable objects.  Returns (poses [B,oc,1,3,4], image-space points [B,oc,kp,2]) as float32 arrays."""
+    from .pose_estimation import pnp as _pnp
+    from .pose_estimation.pose_evaluation import transform_points_back
+
+    c = _host(coords_yx)
+    B, oc, kp, _ = c.shape
+    avail = _host(objects_available).reshape(B, oc)
+    offs = _host(batch["offsets"])
+    cam = _host(batch["cam_mat"])
+    cam = cam[0] if cam.ndim == 3 else cam
+    p3d = _host(batch["keypoints3d"]).reshape(B, oc, -1, 3)
+    poses = np.zeros((B, oc, 1, 3, 4), np.float32)
+    pts = np.zeros((B, oc, kp, 2), np.float32)
+    for n in range(B):
+        for o in range(oc):
+            xy = transform_points_back(c[n, o, :, ::-1], offs[n])
+            if avail[n, o] == 0:
+                continue
+            pts[n, o] = xy
+            p6 = _pnp.pnp_rvec_t(p3d[n, o], xy, cam, rng=rng)
+            if not np.all(np.isfinite(p6)):
+                raise FloatingPointError("PnP returned a non-finite pose (image %d, object %d)" % (n, o))  # tf.Assert, loss_functions.py:299-304
+            R, t = _pnp.rodrigues(p6[:3]), p6[3:].astype(np.float64)
+            P = np.concatenate([R, t.reshape(3, 1)], axis=1)
+            poses[n, o, 0] = -P if t[2] < 0 else P
+    return poses, pts
+
+
+def test_step(net, batch, opt, loss_factors, evaluation_points=None, object_points_3d_count=None):
+    """One evaluation step of test_casapose.py (:268-384): inference forward, (component-filtered) LS keypoint voting or
+    RANSAC voting, host PnP, losses and the eight per-object pose statistics.
+    Returns (losses [5 floats], pose_stats [8 arrays of oc], poses [B,oc,3,4], points, seconds)."""
+    import time
+
+    from .pose_estimation.pose_evaluation import estimate_and_evaluate_poses, evaluate_pose_estimates
+    from .pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+
+    dev = net.device
+    img = batch["img"].to(device=dev, dtype=torch.float32).contiguous()
+    seg = batch["target_seg"].to(device=dev, dtype=torch.float32)
+    K, kp = net.seg_dim, int(getattr(opt, "no_points", 9))
+    with_gt = bool(getattr(opt, "train_vectors_with_ground_truth", False))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = net([img, seg] if with_gt else [img], training=False)
+    o_seg, o_dirs, conf = torch.split(out, [K, 2 * kp, out.shape[3] - K - 2 * kp], dim=3)
+    coords = None
+    if getattr(opt, "estimate_coords", False):
+        voter = CoordLSVotingWeighted(name="coords_ls_voting", num_classes=K, num_points=kp,
+                                      filter_estimates=bool(getattr(opt, "confidence_filter_estimates", True)),
+                                      output_second_largest_component=bool(getattr(opt, "confidence_choose_second", False)))
+        coords = voter([seg if with_gt else o_seg, o_dirs, conf])
+    losses = train_step(net, batch, loss_factors, None, opt, train=False, coords=coords, min_num=int(getattr(opt, "min_object_size_test", 1)),
+                        min_num_gt=1, filter_with_gt=bool(getattr(opt, "filter_test_with_gt", False)))
+    if coords is not None:
+        plan, _ = net.training_plan(img.shape[0], img.shape[1], img.shape[2])
+        poses, pts = poses_from_coords(coords, plan.objects_available, batch)
+        stats, poses, pts = evaluate_pose_estimates(pts, poses, batch["poses_gt"], seg, batch["keypoints3d"], batch["cam_mat"], batch["diameters"],
+                                                    evaluation_points=evaluation_points, object_points_3d_count=object_points_3d_count, min_num=1)
+        poses = np.asarray(poses).reshape(poses.shape[0], poses.shape[1], 3, 4)
+    else:
+        stats, poses, pts = estimate_and_evaluate_poses(o_seg, seg, o_dirs, batch["poses_gt"], batch["keypoints3d"], batch["cam_mat"], batch["diameters"],
+                                                        batch["offsets"], evaluation_points=evaluation_points, object_points_3d_count=object_points_3d_count,
+                                                        min_num=1)
+    torch.cuda.synchronize(dev)
+    return losses, stats, poses, pts, time.perf_counter() - t0
