@@ -45,6 +45,10 @@ STAGE_FILTERS = (64, 128, 256, 512)
 STAGE_STRIDE = (1, 2, 1, 1)  # resnet.py:262-290 (output_stride 8)
 STAGE_DILATION = (1, 1, 2, 4)
 DECODER_DIMS_DEFAULT = (256, 128, 64, 32, 32)
+# decoder-2 configuration of blocks 6..10: which use a partial convolution, which upsample their output with the
+# label-guided gather (else plain nearest x2).  CASAPoseConditional1-5 (pose_models.py:14-635) differ only in these.
+PARTIAL_DEFAULT = (True, True, True, True, True)
+GUIDED_DEFAULT = (False, True, True, True, False)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -217,6 +221,7 @@ class ForwardPlan:
         self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
         self.pnorm = [new(B, hs[l], ws[l]) for l in range(4)]
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
+        self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2 = "guided" with neighbour 0 everywhere
         self._out_bound: List[Tuple[FusedConv, int, str]] = []  # (conv, channel offset, descriptor field) writing into the per-call output
         self._bufs: List[torch.Tensor] = []
 
@@ -337,7 +342,8 @@ class ForwardPlan:
         # ---- decoder 2 (pose_models.py:561-616) -------------------------------------------
         prev, prev_c = None, 0
         for i in range(5):
-            name = "pv_block_%d_prepare_conv2d" % (i + 6)
+            partial = net.partial[i]
+            name = ("pv_block_%d_prepare_conv2d" if partial else "pv_block_%d_conv2d") % (i + 6)
             tab = P["pv_block_%d_clade" % (i + 6)]
             l = lvl[i]
             o = new(B, hs[l], ws[l], dims[i])
@@ -347,28 +353,30 @@ class ForwardPlan:
                 up = i >= 2
                 src0, mode, sel = prev, _lib.SRC_DIRECT, None
                 if up:
+                    selmap = self.sel[l] if net.guided[i - 1] else self.sel_zero[l]  # block i-1 upsampled its output (casapose.py:109-131)
                     if fuse_upsample:
-                        mode, sel = _lib.SRC_NEAREST_SEL, self.sel[l]
+                        mode, sel = _lib.SRC_NEAREST_SEL, selmap
                     else:
                         big = new(B, hs[l], ws[l], prev_c)
-                        self.steps.append(self._guided_step(prev, self.sel[l], big, hs[l] // 2, ws[l] // 2, prev_c))
+                        self.steps.append(self._guided_step(prev, selmap, big, hs[l] // 2, ws[l] // 2, prev_c))
                         self._bufs.append(big)
                         src0 = big
                 srcs = [dict(data=src0, ld=prev_c, mode=mode, sel=sel), dict(data=skips[i][0], ld=skips[i][1])]
-            fused = self.fuse_heads and i == 4
+            pk = dict(tap_label=self.labels[l], row_scale=self.pnorm[l]) if partial else {}
+            # the fused head lives in the halo kernel, which gathers a guided/nearest x2 source only together with the tap mask
+            fused = self.fuse_heads and i == 4 and (partial or not fuse_upsample)
+            self.fuse_head2 = fused if i == 4 else False
             if fused:  # block 10 + pv_final_conv_vertex in one launch
                 L[name].attach_head(net.params["pv_final_conv_vertex.kernel"])
-                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
-                     scale=tab[0], shift=tab[1], epi_label=self.labels[l], act=_lib.ACT_LEAKY01, head_out=self.img4,
-                     head_out_ld=self.out_ld)
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=tab[0], shift=tab[1], epi_label=self.labels[l],
+                     act=_lib.ACT_LEAKY01, head_out=self.img4, head_out_ld=self.out_ld, **pk)
                 self._out_bound.append((L[name], K, "head_out"))
             else:
-                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, tap_label=self.labels[l], row_scale=self.pnorm[l],
-                     scale=tab[0], shift=tab[1], epi_label=self.labels[l],
-                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+                conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=tab[0], shift=tab[1], epi_label=self.labels[l],
+                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o, **pk)
             self._bufs.append(o)
             prev, prev_c = o, dims[i]
-        if not self.fuse_heads:
+        if not self.fuse_head2:
             ver_head = L["pv_final_conv_vertex"]
             conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
             self._out_bound.append((ver_head, K, "out_raw"))
@@ -427,13 +435,15 @@ class CasaposeNet:
     """Parameters + launch plans of casapose_c_gcu5 on one GPU."""
 
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
-                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True):
+                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
         self.device = device
         self.seg_dim, self.ver_dim = seg_dim, ver_dim
         self.decoder_dims = tuple(decoder_dims)
+        self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
@@ -481,7 +491,10 @@ class CasaposeNet:
         for i in range(5):
             srcs = [(512, 512)] if i == 0 else [(dims[i - 1], dims[i - 1]), skip_c[i]]
             add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
-            add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs)
+            if self.partial[i]:
+                add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs)
+            else:
+                add("pv_block_%d_conv2d" % (i + 6), "pv_block_%d_conv2d.kernel" % (i + 6), 0, 3, dims[i], srcs)
         add("pv_final_conv_segmentation", "pv_final_conv_segmentation.kernel", 0, 1, self.seg_dim, [(dims[4], dims[4])])
         add("pv_final_conv_vertex", "pv_final_conv_vertex.kernel", 0, 1, self.ver_dim, [(dims[4], dims[4])])
         self.layers_by_name = L

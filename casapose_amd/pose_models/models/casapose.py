@@ -26,13 +26,19 @@ _GCU5 = [tuple(p) for p in CASAPOSE_PARAMS["clade"]]
 def CASAPose(layer_params, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
              input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18", backbone=None,
              output_lablemap=False, learn_upsampling=False, **kwargs):
-    if [tuple(p) for p in layer_params] != _GCU5 or learn_upsampling:
-        raise NotImplementedError("only the `clade` DecoderParams set (== casapose_c_gcu5) is built for MI355X so far")
+    params = [DecoderParams(*p) for p in layer_params]
+    if len(params) != 5:
+        raise ValueError("layer_params must describe the five decoder blocks")
+    if learn_upsampling or any(p.reuse_conv or p.bilinear_upsampling or not p.weighted_clade for p in params):
+        raise NotImplementedError("built for MI355X: weighted_clade=True with any combination of partial_conv / guided_upsampling; "
+                                  "reuse_conv, bilinear_upsampling (GuidedBilinearUpsampling), plain ClassAdaptiveNormalization and "
+                                  "learn_upsampling are not")
     if base_model != "resnet18":
         raise NotImplementedError("backbone %s is not built for MI355X yet" % base_model)
     return CasaposeModel("casapose_custom", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights, output_lablemap=output_lablemap,
-                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True))
+                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True),
+                         partial=[p.partial_conv for p in params], guided=[p.guided_upsampling for p in params])
 
 
 def CASAPoseConditional(*args, **kwargs):

@@ -20,7 +20,8 @@ def _he_uniform(rng, shape, fan_in):
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
-def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Optional[int] = None,
+                       partial: Sequence[bool] = engine.PARTIAL_DEFAULT) -> Dict[str, np.ndarray]:
     """Keras-default initial state: he_uniform kernels (resnet.py:31; _normalization_layers.py:317),
     BN gamma 1 / beta 0 / moving mean 0 / moving variance 1, CLADE gamma 1 / beta 0
     (_normalization_layers.py:96-107).  Keys are `<keras layer name>.<weight>`."""
@@ -55,7 +56,10 @@ def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Op
         ci, co = dec_in[i], dims[i]
         p["pv_block_%d_conv2d.kernel" % (i + 1)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
         bn("pv_block_%d_bn" % (i + 1), co)
-        p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
+        if partial[i]:
+            p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
+        else:  # ordinary pad + Conv2D in decoder 2 (casapose.py:69-74)
+            p["pv_block_%d_conv2d.kernel" % (i + 6)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
         bn("pv_block_%d_clade" % (i + 6), co, gamma=False, beta=False)
         p["pv_block_%d_clade.gamma" % (i + 6)] = np.ones((seg_dim, co), np.float32)
         p["pv_block_%d_clade.beta" % (i + 6)] = np.zeros((seg_dim, co), np.float32)
@@ -90,7 +94,8 @@ class Layer:
 class CasaposeModel:
     def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
-                 fuse_upsample: bool = True, fuse_heads: bool = True):
+                 fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
+                 guided: Sequence[bool] = engine.GUIDED_DEFAULT):
         if output_lablemap:
             raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
         self.name = name
@@ -106,8 +111,10 @@ class CasaposeModel:
             warnings.warn("weights='imagenet': the reference downloads ImageNet ResNet-18 weights (weights.py:13-39); "
                           "no network here -- using he_uniform initialisation; call load_weights() for real weights")
             weights = None
-        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed)
-        self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads)
+        self._partial, self._guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
+        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial)
+        self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
+                                       self._partial, self._guided)
         if isinstance(weights, str):
             self.load_weights(weights)
         self._layers = self._build_layers()
@@ -123,7 +130,8 @@ class CasaposeModel:
             self._store = train_engine.ParamStore(self._params, self.device)
         p = self._plan
         if p is None or (p.batch, p.h, p.w) != (batch, h, w) or p.group is not group:
-            self._plan = train_engine.TrainPlan(self._store, self.seg_dim, self.ver_dim, batch, h, w, self._dims, group, world_size)
+            self._plan = train_engine.TrainPlan(self._store, self.seg_dim, self.ver_dim, batch, h, w, self._dims, group, world_size,
+                                                self._partial, self._guided)
             self._plan.refresh_weights(torch.cuda.current_stream(self.device).cuda_stream)
         return self._plan, self.device
 

@@ -4,18 +4,48 @@ from __future__ import annotations
 from .model import CasaposeModel
 
 
-def CASAPoseConditional5(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
-                         input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18",
-                         backbone=None, output_lablemap=False, **kwargs):
-    """casapose_c_gcu5: ResNet-18 (OS 8) + segmentation decoder + class-adaptive vector-field
-    decoder with 5 partial convolutions, CLADE and guided upsampling (pose_models.py:513-635)."""
+def _conditional(name, partial, guided, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
+                 input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18",
+                 backbone=None, output_lablemap=False, **kwargs):
     if base_model != "resnet18":
         raise TypeError("Undefined base model type: {}".format(base_model)) if base_model not in (
             "resnet34", "resnet50", "resnet101", "resnet152") else NotImplementedError(
             "backbone %s is not built for MI355X yet (resnet18 is)" % base_model)
     if backbone is not None or input_tensor is not None:
         raise NotImplementedError("external backbone / input_tensor are Keras-graph features without an equivalent here")
-    return CasaposeModel("casapose_c_gcu5", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
+    return CasaposeModel(name, ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
-                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True))
+                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True),
+                         partial=partial, guided=guided)
+
+
+_GU = (False, True, True, True, False)  # blocks 7, 8, 9 upsample with the label-guided gather
+
+
+def CASAPoseConditional1(*args, **kwargs):
+    """casapose_c (pose_models.py:14-129): CLADE in every decoder-2 block, ordinary convolutions, nearest x2 upsampling.
+    The reference leaves the HalfSize 1x1 convolutions of this variant trainable (:59-61); they stay at their identity
+    initialisation here (the conditioning is a hard label map)."""
+    return _conditional("casapose_c", (False,) * 5, (False,) * 5, *args, **kwargs)
+
+
+def CASAPoseConditional2(*args, **kwargs):
+    """casapose_c_gu (pose_models.py:132-256): no partial convolution, guided upsampling."""
+    return _conditional("casapose_c_gu", (False,) * 5, _GU, *args, **kwargs)
+
+
+def CASAPoseConditional3(*args, **kwargs):
+    """casapose_c_gcu3 (pose_models.py:259-383): partial convolution in blocks 6-8, guided upsampling."""
+    return _conditional("casapose_c_gcu3", (True, True, True, False, False), _GU, *args, **kwargs)
+
+
+def CASAPoseConditional4(*args, **kwargs):
+    """casapose_c_gcu4 (pose_models.py:386-510): partial convolution in blocks 6-9, guided upsampling."""
+    return _conditional("casapose_c_gcu4", (True, True, True, True, False), _GU, *args, **kwargs)
+
+
+def CASAPoseConditional5(*args, **kwargs):
+    """casapose_c_gcu5: ResNet-18 (OS 8) + segmentation decoder + class-adaptive vector-field
+    decoder with 5 partial convolutions, CLADE and guided upsampling (pose_models.py:513-635)."""
+    return _conditional("casapose_c_gcu5", (True,) * 5, _GU, *args, **kwargs)

@@ -19,7 +19,7 @@ def _not_built(name):
     def ctor(*args, **kwargs):
         raise NotImplementedError(
             "model `%s` is registered by the reference but its graph has not been built for MI355X yet; "
-            "available: casapose_c_gcu5, casapose_custom" % name
+            "available: casapose_c, casapose_c_gu, casapose_c_gcu3, casapose_c_gcu4, casapose_c_gcu5, casapose_custom" % name
         )
 
     ctor.__name__ = name
@@ -34,10 +34,10 @@ class ModelsFactory:
         "resnet50": _not_built("resnet50"),
         "resnet101": _not_built("resnet101"),
         "resnet152": _not_built("resnet152"),
-        "casapose_c": _not_built("casapose_c"),
-        "casapose_c_gu": _not_built("casapose_c_gu"),
-        "casapose_c_gcu3": _not_built("casapose_c_gcu3"),
-        "casapose_c_gcu4": _not_built("casapose_c_gcu4"),
+        "casapose_c": _pm.CASAPoseConditional1,
+        "casapose_c_gu": _pm.CASAPoseConditional2,
+        "casapose_c_gcu3": _pm.CASAPoseConditional3,
+        "casapose_c_gcu4": _pm.CASAPoseConditional4,
         "casapose_c_gcu5": _pm.CASAPoseConditional5,
         "pvnet_combined": _not_built("pvnet_combined"),
         "casapose_custom": _cp.CASAPoseConditional,

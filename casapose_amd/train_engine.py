@@ -32,7 +32,7 @@ import torch
 
 from . import _lib, parallel
 from ._lib import ConvDesc, check
-from .engine import BN_EPS, DECODER_DIMS_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
+from .engine import BN_EPS, DECODER_DIMS_DEFAULT, GUIDED_DEFAULT, PARTIAL_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
 
 BN_MOMENTUM = 0.99  # resnet.py:43 (Keras default elsewhere)
 
@@ -392,7 +392,8 @@ class TrainPlan:
     VERT_OFF = 32
 
     def __init__(self, store: ParamStore, seg_dim: int, ver_dim: int, batch: int, h: int, w: int,
-                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1):
+                 decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1,
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         if seg_dim > 32 or ver_dim > 32:
@@ -423,6 +424,8 @@ class TrainPlan:
         self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
         self.pnorm = [torch.empty(B, hs[l], ws[l], **f32) for l in range(4)]
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
+        self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2
+        self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
         # keypoint-reprojection loss (LS voter forward/backward)
@@ -509,20 +512,21 @@ class TrainPlan:
         skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
         lvl = [3, 3, 2, 1, 0]
 
-        def upsample(prev: TT, l: int, guided: bool) -> TT:
+        def upsample(prev: TT, l: int, guided: bool, selmap: Optional[torch.Tensor] = None) -> TT:
             big = new(hs[l], ws[l], prev.c)
             sh, sw, c = hs[l] // 2, ws[l] // 2, prev.c
+            selmap = self.sel[l] if selmap is None else selmap
 
             def f(stream):
                 if guided:
-                    check(lib.cp_guided_upsample_x2_f32(prev.data.data_ptr(), self.sel[l].data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_guided_upsample_x2_f32")
+                    check(lib.cp_guided_upsample_x2_f32(prev.data.data_ptr(), selmap.data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_guided_upsample_x2_f32")
                 else:
                     check(lib.cp_upsample_bilinear_x2_f32(prev.data.data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_upsample_bilinear_x2_f32")
 
             def b(stream):
                 assert big.has_grad and not prev.has_grad
                 if guided:
-                    check(lib.cp_guided_upsample_x2_bwd_f32(big.grad.data_ptr(), c, self.sel[l].data_ptr(), B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_guided_upsample_x2_bwd_f32")
+                    check(lib.cp_guided_upsample_x2_bwd_f32(big.grad.data_ptr(), c, selmap.data_ptr(), B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_guided_upsample_x2_bwd_f32")
                 else:
                     check(lib.cp_upsample_bilinear_x2_bwd_f32(big.grad.data_ptr(), c, B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_upsample_bilinear_x2_bwd_f32")
                 prev.has_grad = True
@@ -530,11 +534,12 @@ class TrainPlan:
             self.ops.append(FnOp(f, b))
             return big
 
-        def decoder(first: int, partial: bool):
+        def decoder(first: int, second: bool):
             prev = None
             for i in range(5):
                 l = lvl[i]
                 idx = first + i
+                partial = second and self.partial[i]
                 if partial:
                     key, layout = "pv_block_%d_prepare_conv2d.weights" % idx, 1
                 else:
@@ -542,7 +547,10 @@ class TrainPlan:
                 if i == 0:
                     srcs, tts, gs = [(512, 512)], [(x32s, 512)], [True]
                 else:
-                    src0 = upsample(prev, l, partial) if i >= 2 else prev
+                    if i >= 2:  # the previous block upsampled its output: bilinear (decoder 1), label-guided or plain nearest (decoder 2)
+                        src0 = upsample(prev, l, second, None if (not second or self.guided[i - 1]) else self.sel_zero[l])
+                    else:
+                        src0 = prev
                     srcs = [(dims[i - 1], dims[i - 1]), skip_c[i]]
                     tts = [(src0, dims[i - 1]), (skips[i], skips[i].c)]
                     gs = [True, skips[i].needs_grad]
@@ -553,6 +561,9 @@ class TrainPlan:
                 if partial:
                     conv(L, tts, raw, hs[l], ws[l], pad=1, tap_label=self.labels[l], row_scale=self.pnorm[l])
                     bn("pv_block_%d_clade" % idx, raw, act, act_kind, labels=self.labels[l], classes=K, row_scale=self.pnorm[l])
+                elif second:
+                    conv(L, tts, raw, hs[l], ws[l], pad=1)
+                    bn("pv_block_%d_clade" % idx, raw, act, act_kind, labels=self.labels[l], classes=K)
                 else:
                     conv(L, tts, raw, hs[l], ws[l], pad=1)
                     bn("pv_block_%d_bn" % idx, raw, act, act_kind)

@@ -323,8 +323,19 @@ DECODER_DIMS = (256, 128, 64, 32, 32)  # fcdim, s8dim, s4dim, s2dim, raw_dim (po
 DECODER_IN = (512, 256 + 128, 128 + 64, 64 + 64, 32 + 3)
 
 
-def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, randomize_norm: bool = True):
-    """Random parameters of casapose_c_gcu5 with the reference's shapes/initialisers
+VARIANTS = {  # per decoder-2 block 6..10: (partial convolution, guided upsampling); pose_models.py:14-635
+    "casapose_c": ((False,) * 5, (False,) * 5),                                    # CASAPoseConditional1: CLADE only, nearest x2
+    "casapose_c_gu": ((False,) * 5, (False, True, True, True, False)),            # CASAPoseConditional2
+    "casapose_c_gcu3": ((True, True, True, False, False), (False, True, True, True, False)),
+    "casapose_c_gcu4": ((True, True, True, True, False), (False, True, True, True, False)),
+    "casapose_c_gcu5": ((True,) * 5, (False, True, True, True, False)),
+}
+
+
+def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, randomize_norm: bool = True,
+                partial=(True,) * 5):
+    """Random parameters of casapose_c_gcu5 (or, with ``partial``, of a variant whose decoder-2 block i is an ordinary
+    convolution `pv_block_N_conv2d.kernel` when partial[i] is False) with the reference's shapes/initialisers
     (he_uniform conv kernels: resnet.py:31; _normalization_layers.py:317).  With
     ``randomize_norm`` the BN/CLADE statistics and affine terms are randomised as in
     SURVEY 8(d) so tests exercise every term."""
@@ -361,7 +372,10 @@ def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, 
         p[n1 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
         bn(n1 + "_bn", co)
         n2 = "pv_block_%d" % (i + 6)
-        p[n2 + "_prepare_conv2d.weights"] = he((ci, 3, 3, co), 9 * ci)
+        if partial[i]:
+            p[n2 + "_prepare_conv2d.weights"] = he((ci, 3, 3, co), 9 * ci)
+        else:
+            p[n2 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
         bn(n2 + "_clade", co, has_gamma=False, has_beta=False)
         if randomize_norm:
             p[n2 + "_clade.gamma"] = rng.uniform(0.5, 1.5, (seg_dim, co)).astype(dtype)
@@ -429,24 +443,31 @@ def decoder1_block(p, x, idx, leaky, upsample):
     return x
 
 
-def decoder2_block(p, x, idx, mask, leaky, guide=None, bilinear_guided=False):
-    """casa_layer with partial_conv + weighted CLADE (+ guided upsampling)
-    (casapose.py:61-68,78-82,98-118)."""
+def decoder2_block(p, x, idx, mask, leaky, guide=None, bilinear_guided=False, partial=True, upsample_nearest=False):
+    """casa_layer with [partial_conv | pad+conv] + weighted CLADE (+ guided or plain nearest upsampling)
+    (casapose.py:61-74,78-82,98-131)."""
     n = "pv_block_%d" % idx
-    x = partial_convolution(x, p[n + "_prepare_conv2d.weights"], mask)
+    if partial:
+        x = partial_convolution(x, p[n + "_prepare_conv2d.weights"], mask)
+    else:
+        x = conv2d(x, p[n + "_conv2d.kernel"], pad=1)
     x = clade_weighted(
         x, mask, p[n + "_clade.gamma"], p[n + "_clade.beta"], p[n + "_clade.moving_mean"], p[n + "_clade.moving_variance"]
     )
     x = leaky_as_relu_pair(x) if leaky else relu(x)
     if guide is not None:
         x = guided_bilinear_upsampling(x, mask, guide) if bilinear_guided else guided_upsampling(x, mask, guide)
+    elif upsample_nearest:
+        x = upsample_nearest_x2(x)
     return x
 
 
-def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False):
-    """CASAPoseConditional5 (pose_models.py:513-635).  img [B,H,W,3]; optional
-    seg_input [B,H,W,K] (the `data_segmentation` input, :550-554).
+def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant="casapose_c_gcu5"):
+    """CASAPoseConditional5 (pose_models.py:513-635) and, with ``variant``, its siblings CASAPoseConditional1-4
+    (:14-512) which differ only in which decoder-2 blocks use a partial convolution and guided upsampling.
+    img [B,H,W,3]; optional seg_input [B,H,W,K] (the `data_segmentation` input, :550-554).
     Returns [B,H,W,K+ver_dim] = concat(seg logits, vertex)."""
+    part, guid = VARIANTS[variant]
     x2s, x4s, x8s, _x16s, x32s = resnet18_os8(p, img)
     x = decoder1_block(p, x32s, 1, leaky=False, upsample=False)
     x = decoder1_block(p, np.concatenate([x, x8s], 3), 2, True, True)
@@ -458,11 +479,11 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False):
     mask2 = half_size(mask)
     mask4 = half_size(mask2)
     mask8 = half_size(mask4)
-    y = decoder2_block(p, x32s, 6, mask8, leaky=False)
-    y = decoder2_block(p, np.concatenate([y, x8s], 3), 7, mask8, True, guide=mask4)
-    y = decoder2_block(p, np.concatenate([y, x4s], 3), 8, mask4, True, guide=mask2)
-    y = decoder2_block(p, np.concatenate([y, x2s], 3), 9, mask2, True, guide=mask)
-    y = decoder2_block(p, np.concatenate([y, img], 3), 10, mask, True)
+    y = decoder2_block(p, x32s, 6, mask8, leaky=False, partial=part[0])
+    y = decoder2_block(p, np.concatenate([y, x8s], 3), 7, mask8, True, guide=mask4 if guid[1] else None, partial=part[1], upsample_nearest=True)
+    y = decoder2_block(p, np.concatenate([y, x4s], 3), 8, mask4, True, guide=mask2 if guid[2] else None, partial=part[2], upsample_nearest=True)
+    y = decoder2_block(p, np.concatenate([y, x2s], 3), 9, mask2, True, guide=mask if guid[3] else None, partial=part[3], upsample_nearest=True)
+    y = decoder2_block(p, np.concatenate([y, img], 3), 10, mask, True, partial=part[4])
     vertex = conv2d(y, p["pv_final_conv_vertex.kernel"])
     out = np.concatenate([logits, vertex], 3)
     if return_intermediates:

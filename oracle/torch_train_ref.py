@@ -120,9 +120,11 @@ def guided_upsample(x, lab_lo, lab_hi):
     return x[bi, sy, sx, :]
 
 
-def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None):
-    """casapose_c_gcu5 with training=True and decoder 2 conditioned on the given hard label map (the
-    `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
+def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None,
+                  partial=(True,) * 5, guided=(False, True, True, True, False)):
+    """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
+    convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
+    hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
 
     def bn(name, x):
         return batchnorm_train(x, p.get(name + ".gamma"), p.get(name + ".beta"), stats_out, name)
@@ -166,11 +168,17 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
         n = "pv_block_%d" % (i + 6)
         inp = x32s if i == 0 else torch.cat([d2, skips[i]], dim=3)
         lab = labs[lvl[i]]
-        y = partial_conv(inp, p[n + "_prepare_conv2d.weights"], lab)
+        if partial[i]:
+            y = partial_conv(inp, p[n + "_prepare_conv2d.weights"], lab)
+        else:
+            y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
         y = clade_train(y, lab, p[n + "_clade.gamma"], p[n + "_clade.beta"], stats_out, n + "_clade")
         y = F.relu(y) if i == 0 else leaky_pair(y)
         if 0 < i < 4:
-            y = guided_upsample(y, lab, labs[lvl[i] - 1])
+            if guided[i]:
+                y = guided_upsample(y, lab, labs[lvl[i] - 1])
+            else:
+                y = y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)  # UpSampling2D(nearest), casapose.py:126-131
         d2 = y
     vertex = conv_nhwc(d2, p["pv_final_conv_vertex.kernel"])
     return torch.cat([logits, vertex], dim=3)

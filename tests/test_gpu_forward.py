@@ -98,3 +98,44 @@ def test_ls_voting_sums_and_empty_objects(device):
     s = sums.cpu().numpy()
     assert np.abs(s - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())  # fp32 per-pixel terms: ulp-level softplus differences
     assert (kp.cpu().numpy()[:, 5:] == 0).all()
+
+
+@pytest.mark.parametrize("variant", ["casapose_c", "casapose_c_gu", "casapose_c_gcu3", "casapose_c_gcu4"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_registry_variants_forward(device, variant, fuse):
+    """CASAPoseConditional1-4 (pose_models.py:14-512): same graph as gcu5 with ordinary convolutions / plain nearest
+    upsampling in some decoder-2 blocks.  Given mask, every output value compared with the fp64 oracle."""
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    b, h, w, k, v = 2, 64, 96, 5, 27
+    part, _ = O.VARIANTS[variant]
+    net = Classifiers.get(variant)(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), input_segmentation_shape=(h, w, k), weights=None,
+                                   base_model="resnet18", device=device, fuse_upsample=fuse, fuse_heads=fuse)
+    params = O.init_params(k, v, seed=77, dtype=np.float32, partial=part)
+    assert set(params) == set(net.get_parameters()), "variant parameter names"
+    net.set_parameters(params)
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    lab = np.zeros((b, h, w), np.int64)
+    lab[:, 8:40, 10:50] = 1
+    lab[:, 30:60, 40:90] = 2
+    lab[0, 5:20, 60:80] = 3
+    lab[1, 44:62, 4:30] = 4
+    seg = O.onehot_from_labels(lab, k, np.float32)
+    ref = O.casapose_c_gcu5({n: a.astype(np.float64) for n, a in params.items()}, img.astype(np.float64), seg_input=seg.astype(np.float64), variant=variant)
+    got = net([img, seg], training=False).cpu().numpy().astype(np.float64)
+    assert rel_err(got[..., :k], ref[..., :k]) < 1e-3
+    assert rel_err(got[..., k:], ref[..., k:]) < 1e-3
+
+
+def test_custom_decoder_params(device):
+    from casapose_amd.pose_models.models.casapose import CASAPOSE_PARAMS, CASAPose, DecoderParams
+
+    params = [DecoderParams(True, i % 2 == 0, i in (1, 3), False, False) for i in range(5)]
+    net = CASAPose(params, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
+    assert "pv_block_7_conv2d.kernel" in net.get_parameters() and "pv_block_8_prepare_conv2d.weights" in net.get_parameters()
+    out = net([np.zeros((1, 32, 32, 3), np.float32)], training=False)
+    assert tuple(out.shape) == (1, 32, 32, 30) and bool(torch.isfinite(out).all())
+    with pytest.raises(NotImplementedError):
+        CASAPose([DecoderParams(True, True, True, True, False)] * 5, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
+    assert [tuple(p) for p in CASAPOSE_PARAMS["clade"]][1] == (True, True, True, False, False)

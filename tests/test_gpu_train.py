@@ -303,11 +303,11 @@ def test_adam_matches_keras_formula(device, hip_lib):
 # --------------------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------------------
-def _setup(device, b, h, w, k, seed=1237):
+def _setup(device, b, h, w, k, seed=1237, partial=(True,) * 5, guided=(False, True, True, True, False)):
     from casapose_amd.train_engine import ParamStore, TrainPlan
 
     v = 27
-    params = O.init_params(k, v, seed=seed, dtype=np.float32)
+    params = O.init_params(k, v, seed=seed, dtype=np.float32, partial=partial)
     rng = np.random.default_rng(seed)
     for name in params:  # non-trivial normalisation parameters
         if name.endswith(".gamma"):
@@ -315,23 +315,25 @@ def _setup(device, b, h, w, k, seed=1237):
         if name.endswith(".beta"):
             params[name] = (0.1 * rng.standard_normal(params[name].shape)).astype(np.float32)
     store = ParamStore(params, device)
-    plan = TrainPlan(store, k, v, b, h, w)
+    plan = TrainPlan(store, k, v, b, h, w, partial=partial, guided=guided)
     img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
     lab = blob_labels(b, h, w, k, seed + 1)
     kpts = rng.uniform(0, min(h, w), (b, k - 1, 9, 2)).astype(np.float32)
     return params, store, plan, img, lab, kpts
 
 
-def test_train_forward_backward_matches_autograd(device):
+@pytest.mark.parametrize("variant", ["casapose_c_gcu5", "casapose_c_gcu3", "casapose_c"])
+def test_train_forward_backward_matches_autograd(device, variant):
     b, h, w, k = 2, 32, 48, 4
-    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k)
+    part, guid = O.VARIANTS[variant]
+    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, partial=part, guided=guid)
     stream = torch.cuda.current_stream(device).cuda_stream
     plan.refresh_weights(stream)
     labd = torch.from_numpy(lab).to(device)
     out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd)
     p64 = R.to_torch(params)
     stats = {}
-    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats)
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats, partial=part, guided=guid)
     got = out.cpu().numpy()
     assert rel(got[..., :k], ref.detach().numpy()[..., :k]) < 1e-3
     assert rel(got[..., k:], ref.detach().numpy()[..., k:]) < 1e-3
