@@ -407,7 +407,7 @@ class TrainPlan:
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         B, K, V = batch, seg_dim, ver_dim
-        self.out_ld = K + V
+        self.out_ld = (K + V + 3) // 4 * 4   # row length of the output record, padded to 16 bytes (the LS voter stages rows as float4)
         hs = [h, h // 2, h // 4, h // 8]
         ws = [w, w // 2, w // 4, w // 8]
         self.ops: List = []
@@ -419,7 +419,8 @@ class TrainPlan:
 
         self.img4 = new(h, w, 4, False, "img4")        # raw image, channel 3 = 0 (decoder skip)
         self.x0 = new(h, w, 4, False, "bn_data")        # bn_data(image), channel 3 = 1 (see below)
-        self.out = torch.empty(B, h, w, self.out_ld, **f32)
+        self.out = torch.zeros(B, h, w, self.out_ld, **f32)         # padded record
+        self.out_view = self.out[..., :K + V]                       # what the model returns: concat(seg logits, vertex)
         self.dout = torch.zeros(B, h, w, self.GRAD_LD, **f32)
         self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
         self.pnorm = [torch.empty(B, hs[l], ws[l], **f32) for l in range(4)]
@@ -632,7 +633,7 @@ class TrainPlan:
         check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
         for op in self.ops:
             op.forward(stream)
-        return self.out
+        return self.out_view
 
     def loss_and_grad(self, labels_ce: torch.Tensor, labels_fg: torch.Tensor, keypoints_yx: torch.Tensor, mask_w=1.0, vertex_w=1.0, proxy_w=1.0,
                       filter_with_segmentation=True, kp: int = 9) -> torch.Tensor:

@@ -98,7 +98,7 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
         if with_gt and seg_in.dim() != 4:
             seg_in = torch.nn.functional.one_hot(labels.long(), net.seg_dim)
         out = net([img, seg_in.to(torch.float32)] if with_gt else [img], training=False)
-        plan.out.copy_(out)
+        plan.out_view.copy_(out)
     wts = (float(loss_factors.mask_loss_weight), float(loss_factors.vertex_loss_weight), float(loss_factors.proxy_loss_weight))
     sums = plan.loss_and_grad(labels, fg, kpts, *wts, filter_with_segmentation=bool(loss_factors.filter_vertex_with_segmentation))
     kp_w = float(getattr(loss_factors, "kp_loss_weight", 0.0))

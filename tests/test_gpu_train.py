@@ -441,15 +441,17 @@ def test_keypoint_loss_and_voter_backward(device, conf_reg):
     assert np.all(g[..., :32] == 0)
 
 
-def test_model_api_train_step(device):
-    """The reference's flow (train_casapose.py:494-611) through the factory model and casapose_amd.training.train_step."""
+@pytest.mark.parametrize("k", [5, 14])
+def test_model_api_train_step(device, k):
+    """The reference's flow (train_casapose.py:494-611) through the factory model and casapose_amd.training.train_step;
+    k = 14 is the 13-object configuration (config_13.ini) whose output record (41 floats) is not a multiple of 16 bytes."""
     from types import SimpleNamespace
 
     from casapose_amd.pose_models.tfkeras import Classifiers
     from casapose_amd.training import Adam, train_step
     from casapose_amd.utils.learning_rate_schedules import LossWeightHandler, PiecewiseConstantDecay
 
-    b, h, w, k, kp = 2, 64, 64, 5, 9
+    b, h, w, kp = 2, 64, 64, 9
     lab, out, offsets, A, gt = _kp_case(7, b, h, w, k)
     net = Classifiers.get("casapose_c_gcu5")(ver_dim=27, seg_dim=k, input_shape=(h, w, 3), input_segmentation_shape=(h, w, k), weights=None,
                                              base_model="resnet18", device=device, seed=3)
