@@ -651,12 +651,14 @@ class TrainPlan:
     def kp_loss_and_grad(self, labels_gt: torch.Tensor, gt_xy: torch.Tensor, affine: torch.Tensor, kp_w: float, max_pixel_error: float = 25.0,
                          min_num: int = 50, confidence_regularization: bool = False, vote_with_gt: bool = True, kp: int = 9,
                          min_num_gt: Optional[int] = None, filter_with_gt: bool = True, coords: Optional[torch.Tensor] = None,
-                         backward: bool = True) -> torch.Tensor:
+                         backward: bool = True, host_loss: Optional[Callable] = None) -> torch.Tensor:
         """keypoint_reprojection_loss (loss_functions.py:207-344, use_bpnp_reprojection_loss=False) on the last forward's
         output; ADDS kp_w * d loss / d output to self.dout (call after loss_and_grad).  gt_xy [B,oc,kp,2]: projected
         ground-truth keypoints in image pixels; affine [B,6]: crop->image map (crop_to_image_affine).  Returns the
         fp64 loss value (device scalar).  `coords` (optional, [B,oc,kp,2] (y,x)) replaces the internal vote (evaluation with the
-        component-filtered voter; implies backward=False); min_num_gt / filter_with_gt as in loss_functions.py:221-222,246-252."""
+        component-filtered voter; implies backward=False); min_num_gt / filter_with_gt as in loss_functions.py:221-222,246-252.
+        `host_loss(coords, avail) -> (loss, g_yx)` replaces the reprojection kernel (the BPnP variant, whose PnP solve and
+        implicit gradient run on the host like the reference's BPNP_fast)."""
         lib = _lib.load()
         B, h, w, K = self.batch, self.h, self.w, self.seg_dim
         oc = K - 1
@@ -679,8 +681,13 @@ class TrainPlan:
             avail = avail & (self.kp_counts[0, :, 1:] > (min_num if min_num_gt is None or min_num_gt < 0 else min_num_gt))
         avail = avail.to(torch.float32).contiguous()
         self.objects_available = avail
-        check(lib.cp_kp_reproj_loss_f32(self.ls_coords.data_ptr(), gt_xy.data_ptr(), affine.data_ptr(), avail.data_ptr(), B, oc, kp, max_pixel_error,
-                                        kp_w, self.ls_g.data_ptr(), self.kp_loss_val.data_ptr(), stream), "cp_kp_reproj_loss_f32")
+        if host_loss is not None:
+            lv, g = host_loss(self.ls_coords, avail)
+            self.ls_g.copy_(torch.from_numpy(np.ascontiguousarray(g, dtype=np.float32)).reshape(B, oc, kp, 2))
+            self.kp_loss_val.fill_(float(lv))
+        else:
+            check(lib.cp_kp_reproj_loss_f32(self.ls_coords.data_ptr(), gt_xy.data_ptr(), affine.data_ptr(), avail.data_ptr(), B, oc, kp, max_pixel_error,
+                                            kp_w, self.ls_g.data_ptr(), self.kp_loss_val.data_ptr(), stream), "cp_kp_reproj_loss_f32")
         loss = self.kp_loss_val[0]
         coef = None
         if confidence_regularization:

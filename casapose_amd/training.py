@@ -64,6 +64,66 @@ def _kp_targets(batch, B, oc, dev):
     return gt_xy, aff, cam, p3d
 
 
+def bpnp_reprojection_loss_host(coords_yx, gt_xy, affine, avail, points_3d, cam, max_pixel_error: float = 25.0, weight: float = 1.0, rng=None):
+    """keypoint_reprojection_loss with use_bpnp_reprojection_loss=True (loss_functions.py:264-323), evaluated on the host in
+    fp64 like the reference's BPNP_fast (host PnP inside tf.numpy_function + implicit-function gradient):
+        p' = T(p)  (crop -> image), pose = PnP(p'), r = project(points_3d, pose)
+        loss = sum_n avail * mean_j cap(smoothL1((|r - p'| + |gt - r|) / 2)) / sum(avail)
+    Returns (loss, g_yx = weight * d loss / d coords_yx [B,oc,kp,2], poses [B,oc,1,3,4])."""
+    from .pose_estimation import pnp as _pnp
+
+    c = _host(coords_yx)
+    B, oc, kp, _ = c.shape
+    gt = _host(gt_xy).reshape(B, oc, kp, 2)
+    A = _host(affine).reshape(B, 2, 3)
+    av = _host(avail).reshape(B, oc)
+    X = _host(points_3d).reshape(B, oc, kp, 3)
+    K = _host(cam)
+    na = av.sum()
+    g = np.zeros((B, oc, kp, 2))
+    poses = np.zeros((B, oc, 1, 3, 4), np.float32)
+    total = 0.0
+    for n in range(B):
+        L = A[n, :, :2]                                   # d(X,Y)/d(x,y)
+        for o in range(oc):
+            if av[n, o] == 0:
+                continue
+            xy = c[n, o, :, ::-1] @ L.T + A[n, :, 2]      # image pixels (x,y)
+            p6 = _pnp.pnp_rvec_t(X[n, o], xy, K, rng=rng).astype(np.float64)
+            if not np.all(np.isfinite(p6)):
+                raise FloatingPointError("PnP returned a non-finite pose (image %d, object %d)" % (n, o))
+            rv, t = _pnp.refine_lm(X[n, o], xy, K, p6[:3], p6[3:], iters=30, eps=1e-14)   # tighten the optimum the IFT differentiates
+            p6 = np.concatenate([rv, t])
+            R = _pnp.rodrigues(rv)
+            P = np.concatenate([R, t.reshape(3, 1)], axis=1)
+            poses[n, o, 0] = -P if t[2] < 0 else P
+            res, J = _pnp._residual_and_jacobian(X[n, o], xy, K, rv, t)   # res = r - p' (interleaved u,v), J = d r / d pose6
+            r = res.reshape(kp, 2) + xy
+            d1 = r - xy
+            d2 = gt[n, o] - r
+            n1 = np.sqrt((d1 ** 2).sum(1))
+            n2 = np.sqrt((d2 ** 2).sum(1))
+            e = 0.5 * (n1 + n2)
+            l = np.where(e < 1.0, 0.5 * e * e, e - 0.5)
+            slope = np.where(e < 1.0, e, 1.0)
+            capped = l > max_pixel_error
+            l = np.where(capped, max_pixel_error + (l - max_pixel_error) * 0.01, l)
+            slope = np.where(capped, slope * 0.01, slope)
+            total += l.mean()
+            if na <= 0:
+                continue
+            cf = slope / (kp * na) * 0.5                                   # d loss / d n1 = d loss / d n2
+            u1 = np.where(n1[:, None] > 0, d1 / np.where(n1[:, None] > 0, n1[:, None], 1.0), 0.0)
+            u2 = np.where(n2[:, None] > 0, d2 / np.where(n2[:, None] > 0, n2[:, None], 1.0), 0.0)
+            g_r = cf[:, None] * (u1 - u2)                                   # d loss / d r
+            g_p_direct = -cf[:, None] * u1                                  # d loss / d p' (explicit dependence of |r - p'|)
+            g_pose = J.T @ g_r.reshape(-1)
+            g_p = g_p_direct + _pnp.bpnp_backward(g_pose, xy, X[n, o], K, p6)
+            g[n, o] = (g_p @ L)[:, ::-1]                                   # back through the affine, then (x,y) -> (y,x)
+    loss = total / na if na > 0 else 0.0
+    return float(loss), (weight * g).astype(np.float32), poses
+
+
 def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Optional[Adam], opt, group=None, world_size: int = 1,
                train: bool = True, coords: Optional[torch.Tensor] = None, min_num: int = 50, min_num_gt: Optional[int] = None,
                filter_with_gt: bool = True):
@@ -77,9 +137,6 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
     train_casapose.py:596) and only the loss values are computed; filtered_seg is ignored like in the reference's
     evaluation branch (:637-648).  Returns python floats [loss, mask_loss, vertex_loss, proxy_loss, kp_loss]
     (compute_loss, train_casapose.py:137-145)."""
-    if getattr(opt, "use_bpnp_reprojection_loss", False):
-        raise NotImplementedError("use_bpnp_reprojection_loss in the training loss (BPnP inside keypoint_reprojection_loss) is not wired yet; "
-                                  "the BPnP gradient itself is casapose_amd.pose_estimation.pnp.bpnp_backward")
     if getattr(loss_factors, "filter_high_proxy_errors", False):
         raise NotImplementedError("filter_high_proxy_errors (train_casapose.py:71-93) is not built yet")
     plan, dev = net.training_plan(batch["img"].shape[0], batch["img"].shape[1], batch["img"].shape[2], group, world_size)
@@ -104,10 +161,15 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
     kp_w = float(getattr(loss_factors, "kp_loss_weight", 0.0))
     kp_loss = None
     if getattr(opt, "estimate_coords", False):
-        gt_xy, aff, _, _ = _kp_targets(batch, B, oc, dev)
+        gt_xy, aff, cam, p3d = _kp_targets(batch, B, oc, dev)
+        host_loss = None
+        if getattr(opt, "use_bpnp_reprojection_loss", False):
+            def host_loss(c, av):  # noqa: E306
+                return bpnp_reprojection_loss_host(c, gt_xy, aff, av, p3d, cam, float(getattr(opt, "max_keypoint_pixel_error", 25.0)), kp_w)[:2]
         kp_loss = plan.kp_loss_and_grad(labels, gt_xy, aff, kp_w, max_pixel_error=float(getattr(opt, "max_keypoint_pixel_error", 25.0)), min_num=min_num,
                                         confidence_regularization=bool(getattr(opt, "confidence_regularization", False)) and train,
-                                        vote_with_gt=with_gt, min_num_gt=min_num_gt, filter_with_gt=filter_with_gt, coords=coords, backward=train)
+                                        vote_with_gt=with_gt, min_num_gt=min_num_gt, filter_with_gt=filter_with_gt, coords=coords, backward=train,
+                                        host_loss=host_loss)
     if train:
         stream = torch.cuda.current_stream(dev).cuda_stream
         plan.backward()

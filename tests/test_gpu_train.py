@@ -441,8 +441,8 @@ def test_keypoint_loss_and_voter_backward(device, conf_reg):
     assert np.all(g[..., :32] == 0)
 
 
-@pytest.mark.parametrize("k", [5, 14])
-def test_model_api_train_step(device, k):
+@pytest.mark.parametrize("k,bpnp", [(5, False), (14, False), (5, True)])
+def test_model_api_train_step(device, k, bpnp):
     """The reference's flow (train_casapose.py:494-611) through the factory model and casapose_amd.training.train_step;
     k = 14 is the 13-object configuration (config_13.ini) whose output record (41 floats) is not a multiple of 16 bytes."""
     from types import SimpleNamespace
@@ -470,7 +470,7 @@ def test_model_api_train_step(device, k):
     batch = dict(img=torch.from_numpy(img), target_seg=torch.from_numpy(seg), keypoints3d=torch.from_numpy(p3d), target_vert=torch.from_numpy(xy[..., ::-1].copy()),
                  cam_mat=torch.from_numpy(cam), offsets=torch.from_numpy(ident), poses_gt=torch.from_numpy(poses))
     opt = SimpleNamespace(train_vectors_with_ground_truth=True, estimate_coords=True, max_keypoint_pixel_error=12.5, confidence_regularization=True,
-                          use_bpnp_reprojection_loss=False)
+                          use_bpnp_reprojection_loss=bpnp)  # True: config_13.ini -- host PnP + implicit gradient inside the keypoint loss
     lf = LossWeightHandler(1.0, 0.5, 0.015, 0.007, filter_vertex_with_segmentation=True)
     optim = Adam(learning_rate=PiecewiseConstantDecay([5], [1e-3, 5e-4]))
     hist = [train_step(net, batch, lf, optim, opt) for _ in range(10)]

@@ -181,3 +181,36 @@ def test_poses_pnp_zeroes_small_objects():
     out = E.poses_pnp(pts[..., ::-1].copy(), seg, kp3, cams, oc, min_num=20)
     assert out.shape == (b, oc, 1, 3, 4)
     assert np.abs(out[0, 0, 0] - poses[0, 0, 0]).max() < 1e-2 and np.all(out[0, 1] == 0)
+
+
+def test_bpnp_reprojection_loss_gradient_by_finite_differences():
+    """use_bpnp_reprojection_loss (loss_functions.py:264-323): the host loss's analytic gradient (explicit term + IFT through
+    the PnP optimum) equals central differences of the loss with the PnP re-solved at every perturbed point set."""
+    from casapose_amd.training import bpnp_reprojection_loss_host
+    from casapose_amd.train_engine import crop_to_image_affine
+
+    rng = np.random.default_rng(9)
+    B, oc, kp = 1, 2, 9
+    kp3, poses, cams, offsets, pts = _eval_scene(rng, B, oc)
+    off = np.array([[12.0, 40.0, 0, 0, 3.0, -2.0, 9.0, 1.1, 640, 480]])
+    A = crop_to_image_affine(off).astype(np.float64).reshape(B, 2, 3)
+    Li = np.linalg.inv(A[0, :, :2])
+    crop_xy = (pts[0] + rng.normal(0, 1.5, pts[0].shape) - A[0, :, 2]) @ Li.T      # noisy votes, in crop pixels
+    coords = crop_xy[None, ..., ::-1].copy()                                          # (y,x)
+    gt = pts + rng.normal(0, 2.0, pts.shape)
+    avail = np.ones((B, oc))
+
+    def f(c):
+        return bpnp_reprojection_loss_host(c, gt, A.reshape(B, 6), avail, kp3[:, :, 0], K, 12.5, 1.0, rng=np.random.default_rng(0))
+
+    loss, g, est = f(coords)
+    assert np.isfinite(loss) and est.shape == (B, oc, 1, 3, 4)
+    num = np.zeros_like(coords)
+    for o in range(oc):
+        for j in range(0, kp, 2):
+            for a in range(2):
+                d = np.zeros_like(coords)
+                d[0, o, j, a] = 1e-3
+                num[0, o, j, a] = (f(coords + d)[0] - f(coords - d)[0]) / 2e-3
+    m = num != 0
+    assert np.abs(g[m] - num[m]).max() < 2e-2 * np.abs(num[m]).max()
