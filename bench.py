@@ -44,6 +44,24 @@ def cpu_baseline(h, w, seg_dim, ver_dim):
             "sample": "1 image 480x640 forward + LS voting, NumPy oracle in fp32 (%.1f s)" % dt}
 
 
+TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
+                   5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<"}
+
+
+def measured_traffic(tile):
+    """Average HBM bytes per launch of the instantiation family `tile`, from the committed PMC passes (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or tile not in TILE_PMC_PREFIX:
+        return None
+    tab = json.load(open(path))
+    tot = n = 0.0
+    for name, v in tab.items():
+        if TILE_PMC_PREFIX[tile] in name:
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def bench_train(args):
     """Secondary workload (BASELINE.json configs[2]/[3]): one data-parallel TRAINING step of casapose_c_gcu5 --
     forward with batch statistics (SyncBN all-reduced across ranks), mask/vertex/proxy/keypoint losses, hand-written
@@ -226,6 +244,17 @@ def main():
             t["ms"] += ms
             t["flops"] += conv.flops
             t["launches"] += 1
+        for conv in plan.convs:  # algorithmic HBM bytes: every operand once (sources at their stored resolution, packed weights, outputs)
+            tile = lib.cp_conv_selected_tile(conv.desc)
+            d_ = conv.desc
+            byt = 4.0 * conv.wp.numel()
+            for si in range(d_.num_sources):
+                sc = d_.src[si]
+                div = 1 if sc.mode == 0 else 4
+                byt += 4.0 * d_.batch * d_.in_h * d_.in_w * sc.channels / div
+            byt += 4.0 * d_.batch * d_.out_h * d_.out_w * (d_.cout if (d_.out_raw or d_.out_act) else 0) * ((1 if d_.out_raw else 0) + (1 if d_.out_act else 0))
+            byt += 4.0 * d_.batch * d_.out_h * d_.out_w * d_.head_cout if d_.head_out else 0.0
+            per_tile[tile]["bytes"] = per_tile[tile].get("bytes", 0.0) + byt
         dom = max(per_tile, key=lambda k: per_tile[k]["ms"])
         d = per_tile[dom]
         conv_ms = sum(t["ms"] for t in per_tile.values())
@@ -233,7 +262,9 @@ def main():
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         result["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(dom),
+            "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command; memory-side requests, Infinity-Cache hits included)",
+            "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"]),
             "kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "launches_per_step": d["launches"],
             "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 3), "ms_per_step": round(conv_ms, 3),
