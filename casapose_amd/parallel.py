@@ -17,6 +17,8 @@ def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # CASAPOSE_DIST_BACKEND=gloo lets several ranks share ONE GPU in tests (RCCL refuses duplicate devices)
+    backend = os.environ.get("CASAPOSE_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

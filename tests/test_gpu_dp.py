@@ -1,0 +1,87 @@
+"""Data-parallel training semantics on ONE GPU: two ranks (gloo, both on cuda:0) each take half of a batch; with the SyncBN
+tables all-reduced the forward must equal the single-process forward of the whole batch, and the SUM-all-reduced gradient
+must equal world_size x the whole-batch gradient (per-replica mean losses, SUM reduction: MirroredStrategy semantics,
+train_casapose.py:641-643).  The 8-GPU RCCL run itself is the driver's; this pins the protocol the ranks execute."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import casapose_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+B, H, W, K = 4, 32, 48, 4
+
+
+def _data():
+    rng = np.random.default_rng(123)
+    params = O.init_params(K, 27, seed=9, dtype=np.float32)
+    img = rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)
+    lab = np.zeros((B, H, W), np.uint8)
+    for n in range(B):
+        lab[n, 4 + n:20 + n, 6:22 + 2 * n] = 1
+        lab[n, 14:30, 20 + n:40] = 2
+        lab[n, 2:10, 30:44 - n] = 3
+    kpts = rng.uniform(0, H, (B, K - 1, 9, 2)).astype(np.float32)
+    return params, img, lab, kpts
+
+
+def _run(plan, dev, img, lab, kpts):
+    labd = torch.from_numpy(lab).to(dev)
+    out = plan.forward(torch.from_numpy(img).to(dev), cond_labels=labd).clone()
+    sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(dev), 1.0, 0.5, 0.015, filter_with_segmentation=False).clone()
+    plan.backward()
+    plan.all_reduce_grads()
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), sums.cpu().numpy(), plan.store.grad.cpu().numpy().copy()
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CASAPOSE_DIST_BACKEND="gloo")
+    from casapose_amd import parallel
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    parallel.init_from_env("nccl")
+    dev = torch.device("cuda:0")
+    params, img, lab, kpts = _data()
+    b, e = parallel.shard_range(B, rank, world)
+    plan = TrainPlan(ParamStore(params, dev), K, 27, e - b, H, W, group=torch.distributed.group.WORLD, world_size=world)
+    plan.refresh_weights(torch.cuda.current_stream(dev).cuda_stream)
+    out, sums, grad = _run(plan, dev, img[b:e], lab[b:e], kpts[b:e])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), out=out, sums=sums, grad=grad,
+             mm=plan.store.state["bn0.moving_mean"].cpu().numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_dp_equals_whole_batch(device, tmp_path):
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    params, img, lab, kpts = _data()
+    plan = TrainPlan(ParamStore(params, device), K, 27, B, H, W)
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    out, sums, grad = _run(plan, device, img, lab, kpts)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    dp_out = np.concatenate([r0["out"], r1["out"]])
+    assert np.abs(dp_out - out).max() < 2e-4 * np.abs(out).max(), "SyncBN forward differs from the whole-batch forward"
+    assert np.allclose(r0["grad"], r1["grad"], rtol=0, atol=0), "ranks must hold the same reduced gradient"
+    assert np.allclose(0.5 * (r0["sums"] + r1["sums"]), sums, rtol=2e-4)        # MEAN of the replica losses == whole-batch loss
+    g_dp, g_ref = r0["grad"] / 2.0, grad
+    err = np.linalg.norm(g_dp - g_ref) / np.linalg.norm(g_ref)
+    assert err < 2e-3, "summed replica gradients / world_size differ from the whole-batch gradient: %g" % err
+    assert np.allclose(r0["mm"], plan.store.state["bn0.moving_mean"].cpu().numpy(), atol=1e-6)   # global statistics feed the moving averages
