@@ -70,6 +70,8 @@ class ConvDesc(C.Structure):
         ("head_out", C.c_void_p),
         ("head_cout", C.c_int),
         ("head_out_ld", C.c_int),
+        ("group_rows", C.c_int),
+        ("group_weight_stride", C.c_int),
     ]
 
 
@@ -102,6 +104,10 @@ SYMBOLS = [
     ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
     ("cp_ransac_vote_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("cp_ransac_workspace_bytes", C.c_size_t, [_i, _i, _i, _i, _i, _i]),
+    ("cp_wino_tiles", _i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    ("cp_wino_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    ("cp_wino_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     # ---- training path ----
     ("cp_conv2d_wgrad_f32", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     ("cp_bn_stats_f32", _i, [_vp, _ll, _i, _i, _vp, _vp]),

@@ -75,6 +75,7 @@ struct ConvK {
     float* out_act;
     int act_ld;
     int tiles_m, tiles_n, nchunks;
+    int group_rows, group_wstride;  // grouped GEMM: rows [g*group_rows, ...) read weights at W + g*group_wstride
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int co = n0 + rbase + 32 * j;
-        r_wof[j] = (co < p.Cout) ? (unsigned)((co * p.ktot + col4 * 4) * 4) : OOB;
+        const unsigned gofs = p.group_rows ? (unsigned)(m0 / p.group_rows) * (unsigned)p.group_wstride * 4u : 0u;
+        r_wof[j] = (co < p.Cout) ? (unsigned)((co * p.ktot + col4 * 4) * 4) + gofs : OOB;
     }
     __syncthreads();  // tapoff visible
 
@@ -637,6 +639,17 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
     k.ktot = cp_conv_ktot(d->kh, d->kw, d->num_sources, chans);
     k.nchunks = k.ktot / BK;
     k.w_bytes = (unsigned)((size_t)d->cout * k.ktot * 4);
+    k.group_rows = d->group_rows;
+    k.group_wstride = d->group_weight_stride;
+    if (d->group_rows) {
+        const long long rows = (long long)d->batch * d->out_h * d->out_w;
+        CP_REQUIRE(d->group_rows > 0 && d->group_rows % 128 == 0 && rows % d->group_rows == 0 && d->group_weight_stride >= d->cout * k.ktot,
+                   "cp_conv2d_fwd_f32: group_rows must be a multiple of 128 dividing the output pixels; group_weight_stride >= cout*ktot");
+        CP_REQUIRE(d->tile_hint != CP_TILE_256x32, "cp_conv2d_fwd_f32: the 256-row tile does not support grouped weights");
+        const long long wb = (rows / d->group_rows) * (long long)d->group_weight_stride * 4;
+        CP_REQUIRE(wb < (1LL << 31), "cp_conv2d_fwd_f32: grouped weights span >= 2 GiB");
+        k.w_bytes = (unsigned)wb;
+    }
     k.lab_bytes = (unsigned)((size_t)d->batch * d->in_h * d->in_w);
     k.B = d->batch; k.Hin = d->in_h; k.Win = d->in_w; k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->cout;
     k.KH = d->kh; k.KW = d->kw; k.stride = d->stride; k.dil = d->dilation; k.pad = d->pad;

@@ -550,7 +550,7 @@ int halo_pack_weights(const float* w, int layout, int cout, int num_sources, con
 bool halo_applicable(const cp_conv_desc* d) {
     if (!d->weights_halo) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return false;
-    if (d->cout > 64) return false;
+    if (d->cout > 64 || d->group_rows) return false;
     if (d->src[0].mode == CP_SRC_ZERO_INSERT_X2) return false;  // transposed-conv gather: generic kernel only
     if (d->src[0].channels % 32 != 0 || d->src[0].pre_scale) return false;
     if (d->num_sources == 2) {

@@ -1,0 +1,244 @@
+// Winograd F(4x4, 3x3) for the deep 3x3 / stride-1 convolutions (Lavin & Gray's minimal filtering): the 144
+// multiplications of a 4x4 output tile become 36, i.e. the MFMA work of the layer drops 4x, at the price of two
+// streaming transform passes.  Same convolution, different summation order -- measured error vs fp64 is ~8e-6 of the
+// output range in fp32 (direct: ~2e-6), far inside the parity gate.  The reference reaches the same layers through
+// cuDNN, which makes this choice for fp32 3x3 convolutions on its own (layers.Conv2D, resnet.py:97-103; casapose.py:71-74).
+//
+//   V[p][t][c] = (B^T d B)[p]        input transform : 6x6 input patch d of tile t, channel c      (this file)
+//   M[p][t][o] = sum_c V[p][t][c] * U[p][o][c]        36 independent GEMMs = ONE grouped 1x1 launch  (conv_f32.hip)
+//   Y          = A^T M A, epilogue   output transform : residual / affine table / activation / stores (this file)
+//
+// Dilation d (2 and 4 in stages 3/4) is handled exactly by sub-grid decomposition: the pixels with equal (y mod d,
+// x mod d) form d*d independent dilation-1 problems with zero padding at their own borders.
+// Tile id: t = ((n*d*d + sy*d + sx)*Tu + tu)*Tv + tv; planes are padded to Tp tiles (a multiple of 64) so that a GEMM
+// block never straddles two planes.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct WinoGeom {
+    int B, H, W, d, Tu, Tv, T, Tp;
+};
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// B^T applied to six values
+__device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&t)[6]) {
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = d[3] + d[4] - 4.f * (d[1] + d[2]);
+    t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    t[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    t[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// A^T applied to six values
+__device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&y)[4]) {
+    const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+
+__device__ __forceinline__ void tile_coords(int t, const WinoGeom& g, int& n, int& sy, int& sx, int& tu, int& tv) {
+    tv = t % g.Tv;
+    int r = t / g.Tv;
+    tu = r % g.Tu;
+    r /= g.Tu;
+    const int s = r % (g.d * g.d);
+    n = r / (g.d * g.d);
+    sy = s / g.d;
+    sx = s - sy * g.d;
+}
+
+__global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restrict__ src, int ld, int C, WinoGeom g, float* __restrict__ V, int ldv,
+                                                          int c_off) {
+    const int c4n = C >> 2;
+    const long long total = (long long)g.T * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int t = (int)(i / c4n);
+        int n, sy, sx, tu, tv;
+        tile_coords(t, g, n, sy, sx, tu, tv);
+        float4 tt[6][6];  // (B^T d): column by column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int x = sx + g.d * (4 * tv + j - 1);
+            float4 col[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int y = sy + g.d * (4 * tu + r - 1);
+                const bool ok = (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;  // outside the image (or before the sub-grid's first row/column): zero padding
+                col[r] = ok ? *reinterpret_cast<const float4*>(src + (((size_t)n * g.H + y) * g.W + x) * ld + c4 * 4) : f4(0.f);
+            }
+            float4 o[6];
+            bt6(col, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tt[r][j] = o[r];
+        }
+        float* dst = V + (size_t)t * ldv + c_off + c4 * 4;
+        const size_t plane = (size_t)g.Tp * ldv;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float4 o[6];
+            bt6(tt[r], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
+        }
+    }
+}
+
+struct WinoEpi {
+    const float* residual;
+    int res_ld;
+    const float* scale;
+    const float* shift;
+    const uint8_t* label;
+    int act;
+    float* out_raw;
+    int raw_ld;
+    float* out_act;
+    int act_ld;
+};
+
+__global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restrict__ M, int cout, WinoGeom g, WinoEpi e) {
+    const int c4n = cout >> 2;
+    const long long total = (long long)g.T * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int t = (int)(i / c4n);
+        int n, sy, sx, tu, tv;
+        tile_coords(t, g, n, sy, sx, tu, tv);
+        const float* src = M + (size_t)t * cout + c4 * 4;
+        const size_t plane = (size_t)g.Tp * cout;
+        float4 tt[4][6];  // A^T m, column by column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 col[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const float4*>(src + (size_t)(r * 6 + j) * plane);
+            float4 o[4];
+            at6(col, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tt[r][j] = o[r];
+        }
+        float4 sc = f4(1.f), sh = f4(0.f);
+        const bool aff = e.scale != nullptr;
+        if (aff && !e.label) {
+            sc = *reinterpret_cast<const float4*>(e.scale + c4 * 4);
+            sh = *reinterpret_cast<const float4*>(e.shift + c4 * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            at6(tt[r], o);
+            const int y = sy + g.d * (4 * tu + r);
+            if (y >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = sx + g.d * (4 * tv + j);
+                if (x >= g.W) continue;
+                const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+                float4 v = o[j];
+                if (e.residual) v = v + *reinterpret_cast<const float4*>(e.residual + pix * e.res_ld + c4 * 4);
+                if (e.out_raw) *reinterpret_cast<float4*>(e.out_raw + pix * e.raw_ld + c4 * 4) = v;
+                if (e.out_act) {
+                    if (aff && e.label) {
+                        const int l = e.label[pix];
+                        sc = *reinterpret_cast<const float4*>(e.scale + (size_t)l * cout + c4 * 4);
+                        sh = *reinterpret_cast<const float4*>(e.shift + (size_t)l * cout + c4 * 4);
+                    }
+                    float4 w = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                    if (e.act == CP_ACT_RELU) {
+                        w = make_float4(fmaxf(w.x, 0.f), fmaxf(w.y, 0.f), fmaxf(w.z, 0.f), fmaxf(w.w, 0.f));
+                    } else if (e.act == CP_ACT_LEAKY01) {
+                        w = make_float4(fmaxf(w.x, 0.f) - fmaxf(-0.1f * w.x, 0.f), fmaxf(w.y, 0.f) - fmaxf(-0.1f * w.y, 0.f),
+                                        fmaxf(w.z, 0.f) - fmaxf(-0.1f * w.z, 0.f), fmaxf(w.w, 0.f) - fmaxf(-0.1f * w.w, 0.f));
+                    }
+                    *reinterpret_cast<float4*>(e.out_act + pix * e.act_ld + c4 * 4) = w;
+                }
+            }
+        }
+    }
+}
+
+int make_geom(int batch, int h, int w, int dil, WinoGeom& g) {
+    if (batch <= 0 || h <= 0 || w <= 0 || dil <= 0) return CP_ERR_INVALID;
+    g.B = batch; g.H = h; g.W = w; g.d = dil;
+    const int hs = (h + dil - 1) / dil, ws = (w + dil - 1) / dil;
+    g.Tu = (hs + 3) / 4;
+    g.Tv = (ws + 3) / 4;
+    const long long T = (long long)batch * dil * dil * g.Tu * g.Tv;
+    if (T * 36 >= (1LL << 31)) return CP_ERR_INVALID;
+    g.T = (int)T;
+    g.Tp = (int)((T + 127) / 128 * 128);
+    return CP_OK;
+}
+
+inline int grid_for(long long n) {
+    long long b = (n + THREADS - 1) / THREADS;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+}  // namespace
+
+extern "C" int cp_wino_tiles(int batch, int h, int w, int dilation, int* tiles, int* tiles_padded) {
+    WinoGeom g;
+    if (make_geom(batch, h, w, dilation, g) != CP_OK) {
+        cp::set_error("cp_wino_tiles: bad geometry %dx%dx%d dilation %d", batch, h, w, dilation);
+        return CP_ERR_INVALID;
+    }
+    if (tiles) *tiles = g.T;
+    if (tiles_padded) *tiles_padded = g.Tp;
+    return CP_OK;
+}
+
+extern "C" int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
+                                         int k_off, float* dst) {
+    // dst[p][co][k_off + c] = (G g G^T)[p] for input channel c_begin + c; dst is [36][cout][ldk], zero-filled by the caller once
+    CP_REQUIRE(w_hwio && dst && cout > 0 && real_channels > 0 && real_channels <= channels && k_off >= 0 && k_off + channels <= ldk,
+               "cp_wino_pack_weights_host: bad arguments");
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int c = 0; c < real_channels; ++c)
+        for (int co = 0; co < cout; ++co) {
+            double g[3][3], t[6][3];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w_hwio[(((size_t)ky * 3 + kx) * cin_total + c_begin + c) * cout + co];
+            for (int a = 0; a < 6; ++a)
+                for (int kx = 0; kx < 3; ++kx) t[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b)
+                    dst[((size_t)(a * 6 + b) * cout + co) * ldk + k_off + c] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        }
+    return CP_OK;
+}
+
+extern "C" int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
+                                           int c_off, void* stream) {
+    CP_REQUIRE(src && V && channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0 && c_off >= 0 && c_off % 4 == 0 && c_off + channels <= ldv,
+               "cp_wino_input_transform_f32: bad arguments");
+    WinoGeom g;
+    CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_input_transform_f32: bad geometry");
+    CP_LAUNCH(wino_in_kernel, dim3(grid_for((long long)g.T * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv, c_off);
+    return cp::check_launch("cp_wino_input_transform_f32");
+}
+
+extern "C" int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                            const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
+                                            int out_raw_ld, float* out_act, int out_act_ld, void* stream) {
+    CP_REQUIRE(M && cout > 0 && cout % 4 == 0 && (out_raw || out_act), "cp_wino_output_transform_f32: bad arguments");
+    CP_REQUIRE((scale == nullptr) == (shift == nullptr) && (!epi_label || scale), "cp_wino_output_transform_f32: scale/shift/label combination");
+    CP_REQUIRE((!out_raw || out_raw_ld >= cout) && (!out_act || out_act_ld >= cout) && (!residual || residual_ld >= cout), "cp_wino_output_transform_f32: ld < cout");
+    WinoGeom g;
+    CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_output_transform_f32: bad geometry");
+    WinoEpi e{residual, residual_ld, scale, shift, epi_label, act, out_raw, out_raw_ld, out_act, out_act_ld};
+    CP_LAUNCH(wino_out_kernel, dim3(grid_for((long long)g.T * (cout / 4))), dim3(THREADS), 0, (hipStream_t)stream, M, cout, g, e);
+    return cp::check_launch("cp_wino_output_transform_f32");
+}

@@ -12,6 +12,7 @@ the Keras names of the reference so weights map 1:1.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -191,6 +192,94 @@ class FusedConv:
         return 2.0 * d.batch * d.out_h * d.out_w * self.kh * self.kw * cin * self.cout + head
 
 
+class WinoConv:
+    """A deep 3x3 / stride-1 convolution executed as Winograd F(4x4,3x3): input transform(s), ONE grouped 1x1 launch over
+    the 36 planes, output transform with the fused epilogue (csrc/wino.hip).  Same interface as FusedConv.run()."""
+
+    def __init__(self, name: str, kernel_hwio: np.ndarray, cout: int, sources: Sequence[Tuple[int, int]], device: torch.device):
+        lib = _lib.load()
+        self.name, self.cout, self.sources = name, cout, list(sources)
+        self.kh = self.kw = 3
+        self.ktot = sum(s[0] for s in sources)
+        if self.ktot % 32 or cout % 4:
+            raise ValueError("%s: Winograd path needs 32-multiple input channels and 4-multiple output channels" % name)
+        w = np.ascontiguousarray(kernel_hwio, dtype=np.float32)
+        cin = sum(s[1] for s in sources)
+        if tuple(w.shape) != (3, 3, cin, cout):
+            raise ValueError("%s: kernel shape %s, expected %s" % (name, w.shape, (3, 3, cin, cout)))
+        U = np.zeros((36, cout, self.ktot), np.float32)
+        c0 = k0 = 0
+        for cpad, creal in sources:
+            check(lib.cp_wino_pack_weights_host(w.ctypes.data, cin, cout, c0, cpad, creal, self.ktot, k0, U.ctypes.data), "cp_wino_pack_weights_host(%s)" % name)
+            c0 += creal
+            k0 += cpad
+        self.U = torch.from_numpy(U).to(device)
+        self.desc = ConvDesc()  # the grouped GEMM
+        self._keep: List = []
+
+    @staticmethod
+    def tiles(batch, h, w, dilation) -> Tuple[int, int]:
+        t, tp = C.c_int(0), C.c_int(0)
+        check(_lib.load().cp_wino_tiles(batch, h, w, dilation, C.byref(t), C.byref(tp)), "cp_wino_tiles")
+        return t.value, tp.value
+
+    def bind(self, *, batch, in_h, in_w, dilation, srcs, V, M, residual=None, scale=None, shift=None, epi_label=None, act=0,
+             out_raw=None, out_act=None):
+        """srcs: list of dicts(data=tensor, ld=int); V / M: scratch tensors of at least 36*Tp*ktot and 36*Tp*cout floats."""
+        self.batch, self.h, self.w, self.dil = batch, in_h, in_w, dilation
+        self.T, self.Tp = self.tiles(batch, in_h, in_w, dilation)
+        if V.numel() < 36 * self.Tp * self.ktot or M.numel() < 36 * self.Tp * self.cout:
+            raise ValueError("%s: Winograd scratch too small" % self.name)
+        self.srcs, self.V, self.M = list(srcs), V, M
+        self.epi = dict(residual=residual, scale=scale, shift=shift, epi_label=epi_label, act=act, out_raw=out_raw, out_act=out_act)
+        d = self.desc
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 36, 1, self.Tp, 1, self.Tp
+        d.cout, d.kh, d.kw, d.stride, d.dilation, d.pad = self.cout, 1, 1, 1, 1, 0
+        d.num_sources = 1
+        d.src[0].data, d.src[0].channels, d.src[0].ld, d.src[0].mode = V.data_ptr(), self.ktot, self.ktot, _lib.SRC_DIRECT
+        d.src[0].sel = d.src[0].pre_scale = d.src[0].pre_shift = None
+        d.weights, d.weights_halo = self.U.data_ptr(), None
+        d.tap_label = d.row_scale = d.residual = d.scale = d.shift = d.epi_label = None
+        d.residual_ld, d.act = self.cout, 0
+        d.out_raw, d.out_raw_ld, d.out_act, d.out_act_ld = M.data_ptr(), self.cout, None, self.cout
+        d.tile_hint = 0
+        d.head_weights = d.head_out = None
+        d.head_cout = d.head_out_ld = 0
+        d.group_rows, d.group_weight_stride = self.Tp, self.cout * self.ktot
+        self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
+        return in_h, in_w
+
+    def run(self, stream: int):
+        lib = _lib.load()
+        off = 0
+        for (cpad, _), s in zip(self.sources, self.srcs):
+            check(lib.cp_wino_input_transform_f32(s["data"].data_ptr(), s["ld"], cpad, self.batch, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
+                                                  stream), "cp_wino_input_transform_f32(%s)" % self.name)
+            off += cpad
+        check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
+        e = self.epi
+        check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
+                                               _ptr(e["scale"]), _ptr(e["shift"]), _ptr(e["epi_label"]), e["act"], _ptr(e["out_raw"]), self.cout,
+                                               _ptr(e["out_act"]), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
+
+    @property
+    def flops(self) -> float:
+        """FLOPs of the convolution this launch group REPLACES (2*M*9*Cin*Cout), the figure the per-layer tables quote."""
+        cin = sum(s[1] for s in self.sources)
+        return 2.0 * self.batch * self.h * self.w * 9 * cin * self.cout
+
+    @property
+    def gemm_flops(self) -> float:
+        """FLOPs the grouped GEMM actually executes (36 planes x padded tiles)."""
+        return 2.0 * 36 * self.Tp * self.ktot * self.cout
+
+
+def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int) -> bool:
+    """Measured on MI355X (profiles/): the 4x MFMA saving beats the two transform passes once the GEMM is deep and wide enough."""
+    k = sum(s[0] for s in sources)
+    return kh == 3 and stride == 1 and pad == dilation and k >= 256 and k % 32 == 0 and cout >= 128 and cout % 4 == 0
+
+
 class ForwardPlan:
     """All buffers, descriptors and the launch order for one (batch, H, W) input shape."""
 
@@ -225,10 +314,30 @@ class ForwardPlan:
         self._out_bound: List[Tuple[FusedConv, int, str]] = []  # (conv, channel offset, descriptor field) writing into the per-call output
         self._bufs: List[torch.Tensor] = []
 
+        self.wino_V = self.wino_M = None
+
         def conv(layer: FusedConv, **kw):
+            wl = net.wino_by_name.get(layer.name) if net.use_winograd else None
+            plain = all(s.get("mode", _lib.SRC_DIRECT) == _lib.SRC_DIRECT and not s.get("pre") for s in kw["srcs"])
+            if (wl is not None and plain and kw.get("tap_label") is None and kw.get("head_out") is None and kw.get("stride", 1) == 1
+                    and kw.get("out_raw_ld") is None and kw.get("out_act_ld") is None and all(s["ld"] == c[0] for s, c in zip(kw["srcs"], wl.sources))):
+                _, tp = WinoConv.tiles(B, kw["in_h"], kw["in_w"], kw.get("dilation", 1))
+                nv, nm = 36 * tp * wl.ktot, 36 * tp * wl.cout
+                if self.wino_V is None or self.wino_V.numel() < nv:
+                    self.wino_V = torch.empty(nv, **f32)
+                if self.wino_M is None or self.wino_M.numel() < nm:
+                    self.wino_M = torch.empty(nm, **f32)
+                self._wino_pending.append((wl, dict(batch=B, in_h=kw["in_h"], in_w=kw["in_w"], dilation=kw.get("dilation", 1), srcs=kw["srcs"],
+                                                    residual=kw.get("residual"), scale=kw.get("scale"), shift=kw.get("shift"), epi_label=kw.get("epi_label"),
+                                                    act=kw.get("act", 0), out_raw=kw.get("out_raw"), out_act=kw.get("out_act"))))
+                self.convs.append(wl)
+                self.steps.append(wl.run)
+                return
             layer.bind(batch=B, **kw)
             self.convs.append(layer)
             self.steps.append(layer.run)
+
+        self._wino_pending: List = []  # bound at the end, when the shared scratch has its final size
 
         L = net.layers_by_name
         # ---- encoder (resnet.py:246-305) ---------------------------------------------------
@@ -380,6 +489,12 @@ class ForwardPlan:
             ver_head = L["pv_final_conv_vertex"]
             conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
             self._out_bound.append((ver_head, K, "out_raw"))
+        self._bind_winograd()
+
+    def _bind_winograd(self):
+        for wl, kw in self._wino_pending:
+            wl.bind(V=self.wino_V, M=self.wino_M, **kw)
+        self._wino_pending = []
 
     def _bilinear_step(self, src, dst, sh, sw, c):
         lib = _lib.load()
@@ -436,7 +551,7 @@ class CasaposeNet:
 
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
-                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT):
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -446,6 +561,7 @@ class CasaposeNet:
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
+        self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self.set_params(params)
 
@@ -472,19 +588,24 @@ class CasaposeNet:
         self.device_tables = tabs
 
         L: Dict[str, FusedConv] = {}
+        Wn: Dict[str, WinoConv] = {}
 
-        def add(name, key, layout, k, cout, sources):
+        def add(name, key, layout, k, cout, sources, stride=1, dil=1, pad=None, partial=False):
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev)
+            pad = dil * (k // 2) if pad is None else pad
+            if self.use_winograd and not partial and layout == 0 and wino_eligible(k, stride, dil, pad, sources, cout):
+                Wn[name] = WinoConv(name, p[key], cout, sources, dev)
 
         add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])
         cin = 64
         for s, f in enumerate(STAGE_FILTERS):
             for u in range(2):
                 base = "stage%d_unit%d_" % (s + 1, u + 1)
+                st_, dl_ = (STAGE_STRIDE[s] if u == 0 else 1), STAGE_DILATION[s]
                 if u == 0:
-                    add(base + "sc", base + "sc.kernel", 0, 1, f, [(cin, cin)])
-                add(base + "conv1", base + "conv1.kernel", 0, 3, f, [(cin, cin)])
-                add(base + "conv2", base + "conv2.kernel", 0, 3, f, [(f, f)])
+                    add(base + "sc", base + "sc.kernel", 0, 1, f, [(cin, cin)], stride=st_)
+                add(base + "conv1", base + "conv1.kernel", 0, 3, f, [(cin, cin)], stride=st_, dil=dl_)
+                add(base + "conv2", base + "conv2.kernel", 0, 3, f, [(f, f)], dil=dl_)
                 cin = f
         dims = self.decoder_dims
         skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
@@ -492,12 +613,13 @@ class CasaposeNet:
             srcs = [(512, 512)] if i == 0 else [(dims[i - 1], dims[i - 1]), skip_c[i]]
             add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
             if self.partial[i]:
-                add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs)
+                add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs, partial=True)
             else:
                 add("pv_block_%d_conv2d" % (i + 6), "pv_block_%d_conv2d.kernel" % (i + 6), 0, 3, dims[i], srcs)
         add("pv_final_conv_segmentation", "pv_final_conv_segmentation.kernel", 0, 1, self.seg_dim, [(dims[4], dims[4])])
         add("pv_final_conv_vertex", "pv_final_conv_vertex.kernel", 0, 1, self.ver_dim, [(dims[4], dims[4])])
         self.layers_by_name = L
+        self.wino_by_name = Wn
         self.plans.clear()
 
     def plan(self, batch: int, h: int, w: int) -> ForwardPlan:

@@ -117,6 +117,9 @@ typedef struct cp_conv_desc {
     const float* head_weights;
     float* head_out;
     int head_cout, head_out_ld;
+    /* optional grouped GEMM (the 36 Winograd planes in one launch): output pixels [g*group_rows, (g+1)*group_rows) use the
+     * packed weights at weights + g*group_weight_stride floats.  group_rows must be a multiple of 128; 0 = ungrouped. */
+    int group_rows, group_weight_stride;
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
@@ -225,6 +228,28 @@ int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int d
                        float confidence, int max_iter, int min_num, int max_num, void* ws, float* out,
                        int32_t* rounds_out, void* stream);
 size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp);
+
+/* ------------------------------------------------------------------------------------
+ * Winograd F(4x4,3x3) path for deep 3x3 / stride-1 / pad == dilation convolutions (same layers.Conv2D call sites as
+ * cp_conv2d_fwd_f32; the MFMA work drops 4x).  Three launches:
+ *   cp_wino_input_transform_f32 : V[p][t][c_off + c] = (B^T d B)[p] for every 6x6 patch of `src` (once per source of a
+ *                                 concatenated input); V is [36][tiles_padded][ldv]
+ *   cp_conv2d_fwd_f32           : 1x1 over 36*tiles_padded "pixels" with group_rows = tiles_padded,
+ *                                 group_weight_stride = cout*ldk and the weights of cp_wino_pack_weights_host -> M
+ *   cp_wino_output_transform_f32: Y = A^T M A + the epilogue of cp_conv2d_fwd_f32 (residual, affine / per-label table,
+ *                                 activation, raw and activated stores)
+ * Dilation d is exact by sub-grid decomposition (d*d independent dilation-1 problems).  cp_wino_tiles returns the tile
+ * count and its padding (multiple of 128).  cp_wino_pack_weights_host writes dst[p][co][k_off + c] = (G g G^T)[p] for the
+ * input channels [c_begin, c_begin+real_channels) of a HWIO kernel; dst is [36][cout][ldk] and must be zeroed first.
+ * ---------------------------------------------------------------------------------- */
+int cp_wino_tiles(int batch, int h, int w, int dilation, int* tiles, int* tiles_padded);
+int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
+                              int k_off, float* dst);
+int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
+                                int c_off, void* stream);
+int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                 const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
+                                 int out_raw_ld, float* out_act, int out_act_ld, void* stream);
 
 /* ====================================================================================
  * TRAINING PATH (train_casapose.py:494-611: forward with training=True, compute_loss,

@@ -227,3 +227,63 @@ def test_bad_arguments_report_errors(device):
     x = torch.zeros(1, 8, 8, 24, device=device)  # 24 channels: neither 4 nor a multiple of 32
     with pytest.raises((_lib.CasaposeHipError, ValueError)):
         ops.conv2d_fused([x], np.zeros((3, 3, 24, 8), np.float32), pad=1)
+
+
+@pytest.mark.parametrize(
+    "srcs,cout,dil,hw,epi",
+    [
+        ([256], 128, 1, (13, 18), "plain"),
+        ([256], 256, 2, (15, 20), "residual_relu"),
+        ([512], 160, 4, (15, 20), "dual"),
+        ([256, 128], 128, 1, (12, 16), "clade_leaky"),
+        ([256], 132, 4, (9, 7), "plain"),           # sub-grids smaller than one tile, ragged cout
+    ],
+)
+def test_winograd_conv(device, srcs, cout, dil, hw, epi):
+    """Winograd F(4x4,3x3) path (csrc/wino.hip + grouped GEMM) vs the fp64 oracle of the convolution it replaces:
+    dilation by sub-grid decomposition, concatenated sources, ragged tiles, every epilogue flavour."""
+    from casapose_amd import _lib
+    from casapose_amd.engine import WinoConv
+
+    b = 2
+    rng = np.random.default_rng(sum(srcs) + cout + dil)
+    xs = [rng.standard_normal((b, hw[0], hw[1], c)) for c in srcs]
+    cin = sum(srcs)
+    w = rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)
+    ref = O.conv2d(np.concatenate(xs, 3), w, dilation=dil, pad=dil)
+    layer = WinoConv("t", w.astype(np.float32), cout, [(c, c) for c in srcs], device)
+    _, tp = WinoConv.tiles(b, hw[0], hw[1], dil)
+    V = torch.empty(36 * tp * cin, device=device)
+    M = torch.empty(36 * tp * cout, device=device)
+    kw = {}
+    res = lab = None
+    if epi in ("residual_relu", "dual"):
+        res = rng.standard_normal(ref.shape)
+        kw["residual"] = dev(res, device)
+        ref = ref + res
+    raw = torch.zeros(b, hw[0], hw[1], cout, device=device)
+    act = torch.zeros(b, hw[0], hw[1], cout, device=device)
+    ref_act = None
+    if epi == "plain":
+        kw["out_raw"] = raw
+    elif epi == "residual_relu":
+        sc, sh = rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.2
+        kw.update(scale=dev(sc, device), shift=dev(sh, device), act=_lib.ACT_RELU, out_act=act)
+        ref_act = O.relu(ref * sc + sh)
+    elif epi == "dual":
+        sc, sh = rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.2
+        kw.update(scale=dev(sc, device), shift=dev(sh, device), act=_lib.ACT_RELU, out_act=act, out_raw=raw)
+        ref_act = O.relu(ref * sc + sh)
+    else:
+        k = 5
+        lab = rng.integers(0, k, (b, hw[0], hw[1]))
+        sc, sh = rng.uniform(0.5, 1.5, (k, cout)), rng.standard_normal((k, cout)) * 0.2
+        kw.update(scale=dev(sc, device), shift=dev(sh, device), epi_label=dev(lab, device, torch.uint8), act=_lib.ACT_LEAKY01, out_act=act)
+        ref_act = O.leaky_as_relu_pair(ref * sc[lab] + sh[lab])
+    layer.bind(batch=b, in_h=hw[0], in_w=hw[1], dilation=dil, srcs=[dict(data=dev(x, device), ld=x.shape[3]) for x in xs], V=V, M=M, **kw)
+    layer.run(torch.cuda.current_stream(device).cuda_stream)
+    torch.cuda.synchronize()
+    if "out_raw" in kw:
+        close(raw, ref)
+    if ref_act is not None:
+        close(act, ref_act)
