@@ -168,6 +168,34 @@ __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restri
     }
 }
 
+// U[p][o][k_off + c] = (G g G^T)[p] on the device, g read from the MASTER weights through strides so that one kernel serves
+// the forward layout (HWIO or IHWO) and the flipped / transposed data-gradient layout; run after every optimizer step.
+__global__ void wino_weight_kernel(const float* __restrict__ w, long long s_ky, long long s_kx, long long s_in, long long s_out, int flip, int channels,
+                                   int cout, int ldk, int k_off, float* __restrict__ U) {
+    const long long total = (long long)channels * cout;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % channels);   // consecutive lanes -> consecutive k: coalesced U stores
+        const int o = (int)(i / channels);
+        float g[3][3], t[6][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                g[ky][kx] = w[(flip ? 2 - ky : ky) * s_ky + (flip ? 2 - kx : kx) * s_kx + c * s_in + o * s_out];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                U[((size_t)(a * 6 + b) * cout + o) * ldk + k_off + c] = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+    }
+}
+
 int make_geom(int batch, int h, int w, int dil, WinoGeom& g) {
     if (batch <= 0 || h <= 0 || w <= 0 || dil <= 0) return CP_ERR_INVALID;
     g.B = batch; g.H = h; g.W = w; g.d = dil;
@@ -241,4 +269,13 @@ extern "C" int cp_wino_output_transform_f32(const float* M, int cout, int batch,
     WinoEpi e{residual, residual_ld, scale, shift, epi_label, act, out_raw, out_raw_ld, out_act, out_act_ld};
     CP_LAUNCH(wino_out_kernel, dim3(grid_for((long long)g.T * (cout / 4))), dim3(THREADS), 0, (hipStream_t)stream, M, cout, g, e);
     return cp::check_launch("cp_wino_output_transform_f32");
+}
+
+
+extern "C" int cp_wino_transform_weights_f32(const float* w, long long stride_ky, long long stride_kx, long long stride_in, long long stride_out,
+                                             int flip, int channels, int cout, int ldk, int k_off, float* U, void* stream) {
+    CP_REQUIRE(w && U && channels > 0 && cout > 0 && k_off >= 0 && k_off + channels <= ldk, "cp_wino_transform_weights_f32: bad arguments");
+    CP_LAUNCH(wino_weight_kernel, dim3(grid_for((long long)channels * cout)), dim3(THREADS), 0, (hipStream_t)stream, w, stride_ky, stride_kx, stride_in,
+              stride_out, flip, channels, cout, ldk, k_off, U);
+    return cp::check_launch("cp_wino_transform_weights_f32");
 }

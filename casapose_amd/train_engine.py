@@ -25,6 +25,7 @@ derivative vanishes in fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -188,11 +189,16 @@ class TrainConv:
             c0 += cr
         self.desc = ConvDesc()
         self._keep: List = []
+        self.layout = layout
+        self.master_shape = tuple(shape)
+        self.refresh_hooks: List[Callable[[int], None]] = []  # extra weight layouts owned by the ops (Winograd planes)
 
     def refresh(self, stream: int):
         """Re-pack the kernel layouts from the master weights (after an optimizer step / at start)."""
         lib = _lib.load()
         m = self.master.data_ptr()
+        for hook in self.refresh_hooks:
+            hook(stream)
         check(lib.cp_gather_f32(m, self.idx_fwd.data_ptr(), self.idx_fwd.numel(), self.wp.data_ptr(), stream), "cp_gather_f32")
         if self.idx_halo is not None:
             check(lib.cp_gather_f32(m, self.idx_halo.data_ptr(), self.idx_halo.numel(), self.wp_halo.data_ptr(), stream), "cp_gather_f32")
@@ -270,7 +276,82 @@ class ConvOp:
             g.head_weights = g.head_out = None
             g.head_cout = g.head_out_ld = 0
 
+    # ---- Winograd F(4x4,3x3) for the deep layers (csrc/wino.hip): forward and data gradient ------------------------
+    def setup_winograd(self):
+        """Decide which of this op's convolutions (forward, per-source data gradient) take the Winograd path and return the
+        scratch sizes (floats of V, floats of M) they need; bind_winograd() completes the descriptors."""
+        from .engine import WinoConv, wino_eligible
+
+        L = self.layer
+        self.wino_fwd = None
+        self.wino_dgrad: Dict[int, dict] = {}
+        nv = nm = 0
+        if L.k != 3 or self.stride != 1 or self.pad != self.dil or self.tap_label is not None or L.layout != 0:
+            return 0, 0
+        _, tp = WinoConv.tiles(self.batch, self.in_h, self.in_w, self.dil)
+        dev = L.master.device
+        cin = sum(s[1] for s in L.sources)
+        if all(s[0] == s[1] for s in L.sources) and wino_eligible(3, 1, self.dil, self.pad, L.sources, L.cout):
+            ktot = sum(s[0] for s in L.sources)
+            self.wino_fwd = dict(U=torch.zeros(36 * L.cout * ktot, dtype=torch.float32, device=dev), ktot=ktot, cout=L.cout, tp=tp, desc=ConvDesc())
+            nv, nm = max(nv, 36 * tp * ktot), max(nm, 36 * tp * L.cout)
+        c0 = 0
+        for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
+            if ent is not None and L.cout % 32 == 0 and wino_eligible(3, 1, self.dil, self.dil, [(L.cout, L.cout)], cr):
+                self.wino_dgrad[s] = dict(U=torch.zeros(36 * cr * L.cout, dtype=torch.float32, device=dev), ktot=L.cout, cout=cr, tp=tp, desc=ConvDesc(), c0=c0)
+                nv, nm = max(nv, 36 * tp * L.cout), max(nm, 36 * tp * cr)
+            c0 += cr
+        if self.wino_fwd is not None or self.wino_dgrad:
+            L.refresh_hooks.append(self._refresh_winograd)
+        self._cin = cin
+        return nv, nm
+
+    def _refresh_winograd(self, stream: int):
+        lib = _lib.load()
+        L = self.layer
+        cin, cout = self._cin, L.cout
+        m = L.master.data_ptr()
+        if self.wino_fwd is not None:
+            c0 = k0 = 0
+            for cp, cr in L.sources:  # master is HWIO [3][3][cin][cout]
+                check(lib.cp_wino_transform_weights_f32(m + 4 * c0 * cout, 3 * cin * cout, cin * cout, cout, 1, 0, cr, cout, self.wino_fwd["ktot"], k0,
+                                                        self.wino_fwd["U"].data_ptr(), stream), "cp_wino_transform_weights_f32")
+                c0 += cr
+                k0 += cp
+        for s, w in self.wino_dgrad.items():  # flipped taps, K index = forward output channel, output = forward input channel
+            check(lib.cp_wino_transform_weights_f32(m + 4 * w["c0"] * cout, 3 * cin * cout, cin * cout, 1, cout, 1, cout, w["cout"], w["ktot"], 0,
+                                                    w["U"].data_ptr(), stream), "cp_wino_transform_weights_f32")
+
+    def bind_winograd(self, V: torch.Tensor, M: torch.Tensor):
+        self._wV, self._wM = V, M
+        for w in ([self.wino_fwd] if self.wino_fwd is not None else []) + list(self.wino_dgrad.values()):
+            d = w["desc"]
+            d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 36, 1, w["tp"], 1, w["tp"]
+            d.cout, d.kh, d.kw, d.stride, d.dilation, d.pad = w["cout"], 1, 1, 1, 1, 0
+            d.num_sources = 1
+            d.src[0].data, d.src[0].channels, d.src[0].ld, d.src[0].mode = V.data_ptr(), w["ktot"], w["ktot"], _lib.SRC_DIRECT
+            d.weights = w["U"].data_ptr()
+            d.out_raw, d.out_raw_ld, d.out_act_ld, d.residual_ld = M.data_ptr(), w["cout"], w["cout"], w["cout"]
+            d.group_rows, d.group_weight_stride = w["tp"], w["cout"] * w["ktot"]
+
+    def _wino_run(self, w, srcs, residual_ptr, out_ptr, stream):
+        """srcs: list of (ptr, ld, channels); writes out_ptr[pix][w.cout] = conv (+ residual)."""
+        lib = _lib.load()
+        off = 0
+        for ptr, ld, ch in srcs:
+            check(lib.cp_wino_input_transform_f32(ptr, ld, ch, self.batch, self.in_h, self.in_w, self.dil, self._wV.data_ptr(), w["ktot"], off, stream),
+                  "cp_wino_input_transform_f32(%s)" % self.layer.name)
+            off += ch
+        check(lib.cp_conv2d_fwd_f32(C.byref(w["desc"]), stream), "cp_conv2d_fwd_f32(wino %s)" % self.layer.name)
+        check(lib.cp_wino_output_transform_f32(self._wM.data_ptr(), w["cout"], self.batch, self.in_h, self.in_w, self.dil, residual_ptr, w["cout"], None, None,
+                                               None, 0, out_ptr, w["cout"], None, w["cout"], stream), "cp_wino_output_transform_f32(%s)" % self.layer.name)
+
     def forward(self, stream: int):
+        if getattr(self, "wino_fwd", None) is not None:
+            d = self.layer.desc
+            self._wino_run(self.wino_fwd, [(t.data.data_ptr(), ld, c[0]) for (t, ld), c in zip(self.srcs, self.layer.sources)],
+                           self.residual.data.data_ptr() if self.residual is not None else None, d.out_raw, stream)
+            return
         check(_lib.load().cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
 
     def _dy(self):
@@ -291,6 +372,10 @@ class ConvOp:
             if ent is None:
                 continue
             t, _ = self.srcs[s]
+            if s in getattr(self, "wino_dgrad", {}):  # stride 1, so the data gradient lives on the forward's input grid
+                self._wino_run(self.wino_dgrad[s], [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream)
+                t.has_grad = True
+                continue
             g = ent["desc"]
             g.src[0].data, g.src[0].ld = dy, dy_ld
             g.residual = t.grad.data_ptr() if t.has_grad else None
@@ -591,6 +676,19 @@ class TrainPlan:
         ver_head = layer("pv_final_conv_vertex.kernel", 0, 1, V, [(dims[4], dims[4])], [True])
         self.ops.append(ConvOp(ver_head, [(feat2, dims[4])], (self.out, K, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, self.VERT_OFF, self.GRAD_LD)))
         self.tensors = [o for o in self._all_tensors()]
+        # Winograd for the deep 3x3 layers (forward and data gradient); shared scratch sized for the largest of them
+        self.use_winograd = os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
+        self.wino_V = self.wino_M = None
+        if self.use_winograd:
+            sizes = [(op, op.setup_winograd()) for op in self.ops if isinstance(op, ConvOp)]
+            nv = max([sz[0] for _, sz in sizes] + [0])
+            nm = max([sz[1] for _, sz in sizes] + [0])
+            if nv:
+                self.wino_V = torch.empty(nv, **f32)
+                self.wino_M = torch.empty(nm, **f32)
+                for op, sz in sizes:
+                    if sz[0]:
+                        op.bind_winograd(self.wino_V, self.wino_M)
         # gather map of conv0's packed weight-gradient entries that belong to the padding channel (c = 3)
         ramp = np.zeros((7, 7, 3, 64), np.int64)  # unused values; only the layout matters
         k0 = np.full((64, c0.ktot), -1, np.int64)

@@ -245,6 +245,11 @@ size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, i
 int cp_wino_tiles(int batch, int h, int w, int dilation, int* tiles, int* tiles_padded);
 int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
                               int k_off, float* dst);
+/* device version of the weight transform (training: after every optimizer step): g(ky,kx,c,o) is read at
+ * w[ky'*stride_ky + kx'*stride_kx + c*stride_in + o*stride_out] with (ky',kx') = flip ? (2-ky,2-kx) : (ky,kx), so the same kernel
+ * serves HWIO / IHWO masters and the flipped, transposed data-gradient kernel.  U[p][o][k_off + c], rows of ldk floats. */
+int cp_wino_transform_weights_f32(const float* w, long long stride_ky, long long stride_kx, long long stride_in, long long stride_out,
+                                  int flip, int channels, int cout, int ldk, int k_off, float* U, void* stream);
 int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
                                 int c_off, void* stream);
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
