@@ -192,6 +192,9 @@ class FusedConv:
         return 2.0 * d.batch * d.out_h * d.out_w * self.kh * self.kw * cin * self.cout + head
 
 
+WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
+
+
 class WinoConv:
     """A deep 3x3 / stride-1 convolution executed as Winograd F(4x4,3x3): input transform(s), ONE grouped 1x1 launch over
     the 36 planes, output transform with the fused epilogue (csrc/wino.hip).  Same interface as FusedConv.run()."""
@@ -256,11 +259,19 @@ class WinoConv:
             check(lib.cp_wino_input_transform_f32(s["data"].data_ptr(), s["ld"], cpad, self.batch, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
                                                   stream), "cp_wino_input_transform_f32(%s)" % self.name)
             off += cpad
-        check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
+        self.run_gemm(stream)
         e = self.epi
         check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
                                                _ptr(e["scale"]), _ptr(e["shift"]), _ptr(e["epi_label"]), e["act"], _ptr(e["out_raw"]), self.cout,
                                                _ptr(e["out_act"]), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
+
+    def run_gemm(self, stream: int):
+        lib = _lib.load()
+        if WINO_GROUPED_CONV:  # the grouped mode of the general conv kernel (kept for comparison)
+            check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
+        else:
+            check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+                  "cp_wino_gemm_f32(%s)" % self.name)
 
     @property
     def flops(self) -> float:

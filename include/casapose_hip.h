@@ -243,6 +243,10 @@ size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, i
  * input channels [c_begin, c_begin+real_channels) of a HWIO kernel; dst is [36][cout][ldk] and must be zeroed first.
  * ---------------------------------------------------------------------------------- */
 int cp_wino_tiles(int batch, int h, int w, int dilation, int* tiles, int* tiles_padded);
+/* The grouped GEMM as a dedicated persistent kernel: M[r][n] = sum_k V[r][k] * U[r / group_rows][n][k], rows = 36*tiles_padded,
+ * k % 32 == 0.  Same arithmetic as the grouped mode of cp_conv2d_fwd_f32 (which remains available); the operand stream is
+ * pipelined ACROSS tiles because a tile only lives for k/32 chunks. */
+int cp_wino_gemm_f32(const float* V, const float* U, float* M, int rows, int group_rows, int k, int n, void* stream);
 int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
                               int k_off, float* dst);
 /* device version of the weight transform (training: after every optimizer step): g(ky,kx,c,o) is read at
