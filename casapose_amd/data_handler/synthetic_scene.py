@@ -133,14 +133,18 @@ class SyntheticSceneDataset:
             keypoints3d=torch.from_numpy(np.tile(self.keypoints3d[None, :, None], (b, 1, 1, 1, 1)).astype(np.float32)),
             target_vert=torch.from_numpy(np.stack([it["kp2"] for it in items])[:, :, None].astype(np.float32)),
             cam_mat=torch.from_numpy(np.tile(CAMERA[None], (b, 1, 1)).astype(np.float32)),
-            diameters=torch.from_numpy(np.tile(self.diameters[None, :, None], (b, 1, 1)).astype(np.float32)),
+            diameters=torch.from_numpy(np.tile(self.diameters[None, :, None, None], (b, 1, 1, 1)).astype(np.float32)),
             offsets=torch.from_numpy(np.stack([it["offsets"] for it in items])),
             filtered_seg=torch.from_numpy(lab[..., None].astype(np.int32)),
             poses_gt=torch.from_numpy(np.stack([it["poses"] for it in items])[:, :, None].astype(np.float32)),
-            pixel_gt_count=torch.from_numpy(np.stack([it["counts"] for it in items])),
+            pixel_gt_count=torch.from_numpy(np.stack([it["counts"] for it in items]).astype(np.float32)[:, :, None, None]),
         )
 
-    def generate_dataset(self, batchsize: int, epochs: int = 1) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
+    def generate_object_vertex_array(self):
+        """(vertex_array [oc,V,3], vertex_count [oc,1]) like VectorfieldDataset.generate_object_vertex_array."""
+        return self.mesh_vertex_array.astype(np.float32), self.mesh_vertex_count
+
+    def generate_dataset(self, batchsize: int, epochs: int = 1, *_unused, **_unused_kw) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
         """(iterator over epochs*batches batches, batches per epoch) -- the shape of VectorfieldDataset.generate_dataset
         (vectorfield_dataset.py:905-1013).  The same `length` images are revisited every epoch."""
         n = self.length // batchsize

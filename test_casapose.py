@@ -5,8 +5,8 @@
 
     python test_casapose.py -c config/config_8.ini --datatest synthetic:32 --load_h5_weights 1 --load_h5_filename result_w
 
-`--datatest synthetic[:N]` selects the built-in scene generator (no dataset on this machine; the NDDS reader is not
-built yet).  Writes <evalf>/loss_test_eval.csv and <evalf>/test_summary_eval.csv with the reference's columns and, with
+`--datatest <folder>` reads an NDDS / converted-BOP tree; `--datatest synthetic[:N]` selects the built-in scene generator
+(no dataset on this machine).  Writes <evalf>/loss_test_eval.csv and <evalf>/test_summary_eval.csv with the reference's columns and, with
 --write_poses, BOP-style per-object pose lines under <evalf>/poses_out/.
 """
 import glob
@@ -48,13 +48,18 @@ def main(argv=None):
     os.makedirs(opt.evalf, exist_ok=True)
     objectsofinterest = [x.strip() for x in opt.object.split(",")]
     no_objects = len(objectsofinterest)
-    if not opt.datatest.startswith("synthetic"):
-        raise NotImplementedError("--datatest %r: the NDDS/BOP reader is not built yet; use synthetic[:N]" % opt.datatest)
-    n = int(opt.datatest.split(":")[1]) if ":" in opt.datatest else 32
     height, width = opt.imagesize_test
-    ds = SyntheticSceneDataset(no_objects, (height, width), opt.no_points, length=n, seed=(opt.manualseed or 0) + 1, random_crop=False)
-    testingdata, test_batches = ds.generate_dataset(1, 1)
-    mesh_vertex_array, mesh_vertex_count = ds.mesh_vertex_array, ds.mesh_vertex_count
+    if opt.datatest.startswith("synthetic"):
+        n = int(opt.datatest.split(":")[1]) if ":" in opt.datatest else 32
+        ds = SyntheticSceneDataset(no_objects, (height, width), opt.no_points, length=n, seed=(opt.manualseed or 0) + 1, random_crop=False)
+    else:  # an NDDS / converted-BOP folder tree, read like test_casapose.py:150-184
+        from casapose_amd.data_handler.vectorfield_dataset import VectorfieldDataset
+
+        ds = VectorfieldDataset(root=opt.datatest, path_meshes=opt.datameshes, path_filter_root=opt.datatest_path_filter, color_input=opt.color_dataset,
+                                no_points=opt.no_points, objectsofinterest=objectsofinterest, noise=0.00001, contrast=0.00001, brightness=0.00001,
+                                random_translation=(0, 0), random_rotation=0, random_crop=False, wxyz_quaterion_input=opt.datatest_wxyz_quaterion)
+    testingdata, test_batches = ds.generate_dataset(1, 1, 0, opt.imagesize_test, 1.0, 1, no_objects, shuffle=False)
+    mesh_vertex_array, mesh_vertex_count = ds.generate_object_vertex_array()
     print("testing data: {} batches".format(test_batches))
     input_segmentation_shape = (height, width, 1 + no_objects) if opt.train_vectors_with_ground_truth else None
     ver_dim = opt.no_points * 2 + (opt.no_points if opt.estimate_confidence else 0)

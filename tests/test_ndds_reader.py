@@ -1,0 +1,89 @@
+"""Round trip of the NDDS / converted-BOP reader against the synthetic scene exported in that on-disk format: every field of
+the batch tuple must come back (labels exactly, geometry to float precision, pixels to 8-bit quantisation)."""
+import numpy as np
+import pytest
+import torch
+
+from casapose_amd.data_handler.synthetic_scene import CAMERA, SyntheticSceneDataset
+from casapose_amd.data_handler.vectorfield_dataset import VectorfieldDataset, matrix_to_quaternion_xyzw, quaternion_matrix, read_vertices, write_ndds_scene
+
+NAMES = ["obj_000001", "obj_000005", "obj_000009"]
+
+
+@pytest.fixture(scope="module")
+def exported(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ndds")
+    scene = SyntheticSceneDataset(len(NAMES), (480, 640), length=4, seed=5)
+    write_ndds_scene(str(root / "data"), str(root / "models"), scene, 4, NAMES)
+    return root, scene
+
+
+def test_quaternion_helpers_and_ply(tmp_path):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        R = quaternion_matrix(q)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        q2 = matrix_to_quaternion_xyzw(R)
+        assert np.allclose(quaternion_matrix(q2), R, atol=1e-9)
+    assert np.allclose(quaternion_matrix([0, 0, 0, 1]), np.eye(3))          # xyzw identity
+    assert np.allclose(quaternion_matrix([1, 0, 0, 0], wxyz_input=True), np.eye(3))
+    v = rng.normal(size=(7, 3)).astype(np.float32)
+    p = tmp_path / "b.ply"
+    with open(p, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 7\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nend_header\n")
+        rec = np.zeros(7, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1")])
+        rec["x"], rec["y"], rec["z"] = v[:, 0], v[:, 1], v[:, 2]
+        f.write(rec.tobytes())
+    assert np.allclose(read_vertices(str(p)), v)
+    o = tmp_path / "m.obj"
+    o.write_text("v 1 2 3\nv 4 5 6\nf 1 2 1\n")
+    assert np.allclose(read_vertices(str(o)), [[1, 2, 3], [4, 5, 6]])
+
+
+def test_full_frame_round_trip(exported):
+    root, scene = exported
+    ds = VectorfieldDataset(str(root / "data"), str(root / "models"), objectsofinterest=NAMES, color_input=True, noise=0, brightness=0, contrast=0,
+                            random_translation=(0, 0), random_rotation=0, random_crop=False)
+    assert len(ds) == 4
+    it, nb = ds.generate_dataset(2, 1, 0, (480, 640), 1.0, 1, len(NAMES), shuffle=False)
+    assert nb == 2
+    got = next(it)
+    ref = scene.batch(0, 2)
+    assert torch.equal(got["filtered_seg"], ref["filtered_seg"]) and torch.equal(got["target_seg"], ref["target_seg"])
+    assert (got["img"] - ref["img"]).abs().max() < 2.0 / 255 + 1e-6
+    assert (got["target_vert"] - ref["target_vert"]).abs().max() < 1e-3          # (y,x) crop pixels
+    assert (got["poses_gt"] - ref["poses_gt"]).abs().max() < 1e-3
+    assert (got["keypoints3d"] - ref["keypoints3d"]).abs().max() < 1e-3
+    assert torch.allclose(got["cam_mat"], ref["cam_mat"], atol=1e-3)
+    assert torch.allclose(got["diameters"], ref["diameters"], atol=1e-3)
+    assert torch.equal(got["pixel_gt_count"], ref["pixel_gt_count"])
+    assert got["offsets"][0].tolist() == [0, 0, 480, 640, 0, 0, 0, 1, 640, 480]
+    va, vc = ds.generate_object_vertex_array()
+    assert vc[:, 0].tolist() == [scene.mesh_vertex_array.shape[1]] * 3 and np.allclose(va, scene.mesh_vertex_array, atol=1e-4)
+    assert got["image_id"][0].endswith("000000_000000")
+
+
+def test_centre_crop_and_augmented_geometry(exported):
+    """config_8.ini: crop_factor 0.9333 of 480 -> a 448x448 crop; the 2-D keypoints must stay the projections of the 3-D keypoints
+    under the returned offsets (the relation keypoint_reprojection_loss relies on), also with rotation / translation jitter."""
+    from casapose_amd.train_engine import crop_to_image_affine, project_keypoints
+
+    root, scene = exported
+    ds = VectorfieldDataset(str(root / "data"), str(root / "models"), objectsofinterest=NAMES, color_input=True, noise=0, brightness=0, contrast=0,
+                            random_translation=(0, 0), random_rotation=0, random_crop=False)
+    b = next(ds.generate_dataset(2, 1, 0, (448, 448), 0.933333333, 1, 3, shuffle=False)[0])
+    assert b["img"].shape == (2, 448, 448, 3) and b["offsets"][0].tolist() == [16, 96, 448, 448, 0, 0, 0, 1, 640, 480]
+    ref = scene.batch(0, 2)
+    assert (b["target_vert"] - (ref["target_vert"] - torch.tensor([16.0, 96.0]))).abs().max() < 1e-3
+    assert torch.equal(b["filtered_seg"][:, :, :, 0], ref["filtered_seg"][:, 16:464, 96:544, 0])
+    aug = VectorfieldDataset(str(root / "data"), str(root / "models"), objectsofinterest=NAMES, color_input=True, noise=0.01, brightness=0.2, contrast=0.2,
+                             random_translation=(10, 10), random_rotation=10, random_crop=True, seed=3)
+    a = next(aug.generate_dataset(2, 1, 0, (224, 224), 0.6, 1, 3, shuffle=True)[0])
+    assert a["img"].shape == (2, 224, 224, 3) and float(a["img"].abs().max()) <= 1.0
+    A = crop_to_image_affine(a["offsets"].numpy()).reshape(2, 2, 3).astype(np.float64)
+    gt = project_keypoints(a["keypoints3d"][:, :, 0].numpy(), CAMERA, a["poses_gt"][:, :, 0].numpy())      # image pixels (x,y)
+    xy = a["target_vert"][:, :, 0].numpy()[..., ::-1].astype(np.float64)
+    back = np.einsum("bij,bokj->boki", A[:, :, :2], xy) + A[:, None, None, :, 2]
+    assert np.abs(back - gt).max() < 0.05, "crop keypoints mapped back with the offsets must hit the projected 3-D keypoints"

@@ -8,8 +8,8 @@
 Differences that are forced by this environment and documented in DESIGN.md:
   * multi-GPU = one process per GPU over torch.distributed/RCCL (SyncBN statistics + SUM gradient all-reduce, the
     semantics of MirroredStrategy) instead of one process driving all GPUs; `--batchsize` stays the GLOBAL batch;
-  * `--data synthetic[:N]` selects the built-in ray-cast scene generator (casapose_amd/data_handler/synthetic_scene.py);
-    the NDDS reader is not built yet, any other --data value raises;
+  * `--data <folder>` reads an NDDS / converted-BOP tree like the reference (casapose_amd/data_handler/vectorfield_dataset.py);
+    `--data synthetic[:N]` selects the built-in ray-cast scene generator (synthetic_scene.py) -- there is no dataset here;
   * weights are stored as .npz under the reference's file names (no h5py here).
 """
 import datetime
@@ -40,8 +40,20 @@ def create_dir(path):
 def open_dataset(spec, opt, no_objects, image_size, random_crop, seed):
     if spec == "":
         return None
-    if not spec.startswith("synthetic"):
-        raise NotImplementedError("--data %r: the NDDS/BOP reader (vectorfield_dataset.py) is not built yet; use synthetic[:N]" % spec)
+    if not spec.startswith("synthetic"):  # an NDDS / converted-BOP folder tree (the reference's format)
+        from casapose_amd.data_handler.vectorfield_dataset import VectorfieldDataset
+
+        objs = [x.strip() for x in opt.object.split(",")]
+        if random_crop:  # training set (train_casapose.py:226-250)
+            return VectorfieldDataset(root=spec, path_meshes=opt.datameshes, path_filter_root=opt.data_path_filter, color_input=opt.color_dataset,
+                                      no_points=opt.no_points, objectsofinterest=objs, noise=opt.noise, contrast=opt.contrast, brightness=opt.brightness,
+                                      random_translation=(opt.translation, opt.translation), random_rotation=opt.rotation, random_crop=True,
+                                      use_train_split=(opt.data == opt.datatest), train_validation_split=opt.train_validation_split,
+                                      wxyz_quaterion_input=opt.data_wxyz_quaterion, seed=seed)
+        return VectorfieldDataset(root=spec, path_meshes=opt.datameshes, path_filter_root=opt.datatest_path_filter, color_input=opt.color_dataset,
+                                  no_points=opt.no_points, objectsofinterest=objs, noise=0.00001, contrast=0.00001, brightness=0.00001,
+                                  random_translation=(0, 0), random_rotation=0, random_crop=False, use_validation_split=(opt.data == opt.datatest),
+                                  train_validation_split=opt.train_validation_split, wxyz_quaterion_input=opt.datatest_wxyz_quaterion, seed=seed)
     n = int(spec.split(":")[1]) if ":" in spec else 64
     return SyntheticSceneDataset(no_objects, image_size, opt.no_points, length=n, seed=seed, random_crop=random_crop)
 
@@ -93,8 +105,9 @@ def main(argv=None):
     local_bs = opt.batchsize // world
     train_ds = open_dataset(opt.data, opt, no_objects, opt.imagesize, True, opt.manualseed)
     test_ds = open_dataset(opt.datatest, opt, no_objects, opt.imagesize, False, opt.manualseed + 1)
-    trainingdata, train_batches = train_ds.generate_dataset(opt.batchsize, opt.epochs) if train_ds else (None, 0)
-    testingdata, test_batches = test_ds.generate_dataset(opt.batchsize, opt.epochs) if test_ds else (None, 0)
+    gen = lambda ds: ds.generate_dataset(opt.batchsize, opt.epochs, opt.prefetch, opt.imagesize, opt.crop_factor, opt.workers, no_objects)  # noqa: E731
+    trainingdata, train_batches = gen(train_ds) if train_ds else (None, 0)
+    testingdata, test_batches = gen(test_ds) if test_ds else (None, 0)
     print("training data: {} batches".format(train_batches))
     print("testing data: {} batches".format(test_batches))
 
