@@ -50,6 +50,7 @@ DECODER_DIMS_DEFAULT = (256, 128, 64, 32, 32)
 # label-guided gather (else plain nearest x2).  CASAPoseConditional1-5 (pose_models.py:14-635) differ only in these.
 PARTIAL_DEFAULT = (True, True, True, True, True)
 GUIDED_DEFAULT = (False, True, True, True, False)
+BILINEAR_DEFAULT = (False, False, False, False, False)  # with guided: GuidedBilinearUpsampling (casapose_c_gcu4_bilat)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -322,6 +323,7 @@ class ForwardPlan:
         self.pnorm = [new(B, hs[l], ws[l]) for l in range(4)]
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
         self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2 = "guided" with neighbour 0 everywhere
+        self.gmask = [torch.empty(B, hs[l], ws[l], **u8) if any(net.bilinear) else None for l in range(3)]  # GuidedBilinearUpsampling match masks
         self._out_bound: List[Tuple[FusedConv, int, str]] = []  # (conv, channel offset, descriptor field) writing into the per-call output
         self._bufs: List[torch.Tensor] = []
 
@@ -456,6 +458,10 @@ class ForwardPlan:
             pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
             sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])
             check(lib.cp_label_pyramid(self.labels[0].data_ptr(), B, h, w, lab, pn, sl, stream), "cp_label_pyramid")
+            for l_ in range(3):
+                if self.gmask[l_] is not None:
+                    check(lib.cp_guided_match_mask(self.labels[l_].data_ptr(), self.labels[l_ + 1].data_ptr(), B, hs[l_], ws[l_], self.gmask[l_].data_ptr(), stream),
+                          "cp_guided_match_mask")
 
         self.steps.append(label_step)
 
@@ -472,7 +478,14 @@ class ForwardPlan:
             else:
                 up = i >= 2
                 src0, mode, sel = prev, _lib.SRC_DIRECT, None
-                if up:
+                if up and net.bilinear[i - 1]:
+                    if not net.guided[i - 1]:
+                        raise NotImplementedError("bilinear_upsampling without guided_upsampling in decoder 2 is not built")
+                    big = new(B, hs[l], ws[l], prev_c)  # GuidedBilinearUpsampling: a 4-tap blend, materialised
+                    self.steps.append(self._guided_bilinear_step(prev, self.gmask[l], big, hs[l] // 2, ws[l] // 2, prev_c))
+                    self._bufs.append(big)
+                    src0 = big
+                elif up:
                     selmap = self.sel[l] if net.guided[i - 1] else self.sel_zero[l]  # block i-1 upsampled its output (casapose.py:109-131)
                     if fuse_upsample:
                         mode, sel = _lib.SRC_NEAREST_SEL, selmap
@@ -484,7 +497,7 @@ class ForwardPlan:
                 srcs = [dict(data=src0, ld=prev_c, mode=mode, sel=sel), dict(data=skips[i][0], ld=skips[i][1])]
             pk = dict(tap_label=self.labels[l], row_scale=self.pnorm[l]) if partial else {}
             # the fused head lives in the halo kernel, which gathers a guided/nearest x2 source only together with the tap mask
-            fused = self.fuse_heads and i == 4 and (partial or not fuse_upsample)
+            fused = self.fuse_heads and i == 4 and (partial or not fuse_upsample or net.bilinear[3])
             self.fuse_head2 = fused if i == 4 else False
             if fused:  # block 10 + pv_final_conv_vertex in one launch
                 L[name].attach_head(net.params["pv_final_conv_vertex.kernel"])
@@ -513,6 +526,15 @@ class ForwardPlan:
 
         def step(stream):
             check(lib.cp_upsample_bilinear_x2_f32(src.data_ptr(), B, sh, sw, c, dst.data_ptr(), stream), "cp_upsample_bilinear_x2_f32")
+
+        return step
+
+    def _guided_bilinear_step(self, src, mask, dst, sh, sw, c):
+        lib = _lib.load()
+        B = self.batch
+
+        def step(stream):
+            check(lib.cp_guided_bilinear_upsample_x2_f32(src.data_ptr(), mask.data_ptr(), B, sh, sw, c, dst.data_ptr(), stream), "cp_guided_bilinear_upsample_x2_f32")
 
         return step
 
@@ -562,7 +584,8 @@ class CasaposeNet:
 
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
-                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True):
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True,
+                 bilinear: Sequence[bool] = BILINEAR_DEFAULT):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -570,6 +593,7 @@ class CasaposeNet:
         self.seg_dim, self.ver_dim = seg_dim, ver_dim
         self.decoder_dims = tuple(decoder_dims)
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
+        self.bilinear = tuple(bool(v) for v in bilinear)
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"

@@ -95,7 +95,7 @@ class CasaposeModel:
     def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
                  fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
-                 guided: Sequence[bool] = engine.GUIDED_DEFAULT):
+                 guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT):
         if output_lablemap:
             raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
         self.name = name
@@ -112,9 +112,10 @@ class CasaposeModel:
                           "no network here -- using he_uniform initialisation; call load_weights() for real weights")
             weights = None
         self._partial, self._guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
+        self._bilinear = tuple(bool(v) for v in bilinear)
         self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial)
         self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
-                                       self._partial, self._guided)
+                                       self._partial, self._guided, bilinear=self._bilinear)
         if isinstance(weights, str):
             self.load_weights(weights)
         self._layers = self._build_layers()
@@ -131,7 +132,7 @@ class CasaposeModel:
         p = self._plan
         if p is None or (p.batch, p.h, p.w) != (batch, h, w) or p.group is not group:
             self._plan = train_engine.TrainPlan(self._store, self.seg_dim, self.ver_dim, batch, h, w, self._dims, group, world_size,
-                                                self._partial, self._guided)
+                                                self._partial, self._guided, bilinear=self._bilinear)
             self._plan.refresh_weights(torch.cuda.current_stream(self.device).cuda_stream)
         return self._plan, self.device
 

@@ -4,7 +4,11 @@ from __future__ import annotations
 from .model import CasaposeModel
 
 
-def _conditional(name, partial, guided, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
+def _conditional(name, partial, guided, ver_dim, seg_dim, *args, bilinear=(False,) * 5, **kwargs):
+    return _conditional_impl(name, partial, guided, bilinear, ver_dim, seg_dim, *args, **kwargs)
+
+
+def _conditional_impl(name, partial, guided, bilinear, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
                  input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18",
                  backbone=None, output_lablemap=False, **kwargs):
     if base_model != "resnet18":
@@ -17,7 +21,7 @@ def _conditional(name, partial, guided, ver_dim, seg_dim, fcdim=256, s8dim=128, 
                          input_segmentation_shape=input_segmentation_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
                          fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True),
-                         partial=partial, guided=guided)
+                         partial=partial, guided=guided, bilinear=bilinear)
 
 
 _GU = (False, True, True, True, False)  # blocks 7, 8, 9 upsample with the label-guided gather
@@ -43,6 +47,11 @@ def CASAPoseConditional3(*args, **kwargs):
 def CASAPoseConditional4(*args, **kwargs):
     """casapose_c_gcu4 (pose_models.py:386-510): partial convolution in blocks 6-9, guided upsampling."""
     return _conditional("casapose_c_gcu4", (True, True, True, True, False), _GU, *args, **kwargs)
+
+
+def CASAPoseConditional9(*args, **kwargs):
+    """casapose_c_gcu4_bilat (pose_models.py:1102-1229): gcu4 with GuidedBilinearUpsampling instead of the guided nearest gather."""
+    return _conditional("casapose_c_gcu4_bilat", (True, True, True, True, False), _GU, *args, bilinear=_GU, **kwargs)
 
 
 def CASAPoseConditional5(*args, **kwargs):

@@ -44,7 +44,7 @@ class ModelsFactory:
         "casapose_c_gcu5_sw5": _not_built("casapose_c_gcu5_sw5"),
         "casapose_c_gcu4_sw1": _not_built("casapose_c_gcu4_sw1"),
         "casapose_c_gcu5_sw1": _not_built("casapose_c_gcu5_sw1"),
-        "casapose_c_gcu4_bilat": _not_built("casapose_c_gcu4_bilat"),
+        "casapose_c_gcu4_bilat": _pm.CASAPoseConditional9,
         "casapose_c_gcu4_sw2": _not_built("casapose_c_gcu4_sw2"),
         "pvnet": _not_built("pvnet"),
     }

@@ -33,7 +33,7 @@ import torch
 
 from . import _lib, parallel
 from ._lib import ConvDesc, check
-from .engine import BN_EPS, DECODER_DIMS_DEFAULT, GUIDED_DEFAULT, PARTIAL_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
+from .engine import BILINEAR_DEFAULT, BN_EPS, DECODER_DIMS_DEFAULT, GUIDED_DEFAULT, PARTIAL_DEFAULT, STAGE_DILATION, STAGE_FILTERS, STAGE_STRIDE
 
 BN_MOMENTUM = 0.99  # resnet.py:43 (Keras default elsewhere)
 
@@ -479,7 +479,7 @@ class TrainPlan:
 
     def __init__(self, store: ParamStore, seg_dim: int, ver_dim: int, batch: int, h: int, w: int,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1,
-                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT):
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, bilinear: Sequence[bool] = BILINEAR_DEFAULT):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         if seg_dim > 32 or ver_dim > 32:
@@ -513,6 +513,8 @@ class TrainPlan:
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
         self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
+        self.bilinear = tuple(bool(v) for v in bilinear)
+        self.gmask = [torch.empty(B, hs[l], ws[l], **u8) if any(self.bilinear) else None for l in range(3)]
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
         # keypoint-reprojection loss (LS voter forward/backward)
@@ -599,20 +601,26 @@ class TrainPlan:
         skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
         lvl = [3, 3, 2, 1, 0]
 
-        def upsample(prev: TT, l: int, guided: bool, selmap: Optional[torch.Tensor] = None) -> TT:
+        def upsample(prev: TT, l: int, guided: bool, selmap: Optional[torch.Tensor] = None, blend: bool = False) -> TT:
             big = new(hs[l], ws[l], prev.c)
             sh, sw, c = hs[l] // 2, ws[l] // 2, prev.c
             selmap = self.sel[l] if selmap is None else selmap
 
             def f(stream):
-                if guided:
+                if blend:
+                    check(lib.cp_guided_bilinear_upsample_x2_f32(prev.data.data_ptr(), self.gmask[l].data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream),
+                          "cp_guided_bilinear_upsample_x2_f32")
+                elif guided:
                     check(lib.cp_guided_upsample_x2_f32(prev.data.data_ptr(), selmap.data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_guided_upsample_x2_f32")
                 else:
                     check(lib.cp_upsample_bilinear_x2_f32(prev.data.data_ptr(), B, sh, sw, c, big.data.data_ptr(), stream), "cp_upsample_bilinear_x2_f32")
 
             def b(stream):
                 assert big.has_grad and not prev.has_grad
-                if guided:
+                if blend:
+                    check(lib.cp_guided_bilinear_upsample_x2_bwd_f32(big.grad.data_ptr(), c, self.gmask[l].data_ptr(), B, sh, sw, c, prev.grad.data_ptr(), stream),
+                          "cp_guided_bilinear_upsample_x2_bwd_f32")
+                elif guided:
                     check(lib.cp_guided_upsample_x2_bwd_f32(big.grad.data_ptr(), c, selmap.data_ptr(), B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_guided_upsample_x2_bwd_f32")
                 else:
                     check(lib.cp_upsample_bilinear_x2_bwd_f32(big.grad.data_ptr(), c, B, sh, sw, c, prev.grad.data_ptr(), stream), "cp_upsample_bilinear_x2_bwd_f32")
@@ -635,7 +643,8 @@ class TrainPlan:
                     srcs, tts, gs = [(512, 512)], [(x32s, 512)], [True]
                 else:
                     if i >= 2:  # the previous block upsampled its output: bilinear (decoder 1), label-guided or plain nearest (decoder 2)
-                        src0 = upsample(prev, l, second, None if (not second or self.guided[i - 1]) else self.sel_zero[l])
+                        src0 = upsample(prev, l, second, None if (not second or self.guided[i - 1]) else self.sel_zero[l],
+                                        blend=second and self.guided[i - 1] and self.bilinear[i - 1])
                     else:
                         src0 = prev
                     srcs = [(dims[i - 1], dims[i - 1]), skip_c[i]]
@@ -671,6 +680,10 @@ class TrainPlan:
             pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
             sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])
             check(lib.cp_label_pyramid(self.labels[0].data_ptr(), B, h, w, lab, pn, sl, stream), "cp_label_pyramid")
+            for l_ in range(3):
+                if self.gmask[l_] is not None:
+                    check(lib.cp_guided_match_mask(self.labels[l_].data_ptr(), self.labels[l_ + 1].data_ptr(), B, hs[l_], ws[l_], self.gmask[l_].data_ptr(), stream),
+                          "cp_guided_match_mask")
 
         self.ops.append(FnOp(label_f, lambda stream: None))
         feat2 = decoder(6, True)

@@ -229,6 +229,15 @@ int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int d
                        int32_t* rounds_out, void* stream);
 size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp);
 
+/* GuidedBilinearUpsampling (_normalization_layers.py:569-664; casapose_c_gcu4_bilat): mask[n,Y,X] bit j = the low-resolution label of
+ * tap j in {(y,x),(y,x+1),(y+1,x),(y+1,x+1)} (zero padded bottom/right) equals labels_hi[n,Y,X]; the upsampling blends the four taps
+ * with the fixed sub-pixel weights after replacing non-matching taps by the mean of the matching ones (0 if none), which is the
+ * 4-tap gather out = sum_j coef_j(mask, sub-pixel) * tap_j.  h, w = LOW-resolution size for the two upsampling calls. */
+int cp_guided_match_mask(const uint8_t* labels_hi, const uint8_t* labels_lo, int batch, int h_hi, int w_hi, uint8_t* mask, void* stream);
+int cp_guided_bilinear_upsample_x2_f32(const float* src, const uint8_t* mask, int batch, int h, int w, int channels, float* dst, void* stream);
+int cp_guided_bilinear_upsample_x2_bwd_f32(const float* dy, int ld_dy, const uint8_t* mask, int batch, int h, int w, int channels, float* dx,
+                                           void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Winograd F(4x4,3x3) path for deep 3x3 / stride-1 / pad == dilation convolutions (same layers.Conv2D call sites as
  * cp_conv2d_fwd_f32; the MFMA work drops 4x).  Three launches:

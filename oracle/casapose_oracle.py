@@ -329,7 +329,9 @@ VARIANTS = {  # per decoder-2 block 6..10: (partial convolution, guided upsampli
     "casapose_c_gcu3": ((True, True, True, False, False), (False, True, True, True, False)),
     "casapose_c_gcu4": ((True, True, True, True, False), (False, True, True, True, False)),
     "casapose_c_gcu5": ((True,) * 5, (False, True, True, True, False)),
+    "casapose_c_gcu4_bilat": ((True, True, True, True, False), (False, True, True, True, False)),   # CASAPoseConditional9
 }
+BILINEAR_GUIDED = {"casapose_c_gcu4_bilat": (False, True, True, True, False)}  # blocks that use GuidedBilinearUpsampling
 
 
 def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, randomize_norm: bool = True,
@@ -468,6 +470,7 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     img [B,H,W,3]; optional seg_input [B,H,W,K] (the `data_segmentation` input, :550-554).
     Returns [B,H,W,K+ver_dim] = concat(seg logits, vertex)."""
     part, guid = VARIANTS[variant]
+    bil = BILINEAR_GUIDED.get(variant, (False,) * 5)
     x2s, x4s, x8s, _x16s, x32s = resnet18_os8(p, img)
     x = decoder1_block(p, x32s, 1, leaky=False, upsample=False)
     x = decoder1_block(p, np.concatenate([x, x8s], 3), 2, True, True)
@@ -480,9 +483,9 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     mask4 = half_size(mask2)
     mask8 = half_size(mask4)
     y = decoder2_block(p, x32s, 6, mask8, leaky=False, partial=part[0])
-    y = decoder2_block(p, np.concatenate([y, x8s], 3), 7, mask8, True, guide=mask4 if guid[1] else None, partial=part[1], upsample_nearest=True)
-    y = decoder2_block(p, np.concatenate([y, x4s], 3), 8, mask4, True, guide=mask2 if guid[2] else None, partial=part[2], upsample_nearest=True)
-    y = decoder2_block(p, np.concatenate([y, x2s], 3), 9, mask2, True, guide=mask if guid[3] else None, partial=part[3], upsample_nearest=True)
+    y = decoder2_block(p, np.concatenate([y, x8s], 3), 7, mask8, True, guide=mask4 if guid[1] else None, partial=part[1], upsample_nearest=True, bilinear_guided=bil[1])
+    y = decoder2_block(p, np.concatenate([y, x4s], 3), 8, mask4, True, guide=mask2 if guid[2] else None, partial=part[2], upsample_nearest=True, bilinear_guided=bil[2])
+    y = decoder2_block(p, np.concatenate([y, x2s], 3), 9, mask2, True, guide=mask if guid[3] else None, partial=part[3], upsample_nearest=True, bilinear_guided=bil[3])
     y = decoder2_block(p, np.concatenate([y, img], 3), 10, mask, True, partial=part[4])
     vertex = conv2d(y, p["pv_final_conv_vertex.kernel"])
     out = np.concatenate([logits, vertex], 3)

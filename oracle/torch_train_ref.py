@@ -120,8 +120,29 @@ def guided_upsample(x, lab_lo, lab_hi):
     return x[bi, sy, sx, :]
 
 
+def guided_bilinear_upsample(x, lab_lo, lab_hi):
+    """GuidedBilinearUpsampling with hard labels (_normalization_layers.py:607-664): taps whose low-res label differs from the
+    hi-res label are replaced by the mean of the matching taps; fixed sub-pixel weights."""
+    b, h2, w2, c = x.shape
+    lo = lab_lo.to(torch.int64) + 1
+    lp = F.pad(lo, (0, 1, 0, 1))
+    cands = torch.stack([lp[:, :h2, :w2], lp[:, :h2, 1:], lp[:, 1:, :w2], lp[:, 1:, 1:]], dim=-1)
+    cu = cands.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    cond = (cu == (lab_hi.to(torch.int64) + 1)[..., None]).to(x.dtype)          # [b,H,W,4]
+    xp = F.pad(x, (0, 0, 0, 1, 0, 1))
+    taps = torch.stack([xp[:, :h2, :w2], xp[:, :h2, 1:], xp[:, 1:, :w2], xp[:, 1:, 1:]], dim=3)
+    taps = taps.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)         # [b,H,W,4,c]
+    n = cond.sum(-1, keepdim=True)
+    mean = (taps * cond[..., None]).sum(3, keepdim=True) / torch.clamp(n, min=1.0)[..., None]
+    filled = torch.where(cond[..., None] > 0, taps, mean * (n[..., None] > 0))
+    interp = torch.tensor([[1.0, 0, 0, 0], [0.5, 0.5, 0, 0], [0.5, 0, 0.5, 0], [0.25, 0.25, 0.25, 0.25]], dtype=x.dtype)
+    yy, xx = torch.meshgrid(torch.arange(2 * h2), torch.arange(2 * w2), indexing="ij")
+    wts = interp[(yy % 2) * 2 + (xx % 2)]                                        # [H,W,4]
+    return (filled * wts[None, :, :, :, None]).sum(3)
+
+
 def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None,
-                  partial=(True,) * 5, guided=(False, True, True, True, False)):
+                  partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5):
     """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
     convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
     hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
@@ -175,7 +196,9 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
         y = clade_train(y, lab, p[n + "_clade.gamma"], p[n + "_clade.beta"], stats_out, n + "_clade")
         y = F.relu(y) if i == 0 else leaky_pair(y)
         if 0 < i < 4:
-            if guided[i]:
+            if guided[i] and bilinear[i]:
+                y = guided_bilinear_upsample(y, lab, labs[lvl[i] - 1])
+            elif guided[i]:
                 y = guided_upsample(y, lab, labs[lvl[i] - 1])
             else:
                 y = y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)  # UpSampling2D(nearest), casapose.py:126-131

@@ -100,7 +100,7 @@ def test_ls_voting_sums_and_empty_objects(device):
     assert (kp.cpu().numpy()[:, 5:] == 0).all()
 
 
-@pytest.mark.parametrize("variant", ["casapose_c", "casapose_c_gu", "casapose_c_gcu3", "casapose_c_gcu4"])
+@pytest.mark.parametrize("variant", ["casapose_c", "casapose_c_gu", "casapose_c_gcu3", "casapose_c_gcu4", "casapose_c_gcu4_bilat"])
 @pytest.mark.parametrize("fuse", [True, False])
 def test_registry_variants_forward(device, variant, fuse):
     """CASAPoseConditional1-4 (pose_models.py:14-512): same graph as gcu5 with ordinary convolutions / plain nearest
@@ -137,5 +137,5 @@ def test_custom_decoder_params(device):
     out = net([np.zeros((1, 32, 32, 3), np.float32)], training=False)
     assert tuple(out.shape) == (1, 32, 32, 30) and bool(torch.isfinite(out).all())
     with pytest.raises(NotImplementedError):
-        CASAPose([DecoderParams(True, True, True, True, False)] * 5, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
+        CASAPose([DecoderParams(True, True, False, True, False)] * 5, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
     assert [tuple(p) for p in CASAPOSE_PARAMS["clade"]][1] == (True, True, True, False, False)
