@@ -396,7 +396,6 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
     __builtin_amdgcn_s_setprio(CP_EXP_SETPRIO);  // MFMA waves win issue arbitration against their producer partners
 #endif
     CP_BARRIER();  // stage 0 is ready
-#ifndef CP_EXP_LOOP2
     read_frags(0, 0, 0);
     for (int q = 0; q < p.nchunks; ++q) {
         const int buf = q & 1;
@@ -410,34 +409,6 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
         CP_BARRIER();  // stage buf^1 now holds chunk q+1; stage buf may be overwritten
         if (q + 1 < p.nchunks) read_frags(buf ^ 1, 0, 0);
     }
-#else
-    // every LDS read is issued >= one 4*TM*TN-MFMA step before its first use; the barrier sits
-    // after step 2 (all reads of the current stage complete), so step 3 covers the first read
-    // of the next stage
-    read_frags(0, 0, 0);
-    read_frags(0, 1, 1);
-    for (int q = 0; q < p.nchunks; ++q) {
-        const int buf = q & 1;
-        mfma_step(0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(buf, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(buf, 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(0);
-        __builtin_amdgcn_sched_barrier(0);
-        CP_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + 1 < p.nchunks) read_frags(buf ^ 1, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + 1 < p.nchunks) read_frags(buf ^ 1, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
 #undef CP_BARRIER
 
     // ---- epilogue (epilogue.h: batched, branch-free) ---------------------------------------

@@ -450,11 +450,6 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                     for (int r = 0; r < 16; ++r) {
                         const int px = rowpix(r);
                         const bool ok = px >= 0 && lrow < p.head_cout;
-#if defined(HX_DBG_KEEP)
-                        a2[r] = keep[r][0];
-#elif defined(HX_DBG_SCR)
-                        a2[r] = scr[((r & 3) + 8 * (r >> 2) + hi4) * AS + lrow];
-#endif
                         const float hv = a2[r];  // (bit_cast directly on a vector element reads element 0)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), rso,
                                                               (int)(ok ? ((unsigned)px * (unsigned)p.head_ld + (unsigned)lrow) * 4u : 0x80000000u), 0, 0);
