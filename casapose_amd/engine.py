@@ -300,7 +300,7 @@ class ForwardPlan:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         self.net, self.batch, self.h, self.w = net, batch, h, w
         self.fuse_upsample = fuse_upsample
-        self.fuse_heads = fuse_heads and net.decoder_dims[4] == 32
+        self.fuse_heads = fuse_heads and net.decoder_dims[4] == 32 and not net.pvnet
         dev = net.device
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -440,6 +440,14 @@ class ForwardPlan:
                      act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
             self._bufs.append(o)
             prev, prev_c = o, dims[i]
+        self.fuse_head2 = False
+        if net.pvnet:  # one head for all K + ver_dim channels; no conditioning, no second decoder
+            head = L["pv_final_conv"]
+            conv(head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
+            self._out_bound.append((head, 0, "out_raw"))
+            self.seg_input_ptr = None
+            self._bind_winograd()
+            return
         if not self.fuse_heads:
             seg_head = L["pv_final_conv_segmentation"]
             conv(seg_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
@@ -570,6 +578,9 @@ class ForwardPlan:
         check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
         for step in self.steps:
             step(stream)
+        if self.net.pvnet:
+            _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
+            return out
         if seg_input is None:  # labels[0] is the arg-max of THIS output's logits
             if len(_LABEL_CACHE) > 8:
                 _LABEL_CACHE.clear()
@@ -585,7 +596,7 @@ class CasaposeNet:
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
                  partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True,
-                 bilinear: Sequence[bool] = BILINEAR_DEFAULT):
+                 bilinear: Sequence[bool] = BILINEAR_DEFAULT, pvnet: bool = False):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -594,6 +605,7 @@ class CasaposeNet:
         self.decoder_dims = tuple(decoder_dims)
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.bilinear = tuple(bool(v) for v in bilinear)
+        self.pvnet = bool(pvnet)  # PVNet (pose_models.py:645-696): decoder 1 only, ONE 1x1 head producing seg + vertex channels
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
@@ -619,7 +631,8 @@ class CasaposeNet:
                 put(base + "bn2", fold_bn(p, base + "bn2"))
         for i in range(5):
             put("pv_block_%d_bn" % (i + 1), fold_bn(p, "pv_block_%d_bn" % (i + 1)))
-            put("pv_block_%d_clade" % (i + 6), fold_clade(p, "pv_block_%d_clade" % (i + 6)))
+            if not self.pvnet:
+                put("pv_block_%d_clade" % (i + 6), fold_clade(p, "pv_block_%d_clade" % (i + 6)))
         self.device_tables = tabs
 
         L: Dict[str, FusedConv] = {}
@@ -647,12 +660,17 @@ class CasaposeNet:
         for i in range(5):
             srcs = [(512, 512)] if i == 0 else [(dims[i - 1], dims[i - 1]), skip_c[i]]
             add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
+            if self.pvnet:
+                continue
             if self.partial[i]:
                 add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs, partial=True)
             else:
                 add("pv_block_%d_conv2d" % (i + 6), "pv_block_%d_conv2d.kernel" % (i + 6), 0, 3, dims[i], srcs)
-        add("pv_final_conv_segmentation", "pv_final_conv_segmentation.kernel", 0, 1, self.seg_dim, [(dims[4], dims[4])])
-        add("pv_final_conv_vertex", "pv_final_conv_vertex.kernel", 0, 1, self.ver_dim, [(dims[4], dims[4])])
+        if self.pvnet:
+            add("pv_final_conv", "pv_final_conv.kernel", 0, 1, self.seg_dim + self.ver_dim, [(dims[4], dims[4])])
+        else:
+            add("pv_final_conv_segmentation", "pv_final_conv_segmentation.kernel", 0, 1, self.seg_dim, [(dims[4], dims[4])])
+            add("pv_final_conv_vertex", "pv_final_conv_vertex.kernel", 0, 1, self.ver_dim, [(dims[4], dims[4])])
         self.layers_by_name = L
         self.wino_by_name = Wn
         self.plans.clear()

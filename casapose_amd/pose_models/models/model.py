@@ -21,7 +21,7 @@ def _he_uniform(rng, shape, fan_in):
 
 
 def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Optional[int] = None,
-                       partial: Sequence[bool] = engine.PARTIAL_DEFAULT) -> Dict[str, np.ndarray]:
+                       partial: Sequence[bool] = engine.PARTIAL_DEFAULT, pvnet: bool = False) -> Dict[str, np.ndarray]:
     """Keras-default initial state: he_uniform kernels (resnet.py:31; _normalization_layers.py:317),
     BN gamma 1 / beta 0 / moving mean 0 / moving variance 1, CLADE gamma 1 / beta 0
     (_normalization_layers.py:96-107).  Keys are `<keras layer name>.<weight>`."""
@@ -56,6 +56,8 @@ def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Op
         ci, co = dec_in[i], dims[i]
         p["pv_block_%d_conv2d.kernel" % (i + 1)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
         bn("pv_block_%d_bn" % (i + 1), co)
+        if pvnet:
+            continue
         if partial[i]:
             p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
         else:  # ordinary pad + Conv2D in decoder 2 (casapose.py:69-74)
@@ -63,6 +65,9 @@ def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Op
         bn("pv_block_%d_clade" % (i + 6), co, gamma=False, beta=False)
         p["pv_block_%d_clade.gamma" % (i + 6)] = np.ones((seg_dim, co), np.float32)
         p["pv_block_%d_clade.beta" % (i + 6)] = np.zeros((seg_dim, co), np.float32)
+    if pvnet:  # PVNet: one head for segmentation + vector field (pose_models.py:678)
+        p["pv_final_conv.kernel"] = _he_uniform(rng, (1, 1, dims[4], seg_dim + ver_dim), dims[4])
+        return p
     p["pv_final_conv_segmentation.kernel"] = _he_uniform(rng, (1, 1, dims[4], seg_dim), dims[4])
     p["pv_final_conv_vertex.kernel"] = _he_uniform(rng, (1, 1, dims[4], ver_dim), dims[4])
     return p
@@ -95,7 +100,7 @@ class CasaposeModel:
     def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
                  fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
-                 guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT):
+                 guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT, pvnet: bool = False):
         if output_lablemap:
             raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
         self.name = name
@@ -113,9 +118,12 @@ class CasaposeModel:
             weights = None
         self._partial, self._guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self._bilinear = tuple(bool(v) for v in bilinear)
-        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial)
+        self._pvnet = bool(pvnet)
+        if self._pvnet and self.input_segmentation_shape is not None:
+            raise ValueError("PVNet has no data_segmentation input")
+        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial, self._pvnet)
         self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
-                                       self._partial, self._guided, bilinear=self._bilinear)
+                                       self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet)
         if isinstance(weights, str):
             self.load_weights(weights)
         self._layers = self._build_layers()
@@ -132,7 +140,7 @@ class CasaposeModel:
         p = self._plan
         if p is None or (p.batch, p.h, p.w) != (batch, h, w) or p.group is not group:
             self._plan = train_engine.TrainPlan(self._store, self.seg_dim, self.ver_dim, batch, h, w, self._dims, group, world_size,
-                                                self._partial, self._guided, bilinear=self._bilinear)
+                                                self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet)
             self._plan.refresh_weights(torch.cuda.current_stream(self.device).cuda_stream)
         return self._plan, self.device
 

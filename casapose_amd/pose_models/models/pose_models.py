@@ -58,3 +58,19 @@ def CASAPoseConditional5(*args, **kwargs):
     """casapose_c_gcu5: ResNet-18 (OS 8) + segmentation decoder + class-adaptive vector-field
     decoder with 5 partial convolutions, CLADE and guided upsampling (pose_models.py:513-635)."""
     return _conditional("casapose_c_gcu5", (True,) * 5, _GU, *args, **kwargs)
+
+
+def PVNet(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None, input_tensor=None, weights=None,
+          base_model="resnet18", backbone=None, output_lablemap=False, **kwargs):
+    """pvnet_combined (pose_models.py:645-696): the baseline without the class-adaptive decoder -- ResNet-18 + decoder 1 + one 1x1 head
+    `pv_final_conv` with seg_dim + ver_dim output channels.  (The registry key `pvnet` is the same graph with per-object vector
+    fields, ver_dim = 2*points*objects; its separated-field losses are not built, so only the merged-output use is supported.)"""
+    if base_model != "resnet18":
+        raise NotImplementedError("backbone %s is not built for MI355X yet (resnet18 is)" % base_model)
+    if backbone is not None or input_tensor is not None:
+        raise NotImplementedError("external backbone / input_tensor are Keras-graph features without an equivalent here")
+    if seg_dim + ver_dim > 64:
+        raise NotImplementedError("PVNet with more than 64 output channels (separated vector fields) is not built")
+    return CasaposeModel("pvnet_combined", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape, weights=weights,
+                         output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
+                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=False, pvnet=True)

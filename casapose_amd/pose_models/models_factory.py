@@ -39,14 +39,14 @@ class ModelsFactory:
         "casapose_c_gcu3": _pm.CASAPoseConditional3,
         "casapose_c_gcu4": _pm.CASAPoseConditional4,
         "casapose_c_gcu5": _pm.CASAPoseConditional5,
-        "pvnet_combined": _not_built("pvnet_combined"),
+        "pvnet_combined": _pm.PVNet,
         "casapose_custom": _cp.CASAPoseConditional,
         "casapose_c_gcu5_sw5": _not_built("casapose_c_gcu5_sw5"),
         "casapose_c_gcu4_sw1": _not_built("casapose_c_gcu4_sw1"),
         "casapose_c_gcu5_sw1": _not_built("casapose_c_gcu5_sw1"),
         "casapose_c_gcu4_bilat": _pm.CASAPoseConditional9,
         "casapose_c_gcu4_sw2": _not_built("casapose_c_gcu4_sw2"),
-        "pvnet": _not_built("pvnet"),
+        "pvnet": _pm.PVNet,  # same graph; raises for the separated-vector-field sizes (> 64 output channels)
     }
 
     @property

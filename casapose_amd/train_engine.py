@@ -479,7 +479,8 @@ class TrainPlan:
 
     def __init__(self, store: ParamStore, seg_dim: int, ver_dim: int, batch: int, h: int, w: int,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1,
-                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, bilinear: Sequence[bool] = BILINEAR_DEFAULT):
+                 partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, bilinear: Sequence[bool] = BILINEAR_DEFAULT,
+                 pvnet: bool = False):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         if seg_dim > 32 or ver_dim > 32:
@@ -487,6 +488,11 @@ class TrainPlan:
         lib = _lib.load()
         self.store, self.seg_dim, self.ver_dim = store, seg_dim, ver_dim
         self.batch, self.h, self.w = batch, h, w
+        self.pvnet = bool(pvnet)
+        if self.pvnet:  # one merged head: its gradient row is the contiguous [seg | vertex] record
+            if seg_dim + ver_dim > self.GRAD_LD:
+                raise ValueError("pvnet_combined: seg_dim + ver_dim must be <= %d" % self.GRAD_LD)
+            self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
         self.update_moving = True
         dev = store.device
@@ -667,6 +673,12 @@ class TrainPlan:
             return prev
 
         feat1 = decoder(1, False)
+        self.cond_labels = None
+        if self.pvnet:  # PVNet (pose_models.py:645-696)
+            head = layer("pv_final_conv.kernel", 0, 1, K + V, [(dims[4], dims[4])], [True])
+            self.ops.append(ConvOp(head, [(feat1, dims[4])], (self.out, 0, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, 0, self.GRAD_LD)))
+            self._finish_plan(f32)
+            return
         seg_head = layer("pv_final_conv_segmentation.kernel", 0, 1, K, [(dims[4], dims[4])], [True])
         self.ops.append(ConvOp(seg_head, [(feat1, dims[4])], (self.out, 0, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, 0, self.GRAD_LD)))
         self.cond_labels: Optional[torch.Tensor] = None  # ground-truth conditioning (train_vectors_with_ground_truth)
@@ -689,6 +701,11 @@ class TrainPlan:
         feat2 = decoder(6, True)
         ver_head = layer("pv_final_conv_vertex.kernel", 0, 1, V, [(dims[4], dims[4])], [True])
         self.ops.append(ConvOp(ver_head, [(feat2, dims[4])], (self.out, K, self.out_ld), B, h, w, out=None, dy_ptr_ld=(self.dout, self.VERT_OFF, self.GRAD_LD)))
+        self._finish_plan(f32)
+
+    def _finish_plan(self, f32):
+        dev = self.store.device
+        c0 = self.conv0
         self.tensors = [o for o in self._all_tensors()]
         # Winograd for the deep 3x3 layers (forward and data gradient); shared scratch sized for the largest of them
         self.use_winograd = os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"

@@ -335,7 +335,7 @@ BILINEAR_GUIDED = {"casapose_c_gcu4_bilat": (False, True, True, True, False)}  #
 
 
 def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, randomize_norm: bool = True,
-                partial=(True,) * 5):
+                partial=(True,) * 5, pvnet: bool = False):
     """Random parameters of casapose_c_gcu5 (or, with ``partial``, of a variant whose decoder-2 block i is an ordinary
     convolution `pv_block_N_conv2d.kernel` when partial[i] is False) with the reference's shapes/initialisers
     (he_uniform conv kernels: resnet.py:31; _normalization_layers.py:317).  With
@@ -374,6 +374,8 @@ def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, 
         p[n1 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
         bn(n1 + "_bn", co)
         n2 = "pv_block_%d" % (i + 6)
+        if pvnet:
+            continue
         if partial[i]:
             p[n2 + "_prepare_conv2d.weights"] = he((ci, 3, 3, co), 9 * ci)
         else:
@@ -385,6 +387,9 @@ def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, 
         else:
             p[n2 + "_clade.gamma"] = np.ones((seg_dim, co), dtype)
             p[n2 + "_clade.beta"] = np.zeros((seg_dim, co), dtype)
+    if pvnet:
+        p["pv_final_conv.kernel"] = he((1, 1, 32, seg_dim + ver_dim), 32)
+        return p
     p["pv_final_conv_segmentation.kernel"] = he((1, 1, 32, seg_dim), 32)
     p["pv_final_conv_vertex.kernel"] = he((1, 1, 32, ver_dim), 32)
     return p
@@ -469,7 +474,7 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     (:14-512) which differ only in which decoder-2 blocks use a partial convolution and guided upsampling.
     img [B,H,W,3]; optional seg_input [B,H,W,K] (the `data_segmentation` input, :550-554).
     Returns [B,H,W,K+ver_dim] = concat(seg logits, vertex)."""
-    part, guid = VARIANTS[variant]
+    part, guid = VARIANTS.get(variant, ((True,) * 5, (False,) * 5))
     bil = BILINEAR_GUIDED.get(variant, (False,) * 5)
     x2s, x4s, x8s, _x16s, x32s = resnet18_os8(p, img)
     x = decoder1_block(p, x32s, 1, leaky=False, upsample=False)
@@ -477,6 +482,8 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     x = decoder1_block(p, np.concatenate([x, x4s], 3), 3, True, True)
     x = decoder1_block(p, np.concatenate([x, x2s], 3), 4, True, True)
     x = decoder1_block(p, np.concatenate([x, img], 3), 5, True, False)
+    if variant == "pvnet_combined":  # PVNet (pose_models.py:645-696): one head, no second decoder
+        return conv2d(x, p["pv_final_conv.kernel"])
     logits = conv2d(x, p["pv_final_conv_segmentation.kernel"])
     mask = saturated_softmax(logits if seg_input is None else seg_input)
     mask2 = half_size(mask)

@@ -142,7 +142,7 @@ def guided_bilinear_upsample(x, lab_lo, lab_hi):
 
 
 def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None,
-                  partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5):
+                  partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, pvnet: bool = False):
     """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
     convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
     hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
@@ -181,6 +181,8 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
         if 0 < i < 4:
             y = bilinear_x2(y)
         d1 = y
+    if pvnet:  # PVNet: one merged head (pose_models.py:678)
+        return conv_nhwc(d1, p["pv_final_conv.kernel"])
     logits = conv_nhwc(d1, p["pv_final_conv_segmentation.kernel"])
     labs = labels_pyramid(labels)
     lvl = [3, 3, 2, 1, 0]

@@ -139,3 +139,43 @@ def test_custom_decoder_params(device):
     with pytest.raises(NotImplementedError):
         CASAPose([DecoderParams(True, True, False, True, False)] * 5, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
     assert [tuple(p) for p in CASAPOSE_PARAMS["clade"]][1] == (True, True, True, False, False)
+
+
+def test_pvnet_combined_forward_and_training(device):
+    """PVNet baseline (pose_models.py:645-696): decoder 1 + one merged 1x1 head; forward vs the fp64 oracle, and one training
+    step's gradients vs the autograd oracle."""
+    import torch_train_ref as R
+    from casapose_amd.pose_models.tfkeras import Classifiers
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    b, h, w, k, v = 2, 32, 48, 4, 27
+    params = O.init_params(k, v, seed=31, dtype=np.float32, pvnet=True)
+    net = Classifiers.get("pvnet_combined")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, device=device)
+    assert set(params) == set(net.get_parameters())
+    net.set_parameters(params)
+    rng = np.random.default_rng(2)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    ref = O.casapose_c_gcu5({n: a.astype(np.float64) for n, a in params.items()}, img.astype(np.float64), variant="pvnet_combined")
+    got = net([img], training=False).cpu().numpy().astype(np.float64)
+    assert got.shape == (b, h, w, k + v) and rel_err(got, ref) < 1e-3
+    # training step
+    store = ParamStore(params, device)
+    plan = TrainPlan(store, k, v, b, h, w, pvnet=True)
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    lab = np.zeros((b, h, w), np.uint8)
+    lab[:, 4:20, 6:30], lab[:, 14:30, 20:44], lab[0, 2:10, 30:44] = 1, 2, 3
+    kpts = rng.uniform(0, h, (b, k - 1, 9, 2)).astype(np.float32)
+    labd = torch.from_numpy(lab).to(device)
+    out = plan.forward(torch.from_numpy(img).to(device))
+    p64 = R.to_torch(params)
+    ref_t = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), pvnet=True)
+    assert rel_err(out.cpu().numpy().astype(np.float64), ref_t.detach().numpy()) < 1e-3
+    sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(device), 1.0, 0.5, 0.015, filter_with_segmentation=False)
+    ml, vl, pl = R.losses(ref_t, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, 9, False)
+    (ml + 0.5 * vl + 0.015 * pl).backward()
+    plan.backward()
+    torch.cuda.synchronize()
+    assert abs(float(sums[0]) - ml.item()) < 1e-3 * abs(ml.item())
+    for name in store.offsets:
+        g, gr = store.grad_view(name).cpu().numpy().astype(np.float64), p64[name].grad.numpy()
+        assert np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-30) < 2e-2, name
