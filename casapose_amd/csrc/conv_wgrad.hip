@@ -44,6 +44,7 @@ struct WgK {
     int Hin, Win, Ho, Wo, Cout, KW, ntaps, stride, dil, pad;
     int M;
     int tiles_co, tiles_k, nsplit, steps_per_split;
+    int groups;  // grouped GEMM (Winograd planes): pixels [g*M, (g+1)*M) accumulate into dw + g*Cout*ktot; M = rows per group
 };
 
 template <int WCO, bool PARTIAL>
@@ -62,7 +63,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgK p) {
     const int lane = tid & 63;
 
     const int ntiles = p.tiles_co * p.tiles_k;
-    const int logical = cp::xcd_remap(blockIdx.x, ntiles * p.nsplit);
+    const int logical_all = cp::xcd_remap(blockIdx.x, ntiles * p.nsplit * p.groups);
+    const int grp = logical_all / (ntiles * p.nsplit);
+    const int logical = logical_all - grp * (ntiles * p.nsplit);
+    const int gbase = grp * p.M;  // first pixel of this group
     const int split = logical / ntiles;
     const int t2 = logical - split * ntiles;
     const int tile_k = t2 / p.tiles_co, tile_co = t2 - tile_k * p.tiles_co;
@@ -125,11 +129,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgK p) {
             const bool valid = m < p.M;
             const int iy0 = valid ? oy * p.stride - p.pad : -0x10000000;
             const int ix0 = ox * p.stride - p.pad;
-            const int pix0 = (n * p.Hin + iy0) * p.Win + ix0;
+            const int pix0 = gbase + (n * p.Hin + iy0) * p.Win + ix0;  // (groups > 1 only with 1x1 / stride 1 geometry: pixel == row)
 #pragma unroll
             for (int j = 0; j < WCO; ++j)
                 dreg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         rsd, (int)((valid && d_coff[j] < OOB) ? (unsigned)m * (unsigned)p.dy_ld * 4u + d_coff[j] : OOB), 0, 0));
+                                                         rsd, (int)((valid && d_coff[j] < OOB) ? (unsigned)(gbase + m) * (unsigned)p.dy_ld * 4u + d_coff[j] : OOB), 0, 0));
             rsv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)(valid ? (unsigned)m * 4u : OOB), 0, 0));
             if constexpr (PARTIAL) clab = __builtin_amdgcn_raw_buffer_load_b8(rsl, valid ? (n * p.Hin + oy) * p.Win + ox : (int)OOB, 0, 0);
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.ktot + k, acc[r]);
+            if (co < p.Cout) atomicAdd(p.dw + ((size_t)grp * p.Cout + co) * p.ktot + k, acc[r]);
         }
     }
 }
@@ -227,13 +231,13 @@ int launch_wgrad(WgK k, hipStream_t st) {
     const int total_steps = (k.M + 31) / 32;
     const int tiles = k.tiles_co * k.tiles_k;
     // enough blocks to fill 256 CUs x 2 several times over, but >= 8 steps per block so the pipeline fill amortises
-    int nsplit = (256 * 8 + tiles - 1) / tiles;
+    int nsplit = (256 * 8 + tiles * k.groups - 1) / (tiles * k.groups);
     if (nsplit > (total_steps + 7) / 8) nsplit = (total_steps + 7) / 8;
     if (nsplit < 1) nsplit = 1;
     k.steps_per_split = (total_steps + nsplit - 1) / nsplit;
     k.nsplit = (total_steps + k.steps_per_split - 1) / k.steps_per_split;
     const size_t lds = (size_t)2 * 32 * ((WCO * 32 + 4) + (WK * 32 + 4)) * sizeof(float);
-    CP_LAUNCH((conv_wgrad_kernel<WCO, PARTIAL>), dim3((unsigned)(tiles * k.nsplit)), dim3(512), lds, st, k);
+    CP_LAUNCH((conv_wgrad_kernel<WCO, PARTIAL>), dim3((unsigned)(tiles * k.nsplit * k.groups)), dim3(512), lds, st, k);
     return cp::check_launch("cp_conv2d_wgrad_f32");
 }
 
@@ -277,9 +281,18 @@ extern "C" int cp_conv2d_wgrad_f32(const cp_conv_desc* d, const float* dy, int d
     k.dw = dw_packed;
     k.Hin = d->in_h; k.Win = d->in_w; k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->cout; k.KW = d->kw; k.ntaps = d->kh * d->kw;
     k.stride = d->stride; k.dil = d->dilation; k.pad = d->pad; k.M = (int)M;
+    k.groups = 1;
+    if (d->group_rows) {  // the 36 Winograd planes in one launch: a 1x1 problem per group of rows, dw_packed is [groups][cout][ktot]
+        CP_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->num_sources == 1 && !d->tap_label && d->batch * d->in_h == 1,
+                   "cp_conv2d_wgrad_f32: grouped mode is a plain 1x1 problem laid out as one row of pixels (batch = in_h = 1)");
+        CP_REQUIRE(d->group_rows % 32 == 0 && M % d->group_rows == 0, "cp_conv2d_wgrad_f32: group_rows must be a multiple of 32 dividing the pixel count");
+        k.groups = (int)(M / d->group_rows);
+        k.M = d->group_rows;
+        k.Win = k.Wo = d->group_rows;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate)
-        if (hipMemsetAsync(dw_packed, 0, sizeof(float) * (size_t)d->cout * k.ktot, st) != hipSuccess) return cp::check_launch("cp_conv2d_wgrad_f32 memset");
+        if (hipMemsetAsync(dw_packed, 0, sizeof(float) * (size_t)k.groups * d->cout * k.ktot, st) != hipSuccess) return cp::check_launch("cp_conv2d_wgrad_f32 memset");
     if (d->cout <= 32) return d->tap_label ? launch_wgrad<1, true>(k, st) : launch_wgrad<1, false>(k, st);
     return d->tap_label ? launch_wgrad<2, true>(k, st) : launch_wgrad<2, false>(k, st);
 }

@@ -196,6 +196,92 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, long long s_ky, 
     }
 }
 
+// A applied to four values (the transpose of the output transform): dM = A dY A^T turns the gradient of a 4x4 output tile into
+// the gradient of the 36 Winograd products (weight gradient: dU[p] = sum_t dM[p][t]^T V[p][t])
+__device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&m)[6]) {
+    m[0] = y[0];
+    m[1] = y[0] + y[1] + y[2] + y[3];
+    m[2] = y[0] - y[1] + y[2] - y[3];
+    m[3] = y[0] + 2.f * y[1] + 4.f * y[2] + 8.f * y[3];
+    m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+    m[5] = y[3];
+}
+
+__global__ __launch_bounds__(THREADS) void wino_dy_kernel(const float* __restrict__ dy, int ld, int C, WinoGeom g, float* __restrict__ dM) {
+    const int c4n = C >> 2;
+    const long long total = (long long)g.Tp * c4n;  // the padding tiles are ZEROED: the weight-gradient GEMM reduces over all Tp rows
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int t = (int)(i / c4n);
+        if (t >= g.T) {
+            float* z = dM + (size_t)t * C + c4 * 4;
+            for (int p = 0; p < 36; ++p) *reinterpret_cast<float4*>(z + (size_t)p * g.Tp * C) = f4(0.f);
+            continue;
+        }
+        int n, sy, sx, tu, tv;
+        tile_coords(t, g, n, sy, sx, tu, tv);
+        float4 tt[6][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = sx + g.d * (4 * tv + j);
+            float4 col[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = sy + g.d * (4 * tu + r);
+                col[r] = (y < g.H && x < g.W) ? *reinterpret_cast<const float4*>(dy + (((size_t)n * g.H + y) * g.W + x) * ld + c4 * 4) : f4(0.f);
+            }
+            float4 o[6];
+            a6(col, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tt[r][j] = o[r];
+        }
+        float* dst = dM + (size_t)t * C + c4 * 4;
+        const size_t plane = (size_t)g.Tp * C;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float4 o[6];
+            a6(tt[r], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
+        }
+    }
+}
+
+// dW(ky,kx,c,o) = sum_{a,b} G[a][ky] G[b][kx] dU[a*6+b][o][k_off + c]   (the adjoint of wino_weight_kernel), written through strides
+__global__ void wino_weight_grad_kernel(const float* __restrict__ dU, int channels, int cout, int ldk, int k_off, long long s_ky, long long s_kx,
+                                        long long s_in, long long s_out, float* __restrict__ dw, int accumulate) {
+    const long long total = (long long)channels * cout;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % channels);
+        const int o = (int)(i / channels);
+        float t[3][6];  // G^T dU
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) t[ky][b] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const float u = dU[((size_t)(a * 6 + b) * cout + o) * ldk + k_off + c];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) t[ky][b] += G[a][ky] * u;
+            }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v = 0.f;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) v += t[ky][b] * G[b][kx];
+                float* dst = dw + ky * s_ky + kx * s_kx + c * s_in + o * s_out;
+                *dst = accumulate ? *dst + v : v;
+            }
+    }
+}
+
 int make_geom(int batch, int h, int w, int dil, WinoGeom& g) {
     if (batch <= 0 || h <= 0 || w <= 0 || dil <= 0) return CP_ERR_INVALID;
     g.B = batch; g.H = h; g.W = w; g.d = dil;
@@ -278,4 +364,21 @@ extern "C" int cp_wino_transform_weights_f32(const float* w, long long stride_ky
     CP_LAUNCH(wino_weight_kernel, dim3(grid_for((long long)channels * cout)), dim3(THREADS), 0, (hipStream_t)stream, w, stride_ky, stride_kx, stride_in,
               stride_out, flip, channels, cout, ldk, k_off, U);
     return cp::check_launch("cp_wino_transform_weights_f32");
+}
+
+
+extern "C" int cp_wino_dy_transform_f32(const float* dy, int ld, int channels, int batch, int h, int w, int dilation, float* dM, void* stream) {
+    CP_REQUIRE(dy && dM && channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0, "cp_wino_dy_transform_f32: bad arguments");
+    WinoGeom g;
+    CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_dy_transform_f32: bad geometry");
+    CP_LAUNCH(wino_dy_kernel, dim3(grid_for((long long)g.Tp * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, dy, ld, channels, g, dM);
+    return cp::check_launch("cp_wino_dy_transform_f32");
+}
+
+extern "C" int cp_wino_weight_grad_f32(const float* dU, int channels, int cout, int ldk, int k_off, long long stride_ky, long long stride_kx,
+                                       long long stride_in, long long stride_out, float* dw, int accumulate, void* stream) {
+    CP_REQUIRE(dU && dw && channels > 0 && cout > 0 && k_off >= 0 && k_off + channels <= ldk, "cp_wino_weight_grad_f32: bad arguments");
+    CP_LAUNCH(wino_weight_grad_kernel, dim3(grid_for((long long)channels * cout)), dim3(THREADS), 0, (hipStream_t)stream, dU, channels, cout, ldk, k_off,
+              stride_ky, stride_kx, stride_in, stride_out, dw, accumulate);
+    return cp::check_launch("cp_wino_weight_grad_f32");
 }

@@ -293,7 +293,10 @@ class ConvOp:
         cin = sum(s[1] for s in L.sources)
         if all(s[0] == s[1] for s in L.sources) and wino_eligible(3, 1, self.dil, self.pad, L.sources, L.cout):
             ktot = sum(s[0] for s in L.sources)
-            self.wino_fwd = dict(U=torch.zeros(36 * L.cout * ktot, dtype=torch.float32, device=dev), ktot=ktot, cout=L.cout, tp=tp, desc=ConvDesc())
+            # the forward's transformed input is kept per layer (not in the shared scratch): the weight gradient multiplies it again
+            self.wino_fwd = dict(U=torch.zeros(36 * L.cout * ktot, dtype=torch.float32, device=dev), ktot=ktot, cout=L.cout, tp=tp, desc=ConvDesc(),
+                                 V=torch.zeros(36 * tp * ktot, dtype=torch.float32, device=dev),  # padding tiles stay zero
+                                 dU=torch.empty(36 * L.cout * ktot, dtype=torch.float32, device=dev), wdesc=ConvDesc())
             nv, nm = max(nv, 36 * tp * ktot), max(nm, 36 * tp * L.cout)
         c0 = 0
         for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
@@ -333,16 +336,25 @@ class ConvOp:
             d.weights = w["U"].data_ptr()
             d.out_raw, d.out_raw_ld, d.out_act_ld, d.residual_ld = M.data_ptr(), w["cout"], w["cout"], w["cout"]
             d.group_rows, d.group_weight_stride = w["tp"], w["cout"] * w["ktot"]
+        if self.wino_fwd is not None:  # grouped 1x1 weight-gradient problem over the 36 planes: dU[p] = dM[p]^T V[p]
+            w = self.wino_fwd
+            g = w["wdesc"]
+            g.batch, g.in_h, g.in_w, g.out_h, g.out_w = 1, 1, 36 * w["tp"], 1, 36 * w["tp"]
+            g.cout, g.kh, g.kw, g.stride, g.dilation, g.pad = w["cout"], 1, 1, 1, 1, 0
+            g.num_sources = 1
+            g.src[0].data, g.src[0].channels, g.src[0].ld, g.src[0].mode = w["V"].data_ptr(), w["ktot"], w["ktot"], _lib.SRC_DIRECT
+            g.group_rows = w["tp"]
 
     def _wino_run(self, w, srcs, residual_ptr, out_ptr, stream):
         """srcs: list of (ptr, ld, channels); writes out_ptr[pix][w.cout] = conv (+ residual)."""
         lib = _lib.load()
         off = 0
+        V = w["V"] if "V" in w else self._wV
         for ptr, ld, ch in srcs:
-            check(lib.cp_wino_input_transform_f32(ptr, ld, ch, self.batch, self.in_h, self.in_w, self.dil, self._wV.data_ptr(), w["ktot"], off, stream),
+            check(lib.cp_wino_input_transform_f32(ptr, ld, ch, self.batch, self.in_h, self.in_w, self.dil, V.data_ptr(), w["ktot"], off, stream),
                   "cp_wino_input_transform_f32(%s)" % self.layer.name)
             off += ch
-        check(lib.cp_wino_gemm_f32(self._wV.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
+        check(lib.cp_wino_gemm_f32(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
               "cp_wino_gemm_f32(%s)" % self.layer.name)
         check(lib.cp_wino_output_transform_f32(self._wM.data_ptr(), w["cout"], self.batch, self.in_h, self.in_w, self.dil, residual_ptr, w["cout"], None, None,
                                                None, 0, out_ptr, w["cout"], None, w["cout"], stream), "cp_wino_output_transform_f32(%s)" % self.layer.name)
@@ -367,8 +379,22 @@ class ConvOp:
         L = self.layer
         dy, dy_ld = self._dy()
         d = L.desc  # one op per layer: filled by this op's constructor
-        check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
-        check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 0, stream), "cp_scatter_f32")
+        if getattr(self, "wino_fwd", None) is not None:
+            # weight gradient through the Winograd planes: a quarter of the MFMA work of the direct kernel (V kept from the forward)
+            w = self.wino_fwd
+            cin, cout = self._cin, L.cout
+            check(lib.cp_wino_dy_transform_f32(dy, dy_ld, cout, self.batch, self.in_h, self.in_w, self.dil, self._wM.data_ptr(), stream),
+                  "cp_wino_dy_transform_f32(%s)" % L.name)
+            check(lib.cp_conv2d_wgrad_f32(C.byref(w["wdesc"]), self._wM.data_ptr(), cout, w["dU"].data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(wino %s)" % L.name)
+            c0 = k0 = 0
+            for cp_, cr in L.sources:
+                check(lib.cp_wino_weight_grad_f32(w["dU"].data_ptr(), cr, cout, w["ktot"], k0, 3 * cin * cout, cin * cout, cout, 1,
+                                                  L.master_grad.data_ptr() + 4 * c0 * cout, 0, stream), "cp_wino_weight_grad_f32(%s)" % L.name)
+                c0 += cr
+                k0 += cp_
+        else:
+            check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
+            check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 0, stream), "cp_scatter_f32")
         for s, ent in enumerate(L.dgrad):
             if ent is None:
                 continue

@@ -263,6 +263,13 @@ int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int 
  * serves HWIO / IHWO masters and the flipped, transposed data-gradient kernel.  U[p][o][k_off + c], rows of ldk floats. */
 int cp_wino_transform_weights_f32(const float* w, long long stride_ky, long long stride_kx, long long stride_in, long long stride_out,
                                   int flip, int channels, int cout, int ldk, int k_off, float* U, void* stream);
+/* weight gradient through the Winograd planes (training): dM[p][t][c] = (A dY A^T)[p] for every 4x4 tile of dy; then
+ * dU[p][o][k] = sum_t dM[p][t][o] * V[p][t][k] is cp_conv2d_wgrad_f32 in its grouped mode (group_rows = tiles_padded) and
+ * cp_wino_weight_grad_f32 folds the 36 planes back: dw(ky,kx,c,o) = sum_{a,b} G[a][ky] G[b][kx] dU[a*6+b][o][k_off+c], written at
+ * dw[ky*stride_ky + kx*stride_kx + c*stride_in + o*stride_out] (the master layout). */
+int cp_wino_dy_transform_f32(const float* dy, int ld, int channels, int batch, int h, int w, int dilation, float* dM, void* stream);
+int cp_wino_weight_grad_f32(const float* dU, int channels, int cout, int ldk, int k_off, long long stride_ky, long long stride_kx,
+                            long long stride_in, long long stride_out, float* dw, int accumulate, void* stream);
 int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
                                 int c_off, void* stream);
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
