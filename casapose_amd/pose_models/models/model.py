@@ -101,8 +101,7 @@ class CasaposeModel:
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
                  fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
                  guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT, pvnet: bool = False):
-        if output_lablemap:
-            raise NotImplementedError("output_lablemap=True (pose_models.py:619-626) is not built yet")
+        self.output_lablemap = bool(output_lablemap)
         self.name = name
         self.ver_dim, self.seg_dim = int(ver_dim), int(seg_dim)
         self.input_shape = tuple(input_shape) if input_shape is not None else None
@@ -255,7 +254,14 @@ class CasaposeModel:
             cond = torch.argmax(seg, dim=-1).to(torch.uint8).contiguous() if seg is not None else None
             return plan.forward(img, cond)
         self._sync_from_store()
-        return self._net.forward(img, seg)
+        out = self._net.forward(img, seg)
+        if self.output_lablemap:
+            # soft-argmax head (pose_models.py:619-626): sum_k softmax(1e6 * logits)_k * k -- with the saturated softmax this is the
+            # arg-max index as a float; the model then returns [label | vertex] instead of [logits | vertex]
+            k = self.seg_dim
+            lab = torch.argmax(out[..., :k], dim=3, keepdim=True).to(out.dtype)
+            return torch.cat([lab, out[..., k:]], dim=3)
+        return out
 
     def predict(self, inputs):
         return self(inputs, training=False)

@@ -179,3 +179,16 @@ def test_pvnet_combined_forward_and_training(device):
     for name in store.offsets:
         g, gr = store.grad_view(name).cpu().numpy().astype(np.float64), p64[name].grad.numpy()
         assert np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-30) < 2e-2, name
+
+
+def test_output_lablemap(device):
+    """output_lablemap=True (pose_models.py:619-626): [arg-max label as float | vertex] instead of [logits | vertex]."""
+    net, _ = build(device, 5, 27, 32, 48)
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=27, seg_dim=5, input_shape=(32, 48, 3), weights=None, device=device, output_lablemap=True)
+    net2.set_parameters(net.get_parameters())
+    img = np.random.default_rng(0).uniform(-1, 1, (1, 32, 48, 3)).astype(np.float32)
+    a, b = net([img]).cpu().numpy(), net2([img]).cpu().numpy()
+    assert b.shape == (1, 32, 48, 28)
+    assert np.array_equal(b[..., 0], a[..., :5].argmax(-1).astype(np.float32)) and np.array_equal(b[..., 1:], a[..., 5:])
