@@ -89,3 +89,33 @@ def test_test_script_on_an_ndds_folder(device, tmp_path):
                               "--net", "", "--pretrained", "0"])
     rows = list(csv.reader(open(out + "/loss_test_eval.csv")))
     assert len(rows) == 3 and np.all(np.isfinite(res["loss"]))
+
+
+def test_ransac_voting_pose_chain_on_ground_truth_fields(device):
+    """estimate_and_evaluate_poses (pose_evaluation.py:11-97; the estimate_coords=0 path of test_casapose.py): RANSAC keypoint voting
+    on the arg-max mask -> crop->image transform -> host PnP -> ADD; ground-truth fields of a 13-object scene (config_13.ini) must be
+    recovered for every sufficiently visible object."""
+    from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
+    from casapose_amd.pose_estimation.pose_evaluation import estimate_and_evaluate_poses
+
+    oc, h, w, kp = 13, 448, 448, 9
+    ds = SyntheticSceneDataset(oc, (h, w), length=1, seed=4)
+    batch = ds.batch(0, 1)
+    lab = batch["filtered_seg"][..., 0].numpy()
+    kp2 = batch["target_vert"][:, :, 0].numpy()
+    yy, xx = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+    dirs = np.zeros((1, h, w, kp, 2), np.float32)
+    for o in range(oc):
+        m = lab[0] == o + 1
+        d = kp2[0, o][None, None] - np.stack([yy, xx], -1)[:, :, None, :]
+        d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+        dirs[0][m] = d[m]
+    seg = (10.0 * batch["target_seg"]).to(device)
+    stats, poses, pts = estimate_and_evaluate_poses(seg, batch["target_seg"], torch.from_numpy(dirs.reshape(1, h, w, 2 * kp)).to(device), batch["poses_gt"],
+                                                    batch["keypoints3d"], batch["cam_mat"], batch["diameters"], batch["offsets"],
+                                                    evaluation_points=ds.mesh_vertex_array, object_points_3d_count=ds.mesh_vertex_count, min_num=200)
+    valid_2d, valid_3d, count_gt, false_pos = stats[0], stats[1], stats[2], stats[3]
+    assert count_gt.sum() >= 6 and np.all(valid_3d == count_gt) and np.all(valid_2d == count_gt)
+    pts = np.asarray(pts.cpu() if hasattr(pts, "cpu") else pts)
+    big = batch["pixel_gt_count"].numpy()[0, :, 0, 0] > 200
+    assert np.abs(pts[0][big] - kp2[0][big][..., ::-1]).max() < 0.5          # RANSAC keypoints are (x,y)
