@@ -174,11 +174,29 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
     }
     __syncthreads();  // tapoff visible
 
+    // PARTIAL: one bit per tap and staged row, [label(tap position) == label(centre)], computed ONCE per tile (nine byte loads per
+    // row) instead of one label load per row and K chunk inside the pipeline
+    unsigned long long r_pm[RM];
+    if constexpr (PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            unsigned long long m = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int to = tapoff[t];
+                const int iy = r_iy0[i] + (to >> 16), ix = r_ix0[i] + (int)(short)(to & 0xffff);
+                const bool inb = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+                const int lb = __builtin_amdgcn_raw_buffer_load_b8(rsl, inb ? (r_pix[i] + (to >> 16) * p.Win + (int)(short)(to & 0xffff)) : (int)OOB, 0, 0);
+                m |= (inb && lb == r_clab[i]) ? (1ull << t) : 0ull;
+            }
+            r_pm[i] = m;
+        }
+    }
+
     // ---- staging registers (chunk q+1 while chunk q is multiplied) ------------------------
     float4 areg[RM][NV], breg[RN];
     float4 pre_s, pre_b;          // PRE
     int aflag[RM];                // bit0 in-bounds, bit1 y parity, bit2 x parity
-    int alab[RM];                 // PARTIAL: label byte at the tap position
+    int st_tap = 0;               // PARTIAL: tap of the staged chunk (per thread for 4-channel sources)
     int selreg[RM];               // SEL: neighbour index for the NEXT chunk to be issued
     int st_si = 0;                // source of the staged chunk (uniform)
     bool st_pre = false;
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
         const int sld = si ? p.s[1].ld : p.s[0].ld;
         const int dpix = dy * p.Win + dx;
         st_si = si;
+        st_tap = tap < MAX_TAPS ? tap : MAX_TAPS - 1;
         if constexpr (PRE) {
             const float* ps = si ? p.s[1].pre_scale : p.s[0].pre_scale;
             const float* pb = si ? p.s[1].pre_shift : p.s[0].pre_shift;
@@ -249,7 +268,6 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
             const bool inb = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
             const int gpix = r_pix[i] + dpix;  // valid when inb
             aflag[i] = (inb ? 1 : 0) | ((iy & 1) << 1) | ((ix & 1) << 2);
-            if constexpr (PARTIAL) alab[i] = __builtin_amdgcn_raw_buffer_load_b8(rsl, inb ? gpix : (int)OOB, 0, 0);
             if constexpr (BILINEAR) {
                 unsigned o00, o01, o10, o11;
                 if (si == 0) {  // uniform: the x2 source
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(512, (TM * TN >= 4) ? 2 : 4) void conv_f32_kernel(c
                 }
             }
             if constexpr (PARTIAL) {
-                if (alab[i] != r_clab[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!((r_pm[i] >> st_tap) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             *reinterpret_cast<float4*>(a + (rbase + 32 * i) * LDS_STRIDE + col4 * 4) = v;
         }
