@@ -38,7 +38,10 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def barrier_sync(device=None) -> None:
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl" and device is not None and torch.device(device).type == "cuda":
+            dist.barrier(device_ids=[torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()])
+        else:
+            dist.barrier()
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
 
