@@ -208,8 +208,8 @@ class CasaposeModel:
             self._params_stale = False
 
     def save_weights(self, path: str):
-        """Reference writes Keras .h5 (train_casapose.py:903); h5py is unavailable here, so the
-        same name->array mapping is stored as .npz (any extension is kept as given)."""
+        """Reference writes Keras .h5 (train_casapose.py:903); here the same name->array mapping is stored as .npz (any
+        extension is kept as given).  load_weights() reads both this format and real Keras HDF5 files (utils/h5_weights.py)."""
         self._sync_from_store()
         with open(path, "wb") as f:
             np.savez(f, **self._params)
@@ -217,7 +217,20 @@ class CasaposeModel:
     def load_weights(self, path: str, by_name: bool = True, skip_mismatch: bool = True):
         """by_name / skip_mismatch follow test_casapose.py:225-228: unknown names are ignored and
         shape mismatches are skipped (with a warning) instead of raising."""
-        data = np.load(path)
+        from ...utils import h5_weights
+
+        if h5_weights.is_hdf5(path):  # a Keras save_weights file (the reference's result_w_8.h5 / result_w_13.h5)
+            found = h5_weights.keras_weights_from_h5(path, {k.split(".")[0] for k in self._params})
+
+            class _Npz:  # same access pattern as np.load
+                files = list(found)
+
+                def __getitem__(self, k):
+                    return found[k]
+
+            data = _Npz()
+        else:
+            data = np.load(path)
         new = dict(self._params)
         for k in data.files:
             if k not in new:

@@ -1,0 +1,304 @@
+"""Minimal HDF5 reader (and a test-only writer) for Keras weight files -- h5py is not available in this environment.
+
+`model.load_weights("result_w_8.h5", by_name=True, skip_mismatch=True)` (test_casapose.py:225-228) needs the float32 datasets
+of a Keras `save_weights` file: every layer is a group, every weight a contiguous little-endian float dataset whose path ends in
+`<layer name>/.../<weight name>:0` (the backbone's layers sit one group deeper).  This module parses exactly
+the subset of the HDF5 1.8 file format such files use when written with the default ("earliest") library bounds:
+
+  superblock version 0/1 -> root symbol-table entry -> object headers version 1 (with continuation blocks) -> old-style
+  groups (symbol-table message -> v1 B-tree -> SNOD leaves -> local heap names) -> datasets with a simple dataspace (v1/v2),
+  a fixed- or floating-point datatype and a contiguous or compact layout (v1-v3).
+
+Anything else (superblock v2/v3, new-style groups with link messages / fractal heaps, chunked or filtered datasets, variable-
+length types) raises `H5FormatError` with the feature named -- never a silent partial read.  Attributes are not needed: the
+weights are addressed by their path.  Format reference: "HDF5 File Format Specification Version 2.0" (The HDF Group); parity
+with libhdf5 is untested here (no h5py, no Keras file on this machine): the reader is pinned against `write_h5()` below, which
+emits the same structures from the specification.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class H5FormatError(ValueError):
+    pass
+
+
+def is_hdf5(path: str) -> bool:
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    return any(head[o:o + 8] == SIGNATURE for o in (0, 512, 1024, 2048))
+
+
+class _File:
+    def __init__(self, path: str):
+        with open(path, "rb") as f:
+            self.buf = f.read()
+        for off in (0, 512, 1024, 2048, 4096):
+            if self.buf[off:off + 8] == SIGNATURE:
+                self.sb = off
+                break
+        else:
+            raise H5FormatError("%s: no HDF5 signature" % path)
+        b = self.buf
+        ver = b[self.sb + 8]
+        if ver not in (0, 1):
+            raise H5FormatError("superblock version %d (written with newer library bounds) is not supported; re-save with libver='earliest'" % ver)
+        self.O, self.L = b[self.sb + 13], b[self.sb + 14]
+        if self.O != 8 or self.L != 8:
+            raise H5FormatError("only 8-byte offsets/lengths are supported (got %d/%d)" % (self.O, self.L))
+        p = self.sb + 24 + (4 if ver == 1 else 0)
+        self.base = self.u64(p)
+        root = p + 32  # root group symbol table entry
+        self.root_header = self.u64(root + 8)
+        cache = self.u32(root + 16)
+        self.root_btree, self.root_heap = (self.u64(root + 24), self.u64(root + 32)) if cache == 1 else (None, None)
+
+    def u16(self, o): return struct.unpack_from("<H", self.buf, o)[0]
+    def u32(self, o): return struct.unpack_from("<I", self.buf, o)[0]
+    def u64(self, o): return struct.unpack_from("<Q", self.buf, o)[0]
+    def addr(self, a): return self.base + a
+
+    # ---- object headers ---------------------------------------------------------------------------------
+    def messages(self, header_addr: int) -> List[Tuple[int, int, int]]:
+        """[(type, data offset, data size)] of a version-1 object header, continuation blocks followed."""
+        o = self.addr(header_addr)
+        if self.buf[o:o + 4] == b"OHDR":
+            raise H5FormatError("version-2 object headers (newer library bounds) are not supported")
+        if self.buf[o] != 1:
+            raise H5FormatError("object header version %d is not supported" % self.buf[o])
+        nmsg, size = self.u16(o + 2), self.u32(o + 8)
+        blocks = [(o + 16, size)]
+        out = []
+        while blocks and len(out) < nmsg:
+            p, remaining = blocks.pop(0)
+            end = p + remaining
+            while p + 8 <= end and len(out) < nmsg:
+                mtype, msize = self.u16(p), self.u16(p + 2)
+                data = p + 8
+                if mtype == 0x0010:  # continuation
+                    blocks.append((self.addr(self.u64(data)), self.u64(data + 8)))
+                out.append((mtype, data, msize))
+                p = data + ((msize + 7) & ~7)
+        return out
+
+    # ---- groups -----------------------------------------------------------------------------------------------
+    def heap_name(self, heap_addr: int, offset: int) -> str:
+        h = self.addr(heap_addr)
+        if self.buf[h:h + 4] != b"HEAP":
+            raise H5FormatError("bad local heap signature")
+        data = self.addr(self.u64(h + 24))
+        s = data + offset
+        e = self.buf.index(b"\x00", s)
+        return self.buf[s:e].decode("utf-8")
+
+    def group_entries(self, btree_addr: int, heap_addr: int) -> List[Tuple[str, int]]:
+        out: List[Tuple[str, int]] = []
+
+        def walk(a):
+            n = self.addr(a)
+            sig = self.buf[n:n + 4]
+            if sig == b"TREE":
+                if self.buf[n + 4] != 0:
+                    raise H5FormatError("unexpected B-tree node type %d in a group" % self.buf[n + 4])
+                used = self.u16(n + 6)
+                p = n + 24
+                for i in range(used):
+                    walk(self.u64(p + 8 + i * 16))  # key_i (8), child_i (8), ..., key_used
+            elif sig == b"SNOD":
+                cnt = self.u16(n + 6)
+                for i in range(cnt):
+                    e = n + 8 + i * 40
+                    out.append((self.heap_name(heap_addr, self.u64(e)), self.u64(e + 8)))
+            else:
+                raise H5FormatError("bad group node signature %r" % sig)
+
+        walk(btree_addr)
+        return out
+
+    # ---- datasets -----------------------------------------------------------------------------------------------
+    def read_dataset(self, msgs) -> np.ndarray:
+        shape = dtype = None
+        layout = None
+        for mtype, d, size in msgs:
+            if mtype == 0x0001:  # dataspace
+                ver, rank, flags = self.buf[d], self.buf[d + 1], self.buf[d + 2]
+                p = d + (8 if ver == 1 else 4)
+                if ver not in (1, 2):
+                    raise H5FormatError("dataspace version %d" % ver)
+                shape = tuple(self.u64(p + 8 * i) for i in range(rank))
+            elif mtype == 0x0003:  # datatype
+                cls, bits0, tsize = self.buf[d] & 0x0F, self.buf[d + 1], self.u32(d + 4)
+                order = ">" if (bits0 & 1) else "<"
+                if cls == 1:
+                    dtype = np.dtype(order + "f%d" % tsize)
+                elif cls == 0:
+                    dtype = np.dtype(order + ("i" if (bits0 & 8) else "u") + "%d" % tsize)
+                else:
+                    raise H5FormatError("datatype class %d is not supported (only fixed / floating point)" % cls)
+            elif mtype == 0x0008:  # layout
+                ver = self.buf[d]
+                if ver == 3:
+                    cls = self.buf[d + 1]
+                    if cls == 1:
+                        layout = ("contiguous", self.u64(d + 2), self.u64(d + 10))
+                    elif cls == 0:
+                        layout = ("compact", d + 4, self.u16(d + 2))
+                    else:
+                        raise H5FormatError("chunked dataset layout is not supported (Keras weight files are contiguous)")
+                elif ver in (1, 2):
+                    rank, cls = self.buf[d + 1], self.buf[d + 2]
+                    if cls == 1:
+                        layout = ("contiguous", self.u64(d + 8), None)
+                    elif cls == 0:
+                        p = d + 8 + 4 * rank
+                        layout = ("compact", p + 4, self.u32(p))
+                    else:
+                        raise H5FormatError("chunked dataset layout is not supported")
+                else:
+                    raise H5FormatError("data layout message version %d" % ver)
+            elif mtype == 0x000B:
+                raise H5FormatError("filtered (compressed) datasets are not supported")
+        if shape is None or dtype is None or layout is None:
+            raise H5FormatError("dataset without dataspace / datatype / layout message")
+        count = int(np.prod(shape)) if shape else 1
+        nbytes = count * dtype.itemsize
+        if layout[0] == "contiguous":
+            if layout[1] == UNDEF:
+                return np.zeros(shape, dtype.newbyteorder("="))
+            start = self.addr(layout[1])
+        else:
+            start = layout[1]
+        if start + nbytes > len(self.buf):
+            raise H5FormatError("dataset extends past the end of the file")
+        return np.frombuffer(self.buf, dtype=dtype, count=count, offset=start).reshape(shape).astype(dtype.newbyteorder("="))
+
+
+def read_h5(path: str) -> Dict[str, np.ndarray]:
+    """{'/group/.../dataset': array} for every dataset of the file."""
+    f = _File(path)
+    out: Dict[str, np.ndarray] = {}
+    seen = set()
+
+    def visit(prefix: str, header_addr: int, btree=None, heap=None):
+        if header_addr in seen:
+            return
+        seen.add(header_addr)
+        msgs = f.messages(header_addr)
+        types = {m[0] for m in msgs}
+        if 0x0002 in types or 0x0006 in types:
+            raise H5FormatError("new-style groups (link messages) are not supported; re-save with libver='earliest'")
+        if 0x0011 in types:  # symbol table message -> group
+            d = [m for m in msgs if m[0] == 0x0011][0][1]
+            btree, heap = f.u64(d), f.u64(d + 8)
+        if btree is not None and 0x0008 not in types:
+            for name, child in f.group_entries(btree, heap):
+                visit(prefix + "/" + name, child)
+        elif 0x0008 in types:
+            out[prefix] = f.read_dataset(msgs)
+
+    visit("", f.root_header, f.root_btree, f.root_heap)
+    return out
+
+
+_FIELDS = ("kernel", "weights", "gamma", "beta", "moving_mean", "moving_variance")
+
+
+def keras_weights_from_h5(path: str, layer_names) -> Dict[str, np.ndarray]:
+    """Map the datasets of a Keras `save_weights` file to '<layer>.<field>' keys.  A dataset belongs to the LAST path component that
+    is a known layer name; its field is the dataset name without ':0' and without the '<layer>_' prefix custom layers add
+    (`pv_block_6_clade_gamma`, `pv_block_6_prepare_conv2d_weights`, _normalization_layers.py:96-107,314-319)."""
+    known = set(layer_names)
+    out: Dict[str, np.ndarray] = {}
+    for p, arr in read_h5(path).items():
+        comps = [c for c in p.split("/") if c]
+        layer = next((c for c in reversed(comps[:-1]) if c in known), None)
+        if layer is None:
+            continue
+        w = comps[-1].split(":")[0]
+        if w.startswith(layer + "_"):
+            w = w[len(layer) + 1:]
+        if w in _FIELDS:
+            out[layer + "." + w] = np.asarray(arr, np.float32)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# test-only writer: the same structures, straight from the specification
+# ------------------------------------------------------------------------------------------------
+def write_h5(path: str, datasets: Dict[str, np.ndarray]):
+    """Write {'a/b/name': float32 array} as superblock v0 + old-style groups + contiguous datasets."""
+    tree: dict = {}
+    for p, a in datasets.items():
+        node = tree
+        comps = [c for c in p.split("/") if c]
+        for c in comps[:-1]:
+            node = node.setdefault(c, {})
+        node[comps[-1]] = np.ascontiguousarray(a, dtype="<f4")
+    buf = bytearray(96)  # superblock placeholder
+
+    def align():
+        while len(buf) % 8:
+            buf.append(0)
+
+    def put(b: bytes) -> int:
+        align()
+        a = len(buf)
+        buf.extend(b)
+        return a
+
+    def message(mtype, data: bytes) -> bytes:
+        data = data + b"\x00" * ((-len(data)) % 8)
+        return struct.pack("<HHB3x", mtype, len(data), 0) + data
+
+    def object_header(msgs: List[bytes]) -> int:
+        body = b"".join(msgs)
+        return put(struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body)
+
+    def write_dataset(a: np.ndarray) -> int:
+        data_addr = put(a.tobytes())
+        space = struct.pack("<BBB5x", 1, a.ndim, 0) + b"".join(struct.pack("<Q", d) for d in a.shape)
+        dtype = struct.pack("<BBBBI", 0x11, 0x20, 0x1F, 0x00, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+        layout = struct.pack("<BBQQ", 3, 1, data_addr, a.nbytes)
+        return object_header([message(0x0001, space), message(0x0003, dtype), message(0x0008, layout)])
+
+    def write_group(node: dict) -> Tuple[int, int, int]:
+        names = sorted(node)
+        children = [(n, write_group(node[n])[0] if isinstance(node[n], dict) else write_dataset(node[n])) for n in names]
+        heap_data = bytearray(b"\x00" * 8)
+        offs = []
+        for n, _ in children:
+            offs.append(len(heap_data))
+            heap_data.extend(n.encode() + b"\x00")
+            while len(heap_data) % 8:
+                heap_data.append(0)
+        data_addr = put(bytes(heap_data))
+        heap = put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, data_addr))
+        snods = []
+        for i in range(0, max(len(children), 1), 8):  # leaf nodes of up to 8 symbols
+            part = list(zip(offs[i:i + 8], children[i:i + 8]))
+            body = b"SNOD" + struct.pack("<BxH", 1, len(part))
+            for off, (_, addr) in part:
+                body += struct.pack("<QQII16x", off, addr, 0, 0)
+            body += b"\x00" * (40 * (8 - len(part)))
+            snods.append((put(body), part[-1][0] if part else 0))
+        node_b = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), UNDEF, UNDEF) + struct.pack("<Q", 0)
+        for addr, last_key in snods:
+            node_b += struct.pack("<QQ", addr, last_key)
+        btree = put(node_b)
+        hdr = object_header([message(0x0011, struct.pack("<QQ", btree, heap))])
+        return hdr, btree, heap
+
+    root_hdr, root_btree, root_heap = write_group(tree)
+    sb = SIGNATURE + struct.pack("<BBBxBBBxHHI", 0, 0, 0, 0, 8, 8, 4, 16, 0)
+    sb += struct.pack("<QQQQ", 0, UNDEF, len(buf), UNDEF)
+    sb += struct.pack("<QQII", 0, root_hdr, 1, 0) + struct.pack("<QQ", root_btree, root_heap)
+    buf[0:len(sb)] = sb
+    with open(path, "wb") as f:
+        f.write(bytes(buf))

@@ -192,3 +192,25 @@ def test_output_lablemap(device):
     a, b = net([img]).cpu().numpy(), net2([img]).cpu().numpy()
     assert b.shape == (1, 32, 48, 28)
     assert np.array_equal(b[..., 0], a[..., :5].argmax(-1).astype(np.float32)) and np.array_equal(b[..., 1:], a[..., 5:])
+
+
+def test_load_weights_from_keras_h5(device, tmp_path):
+    """net.load_weights(<Keras .h5>, by_name=True, skip_mismatch=True) (test_casapose.py:225-228) through the HDF5 subset reader."""
+    from casapose_amd.utils import h5_weights as H
+    from test_h5_weights import _keras_like
+
+    net, _ = build(device, 9, 27, 32, 48)
+    params = O.init_params(9, 27, seed=99, dtype=np.float32)
+    path = str(tmp_path / "result_w_8.h5")
+    H.write_h5(path, _keras_like(params))
+    net.load_weights(path, by_name=True, skip_mismatch=True)
+    got = net.get_parameters()
+    assert all(np.array_equal(got[k], params[k]) for k in params)
+    # a file for a different class count: mismatching tensors are skipped with a warning, the rest is loaded
+    other = O.init_params(5, 27, seed=7, dtype=np.float32)
+    path2 = str(tmp_path / "other.h5")
+    H.write_h5(path2, _keras_like(other))
+    with pytest.warns(UserWarning, match="skipping"):
+        net.load_weights(path2)
+    got = net.get_parameters()
+    assert np.array_equal(got["conv0.kernel"], other["conv0.kernel"]) and np.array_equal(got["pv_block_6_clade.gamma"], params["pv_block_6_clade.gamma"])
