@@ -40,7 +40,11 @@ __global__ void loss_prepare_kernel(const float* __restrict__ out, int ld, int K
 
 __device__ __forceinline__ float sl1(float a) { return a < 1.f ? 0.5f * a * a : a - 0.5f; }
 
-// pass 2
+// pass 2: one pixel per lane; the output record and the gradient row are moved with 16-byte accesses when their strides allow it
+// (ld % 4 == 0 -- true for the padded training record -- and dld % 4 == 0), the arithmetic runs on register copies
+constexpr int MAXREC = 64;   // floats of the output record / gradient row held in registers
+
+template <bool VEC>
 __global__ __launch_bounds__(THREADS) void loss_main_kernel(const float* __restrict__ out, int ld, int K, int kp, const uint8_t* __restrict__ labels_ce,
                                                             const uint8_t* __restrict__ fg, const int* __restrict__ count,
                                                             const float* __restrict__ keypoints, int objects, int batch, int H, int W,
@@ -50,61 +54,101 @@ __global__ __launch_bounds__(THREADS) void loss_main_kernel(const float* __restr
     const int b = blockIdx.y;
     const float inv_ce = 1.f / ((float)batch * (float)pix_per_img);
     const float nrm_b = 1.f / ((2.f * kp * (float)count[b] + 1e-3f) * (float)batch);
+    const int nrec = K + 2 * kp;  // floats of the record that are read
     double s_mask = 0.0, s_vert = 0.0, s_proxy = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pix_per_img; i += gridDim.x * blockDim.x) {
         const size_t p = (size_t)b * pix_per_img + i;
-        const float* z = out + p * ld;
-        float* g = dout + p * dld;
+        float z[MAXREC], g[MAXREC];
+        if constexpr (VEC) {
+            const float4* src = reinterpret_cast<const float4*>(out + p * ld);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)  // the logits live in the first 32 floats
+                if (4 * q < K) {
+                    const float4 t = src[q];
+                    z[4 * q] = t.x; z[4 * q + 1] = t.y; z[4 * q + 2] = t.z; z[4 * q + 3] = t.w;
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXREC; ++q)
+                if (q < nrec) z[q] = out[p * ld + q];
+        }
+#pragma unroll
+        for (int q = 0; q < MAXREC; ++q) g[q] = 0.f;
         // ---- cross-entropy ------------------------------------------------------------------
         float mx = z[0];
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+#pragma unroll
+        for (int k = 1; k < 32; ++k)
+            if (k < K) mx = fmaxf(mx, z[k]);
         float se = 0.f;
-        for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < K) se += __expf(z[k] - mx);
         const int lc = labels_ce[p];
         const float lse = mx + __logf(se);
-        s_mask += (double)(lse - z[lc]);
         const float inv_se = 1.f / se;
-        for (int k = 0; k < K; ++k) g[k] = mask_w * inv_ce * (__expf(z[k] - mx) * inv_se - (k == lc ? 1.f : 0.f));
-        for (int k = K; k < vert_off; ++k) g[k] = 0.f;
+        float zl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < K) {
+                g[k] = mask_w * inv_ce * (__expf(z[k] - mx) * inv_se - (k == lc ? 1.f : 0.f));
+                zl = (k == lc) ? z[k] : zl;
+            }
+        s_mask += (double)(lse - zl);
         // ---- vertex + proxy ------------------------------------------------------------------
         const int l = fg[p];
-        if (l == 0) {
-            for (int k = vert_off; k < dld; ++k) g[k] = 0.f;
-            continue;
-        }
-        const int y = i / W, x = i - y * W;
-        const float cy = y + 0.5f, cx = x + 0.5f;
-        const float* kpt = keypoints + ((size_t)b * objects + (l - 1)) * kp * 2;
-        const float* v = z + K;
-        for (int j = 0; j < kp; ++j) {
-            const float ky = kpt[2 * j], kx = kpt[2 * j + 1];
-            const float ay = ky - cy, ax = kx - cx;  // pixel centre -> keypoint
-            const float vy = v[2 * j], vx = v[2 * j + 1];
-            // vertex: unit target, smooth L1 on both components
-            const float tn = sqrtf(ay * ay + ax * ax);
-            const float it = 1.f / fmaxf(tn, 1e-12f);
-            const float ey = vy - ay * it, ex = vx - ax * it;
-            const float aey = fabsf(ey), aex = fabsf(ex);
-            s_vert += (double)(sl1(aey) + sl1(aex));
-            float gy = vertex_w * nrm_b * (aey < 1.f ? ey : copysignf(1.f, ey));
-            float gx = vertex_w * nrm_b * (aex < 1.f ? ex : copysignf(1.f, ex));
-            // proxy: distance of the keypoint from the line through the pixel centre along (vy,vx)
-            const float num = vy * ax - vx * ay;
-            const float n2 = vy * vy + vx * vx;
-            if (n2 > 0.f) {
-                const float nr = sqrtf(n2), inr = 1.f / nr;
-                const float dist = fabsf(num) * inr;
-                s_proxy += (double)sl1(dist);
-                const float dl = (dist < 1.f ? dist : 1.f) * proxy_w * nrm_b;
-                const float sg = num > 0.f ? 1.f : (num < 0.f ? -1.f : 0.f);
-                const float c2 = dist * inr * inr;  // |num| / nr^3
-                gy += dl * (sg * ax * inr - c2 * vy);
-                gx += dl * (-sg * ay * inr - c2 * vx);
+        if (l != 0) {
+            const int y = i / W, x = i - y * W;
+            const float cy = y + 0.5f, cx = x + 0.5f;
+            const float* kpt = keypoints + ((size_t)b * objects + (l - 1)) * kp * 2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j >= kp) continue;
+                const float ky = kpt[2 * j], kx = kpt[2 * j + 1];
+                const float ay = ky - cy, ax = kx - cx;  // pixel centre -> keypoint
+                // the directions start at the run-time offset K: scalar loads (cache hits, the record was just read) instead of
+                // dynamic register indexing
+                const float vy = out[p * ld + K + 2 * j], vx = out[p * ld + K + 2 * j + 1];
+                const float tn = sqrtf(ay * ay + ax * ax);
+                const float it = 1.f / fmaxf(tn, 1e-12f);
+                const float ey = vy - ay * it, ex = vx - ax * it;
+                const float aey = fabsf(ey), aex = fabsf(ex);
+                s_vert += (double)(sl1(aey) + sl1(aex));
+                float gy = vertex_w * nrm_b * (aey < 1.f ? ey : copysignf(1.f, ey));
+                float gx = vertex_w * nrm_b * (aex < 1.f ? ex : copysignf(1.f, ex));
+                const float num = vy * ax - vx * ay;
+                const float n2 = vy * vy + vx * vx;
+                if (n2 > 0.f) {
+                    const float nr = sqrtf(n2), inr = 1.f / nr;
+                    const float dist = fabsf(num) * inr;
+                    s_proxy += (double)sl1(dist);
+                    const float dl = (dist < 1.f ? dist : 1.f) * proxy_w * nrm_b;
+                    const float sg = num > 0.f ? 1.f : (num < 0.f ? -1.f : 0.f);
+                    const float c2 = dist * inr * inr;  // |num| / nr^3
+                    gy += dl * (sg * ax * inr - c2 * vy);
+                    gx += dl * (-sg * ay * inr - c2 * vx);
+                }
+                if constexpr (VEC) {  // vert_off == 32 (checked by the launcher): static register indices
+                    g[32 + 2 * j] = gy;
+                    g[32 + 2 * j + 1] = gx;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < MAXREC; ++q) {
+                        g[q] = (q == vert_off + 2 * j) ? gy : g[q];
+                        g[q] = (q == vert_off + 2 * j + 1) ? gx : g[q];
+                    }
+                }
             }
-            g[vert_off + 2 * j] = gy;
-            g[vert_off + 2 * j + 1] = gx;
         }
-        for (int k = vert_off + 2 * kp; k < dld; ++k) g[k] = 0.f;
+        if constexpr (VEC) {
+            float4* dst = reinterpret_cast<float4*>(dout + p * dld);
+#pragma unroll
+            for (int q = 0; q < MAXREC / 4; ++q)
+                if (4 * q < dld) dst[q] = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXREC; ++q)
+                if (q < dld) dout[p * dld + q] = g[q];
+        }
     }
     // block reduce (fp64) -> 3 atomics per block
     __shared__ double red[3][THREADS / 64];
@@ -138,6 +182,7 @@ extern "C" int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, c
     CP_REQUIRE(seg_dim >= 2 && seg_dim <= 64 && objects == seg_dim - 1 && kp >= 1, "cp_pose_loss_f32: seg_dim = objects + 1 (2..64), kp >= 1");
     CP_REQUIRE(ld >= seg_dim + 2 * kp, "cp_pose_loss_f32: ld < seg_dim + 2*kp");
     CP_REQUIRE(vert_off >= seg_dim && dld >= vert_off + 2 * kp, "cp_pose_loss_f32: gradient row layout [0,seg_dim) | [vert_off, vert_off+2kp) does not fit dld");
+    CP_REQUIRE(seg_dim <= 32 && kp <= 16 && seg_dim + 2 * kp <= MAXREC && dld <= MAXREC, "cp_pose_loss_f32: at most 32 classes, 16 keypoints, 64-float rows");
     CP_REQUIRE(batch > 0 && h > 0 && w > 0 && (long long)batch * h * w < (1LL << 31), "cp_pose_loss_f32: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int ppi = h * w;
@@ -149,7 +194,12 @@ extern "C" int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, c
     if (gx > 512) gx = 512;
     CP_LAUNCH(loss_prepare_kernel, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, labels_fg, ppi, batch, filter_with_segmentation, fg, count);
     if (cp::check_launch("cp_pose_loss_f32 prepare") != CP_OK) return CP_ERR_LAUNCH;
-    CP_LAUNCH(loss_main_kernel, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, kp, labels_ce, fg, count, keypoints_yx, objects, batch, h, w, mask_w,
-              vertex_w, proxy_w, dout, dld, vert_off, loss_sums);
+    const bool vec = ld % 4 == 0 && dld == 64 && vert_off == 32 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((seg_dim + 3) & ~3) <= ld;
+    if (vec)
+        CP_LAUNCH(loss_main_kernel<true>, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, kp, labels_ce, fg, count, keypoints_yx, objects, batch, h, w,
+                  mask_w, vertex_w, proxy_w, dout, dld, vert_off, loss_sums);
+    else
+        CP_LAUNCH(loss_main_kernel<false>, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, kp, labels_ce, fg, count, keypoints_yx, objects, batch, h, w,
+                  mask_w, vertex_w, proxy_w, dout, dld, vert_off, loss_sums);
     return cp::check_launch("cp_pose_loss_f32");
 }
