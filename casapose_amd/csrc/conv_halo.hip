@@ -46,6 +46,7 @@ struct HaloK {
     const float* scale;
     const float* shift;
     int clade;  // scale/shift indexed by label
+    int norm;   // partial conv: multiply by 9/count (forward); 0 for the data gradient, whose operand already carries that factor
     int act;
     float* out_raw;
     int raw_ld;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pm = __shfl(pmask[i], (r & 3) + 8 * (r >> 2) + hi4);  // the mask lives in the lane owning that column
-                    rsp[r] = 9.0f / (float)max(__popc(pm), 1);
+                    rsp[r] = p.norm ? 9.0f / (float)max(__popc(pm), 1) : 1.0f;
                 }
             }
             const int rowbase = (n * p.H + y) * p.Wd + x0 + hi4;
@@ -553,7 +554,6 @@ bool halo_applicable(const cp_conv_desc* d) {
         if (!(d->src[1].channels == 4 || d->src[1].channels % 32 == 0)) return false;
     }
     if (d->tap_label && d->epi_label && d->tap_label != d->epi_label) return false;
-    if (d->tap_label && !d->row_scale) return false;  // the kernel always applies 9/count with the mask
     if (!d->tap_label && d->row_scale) return false;
     if (d->src[0].mode == CP_SRC_BILINEAR_X2 && d->tap_label) return false;
     if (d->src[0].mode == CP_SRC_NEAREST_SEL && !d->tap_label) return false;
@@ -595,6 +595,7 @@ int launch_halo_conv(const cp_conv_desc* d, hipStream_t st) {
     k.lab_bytes = (unsigned)((size_t)d->batch * d->in_h * d->in_w);
     k.residual = d->residual; k.res_ld = d->residual_ld;
     k.scale = d->scale; k.shift = d->shift; k.clade = d->epi_label != nullptr; k.act = d->act;
+    k.norm = d->row_scale != nullptr;  // tap mask without row_scale = un-normalised (the data gradient of a partial convolution)
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
     k.head_w = d->head_out ? d->head_weights : nullptr; k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     const bool partial = d->tap_label != nullptr;
