@@ -174,7 +174,16 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
         stream = torch.cuda.current_stream(dev).cuda_stream
         plan.backward()
         plan.all_reduce_grads()
+        # layer.trainable = False (Keras surface): the variables of that layer are not in `trainable_variables`, so
+        # apply_gradients never touches them or their moments -- the flat Adam launch runs over everything, frozen slices are restored
+        st = plan.store
+        frozen = [key for layer in net.layers if not layer.trainable for key in layer._keys if key in st.offsets]
+        saved = [(key, st.view(key).clone(), st.view(key, st.m).clone(), st.view(key, st.v).clone()) for key in frozen]
         optimizer.apply(plan.store, stream)
+        for key, p_, m_, v_ in saved:
+            st.view(key).copy_(p_)
+            st.view(key, st.m).copy_(m_)
+            st.view(key, st.v).copy_(v_)
         plan.refresh_weights(stream)
         net.mark_trained()
     s = sums.cpu().numpy()

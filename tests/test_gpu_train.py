@@ -489,6 +489,12 @@ def test_model_api_train_step(device, k, bpnp):
     assert np.abs(after - before).max() > 1e-3, "inference must see the trained weights"
     p = net.get_parameters()
     assert np.abs(p["conv0.kernel"] - net._store.view("conv0.kernel").cpu().numpy()).max() == 0
+    # frozen layers (layer.trainable = False) keep their weights
+    net.get_layer("conv0").trainable = False
+    w0 = net.get_parameters()["conv0.kernel"].copy()
+    w1 = net.get_parameters()["stage1_unit1_conv1.kernel"].copy()
+    train_step(net, batch, lf, optim, opt)
+    assert np.array_equal(net.get_parameters()["conv0.kernel"], w0) and not np.array_equal(net.get_parameters()["stage1_unit1_conv1.kernel"], w1)
     # evaluation-mode step (train=False): no update
     it = optim.iterations
     ev = train_step(net, batch, lf, optim, opt, train=False)
