@@ -261,3 +261,42 @@ def test_step(net, batch, opt, loss_factors, evaluation_points=None, object_poin
                                                         min_num=1)
     torch.cuda.synchronize(dev)
     return losses, stats, poses, pts, time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------
+# weight surgery of the training script (train_casapose.py:352-448)
+# ------------------------------------------------------------------------------------------------
+def copy_weights_add_confidence_maps(net, net_backup, ver_dim_backup: int, print_fn=print):
+    """A network trained WITHOUT confidence maps initialises one with them: the first ver_dim_backup output channels of
+    pv_final_conv_vertex are copied (copy_weights_vertex, :398-405)."""
+    name = "pv_final_conv_vertex"
+    print_fn("Copy weights for {}".format(name))
+    block = net.get_layer(name).get_weights()
+    backup = net_backup.get_layer(name).get_weights()
+    block[0][0, 0, :, :ver_dim_backup] = backup[0][0, 0, :, :ver_dim_backup]
+    net.get_layer(name).set_weights(block)
+    return net
+
+
+def copy_weights_from_backup_network(net, net_backup, objects_to_copy, print_fn=print):
+    """Initialise a network for a new object set from one trained on another set: class-indexed weights (segmentation head columns,
+    CLADE gamma / beta rows) are copied for the class pairs (in, out) of `objects_to_copy` (row 0 = background), everything
+    class-independent comes from load_weights(by_name) (:407-442)."""
+    table = np.asarray(objects_to_copy, dtype=np.int64).reshape(-1, 2)
+    range_in, range_out = table[:, 0].tolist(), table[:, 1].tolist()
+    name = "pv_final_conv_segmentation"
+    print_fn("Copy weights for {}".format(name))
+    block = net.get_layer(name).get_weights()
+    backup = net_backup.get_layer(name).get_weights()
+    block[0][0, 0, :, range_out] = backup[0][0, 0, :, range_in]
+    net.get_layer(name).set_weights(block)
+    for i in range(6, 11):
+        name = "pv_block_%d_clade" % i
+        print_fn("Copy weights for {}".format(name))
+        block = net.get_layer(name).get_weights()
+        backup = net_backup.get_layer(name).get_weights()
+        for j in range(len(block)):
+            if block[j].ndim == 2:  # gamma / beta tables [classes, channels]
+                block[j][range_out] = backup[j][range_in]
+        net.get_layer(name).set_weights(block)
+    return net

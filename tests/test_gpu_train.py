@@ -499,3 +499,28 @@ def test_model_api_train_step(device, k, bpnp):
     it = optim.iterations
     ev = train_step(net, batch, lf, optim, opt, train=False)
     assert optim.iterations == it and np.isfinite(ev).all()
+
+
+def test_weight_surgery_helpers(device):
+    """copy_weights_from_backup_network / copy_weights_add_confidence_maps (train_casapose.py:352-448) on the Keras-like layer API."""
+    from casapose_amd.pose_models.tfkeras import Classifiers
+    from casapose_amd.training import copy_weights_add_confidence_maps, copy_weights_from_backup_network
+
+    mk = lambda k, v, seed: Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(32, 32, 3), weights=None, device=device, seed=seed)  # noqa: E731
+    old, new = mk(4, 27, 1), mk(6, 27, 2)
+    table = np.array([[0, 0], [1, 3], [3, 5]])     # background, old object 1 -> new class 3, old object 3 -> new class 5
+    before = new.get_parameters()
+    copy_weights_from_backup_network(new, old, table, print_fn=lambda *_: None)
+    po, pn = old.get_parameters(), new.get_parameters()
+    assert np.array_equal(pn["pv_final_conv_segmentation.kernel"][0, 0, :, [0, 3, 5]], po["pv_final_conv_segmentation.kernel"][0, 0, :, [0, 1, 3]])
+    assert np.array_equal(pn["pv_final_conv_segmentation.kernel"][..., [1, 2, 4]], before["pv_final_conv_segmentation.kernel"][..., [1, 2, 4]])
+    for i in range(6, 11):
+        for f in ("gamma", "beta"):
+            key = "pv_block_%d_clade.%s" % (i, f)
+            assert np.array_equal(pn[key][[0, 3, 5]], po[key][[0, 1, 3]]) and np.array_equal(pn[key][[1, 2, 4]], before[key][[1, 2, 4]])
+    assert np.array_equal(pn["conv0.kernel"], before["conv0.kernel"])
+    noconf, conf = mk(4, 18, 3), mk(4, 27, 4)
+    b2 = conf.get_parameters()["pv_final_conv_vertex.kernel"].copy()
+    copy_weights_add_confidence_maps(conf, noconf, 18, print_fn=lambda *_: None)
+    k2 = conf.get_parameters()["pv_final_conv_vertex.kernel"]
+    assert np.array_equal(k2[..., :18], noconf.get_parameters()["pv_final_conv_vertex.kernel"]) and np.array_equal(k2[..., 18:], b2[..., 18:])

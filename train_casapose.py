@@ -28,7 +28,7 @@ from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset  # n
 from casapose_amd.pose_estimation.pose_evaluation import estimate_and_evaluate_poses, evaluate_pose_estimates  # noqa: E402
 from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted  # noqa: E402
 from casapose_amd.pose_models.tfkeras import Classifiers  # noqa: E402
-from casapose_amd.training import Adam, train_step  # noqa: E402
+from casapose_amd.training import Adam, copy_weights_add_confidence_maps, copy_weights_from_backup_network, train_step  # noqa: E402
 from casapose_amd.utils.config_parser import parse_config  # noqa: E402
 from casapose_amd.utils.learning_rate_schedules import ExponentialDecayLateStart, LossWeightHandler, PiecewiseConstantDecay  # noqa: E402
 
@@ -125,8 +125,24 @@ def main(argv=None):
         lr_schedule = ExponentialDecayLateStart(opt.lr, decay_steps=train_batches * opt.lr_epochs, decay_steps_start=train_batches * opt.lr_epochs_start,
                                                 decay_rate=opt.lr_decay, staircase=True)
     optimizer = Adam(learning_rate=lr_schedule)
+    net_backup = None
+    ctor = Classifiers.get(opt.modelname)
+    if opt.copy_weights_add_confidence_maps and opt.estimate_confidence:  # train_casapose.py:352-361
+        net_backup = ctor(ver_dim=ver_dim - opt.no_points, seg_dim=1 + no_objects, input_shape=(height, width, 3),
+                          input_segmentation_shape=input_segmentation_shape, weights=None, base_model=opt.backbonename, device=device)
+    elif opt.copy_weights_from_backup_network:  # :362-370
+        net_backup = ctor(ver_dim=ver_dim, seg_dim=1 + opt.objects_in_input_network, input_shape=(height, width, 3), input_segmentation_shape=None,
+                          weights=None, base_model=opt.backbonename, device=device)
+    if net_backup is not None:
+        net_backup.load_weights(frozen_path + "/" + opt.load_h5_filename + ".h5", by_name=True, skip_mismatch=True)
+        print("loaded backup network")
     if opt.load_h5_weights:
         net.load_weights(frozen_path + "/" + opt.load_h5_filename + ".h5", by_name=True, skip_mismatch=True)
+    if opt.copy_weights_add_confidence_maps and opt.estimate_confidence:
+        copy_weights_add_confidence_maps(net, net_backup, ver_dim - opt.no_points)
+    elif opt.copy_weights_from_backup_network:
+        copy_weights_from_backup_network(net, net_backup, opt.objects_to_copy)
+    del net_backup
     net.summary(print_fn=print if rank == 0 else (lambda *_: None))
     loss_factors = LossWeightHandler(mask_loss_weight=opt.mask_loss_weight, vertex_loss_weight=opt.vertex_loss_weight,
                                      proxy_loss_weight=opt.proxy_loss_weight, kp_loss_weight=opt.keypoint_loss_weight,
