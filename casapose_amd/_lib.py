@@ -134,7 +134,7 @@ SYMBOLS = [
     ("cp_ls_vote_bwd_f32", _i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     ("cp_kp_stats_f32", _i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_kp_reproj_loss_f32", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
-    ("cp_pose_loss_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
+    ("cp_pose_loss_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -169,15 +169,81 @@ __global__ __launch_bounds__(THREADS) void loss_main_kernel(const float* __restr
     }
 }
 
+// filter_high_proxy_errors (train_casapose.py:71-93 with proxy_voting_dist, loss_functions.py:47-129): per image and object the mean
+// smooth-L1 proxy distance over its (already segmentation-filtered) pixels; objects whose value is >= 5 are removed from the
+// foreground of the vertex / proxy losses (a constant of the gradient).
+__global__ __launch_bounds__(THREADS) void proxy_object_sums_kernel(const float* __restrict__ out, int ld, int K, int kp, const uint8_t* __restrict__ fg,
+                                                                    const float* __restrict__ keypoints, int objects, int H, int W,
+                                                                    double* __restrict__ objsum, int* __restrict__ objcnt) {
+    extern __shared__ double ssum[];                 // [objects] doubles, then [objects] ints
+    int* scnt = reinterpret_cast<int*>(ssum + objects);
+    const int b = blockIdx.y, ppi = H * W;
+    for (int i = threadIdx.x; i < objects; i += blockDim.x) { ssum[i] = 0.0; scnt[i] = 0; }
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ppi; i += gridDim.x * blockDim.x) {
+        const size_t p = (size_t)b * ppi + i;
+        const int l = fg[p];
+        if (l == 0) continue;
+        const int y = i / W, x = i - y * W;
+        const float cy = y + 0.5f, cx = x + 0.5f;
+        const float* kpt = keypoints + ((size_t)b * objects + (l - 1)) * kp * 2;
+        const float* v = out + p * ld + K;
+        float s = 0.f;
+        for (int j = 0; j < kp; ++j) {
+            const float ay = kpt[2 * j] - cy, ax = kpt[2 * j + 1] - cx;
+            const float vy = v[2 * j], vx = v[2 * j + 1];
+            const float n2 = vy * vy + vx * vx;
+            const float dist = n2 > 0.f ? fabsf(vy * ax - vx * ay) / sqrtf(n2) : 0.f;
+            s += sl1(dist);
+        }
+        atomicAdd(&ssum[l - 1], (double)s);
+        atomicAdd(&scnt[l - 1], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < objects; i += blockDim.x) {
+        if (scnt[i]) {
+            atomicAdd(&objsum[b * objects + i], ssum[i]);
+            atomicAdd(&objcnt[b * objects + i], scnt[i]);
+        }
+    }
+}
+
+__global__ void proxy_filter_finalize_kernel(const double* __restrict__ objsum, const int* __restrict__ objcnt, int batch, int objects, int kp,
+                                             int min_object_pixel, uint8_t* __restrict__ bad, int* __restrict__ count, float* __restrict__ values) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    int good = 0;
+    for (int o = 0; o < objects; ++o) {
+        const int c = objcnt[b * objects + o];
+        const float v = c >= min_object_pixel ? (float)(objsum[b * objects + o] / ((double)kp * c + 1e-3)) : 0.f;
+        const bool is_bad = !(v < 5.f);
+        bad[b * objects + o] = is_bad ? 1 : 0;  // keep iff value < 5 (train_casapose.py:82)
+        if (values) values[b * objects + o] = v;
+        good += is_bad ? 0 : c;
+    }
+    if (count) count[b] = good;
+}
+
+__global__ void proxy_filter_apply_kernel(uint8_t* __restrict__ fg, const uint8_t* __restrict__ bad, int ppi, int objects) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ppi; i += gridDim.x * blockDim.x) {
+        const size_t p = (size_t)b * ppi + i;
+        const int l = fg[p];
+        if (l && bad[b * objects + l - 1]) fg[p] = 0;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t cp_pose_loss_workspace_bytes(int batch, int h, int w) {
-    return (size_t)batch * h * w + 256 + sizeof(int) * (size_t)batch;
+    // filtered label map | per-image counts | per-object proxy sums (fp64), counts, flags (up to 64 objects)
+    return (((size_t)batch * h * w + 255) & ~(size_t)255) + (((sizeof(int) * (size_t)batch) + 255) & ~(size_t)255) + (size_t)batch * 64 * (8 + 4 + 1) + 256;
 }
 
 extern "C" int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, const uint8_t* labels_ce, const uint8_t* labels_fg,
-                                const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation, float mask_w,
-                                float vertex_w, float proxy_w, void* ws, float* dout, int dld, int vert_off, double* loss_sums, void* stream) {
+                                const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation,
+                                int filter_high_proxy_errors, float mask_w, float vertex_w, float proxy_w, void* ws, float* dout, int dld,
+                                int vert_off, double* loss_sums, float* object_loss_values, void* stream) {
     CP_REQUIRE(out && labels_ce && labels_fg && keypoints_yx && ws && dout && loss_sums, "cp_pose_loss_f32: null pointer");
     CP_REQUIRE(seg_dim >= 2 && seg_dim <= 64 && objects == seg_dim - 1 && kp >= 1, "cp_pose_loss_f32: seg_dim = objects + 1 (2..64), kp >= 1");
     CP_REQUIRE(ld >= seg_dim + 2 * kp, "cp_pose_loss_f32: ld < seg_dim + 2*kp");
@@ -194,6 +260,21 @@ extern "C" int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, c
     if (gx > 512) gx = 512;
     CP_LAUNCH(loss_prepare_kernel, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, labels_fg, ppi, batch, filter_with_segmentation, fg, count);
     if (cp::check_launch("cp_pose_loss_f32 prepare") != CP_OK) return CP_ERR_LAUNCH;
+    if (filter_high_proxy_errors || object_loss_values) {
+        char* base = (char*)count + (((sizeof(int) * (size_t)batch) + 255) & ~(size_t)255);
+        double* objsum = (double*)base;
+        int* objcnt = (int*)(base + (size_t)batch * 64 * 8);
+        uint8_t* bad = (uint8_t*)(base + (size_t)batch * 64 * 12);
+        if (hipMemsetAsync(base, 0, (size_t)batch * 64 * 13, st) != hipSuccess) return cp::check_launch("cp_pose_loss_f32 memset");
+        CP_LAUNCH(proxy_object_sums_kernel, dim3(gx, batch), dim3(THREADS), objects * (sizeof(double) + sizeof(int)), st, out, ld, seg_dim, kp, fg, keypoints_yx,
+                  objects, h, w, objsum, objcnt);
+        // values are always reported against the segmentation-filtered mask; the foreground is only edited when the filter is on
+        CP_LAUNCH(proxy_filter_finalize_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, objsum, objcnt, batch, objects, kp, 20, bad,
+                  filter_high_proxy_errors ? count : (int*)nullptr, object_loss_values);
+        if (filter_high_proxy_errors)
+            CP_LAUNCH(proxy_filter_apply_kernel, dim3(gx, batch), dim3(THREADS), 0, st, fg, bad, ppi, objects);
+        if (cp::check_launch("cp_pose_loss_f32 proxy filter") != CP_OK) return CP_ERR_LAUNCH;
+    }
     const bool vec = ld % 4 == 0 && dld == 64 && vert_off == 32 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((seg_dim + 3) & ~3) <= ld;
     if (vec)
         CP_LAUNCH(loss_main_kernel<true>, dim3(gx, batch), dim3(THREADS), 0, st, out, ld, seg_dim, kp, labels_ce, fg, count, keypoints_yx, objects, batch, h, w,

@@ -549,6 +549,7 @@ class TrainPlan:
         self.gmask = [torch.empty(B, hs[l], ws[l], **u8) if any(self.bilinear) else None for l in range(3)]
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
+        self.object_loss_values = torch.zeros(B, K - 1, **f32)  # per-object proxy distances (proxy_voting_dist)
         # keypoint-reprojection loss (LS voter forward/backward)
         oc, kp = K - 1, 9
         self.est_labels = torch.empty(B, h, w, **u8)
@@ -791,7 +792,7 @@ class TrainPlan:
         return self.out_view
 
     def loss_and_grad(self, labels_ce: torch.Tensor, labels_fg: torch.Tensor, keypoints_yx: torch.Tensor, mask_w=1.0, vertex_w=1.0, proxy_w=1.0,
-                      filter_with_segmentation=True, kp: int = 9) -> torch.Tensor:
+                      filter_with_segmentation=True, kp: int = 9, filter_high_proxy_errors: bool = False) -> torch.Tensor:
         """Losses of compute_loss on the last forward's output and d loss / d output into self.dout. Returns fp64 [mask, vertex, proxy]."""
         lib = _lib.load()
         B, h, w = self.batch, self.h, self.w
@@ -799,8 +800,9 @@ class TrainPlan:
         assert labels_ce.dtype == torch.uint8 and labels_fg.dtype == torch.uint8 and keypoints_yx.dtype == torch.float32
         assert tuple(keypoints_yx.shape) == (B, self.seg_dim - 1, kp, 2) and keypoints_yx.is_contiguous()
         check(lib.cp_pose_loss_f32(self.out.data_ptr(), self.out_ld, self.seg_dim, kp, labels_ce.data_ptr(), labels_fg.data_ptr(), keypoints_yx.data_ptr(),
-                                   self.seg_dim - 1, B, h, w, 1 if filter_with_segmentation else 0, mask_w, vertex_w, proxy_w, self.loss_ws.data_ptr(),
-                                   self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(), stream), "cp_pose_loss_f32")
+                                   self.seg_dim - 1, B, h, w, 1 if filter_with_segmentation else 0, 1 if filter_high_proxy_errors else 0, mask_w, vertex_w,
+                                   proxy_w, self.loss_ws.data_ptr(), self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(),
+                                   self.object_loss_values.data_ptr(), stream), "cp_pose_loss_f32")
         return self.loss_sums
 
     def kp_loss_and_grad(self, labels_gt: torch.Tensor, gt_xy: torch.Tensor, affine: torch.Tensor, kp_w: float, max_pixel_error: float = 25.0,

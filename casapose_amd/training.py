@@ -137,8 +137,6 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
     train_casapose.py:596) and only the loss values are computed; filtered_seg is ignored like in the reference's
     evaluation branch (:637-648).  Returns python floats [loss, mask_loss, vertex_loss, proxy_loss, kp_loss]
     (compute_loss, train_casapose.py:137-145)."""
-    if getattr(loss_factors, "filter_high_proxy_errors", False):
-        raise NotImplementedError("filter_high_proxy_errors (train_casapose.py:71-93) is not built yet")
     plan, dev = net.training_plan(batch["img"].shape[0], batch["img"].shape[1], batch["img"].shape[2], group, world_size)
     img = batch["img"].to(device=dev, dtype=torch.float32).contiguous()
     seg_in = batch["target_seg"].to(dev)
@@ -157,7 +155,8 @@ def train_step(net, batch: Dict[str, torch.Tensor], loss_factors, optimizer: Opt
         out = net([img, seg_in.to(torch.float32)] if with_gt else [img], training=False)
         plan.out_view.copy_(out)
     wts = (float(loss_factors.mask_loss_weight), float(loss_factors.vertex_loss_weight), float(loss_factors.proxy_loss_weight))
-    sums = plan.loss_and_grad(labels, fg, kpts, *wts, filter_with_segmentation=bool(loss_factors.filter_vertex_with_segmentation))
+    sums = plan.loss_and_grad(labels, fg, kpts, *wts, filter_with_segmentation=bool(loss_factors.filter_vertex_with_segmentation),
+                              filter_high_proxy_errors=bool(getattr(loss_factors, "filter_high_proxy_errors", False)) and train and batch.get("pixel_gt_count") is not None)
     kp_w = float(getattr(loss_factors, "kp_loss_weight", 0.0))
     kp_loss = None
     if getattr(opt, "estimate_coords", False):

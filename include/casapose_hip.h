@@ -367,13 +367,16 @@ int cp_adam_step_f32(float* params, const float* grads, float* m, float* v, long
  * out: network output [batch,h,w,ld] = [seg_dim logits | 2*kp directions (dy,dx) | ...]; labels_ce / labels_fg:
  * uint8 [batch,h,w] (target_seg / filtered_seg as class indices); keypoints_yx: fp32 [batch][objects][kp][2].
  * With filter_with_segmentation the foreground keeps only pixels whose arg-max prediction equals labels_fg
- * (:64-69).  dout [batch*h*w][dld] receives d(mask_w*mask + vertex_w*vertex + proxy_w*proxy)/d out with the
+ * (:64-69); with filter_high_proxy_errors objects whose mean smooth-L1 proxy distance (proxy_voting_dist, loss_functions.py:47-129;
+ * objects with < 20 pixels count as 0) is >= 5 are dropped from it as well (:71-93).  object_loss_values (optional, [batch][objects])
+ * receives those per-object values.  dout [batch*h*w][dld] receives d(mask_w*mask + vertex_w*vertex + proxy_w*proxy)/d out with the
  * logit gradients in columns [0,seg_dim) and the direction gradients in [vert_off, vert_off+2kp); every other
  * column is zeroed.  ws: cp_pose_loss_workspace_bytes. */
 size_t cp_pose_loss_workspace_bytes(int batch, int h, int w);
 int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, const uint8_t* labels_ce, const uint8_t* labels_fg,
-                     const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation, float mask_w,
-                     float vertex_w, float proxy_w, void* ws, float* dout, int dld, int vert_off, double* loss_sums, void* stream);
+                     const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation,
+                     int filter_high_proxy_errors, float mask_w, float vertex_w, float proxy_w, void* ws, float* dout, int dld,
+                     int vert_off, double* loss_sums, float* object_loss_values, void* stream);
 
 /* Backward of cp_ls_vote_f32 (the reference differentiates CoordLSVotingWeighted with tf.GradientTape,
  * train_casapose.py:555-579): dkeypoints = d loss / d keypoints [batch][objects][kp][2] (y,x px); sums_ws = the workspace

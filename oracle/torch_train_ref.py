@@ -236,7 +236,7 @@ def smooth_l1(e):
 
 
 def losses(output: torch.Tensor, labels: torch.Tensor, keypoints_yx: torch.Tensor, seg_dim: int, kp: int = 9,
-           filter_vertex_with_segmentation: bool = True):
+           filter_vertex_with_segmentation: bool = True, filter_high_proxy_errors: bool = False):
     """mask / vertex / proxy losses of compute_loss (train_casapose.py:40-145) for the merged-output
     models (not `pvnet`): returns (mask_loss, vertex_loss, proxy_loss).
       mask   : mean softmax cross-entropy (:59-60)
@@ -254,6 +254,25 @@ def losses(output: torch.Tensor, labels: torch.Tensor, keypoints_yx: torch.Tenso
     if filter_vertex_with_segmentation:
         pred = torch.argmax(logits.detach(), dim=-1)
         fg_lab = torch.where(pred == lab, lab, torch.zeros_like(lab))
+    if filter_high_proxy_errors:
+        # proxy_voting_dist per object (loss_functions.py:47-129) on the filtered mask; objects with value >= 5 leave the foreground
+        # (train_casapose.py:71-93); everything here is a constant of the gradient
+        with torch.no_grad():
+            vd = output[..., seg_dim:seg_dim + 2 * kp].reshape(b, h, w, kp, 2)
+            bi0 = torch.arange(b)[:, None, None]
+            kk = keypoints_yx[bi0, torch.clamp(fg_lab - 1, min=0)]
+            yy0, xx0 = torch.meshgrid(torch.arange(h, dtype=output.dtype) + 0.5, torch.arange(w, dtype=output.dtype) + 0.5, indexing="ij")
+            num0 = torch.abs(vd[..., 0] * (kk[..., 1] - xx0[None, :, :, None]) - vd[..., 1] * (kk[..., 0] - yy0[None, :, :, None]))
+            nr0 = torch.sqrt((vd * vd).sum(-1))
+            dist0 = torch.where(nr0 > 0, num0 / torch.where(nr0 > 0, nr0, torch.ones_like(nr0)), torch.zeros_like(num0))
+            per_px = smooth_l1(dist0).sum(-1) * (fg_lab != 0)
+            keep = torch.ones(b, seg_dim, dtype=torch.bool)
+            for o in range(1, seg_dim):
+                m = fg_lab == o
+                cnt = m.reshape(b, -1).sum(1).to(output.dtype)
+                val = torch.where(cnt >= 20, (per_px * m).reshape(b, -1).sum(1) / (kp * cnt + 1e-3), torch.zeros_like(cnt))
+                keep[:, o] = val < 5
+            fg_lab = torch.where(keep[bi0, fg_lab], fg_lab, torch.zeros_like(fg_lab))
     wgt = (fg_lab != 0).to(output.dtype)  # [b,h,w]
     target = target_vector_field(labels, keypoints_yx)
     # vertex loss

@@ -249,8 +249,8 @@ def test_resampling_adjoints(device, hip_lib):
     assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("filt", [True, False])
-def test_pose_loss_value_and_gradient(device, hip_lib, filt):
+@pytest.mark.parametrize("filt,high", [(True, False), (False, False), (True, True)])
+def test_pose_loss_value_and_gradient(device, hip_lib, filt, high):
     lib = hip_lib
     from casapose_amd._lib import check
 
@@ -263,7 +263,18 @@ def test_pose_loss_value_and_gradient(device, hip_lib, filt):
     out[..., k:k + 2 * kp] *= np.where(rng.uniform(size=(b, h, w, 1)) < 0.5, 0.3, 3.0)  # both smooth-L1 branches
     kpts = rng.uniform(-10, 40, (b, k - 1, kp, 2)).astype(np.float32)
     ot = torch.tensor(out.astype(np.float64), requires_grad=True)
-    ml, vl, pl = R.losses(ot, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, kp, filt)
+    if high:  # make two objects of image 0 point exactly at their keypoints so that they survive the proxy-error filter, the rest fails it
+        yy, xx = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+        for o in (1, 2):
+            m = lab[0] == o
+            d = kpts[0, o - 1][None, None] - np.stack([yy, xx], -1)[:, :, None, :]
+            d = d / np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+            an = rng.normal(0, 0.05, d.shape[:-1])  # a little angular noise and a non-unit length: small but non-zero losses
+            d = np.stack([np.cos(an) * d[..., 0] - np.sin(an) * d[..., 1], np.sin(an) * d[..., 0] + np.cos(an) * d[..., 1]], -1) * 1.3
+            out[0][m, k:k + 2 * kp] = d.reshape(h, w, -1)[m]
+            out[0][m, :k] = 5.0 * np.eye(k, dtype=np.float32)[o]
+    ot = torch.tensor(out.astype(np.float64), requires_grad=True)
+    ml, vl, pl = R.losses(ot, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, kp, filt, high)
     wts = (1.0, 0.5, 0.015)
     (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
     st = torch.cuda.current_stream(device).cuda_stream
@@ -272,9 +283,13 @@ def test_pose_loss_value_and_gradient(device, hip_lib, filt):
     ws = torch.empty(lib.cp_pose_loss_workspace_bytes(b, h, w), dtype=torch.uint8, device=device)
     dout = torch.full((b, h, w, 64), 5.0, device=device)
     sums = torch.zeros(3, dtype=torch.float64, device=device)
-    check(lib.cp_pose_loss_f32(od.data_ptr(), ld, k, kp, labd.data_ptr(), labd.data_ptr(), kd.data_ptr(), k - 1, b, h, w, int(filt), *wts, ws.data_ptr(),
-                               dout.data_ptr(), 64, 32, sums.data_ptr(), st))
+    vals = torch.zeros(b, k - 1, device=device)
+    check(lib.cp_pose_loss_f32(od.data_ptr(), ld, k, kp, labd.data_ptr(), labd.data_ptr(), kd.data_ptr(), k - 1, b, h, w, int(filt), int(high), *wts, ws.data_ptr(),
+                               dout.data_ptr(), 64, 32, sums.data_ptr(), vals.data_ptr(), st))
     s = sums.cpu().numpy()
+    if high:  # per-object proxy values (proxy_voting_dist): the two exact objects pass, at least one noisy object is filtered out
+        v = vals.cpu().numpy()
+        assert (v[0, :2] < 5).all() and (v >= 5).any()
     assert abs(s[0] - ml.item()) < 1e-5 * abs(ml.item())
     assert abs(s[1] - vl.item()) < 1e-5 * abs(vl.item())
     assert abs(s[2] - pl.item()) < 1e-5 * abs(pl.item())
