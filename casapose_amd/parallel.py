@@ -69,3 +69,9 @@ def all_reduce_sum_(t: torch.Tensor, group=None, world_size: int = 1) -> torch.T
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def all_reduce_sum_async(t: torch.Tensor, group=None):
+    """Start a SUM all-reduce of `t` and return the work handle (`.wait()` makes the current stream wait for it).  RCCL runs it on its
+    own stream after the work already queued on the current stream, so it overlaps whatever is launched next."""
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)

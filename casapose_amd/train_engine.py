@@ -45,6 +45,28 @@ def _ptr(t):
 # ------------------------------------------------------------------------------------------------
 # parameters
 # ------------------------------------------------------------------------------------------------
+def forward_order() -> List[str]:
+    """Layer names in the order the forward uses them (resnet.py:246-305; pose_models.py:541-616).  The flat parameter buffer follows
+    this order, so the backward completes it from the END towards the start and gradient buckets are contiguous tail slices."""
+    order = ["bn_data", "conv0", "bn0"]
+    for s in range(1, 5):
+        for u in range(1, 3):
+            base = "stage%d_unit%d_" % (s, u)
+            order += [base + "bn1", base + "sc", base + "conv1", base + "bn2", base + "conv2"]
+    order.append("bn1")
+    for i in range(1, 6):
+        order += ["pv_block_%d_conv2d" % i, "pv_block_%d_bn" % i]
+    order += ["pv_final_conv_segmentation", "pv_final_conv"]
+    for i in range(6, 11):
+        order += ["pv_block_%d_prepare_conv2d" % i, "pv_block_%d_conv2d" % i, "pv_block_%d_clade" % i]
+    order.append("pv_final_conv_vertex")
+    return order
+
+
+# gradient buckets = groups of consecutive layers whose all-reduce is launched as soon as the backward has passed them
+BUCKET_STARTS = ("bn_data", "stage4_unit1_bn1", "pv_block_1_conv2d", "pv_block_6_prepare_conv2d")
+
+
 class ParamStore:
     """Flat master parameters / gradients / Adam moments with named views."""
 
@@ -53,7 +75,9 @@ class ParamStore:
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         self.state: Dict[str, torch.Tensor] = {}  # non-trainable: moving statistics
         chunks, off = [], 0
-        for name, v in params.items():
+        rank = {n: i for i, n in enumerate(forward_order())}
+        ordered = sorted(params.items(), key=lambda kv: rank.get(kv[0].split(".")[0], len(rank)))  # stable: unknown layers keep their order at the end
+        for name, v in ordered:
             a = np.asarray(v, dtype=np.float32)
             if name.endswith(".moving_mean") or name.endswith(".moving_variance"):
                 self.state[name] = torch.from_numpy(a.copy()).to(device)
@@ -520,6 +544,8 @@ class TrainPlan:
                 raise ValueError("pvnet_combined: seg_dim + ver_dim must be <= %d" % self.GRAD_LD)
             self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
+        self._buckets = None
+        self._pending: List = []
         self.update_moving = True
         dev = store.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -860,21 +886,69 @@ class TrainPlan:
         self._keep_coef = coef
         return loss
 
+    def _gradient_buckets(self):
+        """[(first op index, start, end)] of the contiguous slices of the flat gradient that are final once the backward has executed
+        the op `first op index` (ops run in reverse): decoder 2 | decoder 1 | stage 4 | the rest of the encoder."""
+        st = self.store
+        rank = {n: i for i, n in enumerate(forward_order())}
+        starts = sorted(rank[b] for b in BUCKET_STARTS if b in rank)
+
+        def bucket_of(layer):
+            r = rank.get(layer, len(rank))
+            return max([i for i, s0 in enumerate(starts) if r >= s0] + [0])
+
+        nb = len(starts)
+        lo, hi, first = [st.size] * nb, [0] * nb, [len(self.ops)] * nb
+        for name, (off, shape) in st.offsets.items():
+            b = bucket_of(name.split(".")[0])
+            n = int(np.prod(shape))
+            lo[b], hi[b] = min(lo[b], off), max(hi[b], off + n + ((-n) % 4))
+        for i, op in enumerate(self.ops):
+            keys = [op.layer.key] if isinstance(op, ConvOp) else ([k for k in (op.gamma_key, op.beta_key) if k] if isinstance(op, BnActOp) else [])
+            for k in keys:
+                b = bucket_of(k.split(".")[0])
+                first[b] = min(first[b], i)
+        out = [(first[b], lo[b], hi[b]) for b in range(nb) if hi[b] > lo[b]]
+        covered = sorted((a, e) for _, a, e in out)
+        assert covered[0][0] == 0 and covered[-1][1] == st.size and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1)), \
+            "gradient buckets must tile the flat buffer"
+        return out
+
     def backward(self):
-        """Back-propagate self.dout through the tape into store.grad."""
+        """Back-propagate self.dout through the tape into store.grad.  With replicas, the SUM all-reduce of each gradient bucket is
+        launched (asynchronously, on the collective library's stream) as soon as the backward has passed the bucket's first layer, so
+        the exchange of the decoders' gradients overlaps the encoder's backward convolutions; all_reduce_grads() waits for them."""
         stream = torch.cuda.current_stream(self.out.device).cuda_stream
         for t in self.tensors:
             t.has_grad = False
-        for op in reversed(self.ops):
-            op.backward(stream)
+        self._pending = []
+        multi = self.group is not None and self.world_size > 1
+        if multi and self._buckets is None:
+            self._buckets = self._gradient_buckets()
+        for i in range(len(self.ops) - 1, -1, -1):
+            self.ops[i].backward(stream)
+            if multi:
+                for first, a, e in self._buckets:
+                    if first == i and not (a == 0):  # the bucket holding bn_data.beta is completed below
+                        self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
         # d beta of bn_data from the padding-channel entries of conv0's weight gradient (see __init__)
         G = self.conv0.dwp[self.g_idx.reshape(-1)].view(49, 64)            # [tap][cout]
         W0 = self.store.view("conv0.kernel").reshape(49, 3, 64)               # [tap][c][cout]
         dbeta = torch.einsum("tco,to->c", W0.double(), G.double())
         self.store.grad_view("bn_data.beta").copy_(dbeta)
+        if multi:
+            for first, a, e in self._buckets:
+                if a == 0:
+                    self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
 
     def all_reduce_grads(self):
-        parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
+        """Complete the gradient exchange started by backward() (or run it as one all-reduce if none is pending)."""
+        if getattr(self, "_pending", None):
+            for h in self._pending:
+                h.wait()
+            self._pending = []
+        else:
+            parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
 
     def train_step(self, img, labels_ce, labels_fg, keypoints_yx, lr: float, cond_labels=None, weights=(1.0, 1.0, 1.0),
                    filter_with_segmentation=True, kp_args: Optional[dict] = None):

@@ -172,3 +172,20 @@ def test_crop_affine_and_projection_match_oracle():
     RT = np.concatenate([np.tile(np.eye(3), (b, 1, 1)), np.tile(np.array([[0.0], [0.0], [800.0]]), (b, 1, 1))], axis=2)
     got = project_keypoints(xyz, K, RT)
     assert np.allclose(got, R.project_points(xyz, K, RT), rtol=1e-5, atol=1e-3)
+
+
+def test_flat_parameter_buffer_follows_forward_order_for_gradient_buckets():
+    """the backward completes the flat gradient from the end towards the start, so each bucket of consecutive layers is a contiguous
+    slice that is final when the backward has passed the bucket's first layer (train_engine.TrainPlan.backward)."""
+    from casapose_amd.train_engine import BUCKET_STARTS, ParamStore, forward_order
+
+    params = O.init_params(4, 27, seed=1, dtype=np.float32)
+    st = ParamStore(dict(reversed(list(params.items()))), torch.device("cpu"))  # input order must not matter
+    rank = {n: i for i, n in enumerate(forward_order())}
+    names = sorted(st.offsets, key=lambda n: st.offsets[n][0])
+    assert all(n.split(".")[0] in rank for n in names), "every trainable layer has a place in the forward order"
+    ranks = [rank[n.split(".")[0]] for n in names]
+    assert ranks == sorted(ranks)
+    assert [rank[b] for b in BUCKET_STARTS] == sorted(rank[b] for b in BUCKET_STARTS) and rank[BUCKET_STARTS[0]] == 0
+    assert all(st.offsets[n][0] % 4 == 0 for n in names)
+    np.testing.assert_array_equal(st.view("conv0.kernel").numpy(), params["conv0.kernel"])
