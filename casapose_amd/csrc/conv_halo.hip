@@ -14,13 +14,18 @@
 // range-checked buffer loads, the same operand modes (bilinear x2, guided-nearest x2, partial-conv
 // tap mask -- applied by the consumers because it depends on (output pixel, tap)) and epilogue.
 #include "common.h"
-#include "epilogue.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HW_COLS = 34;  // 32 output columns + 2 halo columns
+#ifndef CP_HALO_RING1
+#define CP_HALO_RING1 6   // weight-prefetch ring of the 32-channel kernels (divides 36)
+#endif
 enum : int { H_BILINEAR = 2, H_PARTIAL = 4, H_SEL = 8 };
 
 struct HSrc {
@@ -255,7 +260,6 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                 if (has_img && fk < my_tiles) fill_img(ftile, fk & 1);  // image stage fk&1 was last read in tile fk-2
             }
             if (gc + 1 < total_chunks) fill(ftile, fc, (gc + 1) & 1);
-            if ((TN == 1) && p.head_out != nullptr && fc == 0) CP_BARRIER();  // chunk gc closes a tile: head-scratch barrier
             CP_BARRIER();
         }
         return;
@@ -265,16 +269,37 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
     const int wy = wave;  // consumer wave w owns tile rows [w*TMW, (w+1)*TMW)
     const int lrow = lane & 31;
     const int khalf = (lane >> 5) * 4;
-    const int hi4 = (lane >> 5) * 4;
     const int half = lane >> 5;
+    // Accumulators are TRANSPOSED (MFMA A = weights, B = pixels): lane l holds pixel column l&31 of its tile row and, in register
+    // r, output channel (r&3) + 8*(r>>2) + 4*(l>>5) of block j.  Everything that is per pixel (label, partial-conv norm, CLADE
+    // table row, bounds) is therefore per LANE, four consecutive channels sit in four consecutive registers (16-byte loads and
+    // stores), and the activated tile is already in the B-operand layout of the fused 1x1 head -- no LDS round trip.
     f32x16 acc[TMW][TN];
-    cp::EpiArgs ea;
-    ea.row_scale = nullptr; ea.label = p.clade ? p.label : nullptr; ea.residual = p.residual; ea.scale = p.scale; ea.shift = p.shift;
-    ea.out_raw = p.out_raw; ea.out_act = p.out_act; ea.res_ld = p.res_ld; ea.raw_ld = p.raw_ld; ea.act_ld = p.act_ld;
-    ea.cout = p.Cout; ea.act = p.act; ea.npix = (unsigned)(p.B * p.H * p.Wd);
-    const cp::EpiRsrc er = cp::epi_make(ea, p.W);
-    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(PARTIAL ? (const void*)p.label : (const void*)p.W), 0,
-                                                                          PARTIAL ? p.lab_bytes : 0u, 0x00020000);
+    const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
+    const bool has_lab = PARTIAL || p.clade;
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(has_lab ? (const void*)p.label : (const void*)p.W), 0,
+                                                                          has_lab ? p.lab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tab_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.scale : (const void*)p.W), 0,
+                                                                              p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tab_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.shift : (const void*)p.W), 0,
+                                                                              p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? (const void*)p.residual : (const void*)p.W), 0,
+                                                                            p.residual ? npix * (unsigned)p.res_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_raw ? (void*)p.out_raw : (void*)p.W), 0,
+                                                                            p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
+                                                                            p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
+    const bool head = (TN == 1) && p.head_out != nullptr;
+    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc((void*)(head ? (void*)p.head_out : (void*)p.W), 0,
+                                                                             head ? npix * (unsigned)p.head_ld * 4u : 0u, 0x00020000);
+    // fused-head weights: A fragments of the 16 MFMA steps (constant for the whole launch)
+    float4 hw[4];
+    if (head) {
+        const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 4096u, 0x00020000);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            hw[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsh, (int)(((g4 * 2 + half) * 32 + lrow) * 16), 0, 0));
+    }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
     // weight fragment of k8-step u of wide chunk c: 16 B at ((c*36 + u)*2 + half)*BN + co  (x16 B); image block after the wide part
     const unsigned wlane = (unsigned)((half * BN + lrow) * 16);
@@ -284,71 +309,175 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
     constexpr unsigned STEP_BYTES = 2u * BN * 16u;      // one k8-step of weights
     constexpr unsigned CHUNK_BYTES = 36u * STEP_BYTES;
     const unsigned img_w_off = (unsigned)p.nwide * CHUNK_BYTES;
-    float4 fb[4][TN];  // ring: the fragment of step u lives in slot u%4 and is fetched 3 steps ahead
+    // ring: the fragment of step u lives in slot u%RING and is fetched RD = RING-1 steps ahead.  A step is 4*TMW*TN MFMAs (256 cycles
+    // for a 32-channel layer), and the weight stream of all but the smallest layers comes from L2 (> 32 KiB), so the 32-channel
+    // kernels need the deeper ring to cover that latency.  RING divides 36: the slot indices stay compile-time constants.
+    constexpr int RING = (TMW * TN == 1) ? CP_HALO_RING1 : 4;
+    constexpr int RD = RING - 1;
+    static_assert(36 % RING == 0 && RD >= 3, "ring must divide the 36 steps of a wide chunk");
+    float4 fb[RING][TN];
     float4 fa[2][TMW];
-    // prime the ring with steps 0..2 of chunk 0
+    // prime the ring with steps 0..RD-1 of chunk 0
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < RD; ++u)
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[u][j] = ldw(u * STEP_BYTES, j);
 
+    static_assert(TMW == 1, "one tile row per consumer wave");
+    // ---- per-tile label state -------------------------------------------------------------------
+    // partial conv: 9-bit tap mask of this lane's pixel; CLADE: label of this lane's pixel.  The nine label bytes are fetched as
+    // one batch of range-checked loads (outside the image -> never equal to the centre).
+    int pmask = 0, clab = 0;
+    int lbn[9];
+    auto issue_labels = [&](const TilePos& t) {
+        const int y = t.ty * TH + wy, x = t.tx * 32 + lrow;
+        if constexpr (PARTIAL) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+                lbn[tp] = __builtin_amdgcn_raw_buffer_load_b8(rsl, ok ? ((t.n * p.H + yy) * p.Wd + xx) : (int)OOB, 0, 0) | (ok ? 0 : 0xff00);
+            }
+        } else {
+            const bool ok = y < p.H && x < p.Wd;
+            lbn[4] = __builtin_amdgcn_raw_buffer_load_b8(rsl, (ok && p.clade) ? ((t.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
+        }
+    };
+    auto finish_labels = [&]() {
+        if constexpr (PARTIAL) {
+            int m = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) m |= (lbn[tp] == lbn[4]) ? (1 << tp) : 0;
+            pmask = (lbn[4] & 0xff00) ? 0 : m;
+        }
+        clab = lbn[4] & 0xff;
+    };
+
+    // ---- epilogue: lane = pixel, 4 consecutive channels per 16-byte access -----------------------
+    // scale / shift of this lane's 16 channels per block (row `clab` of a CLADE table).  The 32-channel kernels request them
+    // during the tile's last chunk; the 64-channel kernels have no registers to park them and fetch per block in the epilogue.
+    constexpr bool EPI_PREFETCH = (TN == 1);
+    float4 esc[TN][4], esh[TN][4];
+    auto load_tables = [&](int j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int ch = j * 32 + g4 * 8 + half * 4;
+            const unsigned to = (ch < p.Cout) ? (unsigned)((clab * (p.clade ? p.Cout : 0) + ch) * 4) : OOB;
+            esc[j][g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+            esh[j][g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+        }
+    };
+    auto epilogue = [&](int n, int y0, int x0) {
+        const int y = y0 + wy, x = x0 + lrow;
+        const bool pok = y < p.H && x < p.Wd;
+        const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
+        float f = 1.f;
+        if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask), 1) : 1.0f;
+        float4 keep[4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float4 res[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int ch = j * 32 + g4 * 8 + half * 4;
+                const unsigned o = (pok && ch < p.Cout) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB;
+                res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)o, 0, 0));  // empty descriptor without a residual: zeros
+            }
+            if constexpr (!EPI_PREFETCH) load_tables(j);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int ch = j * 32 + g4 * 8 + half * 4;
+                const bool ok = pok && ch < p.Cout;
+                float4 v;
+                v.x = acc[0][j][g4 * 4 + 0] * f + res[g4].x;
+                v.y = acc[0][j][g4 * 4 + 1] * f + res[g4].y;
+                v.z = acc[0][j][g4 * 4 + 2] * f + res[g4].z;
+                v.w = acc[0][j][g4 * 4 + 3] * f + res[g4].w;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                float4 t = v;
+                if (p.scale) {
+                    t.x = v.x * esc[j][g4].x + esh[j][g4].x;
+                    t.y = v.y * esc[j][g4].y + esh[j][g4].y;
+                    t.z = v.z * esc[j][g4].z + esh[j][g4].z;
+                    t.w = v.w * esc[j][g4].w + esh[j][g4].w;
+                }
+                if (p.act == CP_ACT_RELU) {
+                    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                } else if (p.act == CP_ACT_LEAKY01) {
+                    t.x = fmaxf(t.x, 0.f) - fmaxf(-0.1f * t.x, 0.f);
+                    t.y = fmaxf(t.y, 0.f) - fmaxf(-0.1f * t.y, 0.f);
+                    t.z = fmaxf(t.z, 0.f) - fmaxf(-0.1f * t.z, 0.f);
+                    t.w = fmaxf(t.w, 0.f) - fmaxf(-0.1f * t.w, 0.f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                if (j == 0) keep[g4] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (TN == 1) {
+            if (head) {
+                // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel].  Step (g4, e) multiplies channel 8*g4 + 4*half + e on
+                // both operands: A = the head-weight fragment (row q = lane), B = the activated value already in this lane.
+                f32x16 a2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g4].x, keep[g4].x, a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g4].y, keep[g4].y, a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g4].z, keep[g4].z, a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g4].w, keep[g4].w, a2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int q0 = g4 * 8 + half * 4;
+                    const int nq = pok ? p.head_cout - q0 : 0;  // valid head channels of this group (<= 0: none)
+                    const unsigned o = (pix * (unsigned)p.head_ld + (unsigned)q0) * 4u;
+                    const unsigned v0 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), v1 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]);
+                    const unsigned v2 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), v3 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3]);
+                    if (nq >= 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, v1, v2, v3}, r_head, (int)o, 0, 0);
+                    else if (nq == 3) __builtin_amdgcn_raw_buffer_store_b96(u32x3{v0, v1, v2}, r_head, (int)o, 0, 0);
+                    else if (nq == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v0, v1}, r_head, (int)o, 0, 0);
+                    else if (nq == 1) __builtin_amdgcn_raw_buffer_store_b32(v0, r_head, (int)o, 0, 0);
+                }
+            }
+        }
+    };
+
     int gwc = 0;  // global wide-chunk counter
-    int hstage_last = 0;
     TilePos ctile = first;
     CP_BARRIER();  // prologue data is in LDS
     for (int k = 0; k < my_tiles; ++k) {
         const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        if (has_lab) {
+            issue_labels(ctile);
+            finish_labels();
+        }
         next_tile(ctile);
 #pragma unroll
-        for (int i = 0; i < TMW; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // partial conv: 9-bit tap mask of this lane's pixel in each of its rows.  The nine label
-        // bytes are fetched as one batch of range-checked loads (outside the image -> never equal)
-        int pmask[TMW];
-        if constexpr (PARTIAL) {
-#pragma unroll
-            for (int i = 0; i < TMW; ++i) {
-                const int y = y0 + wy * TMW + i, x = x0 + lrow;
-                int lb[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
-                    lb[t] = __builtin_amdgcn_raw_buffer_load_b8(rsl, ok ? ((n * p.H + yy) * p.Wd + xx) : (int)OOB, 0, 0) | (ok ? 0 : 0xff00);
-                }
-                int m = 0;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) m |= (lb[t] == lb[4]) ? (1 << t) : 0;
-                pmask[i] = (lb[4] & 0xff00) ? 0 : m;
-            }
-        }
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
         auto mfma4 = [&](int aslot, int bslot, int tap_lo, int tap_hi) {
+            float4 av = fa[aslot][0];
+            if constexpr (PARTIAL) {
+                const int tp = half ? tap_hi : tap_lo;
+                if (!((pmask >> tp) & 1)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
-                float4 av = fa[aslot][i];
-                if constexpr (PARTIAL) {
-                    const int tp = half ? tap_hi : tap_lo;
-                    if (!((pmask[i] >> tp) & 1)) av = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j) {
 #ifdef HX_NOMFMA
-                    acc[i][j][0] += av.x * fb[bslot][j].x + av.y * fb[bslot][j].y + av.z * fb[bslot][j].z + av.w * fb[bslot][j].w;  // timing experiment
+                acc[0][j][0] += av.x * fb[bslot][j].x + av.y * fb[bslot][j].y + av.z * fb[bslot][j].z + av.w * fb[bslot][j].w;  // timing experiment
 #else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, fb[bslot][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, fb[bslot][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, fb[bslot][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, fb[bslot][j].w, acc[i][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[bslot][j].x, av.x, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[bslot][j].y, av.y, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[bslot][j].z, av.z, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[bslot][j].w, av.w, acc[0][j], 0, 0, 0);
 #endif
-                }
             }
         };
         // ---- wide chunks: 36 k8-steps each, no barrier inside --------------------------------------
         for (int c = 0; c < p.nwide; ++c, ++gwc) {
-            const float* hb = halo + (gwc & 1) * HP * AS + ((wy * TMW) * HW_COLS + lrow) * AS + khalf;
+            const float* hb = halo + (gwc & 1) * HP * AS + (wy * HW_COLS + lrow) * AS + khalf;
             const bool last = (c + 1 == p.nwide);
             // where the weight stream continues after this chunk: next chunk, the image block, or chunk 0 of the next tile
             const unsigned wcur = (unsigned)c * CHUNK_BYTES;
@@ -356,109 +485,60 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
             auto read_a = [&](int u, int slot) {
                 const int tap = u >> 2, k8 = u & 3;  // compile-time after unrolling
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const float* a = hb + (ky * HW_COLS + kx) * AS + k8 * 8;
-#pragma unroll
-                for (int i = 0; i < TMW; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(a + i * HW_COLS * AS);
+                fa[slot][0] = *reinterpret_cast<const float4*>(hb + (ky * HW_COLS + kx) * AS + k8 * 8);
             };
             read_a(0, 0);
 #pragma unroll
             for (int u = 0; u < 36; ++u) {
-                // prefetch the weights of step u+3 (possibly in the next block of the stream) and the halo fragment of step u+1
+                // prefetch the weights of step u+RD (possibly in the next block of the stream) and the halo fragment of step u+1
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[(u + 3) & 3][j] = (u + 3 < 36) ? ldw(wcur + (unsigned)(u + 3) * STEP_BYTES, j) : ldw(wnext + (unsigned)(u + 3 - 36) * STEP_BYTES, j);
+                for (int j = 0; j < TN; ++j) {
+                    const int nu = u + RD - 36;  // >= 0: past this chunk
+                    fb[(u + RD) % RING][j] = (nu < 0)                        ? ldw(wcur + (unsigned)(u + RD) * STEP_BYTES, j)
+                                             : (last && has_img && nu >= 5) ? ldw((unsigned)(nu - 5) * STEP_BYTES, j)  // beyond the 5 image steps: next tile
+                                                                            : ldw(wnext + (unsigned)nu * STEP_BYTES, j);
+                }
                 if (u + 1 < 36) read_a(u + 1, (u + 1) & 1);
-                mfma4(u & 1, u & 3, u >> 2, u >> 2);
+                if (u == 16) {
+                    if constexpr (EPI_PREFETCH) {
+                        if (last) load_tables(0);
+                    }
+                }
+                mfma4(u & 1, u % RING, u >> 2, u >> 2);
             }
-            hstage_last = gwc;
-            if (!last) CP_BARRIER();  // halo stage consumed; the other stage is ready (the tile's last barrier follows the epilogue)
+            if (!last) CP_BARRIER();  // halo stage consumed; the other stage is ready (the tile's last barrier follows below)
         }
         // ---- image step: K = 9 taps x 4 channels (+4 zero) = 5 k8-steps; half-wave h handles tap 2s+h ----
         if (has_img) {
-            const float* ib = imgh + (k & 1) * HP * 4 + ((wy * TMW) * HW_COLS + lrow) * 4;
+            const float* ib = imgh + (k & 1) * HP * 4 + (wy * HW_COLS + lrow) * 4;
 #pragma unroll
             for (int s5 = 0; s5 < 5; ++s5) {
                 const int tl = 2 * s5, th = (2 * s5 + 1 < 9) ? 2 * s5 + 1 : 8;  // tap 9 does not exist: its weights are zero
                 const int offl = ((tl / 3) * HW_COLS + tl % 3) * 4, offh = ((th / 3) * HW_COLS + th % 3) * 4;
-                const float* a = ib + (half ? offh : offl);
-#pragma unroll
-                for (int i = 0; i < TMW; ++i) fa[s5 & 1][i] = *reinterpret_cast<const float4*>(a + i * HW_COLS * 4);
-                // the ring continues from the wide part (36 % 4 == 0): image step s5 sits in slot s5 % 4
+                fa[s5 & 1][0] = *reinterpret_cast<const float4*>(ib + (half ? offh : offl));
+                // the ring continues from the wide part (36 % RING == 0): image step s5 sits in slot s5 % RING
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int nu = s5 + 3;  // next fragments: image steps 3,4, then steps 0..2 of the next tile's chunk 0
-                    fb[nu & 3][j] = (nu < 5) ? ldw(img_w_off + (unsigned)nu * STEP_BYTES, j) : ldw((unsigned)(nu - 5) * STEP_BYTES, j);
+                    const int nu = s5 + RD;  // next fragments: the remaining image steps, then steps 0.. of the next tile's chunk 0
+                    fb[nu % RING][j] = (nu < 5) ? ldw(img_w_off + (unsigned)nu * STEP_BYTES, j) : ldw((unsigned)(nu - 5) * STEP_BYTES, j);
                 }
-                mfma4(s5 & 1, s5 & 3, tl, th);
+                mfma4(s5 & 1, s5 % RING, tl, th);
             }
-            // the ring is now one step out of phase (5 % 4 == 1): realign slots 1,2,3 -> 0,1,2
+            // the ring is now 5 steps out of phase: step v of the next tile sits in slot (5 + v) % RING -> realign to slot v
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                fb[0][j] = fb[1][j];
-                fb[1][j] = fb[2][j];
-                fb[2][j] = fb[3][j];
+                float4 tmp[RD];
+#pragma unroll
+                for (int v = 0; v < RD; ++v) tmp[v] = fb[(5 + v) % RING][j];
+#pragma unroll
+                for (int v = 0; v < RD; ++v) fb[v][j] = tmp[v];
             }
         }
-        // ---- epilogue (epilogue.h) ------------------------------------------------------------
-        if ((TN == 1) && p.head_out != nullptr) CP_BARRIER();  // every wave is done with the halo stage that now becomes head scratch
-        int cos[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) cos[j] = j * 32 + lrow;
-        const bool head = (TN == 1) && p.head_out != nullptr;
-#pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            const int y = y0 + wy * TMW + i;
-            float rsp[16];
-            if constexpr (PARTIAL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pm = __shfl(pmask[i], (r & 3) + 8 * (r >> 2) + hi4);  // the mask lives in the lane owning that column
-                    rsp[r] = p.norm ? 9.0f / (float)max(__popc(pm), 1) : 1.0f;
-                }
-            }
-            const int rowbase = (n * p.H + y) * p.Wd + x0 + hi4;
-            auto rowpix = [&](int r) { const int xr = (r & 3) + 8 * (r >> 2); return (y < p.H && x0 + hi4 + xr < p.Wd) ? rowbase + xr : -1; };
-            float keep[16][TN];
 #ifdef HX_NOEPI
-            if (p.B < 0)  // timing experiment: never true, keeps the accumulators alive
+        if (p.B < 0)  // timing experiment: never true, keeps the accumulators alive
 #endif
-            cp::epilogue_block<TN, (TN == 1) ? 8 : 4>(acc[i], cos, ea, er, rowpix, PARTIAL ? rsp : nullptr, keep);
-            if constexpr (TN == 1) {
-                if (head) {
-                    // Fused 1x1 head: the activated 32(px) x 32(ch) tile goes through this wave's private corner of the halo
-                    // stage it has just finished reading (the stage is not refilled before the tile's closing barrier) to
-                    // become an MFMA A operand; B = head weights straight from L1/L2; 16 more MFMAs; store head_cout columns.
-                    float* scr = halo + (hstage_last & 1) * HP * AS + (wy * TMW + i) * 32 * AS;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + hi4) * AS + lrow] = keep[r][0];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    f32x16 a2;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a2[r] = 0.f;
-                    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 4096u, 0x00020000);
-#pragma unroll
-                    for (int k8 = 0; k8 < 4; ++k8) {
-                        const float4 av = *reinterpret_cast<const float4*>(scr + lrow * AS + k8 * 8 + khalf);
-                        const float4 bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsh, (int)(((k8 * 2 + half) * 32 + lrow) * 16), 0, 0));
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, a2, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, a2, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, a2, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, a2, 0, 0, 0);
-                    }
-                    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_out, 0, ea.npix * (unsigned)p.head_ld * 4u, 0x00020000);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int px = rowpix(r);
-                        const bool ok = px >= 0 && lrow < p.head_cout;
-                        const float hv = a2[r];  // (bit_cast directly on a vector element reads element 0)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), rso,
-                                                              (int)(ok ? ((unsigned)px * (unsigned)p.head_ld + (unsigned)lrow) * 4u : 0x80000000u), 0, 0);
-                    }
-                }
-            }
-        }
-        CP_BARRIER();  // tile done: the consumed halo stage (and, above, its use as head scratch) may be refilled
+        epilogue(n, y0, x0);
+        CP_BARRIER();  // tile done: the consumed halo stage may be refilled
     }
 }
 
@@ -546,7 +626,10 @@ int halo_pack_weights(const float* w, int layout, int cout, int num_sources, con
 bool halo_applicable(const cp_conv_desc* d) {
     if (!d->weights_halo) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return false;
-    if (d->cout > 64 || d->group_rows) return false;
+    if (d->cout > 64 || d->cout % 4 != 0 || d->group_rows) return false;
+    // the epilogue moves four channels per 16-byte access
+    if ((d->out_raw && d->out_raw_ld % 4) || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return false;
+    if ((((uintptr_t)d->out_raw) | ((uintptr_t)d->out_act) | ((uintptr_t)d->residual)) & 15) return false;
     if (d->src[0].mode == CP_SRC_ZERO_INSERT_X2) return false;  // transposed-conv gather: generic kernel only
     if (d->src[0].channels % 32 != 0 || d->src[0].pre_scale) return false;
     if (d->num_sources == 2) {

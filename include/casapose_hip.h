@@ -96,7 +96,8 @@ typedef struct cp_conv_desc {
     cp_conv_source src[2];
     const float* weights;       /* packed [cout][ktot]                                        */
     const float* weights_halo;  /* optional second packing (cp_conv_pack_weights_halo_host): lets 3x3/s1/p1   */
-                                /* layers with cout <= 64 run on the LDS-resident halo-tile kernel            */
+                                /* layers with cout <= 64 (a multiple of 4; outputs / residual 16-byte aligned  */
+                                /* with ld % 4 == 0) run on the LDS-resident halo-tile kernel                 */
     const uint8_t* tap_label;   /* optional [n,in_h,in_w] -> partial-conv tap mask            */
     /* epilogue */
     const float* row_scale;     /* optional [n,out_h,out_w]                                   */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 HALO, GENERIC = 7, 5
 
 
-@pytest.mark.parametrize("cin,cout,hw", [(32, 32, (8, 32)), (64, 32, (13, 45)), (64, 64, (21, 70)), (128, 48, (6, 33)), (96, 9, (4, 31))])
+@pytest.mark.parametrize("cin,cout,hw", [(32, 32, (8, 32)), (64, 32, (13, 45)), (64, 64, (21, 70)), (128, 48, (6, 33)), (96, 12, (4, 31))])
 def test_plain_and_ragged(device, cin, cout, hw):
     from casapose_amd import ops
 
@@ -74,6 +74,19 @@ def test_feature_plus_image_and_bilinear(device):
     w2 = rng.standard_normal((3, 3, 128, 32)) / 34.0
     raw3, _ = ops.conv2d_fused([dev(low2, device), dev(skip, device)], w2.astype(np.float32), pad=1, modes=[2, 0], tile_hint=HALO)
     close(raw3, O.conv2d(np.concatenate([O.upsample_bilinear_x2(low2), skip], 3), w2, pad=1))
+
+
+def test_halo_needs_four_channel_groups(device):
+    """the halo kernel's epilogue moves four channels per 16-byte access: cout % 4 != 0 goes to the generic kernel, and forcing
+    CP_TILE_HALO for such a layer is an error, not a silent switch."""
+    from casapose_amd import _lib, ops
+
+    rng = np.random.default_rng(5)
+    x, w = rng.standard_normal((1, 4, 31, 96)), rng.standard_normal((3, 3, 96, 9)) * 0.1
+    with pytest.raises(_lib.CasaposeHipError):
+        ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=HALO)
+    raw, _ = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1)
+    close(raw, O.conv2d(x, w, pad=1))
 
 
 @pytest.mark.parametrize("hw", [(24, 32), (22, 50)])
