@@ -4,12 +4,13 @@
 // ds_read_b128 per 8 k, four consumer + four producer waves), but written for what this GEMM is: K is only 256-512, so
 // a 64x64 tile lives for 8-16 chunks and the per-tile start-up (first operand rows arrive from HBM, address set-up,
 // epilogue) is a large fraction of its life.  Therefore
-//   * blocks are PERSISTENT: 512 blocks walk the tile list, and the operand stream is flattened across tiles -- while
+//   * blocks are PERSISTENT: 1024 blocks (4 per CU) walk the tile list, and the operand stream is flattened across tiles -- while
 //     the consumers finish tile i (last chunks + stores) the producers already fetch the first chunks of tile i+1;
 //   * the tile order keeps the blocks that run concurrently on one XCD on the same few row-panels of V (8 n-tiles of
 //     a row-tile side by side), so V is fetched from memory once per XCD and re-read from that XCD's L2;
 //   * no per-row coordinate arithmetic at all: a row is a contiguous K-vector.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -172,6 +173,8 @@ extern "C" int cp_wino_gemm_f32(const float* V, const float* U, float* M, int ro
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.b_group_stride_bytes = (unsigned)((long long)n * k * 4);
     const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
-    CP_LAUNCH(wino_gemm_kernel, dim3(512), dim3(512), lds, (hipStream_t)stream, g);
+    static int grid = 0;
+    if (!grid) { const char* e = getenv("CP_WINO_GRID"); grid = e ? atoi(e) : 1024; }
+    CP_LAUNCH(wino_gemm_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, g);
     return cp::check_launch("cp_wino_gemm_f32");
 }

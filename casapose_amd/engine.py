@@ -436,8 +436,12 @@ class ForwardPlan:
                      head_out=self.img4, head_out_ld=self.out_ld)
                 self._out_bound.append((L[name], 0, "head_out"))
             else:
+                extra = {}
+                if i == 0 and net.reuse_first:
+                    self.y_raw = new(B, hs[l], ws[l], dims[0])
+                    extra = dict(out_raw=self.y_raw)
                 conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1],
-                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o)
+                     act=_lib.ACT_RELU if i == 0 else _lib.ACT_LEAKY01, out_act=o, **extra)
             self._bufs.append(o)
             prev, prev_c = o, dims[i]
         self.fuse_head2 = False
@@ -481,6 +485,15 @@ class ForwardPlan:
             tab = P["pv_block_%d_clade" % (i + 6)]
             l = lvl[i]
             o = new(B, hs[l], ws[l], dims[i])
+            if i == 0 and net.reuse_first:  # casa_layer(y, "6", skip_conv=True): CLADE + ReLU on block 1's raw convolution output
+                def clade_step(stream, src=self.y_raw, dst=o, tab=tab, lab=self.labels[l], n=B * hs[l] * ws[l], c=dims[0]):
+                    check(lib.cp_affine_act_f32(src.data_ptr(), n, c, c, tab[0].data_ptr(), tab[1].data_ptr(), lab.data_ptr(), _lib.ACT_RELU,
+                                                dst.data_ptr(), c, stream), "cp_affine_act_f32(pv_block_6_clade)")
+
+                self.steps.append(clade_step)
+                self._bufs.append(o)
+                prev, prev_c = o, dims[i]
+                continue
             if i == 0:
                 srcs = [dict(data=x32s, ld=512)]
             else:
@@ -503,6 +516,8 @@ class ForwardPlan:
                         self._bufs.append(big)
                         src0 = big
                 srcs = [dict(data=src0, ld=prev_c, mode=mode, sel=sel), dict(data=skips[i][0], ld=skips[i][1])]
+                if not net.skips2:
+                    srcs = srcs[:1]
             pk = dict(tap_label=self.labels[l], row_scale=self.pnorm[l]) if partial else {}
             # the fused head lives in the halo kernel, which gathers a guided/nearest x2 source only together with the tap mask
             fused = self.fuse_heads and i == 4 and (partial or not fuse_upsample or net.bilinear[3])
@@ -596,7 +611,8 @@ class CasaposeNet:
     def __init__(self, params: Dict[str, np.ndarray], seg_dim: int, ver_dim: int, device: torch.device,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
                  partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True,
-                 bilinear: Sequence[bool] = BILINEAR_DEFAULT, pvnet: bool = False):
+                 bilinear: Sequence[bool] = BILINEAR_DEFAULT, pvnet: bool = False, shared: Sequence[bool] = (False,) * 5,
+                 reuse_first: bool = False, skips2: bool = True):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -606,6 +622,11 @@ class CasaposeNet:
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.bilinear = tuple(bool(v) for v in bilinear)
         self.pvnet = bool(pvnet)  # PVNet (pose_models.py:645-696): decoder 1 only, ONE 1x1 head producing seg + vertex channels
+        # weight sharing between the decoders (pose_models.py:699-1362, the `_sw*` registry entries): shared[i] -- blocks i+1 and i+6
+        # use the PartialConvolution weights pv_block_{i+1}_{i+6}_conv2d; reuse_first -- block 6 normalises the raw output of block
+        # 1's convolution instead of convolving; skips2 False -- decoder 2 has no skip connections
+        self.shared = tuple(bool(v) for v in shared)
+        self.reuse_first, self.skips2 = bool(reuse_first), bool(skips2)
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
@@ -641,8 +662,8 @@ class CasaposeNet:
         def add(name, key, layout, k, cout, sources, stride=1, dil=1, pad=None, partial=False):
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev)
             pad = dil * (k // 2) if pad is None else pad
-            if self.use_winograd and not partial and layout == 0 and wino_eligible(k, stride, dil, pad, sources, cout):
-                Wn[name] = WinoConv(name, p[key], cout, sources, dev)
+            if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout):
+                Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev)
 
         add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])
         cin = 64
@@ -659,13 +680,21 @@ class CasaposeNet:
         skip_c = [None, (128, 128), (64, 64), (64, 64), (4, 3)]
         for i in range(5):
             srcs = [(512, 512)] if i == 0 else [(dims[i - 1], dims[i - 1]), skip_c[i]]
-            add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
-            if self.pvnet:
-                continue
-            if self.partial[i]:
-                add("pv_block_%d_prepare_conv2d" % (i + 6), "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs, partial=True)
+            shared_key = "pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6)
+            if self.shared[i]:  # one-input PartialConvolution = ordinary SAME conv with [Cin,3,3,Cout] weights
+                add("pv_block_%d_conv2d" % (i + 1), shared_key, 1, 3, dims[i], srcs)
             else:
-                add("pv_block_%d_conv2d" % (i + 6), "pv_block_%d_conv2d.kernel" % (i + 6), 0, 3, dims[i], srcs)
+                add("pv_block_%d_conv2d" % (i + 1), "pv_block_%d_conv2d.kernel" % (i + 1), 0, 3, dims[i], srcs)
+            if self.pvnet or (i == 0 and self.reuse_first):
+                continue
+            srcs2 = srcs if (self.skips2 or i == 0) else [(dims[i - 1], dims[i - 1])]
+            name2 = ("pv_block_%d_prepare_conv2d" if self.partial[i] else "pv_block_%d_conv2d") % (i + 6)
+            if self.shared[i]:
+                add(name2, shared_key, 1, 3, dims[i], srcs2, partial=self.partial[i])
+            elif self.partial[i]:
+                add(name2, "pv_block_%d_prepare_conv2d.weights" % (i + 6), 1, 3, dims[i], srcs2, partial=True)
+            else:
+                add(name2, "pv_block_%d_conv2d.kernel" % (i + 6), 0, 3, dims[i], srcs2)
         if self.pvnet:
             add("pv_final_conv", "pv_final_conv.kernel", 0, 1, self.seg_dim + self.ver_dim, [(dims[4], dims[4])])
         else:

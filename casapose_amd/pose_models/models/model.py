@@ -21,7 +21,8 @@ def _he_uniform(rng, shape, fan_in):
 
 
 def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Optional[int] = None,
-                       partial: Sequence[bool] = engine.PARTIAL_DEFAULT, pvnet: bool = False) -> Dict[str, np.ndarray]:
+                       partial: Sequence[bool] = engine.PARTIAL_DEFAULT, pvnet: bool = False, shared: Sequence[bool] = (False,) * 5,
+                       reuse_first: bool = False, skips2: bool = True) -> Dict[str, np.ndarray]:
     """Keras-default initial state: he_uniform kernels (resnet.py:31; _normalization_layers.py:317),
     BN gamma 1 / beta 0 / moving mean 0 / moving variance 1, CLADE gamma 1 / beta 0
     (_normalization_layers.py:96-107).  Keys are `<keras layer name>.<weight>`."""
@@ -54,14 +55,20 @@ def initial_parameters(seg_dim: int, ver_dim: int, dims: Sequence[int], seed: Op
     dec_in = (512, dims[0] + 128, dims[1] + 64, dims[2] + 64, dims[3] + 3)
     for i in range(5):
         ci, co = dec_in[i], dims[i]
-        p["pv_block_%d_conv2d.kernel" % (i + 1)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
+        if shared[i]:  # one PartialConvolution for blocks i+1 and i+6 (pose_models.py:727-731)
+            p["pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
+        else:
+            p["pv_block_%d_conv2d.kernel" % (i + 1)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
         bn("pv_block_%d_bn" % (i + 1), co)
         if pvnet:
             continue
-        if partial[i]:
-            p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci, 3, 3, co), 9 * ci)
+        ci2 = ci if (skips2 or i == 0) else dims[i - 1]
+        if shared[i] or (i == 0 and reuse_first):
+            pass  # no convolution weights of its own
+        elif partial[i]:
+            p["pv_block_%d_prepare_conv2d.weights" % (i + 6)] = _he_uniform(rng, (ci2, 3, 3, co), 9 * ci2)
         else:  # ordinary pad + Conv2D in decoder 2 (casapose.py:69-74)
-            p["pv_block_%d_conv2d.kernel" % (i + 6)] = _he_uniform(rng, (3, 3, ci, co), 9 * ci)
+            p["pv_block_%d_conv2d.kernel" % (i + 6)] = _he_uniform(rng, (3, 3, ci2, co), 9 * ci2)
         bn("pv_block_%d_clade" % (i + 6), co, gamma=False, beta=False)
         p["pv_block_%d_clade.gamma" % (i + 6)] = np.ones((seg_dim, co), np.float32)
         p["pv_block_%d_clade.beta" % (i + 6)] = np.zeros((seg_dim, co), np.float32)
@@ -100,7 +107,8 @@ class CasaposeModel:
     def __init__(self, name: str, ver_dim: int, seg_dim: int, dims: Sequence[int], input_shape=None,
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
                  fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
-                 guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT, pvnet: bool = False):
+                 guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT, pvnet: bool = False,
+                 shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True):
         self.output_lablemap = bool(output_lablemap)
         self.name = name
         self.ver_dim, self.seg_dim = int(ver_dim), int(seg_dim)
@@ -120,9 +128,10 @@ class CasaposeModel:
         self._pvnet = bool(pvnet)
         if self._pvnet and self.input_segmentation_shape is not None:
             raise ValueError("PVNet has no data_segmentation input")
-        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial, self._pvnet)
+        self._sharing = dict(shared=tuple(bool(v) for v in shared), reuse_first=bool(reuse_first), skips2=bool(skips2))
+        self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial, self._pvnet, **self._sharing)
         self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
-                                       self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet)
+                                       self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet, **self._sharing)
         if isinstance(weights, str):
             self.load_weights(weights)
         self._layers = self._build_layers()
@@ -139,7 +148,7 @@ class CasaposeModel:
         p = self._plan
         if p is None or (p.batch, p.h, p.w) != (batch, h, w) or p.group is not group:
             self._plan = train_engine.TrainPlan(self._store, self.seg_dim, self.ver_dim, batch, h, w, self._dims, group, world_size,
-                                                self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet)
+                                                self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet, **self._sharing)
             self._plan.refresh_weights(torch.cuda.current_stream(self.device).cuda_stream)
         return self._plan, self.device
 

@@ -4,11 +4,11 @@ from __future__ import annotations
 from .model import CasaposeModel
 
 
-def _conditional(name, partial, guided, ver_dim, seg_dim, *args, bilinear=(False,) * 5, **kwargs):
-    return _conditional_impl(name, partial, guided, bilinear, ver_dim, seg_dim, *args, **kwargs)
+def _conditional(name, partial, guided, ver_dim, seg_dim, *args, bilinear=(False,) * 5, sharing=None, **kwargs):
+    return _conditional_impl(name, partial, guided, bilinear, sharing or {}, ver_dim, seg_dim, *args, **kwargs)
 
 
-def _conditional_impl(name, partial, guided, bilinear, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
+def _conditional_impl(name, partial, guided, bilinear, sharing, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None,
                  input_segmentation_shape=None, input_tensor=None, weights=None, base_model="resnet18",
                  backbone=None, output_lablemap=False, **kwargs):
     if base_model != "resnet18":
@@ -21,7 +21,7 @@ def _conditional_impl(name, partial, guided, bilinear, ver_dim, seg_dim, fcdim=2
                          input_segmentation_shape=input_segmentation_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
                          fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True),
-                         partial=partial, guided=guided, bilinear=bilinear)
+                         partial=partial, guided=guided, bilinear=bilinear, **sharing)
 
 
 _GU = (False, True, True, True, False)  # blocks 7, 8, 9 upsample with the label-guided gather
@@ -52,6 +52,33 @@ def CASAPoseConditional4(*args, **kwargs):
 def CASAPoseConditional9(*args, **kwargs):
     """casapose_c_gcu4_bilat (pose_models.py:1102-1229): gcu4 with GuidedBilinearUpsampling instead of the guided nearest gather."""
     return _conditional("casapose_c_gcu4_bilat", (True, True, True, True, False), _GU, *args, bilinear=_GU, **kwargs)
+
+
+def CASAPoseConditional6(*args, **kwargs):
+    """casapose_c_gcu5_sw5 (pose_models.py:699-839): both decoders use the SAME five PartialConvolution weight sets
+    (`pv_block_{i}_{i+5}_conv2d`): plain SAME convolutions in decoder 1, mask-aware in decoder 2; block 6 has no convolution -- it
+    applies CLADE to the raw output of block 1's convolution (:731,:762-770)."""
+    return _conditional("casapose_c_gcu5_sw5", (False, True, True, True, True), _GU, *args,
+                        sharing=dict(shared=(True,) * 5, reuse_first=True), **kwargs)
+
+
+def CASAPoseConditional7(*args, **kwargs):
+    """casapose_c_gcu4_sw1 (pose_models.py:842-969): the decoders share the first convolution (and its output); blocks 7-10 are partial."""
+    return _conditional("casapose_c_gcu4_sw1", (False, True, True, True, True), _GU, *args,
+                        sharing=dict(shared=(True, False, False, False, False), reuse_first=True), **kwargs)
+
+
+def CASAPoseConditional8(*args, **kwargs):
+    """casapose_c_gcu5_sw1 (pose_models.py:972-1099): like _sw1 above, but decoder 2 takes NO skip connections (:1033-1079 feed y alone)."""
+    return _conditional("casapose_c_gcu5_sw1", (False, True, True, True, True), _GU, *args,
+                        sharing=dict(shared=(True, False, False, False, False), reuse_first=True, skips2=False), **kwargs)
+
+
+def CASAPoseConditional10(*args, **kwargs):
+    """casapose_c_gcu4_sw2 (pose_models.py:1232-1362): blocks 1/6 and 2/7 share their weights (decoder 2 applies them mask-aware to its
+    own inputs); blocks 8, 9 partial, block 10 an ordinary convolution."""
+    return _conditional("casapose_c_gcu4_sw2", (True, True, True, True, False), _GU, *args,
+                        sharing=dict(shared=(True, True, False, False, False)), **kwargs)
 
 
 def CASAPoseConditional5(*args, **kwargs):

@@ -19,7 +19,7 @@ def _not_built(name):
     def ctor(*args, **kwargs):
         raise NotImplementedError(
             "model `%s` is registered by the reference but its graph has not been built for MI355X yet; "
-            "available: casapose_c, casapose_c_gu, casapose_c_gcu3, casapose_c_gcu4, casapose_c_gcu5, casapose_custom" % name
+            "every casapose_* / pvnet* entry is" % name
         )
 
     ctor.__name__ = name
@@ -41,11 +41,11 @@ class ModelsFactory:
         "casapose_c_gcu5": _pm.CASAPoseConditional5,
         "pvnet_combined": _pm.PVNet,
         "casapose_custom": _cp.CASAPoseConditional,
-        "casapose_c_gcu5_sw5": _not_built("casapose_c_gcu5_sw5"),
-        "casapose_c_gcu4_sw1": _not_built("casapose_c_gcu4_sw1"),
-        "casapose_c_gcu5_sw1": _not_built("casapose_c_gcu5_sw1"),
+        "casapose_c_gcu5_sw5": _pm.CASAPoseConditional6,
+        "casapose_c_gcu4_sw1": _pm.CASAPoseConditional7,
+        "casapose_c_gcu5_sw1": _pm.CASAPoseConditional8,
         "casapose_c_gcu4_bilat": _pm.CASAPoseConditional9,
-        "casapose_c_gcu4_sw2": _not_built("casapose_c_gcu4_sw2"),
+        "casapose_c_gcu4_sw2": _pm.CASAPoseConditional10,
         "pvnet": _pm.PVNet,  # same graph; raises for the separated-vector-field sizes (> 64 output channels)
     }
 

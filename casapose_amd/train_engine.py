@@ -55,7 +55,7 @@ def forward_order() -> List[str]:
             order += [base + "bn1", base + "sc", base + "conv1", base + "bn2", base + "conv2"]
     order.append("bn1")
     for i in range(1, 6):
-        order += ["pv_block_%d_conv2d" % i, "pv_block_%d_bn" % i]
+        order += ["pv_block_%d_conv2d" % i, "pv_block_%d_%d_conv2d" % (i, i + 5), "pv_block_%d_bn" % i]
     order += ["pv_final_conv_segmentation", "pv_final_conv"]
     for i in range(6, 11):
         order += ["pv_block_%d_prepare_conv2d" % i, "pv_block_%d_conv2d" % i, "pv_block_%d_clade" % i]
@@ -413,12 +413,14 @@ class ConvOp:
             c0 = k0 = 0
             for cp_, cr in L.sources:
                 check(lib.cp_wino_weight_grad_f32(w["dU"].data_ptr(), cr, cout, w["ktot"], k0, 3 * cin * cout, cin * cout, cout, 1,
-                                                  L.master_grad.data_ptr() + 4 * c0 * cout, 0, stream), "cp_wino_weight_grad_f32(%s)" % L.name)
+                                                  L.master_grad.data_ptr() + 4 * c0 * cout, 1 if self.accumulate_master else 0, stream),
+                      "cp_wino_weight_grad_f32(%s)" % L.name)
                 c0 += cr
                 k0 += cp_
         else:
             check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
-            check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 0, stream), "cp_scatter_f32")
+            check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 1 if self.accumulate_master else 0,
+                                     stream), "cp_scatter_f32")
         for s, ent in enumerate(L.dgrad):
             if ent is None:
                 continue
@@ -530,7 +532,7 @@ class TrainPlan:
     def __init__(self, store: ParamStore, seg_dim: int, ver_dim: int, batch: int, h: int, w: int,
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, group=None, world_size: int = 1,
                  partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, bilinear: Sequence[bool] = BILINEAR_DEFAULT,
-                 pvnet: bool = False):
+                 pvnet: bool = False, shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
         if seg_dim > 32 or ver_dim > 32:
@@ -572,6 +574,8 @@ class TrainPlan:
         self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2
         self.partial, self.guided = tuple(bool(v) for v in partial), tuple(bool(v) for v in guided)
         self.bilinear = tuple(bool(v) for v in bilinear)
+        # weight sharing between the decoders (the `_sw*` registry entries; see engine.CasaposeNet)
+        self.shared, self.reuse_first, self.skips2 = tuple(bool(v) for v in shared), bool(reuse_first), bool(skips2)
         self.gmask = [torch.empty(B, hs[l], ws[l], **u8) if any(self.bilinear) else None for l in range(3)]
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
@@ -694,7 +698,15 @@ class TrainPlan:
                 l = lvl[i]
                 idx = first + i
                 partial = second and self.partial[i]
-                if partial:
+                act_kind = RELU if i == 0 else LEAKY
+                if second and i == 0 and self.reuse_first:  # casa_layer(y, "6", skip_conv=True): CLADE on block 1's raw convolution output
+                    act = new(hs[l], ws[l], dims[i])
+                    bn("pv_block_%d_clade" % idx, self._y_raw, act, act_kind, labels=self.labels[l], classes=K)
+                    prev = act
+                    continue
+                if self.shared[i]:  # one PartialConvolution weight set for blocks i+1 and i+6 ([Cin,3,3,Cout])
+                    key, layout = "pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6), 1
+                elif partial:
                     key, layout = "pv_block_%d_prepare_conv2d.weights" % idx, 1
                 else:
                     key, layout = "pv_block_%d_conv2d.kernel" % idx, 0
@@ -709,10 +721,13 @@ class TrainPlan:
                     srcs = [(dims[i - 1], dims[i - 1]), skip_c[i]]
                     tts = [(src0, dims[i - 1]), (skips[i], skips[i].c)]
                     gs = [True, skips[i].needs_grad]
+                    if second and not self.skips2:
+                        srcs, tts, gs = srcs[:1], tts[:1], gs[:1]
                 L = layer(key, layout, 3, dims[i], srcs, gs)
                 raw = new(hs[l], ws[l], dims[i])
                 act = new(hs[l], ws[l], dims[i])
-                act_kind = RELU if i == 0 else LEAKY
+                if not second and i == 0:
+                    self._y_raw = raw
                 if partial:
                     conv(L, tts, raw, hs[l], ws[l], pad=1, tap_label=self.labels[l], row_scale=self.pnorm[l])
                     bn("pv_block_%d_clade" % idx, raw, act, act_kind, labels=self.labels[l], classes=K, row_scale=self.pnorm[l])
@@ -759,6 +774,12 @@ class TrainPlan:
     def _finish_plan(self, f32):
         dev = self.store.device
         c0 = self.conv0
+        # two convolutions on one weight set: the op that runs LAST in the backward (first in the forward) adds to the master gradient
+        seen = set()
+        for op in reversed(self.ops):
+            if isinstance(op, ConvOp):
+                op.accumulate_master = op.layer.key in seen
+                seen.add(op.layer.key)
         self.tensors = [o for o in self._all_tensors()]
         # Winograd for the deep 3x3 layers (forward and data gradient); shared scratch sized for the largest of them
         self.use_winograd = os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"

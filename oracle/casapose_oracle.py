@@ -332,10 +332,31 @@ VARIANTS = {  # per decoder-2 block 6..10: (partial convolution, guided upsampli
     "casapose_c_gcu4_bilat": ((True, True, True, True, False), (False, True, True, True, False)),   # CASAPoseConditional9
 }
 BILINEAR_GUIDED = {"casapose_c_gcu4_bilat": (False, True, True, True, False)}  # blocks that use GuidedBilinearUpsampling
+# "Alternative models" that share convolution weights between the decoders (pose_models.py:699-1362).  shared[i]: block i+1 of
+# decoder 1 is the one-input PartialConvolution `pv_block_{i+1}_{i+6}_conv2d` ([Cin,3,3,Cout] weights, SAME conv) and block i+6
+# of decoder 2 uses the same weights with the mask; reuse_first: block 6 has NO convolution of its own -- it normalises the raw
+# output y of block 1's convolution (:731,:762-770); skips2 False: decoder 2 takes no skip connections (CASAPoseConditional8).
+SHARED = {
+    "casapose_c_gcu5_sw5": dict(shared=(True,) * 5, reuse_first=True, skips2=True),                           # CASAPoseConditional6
+    "casapose_c_gcu4_sw1": dict(shared=(True, False, False, False, False), reuse_first=True, skips2=True),   # CASAPoseConditional7
+    "casapose_c_gcu5_sw1": dict(shared=(True, False, False, False, False), reuse_first=True, skips2=False),  # CASAPoseConditional8
+    "casapose_c_gcu4_sw2": dict(shared=(True, True, False, False, False), reuse_first=False, skips2=True),   # CASAPoseConditional10
+}
+NOT_SHARED = dict(shared=(False,) * 5, reuse_first=False, skips2=True)
+VARIANTS.update({
+    "casapose_c_gcu5_sw5": ((False, True, True, True, True), (False, True, True, True, False)),
+    "casapose_c_gcu4_sw1": ((False, True, True, True, True), (False, True, True, True, False)),
+    "casapose_c_gcu5_sw1": ((False, True, True, True, True), (False, True, True, True, False)),
+    "casapose_c_gcu4_sw2": ((True, True, True, True, False), (False, True, True, True, False)),
+})
+
+
+def shared_key(i: int) -> str:
+    return "pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6)
 
 
 def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, randomize_norm: bool = True,
-                partial=(True,) * 5, pvnet: bool = False):
+                partial=(True,) * 5, pvnet: bool = False, shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True):
     """Random parameters of casapose_c_gcu5 (or, with ``partial``, of a variant whose decoder-2 block i is an ordinary
     convolution `pv_block_N_conv2d.kernel` when partial[i] is False) with the reference's shapes/initialisers
     (he_uniform conv kernels: resnet.py:31; _normalization_layers.py:317).  With
@@ -371,15 +392,21 @@ def init_params(seg_dim: int, ver_dim: int, seed: int = 1237, dtype=np.float32, 
     for i in range(5):
         ci, co = DECODER_IN[i], DECODER_DIMS[i]
         n1 = "pv_block_%d" % (i + 1)
-        p[n1 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
+        if shared[i]:
+            p[shared_key(i)] = he((ci, 3, 3, co), 9 * ci)
+        else:
+            p[n1 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
         bn(n1 + "_bn", co)
         n2 = "pv_block_%d" % (i + 6)
         if pvnet:
             continue
-        if partial[i]:
-            p[n2 + "_prepare_conv2d.weights"] = he((ci, 3, 3, co), 9 * ci)
+        ci2 = ci if (skips2 or i == 0) else DECODER_DIMS[i - 1]
+        if shared[i] or (i == 0 and reuse_first):
+            pass  # no weights of its own
+        elif partial[i]:
+            p[n2 + "_prepare_conv2d.weights"] = he((ci2, 3, 3, co), 9 * ci2)
         else:
-            p[n2 + "_conv2d.kernel"] = he((3, 3, ci, co), 9 * ci)
+            p[n2 + "_conv2d.kernel"] = he((3, 3, ci2, co), 9 * ci2)
         bn(n2 + "_clade", co, has_gamma=False, has_beta=False)
         if randomize_norm:
             p[n2 + "_clade.gamma"] = rng.uniform(0.5, 1.5, (seg_dim, co)).astype(dtype)
@@ -439,22 +466,33 @@ def resnet18_os8(p, img):
     return [x2s] + taps + [x32s]
 
 
-def decoder1_block(p, x, idx, leaky, upsample):
-    """casa_layer with seg_mask=None (casapose.py:61-77,98-140)."""
+def decoder1_block(p, x, idx, leaky, upsample, shared=False, return_raw=False):
+    """casa_layer with seg_mask=None (casapose.py:61-77,98-140); `shared`: the convolution is the one-input PartialConvolution
+    pv_block_{idx}_{idx+5}_conv2d (an ordinary SAME conv, _normalization_layers.py:327-331) followed by casa_layer(skip_conv=True)."""
     n = "pv_block_%d" % idx
-    x = conv2d(x, p[n + "_conv2d.kernel"], pad=1)
+    if shared:
+        x = partial_convolution(x, p[shared_key(idx - 1)])
+    else:
+        x = conv2d(x, p[n + "_conv2d.kernel"], pad=1)
+    raw = x
     x = _bn(p, n + "_bn", x)
     x = leaky_as_relu_pair(x) if leaky else relu(x)
     if upsample:
         x = upsample_bilinear_x2(x)
-    return x
+    return (x, raw) if return_raw else x
 
 
-def decoder2_block(p, x, idx, mask, leaky, guide=None, bilinear_guided=False, partial=True, upsample_nearest=False):
-    """casa_layer with [partial_conv | pad+conv] + weighted CLADE (+ guided or plain nearest upsampling)
-    (casapose.py:61-74,78-82,98-131)."""
+def decoder2_block(p, x, idx, mask, leaky, guide=None, bilinear_guided=False, partial=True, upsample_nearest=False, shared=False,
+                   skip_conv=False):
+    """casa_layer with [partial_conv | pad+conv | nothing] + weighted CLADE (+ guided or plain nearest upsampling)
+    (casapose.py:61-74,78-82,98-131).  `shared`: the weights are decoder 1's pv_block_{idx-5}_{idx}_conv2d; `skip_conv`: x already is
+    the convolution output (casa_layer(skip_conv=True))."""
     n = "pv_block_%d" % idx
-    if partial:
+    if skip_conv:
+        pass
+    elif shared:
+        x = partial_convolution(x, p[shared_key(idx - 6)], mask if partial else None)
+    elif partial:
         x = partial_convolution(x, p[n + "_prepare_conv2d.weights"], mask)
     else:
         x = conv2d(x, p[n + "_conv2d.kernel"], pad=1)
@@ -476,12 +514,14 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     Returns [B,H,W,K+ver_dim] = concat(seg logits, vertex)."""
     part, guid = VARIANTS.get(variant, ((True,) * 5, (False,) * 5))
     bil = BILINEAR_GUIDED.get(variant, (False,) * 5)
+    sv = SHARED.get(variant, NOT_SHARED)
+    sh, reuse_first, skips2 = sv["shared"], sv["reuse_first"], sv["skips2"]
     x2s, x4s, x8s, _x16s, x32s = resnet18_os8(p, img)
-    x = decoder1_block(p, x32s, 1, leaky=False, upsample=False)
-    x = decoder1_block(p, np.concatenate([x, x8s], 3), 2, True, True)
-    x = decoder1_block(p, np.concatenate([x, x4s], 3), 3, True, True)
-    x = decoder1_block(p, np.concatenate([x, x2s], 3), 4, True, True)
-    x = decoder1_block(p, np.concatenate([x, img], 3), 5, True, False)
+    x, y_raw = decoder1_block(p, x32s, 1, leaky=False, upsample=False, shared=sh[0], return_raw=True)
+    x = decoder1_block(p, np.concatenate([x, x8s], 3), 2, True, True, shared=sh[1])
+    x = decoder1_block(p, np.concatenate([x, x4s], 3), 3, True, True, shared=sh[2])
+    x = decoder1_block(p, np.concatenate([x, x2s], 3), 4, True, True, shared=sh[3])
+    x = decoder1_block(p, np.concatenate([x, img], 3), 5, True, False, shared=sh[4])
     if variant == "pvnet_combined":  # PVNet (pose_models.py:645-696): one head, no second decoder
         return conv2d(x, p["pv_final_conv.kernel"])
     logits = conv2d(x, p["pv_final_conv_segmentation.kernel"])
@@ -489,11 +529,15 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
     mask2 = half_size(mask)
     mask4 = half_size(mask2)
     mask8 = half_size(mask4)
-    y = decoder2_block(p, x32s, 6, mask8, leaky=False, partial=part[0])
-    y = decoder2_block(p, np.concatenate([y, x8s], 3), 7, mask8, True, guide=mask4 if guid[1] else None, partial=part[1], upsample_nearest=True, bilinear_guided=bil[1])
-    y = decoder2_block(p, np.concatenate([y, x4s], 3), 8, mask4, True, guide=mask2 if guid[2] else None, partial=part[2], upsample_nearest=True, bilinear_guided=bil[2])
-    y = decoder2_block(p, np.concatenate([y, x2s], 3), 9, mask2, True, guide=mask if guid[3] else None, partial=part[3], upsample_nearest=True, bilinear_guided=bil[3])
-    y = decoder2_block(p, np.concatenate([y, img], 3), 10, mask, True, partial=part[4])
+    cat = (lambda a, b: np.concatenate([a, b], 3)) if skips2 else (lambda a, b: a)
+    if reuse_first:
+        y = decoder2_block(p, y_raw, 6, mask8, leaky=False, skip_conv=True)
+    else:
+        y = decoder2_block(p, x32s, 6, mask8, leaky=False, partial=part[0], shared=sh[0])
+    y = decoder2_block(p, cat(y, x8s), 7, mask8, True, guide=mask4 if guid[1] else None, partial=part[1], upsample_nearest=True, bilinear_guided=bil[1], shared=sh[1])
+    y = decoder2_block(p, cat(y, x4s), 8, mask4, True, guide=mask2 if guid[2] else None, partial=part[2], upsample_nearest=True, bilinear_guided=bil[2], shared=sh[2])
+    y = decoder2_block(p, cat(y, x2s), 9, mask2, True, guide=mask if guid[3] else None, partial=part[3], upsample_nearest=True, bilinear_guided=bil[3], shared=sh[3])
+    y = decoder2_block(p, cat(y, img), 10, mask, True, partial=part[4], shared=sh[4])
     vertex = conv2d(y, p["pv_final_conv_vertex.kernel"])
     out = np.concatenate([logits, vertex], 3)
     if return_intermediates:

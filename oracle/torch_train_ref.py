@@ -142,7 +142,8 @@ def guided_bilinear_upsample(x, lab_lo, lab_hi):
 
 
 def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None,
-                  partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, pvnet: bool = False):
+                  partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, pvnet: bool = False,
+                  shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True):
     """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
     convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
     hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
@@ -175,7 +176,12 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
     for i in range(5):
         n = "pv_block_%d" % (i + 1)
         inp = x32s if i == 0 else torch.cat([d1, skips[i]], dim=3)
-        y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
+        if shared[i]:  # one-input PartialConvolution pv_block_{i+1}_{i+6}_conv2d: ordinary SAME conv, [Cin,3,3,Cout] weights
+            y = conv_nhwc(inp, p["pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6)].permute(1, 2, 0, 3), pad=1)
+        else:
+            y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
+        if i == 0:
+            y_raw = y
         y = bn(n + "_bn", y)
         y = F.relu(y) if i == 0 else leaky_pair(y)
         if 0 < i < 4:
@@ -189,9 +195,14 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
     d2 = None
     for i in range(5):
         n = "pv_block_%d" % (i + 6)
-        inp = x32s if i == 0 else torch.cat([d2, skips[i]], dim=3)
+        inp = x32s if i == 0 else (torch.cat([d2, skips[i]], dim=3) if skips2 else d2)
         lab = labs[lvl[i]]
-        if partial[i]:
+        if i == 0 and reuse_first:  # casa_layer(y, "6", skip_conv=True) on the raw output of block 1's convolution
+            y = y_raw
+        elif shared[i]:
+            w = p["pv_block_%d_%d_conv2d.weights" % (i + 1, i + 6)]
+            y = partial_conv(inp, w, lab) if partial[i] else conv_nhwc(inp, w.permute(1, 2, 0, 3), pad=1)
+        elif partial[i]:
             y = partial_conv(inp, p[n + "_prepare_conv2d.weights"], lab)
         else:
             y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)

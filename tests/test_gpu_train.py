@@ -325,11 +325,12 @@ def test_adam_matches_keras_formula(device, hip_lib):
 # --------------------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------------------
-def _setup(device, b, h, w, k, seed=1237, partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5):
+def _setup(device, b, h, w, k, seed=1237, partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, sharing=None):
     from casapose_amd.train_engine import ParamStore, TrainPlan
 
     v = 27
-    params = O.init_params(k, v, seed=seed, dtype=np.float32, partial=partial)
+    sharing = sharing or {}
+    params = O.init_params(k, v, seed=seed, dtype=np.float32, partial=partial, **sharing)
     rng = np.random.default_rng(seed)
     for name in params:  # non-trivial normalisation parameters
         if name.endswith(".gamma"):
@@ -337,26 +338,29 @@ def _setup(device, b, h, w, k, seed=1237, partial=(True,) * 5, guided=(False, Tr
         if name.endswith(".beta"):
             params[name] = (0.1 * rng.standard_normal(params[name].shape)).astype(np.float32)
     store = ParamStore(params, device)
-    plan = TrainPlan(store, k, v, b, h, w, partial=partial, guided=guided, bilinear=bilinear)
+    plan = TrainPlan(store, k, v, b, h, w, partial=partial, guided=guided, bilinear=bilinear, **sharing)
     img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
     lab = blob_labels(b, h, w, k, seed + 1)
     kpts = rng.uniform(0, min(h, w), (b, k - 1, 9, 2)).astype(np.float32)
     return params, store, plan, img, lab, kpts
 
 
-@pytest.mark.parametrize("variant", ["casapose_c_gcu5", "casapose_c_gcu3", "casapose_c", "casapose_c_gcu4_bilat"])
+@pytest.mark.parametrize("variant", ["casapose_c_gcu5", "casapose_c_gcu3", "casapose_c", "casapose_c_gcu4_bilat",
+                                     "casapose_c_gcu5_sw5", "casapose_c_gcu4_sw1", "casapose_c_gcu5_sw1", "casapose_c_gcu4_sw2"])
 def test_train_forward_backward_matches_autograd(device, variant):
     b, h, w, k = 2, 32, 48, 4
     part, guid = O.VARIANTS[variant]
     bil = O.BILINEAR_GUIDED.get(variant, (False,) * 5)
-    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, partial=part, guided=guid, bilinear=bil)
+    sharing = O.SHARED.get(variant, {})
+    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, partial=part, guided=guid, bilinear=bil, sharing=sharing)
     stream = torch.cuda.current_stream(device).cuda_stream
     plan.refresh_weights(stream)
     labd = torch.from_numpy(lab).to(device)
     out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd)
     p64 = R.to_torch(params)
     stats = {}
-    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats, partial=part, guided=guid, bilinear=bil)
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats, partial=part, guided=guid, bilinear=bil,
+                          **sharing)
     got = out.cpu().numpy()
     assert rel(got[..., :k], ref.detach().numpy()[..., :k]) < 1e-3
     assert rel(got[..., k:], ref.detach().numpy()[..., k:]) < 1e-3

@@ -21,8 +21,8 @@ def test_registry_names_match_reference_and_unknown_name_raises():
     assert len(names) == 18  # models_factory.py:9-32
     with pytest.raises(ValueError, match="No such model"):
         Classifiers.get("does_not_exist")
-    with pytest.raises(NotImplementedError):   # registered by the reference, graph not built here (shared decoder weights)
-        Classifiers.get("casapose_c_gcu5_sw5")(ver_dim=27, seg_dim=9)
+    with pytest.raises(NotImplementedError):   # registered by the reference, not built here: the bare backbones
+        Classifiers.get("resnet34")(input_shape=(64, 64, 3))
     with pytest.raises(NotImplementedError):   # pvnet with separated vector fields: 9 + 18*8 output channels
         Classifiers.get("pvnet")(ver_dim=144, seg_dim=9)
 
