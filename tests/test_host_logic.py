@@ -86,6 +86,35 @@ def test_initial_parameters_cover_the_oracle_parameter_set():
     assert w.shape == (512, 3, 3, 256) and abs(w).max() <= np.sqrt(6.0 / (9 * 512))  # he_uniform, fan_in 9*Cin
 
 
+@pytest.mark.parametrize("variant", sorted(O.VARIANTS))
+def test_variant_parameter_sets_and_oracle_sharing(variant):
+    """every registry variant: the model's initial parameter set equals the oracle's (names + shapes); for the shared-weight models the
+    oracle's forward must really use ONE weight set in both decoders: perturbing it changes the segmentation logits (decoder 1) and
+    the vector field (decoder 2), and with reuse_first block 6 reads block 1's convolution output."""
+    from casapose_amd.pose_models.models.model import initial_parameters
+
+    part, _ = O.VARIANTS[variant]
+    sharing = O.SHARED.get(variant, {})
+    mine = initial_parameters(4, 27, (256, 128, 64, 32, 32), seed=0, partial=part, **sharing)
+    ref = O.init_params(4, 27, partial=part, dtype=np.float64, **sharing)
+    assert set(mine) == set(ref)
+    assert all(mine[k].shape == ref[k].shape for k in mine)
+    if not sharing:
+        return
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-1, 1, (1, 16, 24, 3))
+    lab = np.zeros((1, 16, 24), np.int64)
+    lab[:, 4:12, 6:18] = 1
+    seg = O.onehot_from_labels(lab, 4, np.float64)
+    base = O.casapose_c_gcu5(ref, img, seg_input=seg, variant=variant)
+    i = max(j for j in range(5) if sharing["shared"][j])
+    bumped = dict(ref)
+    bumped[O.shared_key(i)] = ref[O.shared_key(i)] * 1.5
+    out = O.casapose_c_gcu5(bumped, img, seg_input=seg, variant=variant)
+    assert np.abs(out[..., :4] - base[..., :4]).max() > 1e-6 and np.abs(out[..., 4:] - base[..., 4:]).max() > 1e-6
+    assert ("pv_block_6_prepare_conv2d.weights" in ref) == (not sharing["reuse_first"] and not sharing["shared"][0])
+
+
 def test_config_precedence_and_postprocessing(tmp_path):
     from casapose_amd.utils.config_parser import parse_config
 
