@@ -244,6 +244,7 @@ class ConvOp:
         gradient of the output lives (default: out.grad)."""
         self.layer, self.srcs, self.out, self.residual = layer, list(srcs), out, residual
         self.tap_label, self.row_scale = tap_label, row_scale
+        self.accumulate_master = False  # True: another convolution on the same weights has already written the master gradient
         self.stride, self.dil, self.pad = stride, dilation, pad
         self.batch, self.in_h, self.in_w = batch, in_h, in_w
         k = layer.k
