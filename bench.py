@@ -138,9 +138,106 @@ def bench_train(args):
         dist.destroy_process_group()
 
 
+def bench_vote(args):
+    """Voting stage alone on the SURVEY 8(d) voting inputs (exact unit field towards random keypoints + N(0, 0.05 rad) angular noise,
+    confidences N(0,1), 8 elliptical masks): the LS voter with the component filter (HBM-bound: H*W*36*4 = 44.24 MB per image read
+    once) and the RANSAC voter (VALU / ballot-bound: reported as cosine tests per second)."""
+    import numpy as np
+    import torch
+
+    from casapose_amd import parallel
+    from casapose_amd.pose_estimation.ransac_voting import ransac_voting_layer_all_masks
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+
+    rank, local, world = parallel.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, H, W, K, kp = args.batch, args.height, args.width, 9, 9
+    g = torch.Generator(device="cpu").manual_seed(1237 + rank)
+    lab = torch.zeros(B, H, W, dtype=torch.long)
+    kpts = torch.zeros(B, K - 1, kp, 2)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32) + 0.5, torch.arange(W, dtype=torch.float32) + 0.5, indexing="ij")
+    direct = torch.zeros(B, H, W, kp, 2)
+    for o in range(K - 1):
+        cy, cx = H * (0.25 + 0.5 * (o // 4)), W * (0.125 + 0.25 * (o % 4))
+        ry, rx = H * 0.2, W * 0.1
+        m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        lab[:, m] = o + 1
+        kpts[:, o, :, 0] = cy + ry * (2 * torch.rand(B, kp, generator=g) - 1)
+        kpts[:, o, :, 1] = cx + rx * (2 * torch.rand(B, kp, generator=g) - 1)
+        d = kpts[:, o][:, None, :, :] - torch.stack([yy[m], xx[m]], -1)[None, :, None, :]           # [B, px, kp, 2] (dy, dx)
+        ang = torch.atan2(d[..., 0], d[..., 1]) + 0.05 * torch.randn(d.shape[:-1], generator=g)
+        direct[:, m] = torch.stack([torch.sin(ang), torch.cos(ang)], -1)
+    seg = (10.0 * torch.nn.functional.one_hot(lab, K).float()).to(dev)
+    direct = direct.reshape(B, H, W, 2 * kp).to(dev)
+    conf = torch.randn(B, H, W, kp, generator=g).to(dev)
+    rec = torch.cat([seg, direct, conf], 3).contiguous()   # the record layout the forward writes: [9 | 18 | 9]
+    voter = CoordLSVotingWeighted(name="coords_ls_voting", num_classes=K, num_points=kp, filter_estimates=True)
+    mask = torch.nn.functional.one_hot(lab, K)[..., 1:].float().to(dev)
+    vertex = direct.reshape(B, H, W, kp, 2)
+    draws = torch.randint(0, 2**31 - 1, (20, B, K - 1, 512, kp, 2), device=dev, dtype=torch.int32, generator=torch.Generator(device=dev).manual_seed(7))
+
+    def ls_step():
+        return voter([rec[..., :K], rec[..., K:K + 2 * kp], rec[..., K + 2 * kp:]])
+
+    for _ in range(args.warmup):
+        coords = ls_step()
+    parallel.barrier_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coords = ls_step()
+    parallel.barrier_sync(dev)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    err = float((coords.cpu() - kpts).abs().max())
+    # the accumulation kernel alone, HIP events on the launch stream
+    from casapose_amd import ops
+    labels8 = lab.to(torch.uint8).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.ls_vote(rec, 0, K, K + 2 * kp, K - 1, kp, labels=labels8)
+    e0.record()
+    for _ in range(args.steps):
+        ops.ls_vote(rec, 0, K, K + 2 * kp, K - 1, kp, labels=labels8)
+    e1.record()
+    e1.synchronize()
+    ls_us = 1e3 * e0.elapsed_time(e1) / args.steps
+    alg_bytes = B * H * W * 36 * 4
+    # RANSAC voter
+    out, rounds = ransac_voting_layer_all_masks(mask, vertex, 512, draws=draws, return_rounds=True)
+    e0.record()
+    for _ in range(args.steps):
+        out, rounds = ransac_voting_layer_all_masks(mask, vertex, 512, draws=draws, return_rounds=True)
+    e1.record()
+    e1.synchronize()
+    rs_ms = e0.elapsed_time(e1) / args.steps
+    tn = torch.clamp(mask.sum((1, 2)), max=30000).double()                                     # pixels per (image, object)
+    tests = float((rounds.double() * 512 * kp * tn).sum())
+    rerr = float((out.cpu().flip(-1) - kpts).abs().max())
+    result = {
+        "metric": "keypoint-voting images/sec at 640x480, 8 objects (component filter + LS voter)", "value": round(world * B * args.steps / dt, 3),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp64 accumulation)",
+        "data": "synthetic (SURVEY 8d voting inputs: exact field + N(0, 0.05 rad) noise, conf N(0,1), 8 ellipses)",
+        "config": {"workload": "voting stage: bs=%d per GPU, %dx%d, 8 objects, 9 keypoints, record [9|18|9] fp32" % (B, H, W), "images_per_gpu_per_step": B,
+                   "parallelism": "replicas x%d (no collective)" % world},
+        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ls_us / 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_bytes / ls_us / 1e3 / 8000.0, 4),
+                     "traffic": None, "kernel": "ls_accumulate36_kernel (+ ls_solve_kernel)", "avg_launch_us": round(ls_us, 2),
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "ls_max_keypoint_error_px": round(err, 3),
+        "ransac": {"ms_per_call": round(rs_ms, 3), "images_per_s": round(B / rs_ms * 1e3, 1), "cosine_tests_per_s": round(tests / rs_ms * 1e3, 1),
+                   "rounds_mean": round(float(rounds.double().mean()), 2), "max_keypoint_error_px": round(rerr, 3),
+                   "note": "512 hypotheses x 9 keypoints x object pixels per round; fp32 VALU + wave ballots, no MFMA"},
+    }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer", help="infer = the headline metric (default); train = one DP training step")
+    ap.add_argument("--mode", choices=["infer", "train", "vote"], default="infer",
+                    help="infer = the headline metric (default); train = one DP training step; vote = the voting stage alone (LS + RANSAC)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -154,6 +251,8 @@ def main():
         if args.batch == 16 and args.height == 480 and args.width == 640:  # training defaults (config_8.ini:18, BASELINE configs[2])
             args.batch, args.height, args.width = 32, 448, 448
         return bench_train(args)
+    if args.mode == "vote":
+        return bench_vote(args)
 
     import numpy as np
     import torch

@@ -16,6 +16,7 @@
 // only flushes (LDS fp64 atomics) when its label changes or the strip ends; the block then
 // adds its LDS table to the global fp64 sums with one atomic per entry.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -101,13 +102,21 @@ __global__ __launch_bounds__(256) void ls_accumulate_kernel(const float* __restr
                 flush();
                 cur = lab;
             }
+#ifdef LS_NOCOMPUTE
+            if (lab > 250) {
+#else
             if (lab > 0) {
+#endif
                 const float cy = ((float)y + 0.5f) / (float)H;
 #pragma unroll
                 for (int j = 0; j < KP; ++j) {
                     float dy = px[dir_off + 2 * j], dx = px[dir_off + 2 * j + 1];
                     float cf = px[conf_off + j];
+#ifdef LS_NOSOFTPLUS
+                    float w = fmaxf(cf, 0.f);
+#else
                     float w = fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf)));  // softplus (:35)
+#endif
                     float nrm = sqrtf(dy * dy + dx * dx);
                     float ny = (nrm > 0.f) ? dy / nrm : 0.f;  // divide_no_nan (:90)
                     float nx = (nrm > 0.f) ? dx / nrm : 0.f;
@@ -116,6 +125,140 @@ __global__ __launch_bounds__(256) void ls_accumulate_kernel(const float* __restr
                     float r11 = (1.0f - nx * nx) * w;
                     float q0 = r00 * cy + r01 * cx;  // (:103-105)
                     float q1 = r01 * cy + r11 * cx;
+                    a[j][0] += (double)r00;
+                    a[j][1] += (double)r01;
+                    a[j][2] += (double)r11;
+                    a[j][3] += (double)q0;
+                    a[j][4] += (double)q1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // all lanes done reading before the next row overwrites
+        }
+        flush();
+    }
+    __syncthreads();
+    double* gdst = sums + (size_t)img * nacc;
+    for (int i = tid; i < nacc; i += blockDim.x) {
+        double v = acc_lds[i];
+        if (v != 0.0) atomicAdd(gdst + i, v);
+    }
+}
+
+// Fast path for the production record [9 logits | 18 directions | 9 confidences] (ld = 36, 8 objects, 9 keypoints): same strip
+// decomposition and arithmetic as above, but
+//   * the next row segment (64 pixels = 9216 contiguous bytes = nine 16-byte loads per lane) is fetched into registers while the
+//     current one is processed -- the generic kernel waits for every row's memory latency (measured 3.1 TB/s with the arithmetic
+//     removed); and
+//   * a lane reads its pixel back from the staging buffer as nine 16-byte LDS reads (144-byte pixel stride: conflict-free) with
+//     compile-time channel positions, instead of 27 scalar reads with 4-way bank conflicts.
+__global__ __launch_bounds__(256) void ls_accumulate36_kernel(const float* __restrict__ field, const uint8_t* __restrict__ labels, int B, int H,
+                                                              int W, double* __restrict__ sums, int strips_x, int strips_y) {
+    constexpr int KP = 9, LD = 36, OBJ = 8, NV = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* acc_lds = reinterpret_cast<double*>(smem_raw);                                // [OBJ][KP][5]
+    float4* stage = reinterpret_cast<float4*>(smem_raw + sizeof(double) * OBJ * KP * 5);   // [WAVES][64*NV]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int nacc = OBJ * KP * 5;
+    for (int i = tid; i < nacc; i += blockDim.x) acc_lds[i] = 0.0;
+    __syncthreads();
+
+    const int strips_per_img = strips_x * strips_y;
+    const int blocks_per_img = (strips_per_img + WAVES - 1) / WAVES;
+    const int img = blockIdx.x / blocks_per_img;
+    const int sidx = (blockIdx.x % blocks_per_img) * WAVES + wave;
+    float4* wstage = stage + (size_t)wave * 64 * NV;
+
+    if (sidx < strips_per_img) {
+        const int sy = sidx / strips_x, sx = sidx % strips_x;
+        const int x0 = sx * 64, y0 = sy * ROWS;
+        const int x = x0 + lane;
+        const int ncols = min(64, W - x0);
+        const int nvec = ncols * NV;
+        const float cx = ((float)x + 0.5f) / (float)H;
+
+        double a[KP][5];
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) a[j][c] = 0.0;
+        int cur = 0;
+        auto flush = [&]() {
+            if (cur > 0) {
+                double* dst = acc_lds + (size_t)(cur - 1) * KP * 5;
+#pragma unroll
+                for (int j = 0; j < KP; ++j)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        atomicAdd(dst + j * 5 + c, a[j][c]);
+                        a[j][c] = 0.0;
+                    }
+            }
+        };
+
+        float4 pre[NV];
+        int lab_pre = 0;
+        auto issue = [&](int y) {
+            const float4* g = reinterpret_cast<const float4*>(field + (((size_t)img * H + y) * W + x0) * LD);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = lane + 64 * i;
+                pre[i] = (v < nvec) ? g[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (labels) lab_pre = (lane < ncols) ? (int)labels[((size_t)img * H + y) * W + x] : 0;
+        };
+        const int y_end = min(y0 + ROWS, H);
+        issue(y0);
+        for (int y = y0; y < y_end; ++y) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) wstage[lane + 64 * i] = pre[i];
+            int lab = lab_pre;
+            if (y + 1 < y_end) issue(y + 1);  // in flight while this row is processed
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed (the prefetch stays in flight)
+            float r[LD];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 q = wstage[lane * NV + i];
+                r[4 * i] = q.x; r[4 * i + 1] = q.y; r[4 * i + 2] = q.z; r[4 * i + 3] = q.w;
+            }
+            if (!labels) {
+                lab = 0;
+                float best = r[0];
+#pragma unroll
+                for (int k = 1; k <= OBJ; ++k)
+                    if (r[k] > best) { best = r[k]; lab = k; }
+                if (lane >= ncols) lab = 0;
+            }
+            if (lab != cur) {
+                flush();
+                cur = lab;
+            }
+#ifdef LS_NOCOMPUTE
+            if (lab > 250) {
+#else
+            if (lab > 0) {
+#endif
+                const float cy = ((float)y + 0.5f) / (float)H;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const float dy = r[9 + 2 * j], dx = r[9 + 2 * j + 1];
+                    const float cf = r[27 + j];
+                    // softplus (:35) = max(x,0) + log1p(exp(-|x|)) on the hardware exp2 / log2 units: t = exp(-|x|) in (0,1], and
+                    // log1p(t) = log(u) + (t - (u - 1)) / u with u = fl(1 + t) restores the bits the addition drops (error ~1e-7 of w;
+                    // the libm calls of the generic kernel cost as much as the whole memory stream)
+                    const float t = __expf(-fabsf(cf));
+                    const float u = 1.0f + t;
+                    const float w = fmaxf(cf, 0.f) + (__logf(u) + (t - (u - 1.0f)) * __frcp_rn(u));
+                    const float n2 = dy * dy + dx * dx;
+                    const float inv = (n2 > 0.f) ? __frsqrt_rn(n2) : 0.f;  // divide_no_nan (:90); one reciprocal square root for both components
+                    const float ny = dy * inv, nx = dx * inv;
+                    const float r00 = (1.0f - ny * ny) * w;
+                    const float r01 = (0.0f - ny * nx) * w;
+                    const float r11 = (1.0f - nx * nx) * w;
+                    const float q0 = r00 * cy + r01 * cx;  // (:103-105)
+                    const float q1 = r01 * cy + r11 * cx;
                     a[j][0] += (double)r00;
                     a[j][1] += (double)r01;
                     a[j][2] += (double)r11;
@@ -373,8 +516,12 @@ extern "C" int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_o
     int strips_x = (w + 63) / 64, strips_y = (h + ROWS - 1) / ROWS;
     int blocks_per_img = (strips_x * strips_y + WAVES - 1) / WAVES;
     size_t lds = sizeof(double) * objects * kp * 5 + sizeof(float) * WAVES * 64 * ld;
-    CP_LAUNCH((ls_accumulate_kernel<MAXKP>), dim3(batch * blocks_per_img), dim3(256), lds, st, field, ld, seg_off,
-                       dir_off, conf_off, labels, batch, h, w, objects, sums_ws, strips_x, strips_y);
+    if (ld == 36 && seg_off == 0 && dir_off == 9 && conf_off == 27 && objects == 8 && !getenv("CP_LS_GENERIC")) {  // the production record
+        CP_LAUNCH(ls_accumulate36_kernel, dim3(batch * blocks_per_img), dim3(256), lds, st, field, labels, batch, h, w, sums_ws, strips_x, strips_y);
+    } else {
+        CP_LAUNCH((ls_accumulate_kernel<MAXKP>), dim3(batch * blocks_per_img), dim3(256), lds, st, field, ld, seg_off,
+                  dir_off, conf_off, labels, batch, h, w, objects, sums_ws, strips_x, strips_y);
+    }
     int total = batch * objects * kp;
     CP_LAUNCH(ls_solve_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, total, h, keypoints);
     return cp::check_launch("cp_ls_vote_f32");

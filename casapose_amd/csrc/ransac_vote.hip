@@ -139,8 +139,8 @@ __global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_
 }
 
 // ---- 3. voting --------------------------------------------------------------------------------
+// the reference's expression (voting_for_hypothesis, :236-247) as written; used by the refinement pass over the winners' inliers
 __device__ __forceinline__ bool inlier_test(float dx, float dy, float nd, float cx, float cy, float hx, float hy, float thresh) {
-    // voting_for_hypothesis (:236-247)
     const float ex = hx - cx, ey = hy - cy;
     const float nh = sqrtf(ex * ex + ey * ey);
     const bool valid = nd > 1e-6f && nh > 1e-6f && fabsf(hx + hy) > 1e-6f;
@@ -148,12 +148,19 @@ __device__ __forceinline__ bool inlier_test(float dx, float dy, float nd, float 
     return valid && ang > thresh;
 }
 
+// voting_for_hypothesis (:236-247): a pixel is an inlier of hypothesis h iff cos(angle between its direction d and the ray e = h - c) >
+// thresh, with |d| > 1e-6, |e| > 1e-6 and |hx + hy| > 1e-6.  Almost every test is decided without the square root and the division:
+// with s = d.e the inequality s / (|d||e|) > t is s > 0 and s^2 > t^2 |d|^2 |e|^2 (t >= 0); only when the two sides agree to 1e-5 (far
+// more than the rounding of either form) the reference's own expression is evaluated, so the decision is the reference's in every case.
+// Per pixel (dx, dy, |d|, t^2|d|^2) are prepared once for all hypotheses (|d| <= 1e-6: d = 0 and t^2|d|^2 = 1, never an inlier); an invalid
+// hypothesis is stored as NaN (every comparison false).
 __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects,
                                                    const int* __restrict__ pixlist, int list_stride, const float* __restrict__ hyp_pts,
                                                    int hyp, const ObjState* __restrict__ st, int* __restrict__ counts, float thresh,
                                                    int px_chunks) {
-    // grid: (hyp / HB, px_chunks, image*object).  A block votes HB hypotheses x 9 keypoints over one chunk of pixels.
-    __shared__ float hp[HB * KP * 2];
+    // grid: (hyp / HB, px_chunks, image*object).  A block votes HB hypotheses x 9 keypoints over one chunk of pixels: a lane per pixel, the
+    // wave's inlier count of a (hypothesis, keypoint) pair is popcount(ballot) and lands in lane `hypothesis` of counter register `keypoint`.
+    __shared__ float2 hp[HB * KP];
     __shared__ int cnt[HB * KP];
     const int io = blockIdx.z;
     const ObjState& s = st[io];
@@ -161,19 +168,27 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ ver
     const int img = io / objects;
     const int h0 = blockIdx.x * HB;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < HB * KP * 2; i += blockDim.x) hp[i] = hyp_pts[((size_t)io * hyp + h0) * KP * 2 + i];
-    for (int i = tid; i < HB * KP; i += blockDim.x) cnt[i] = 0;
+    for (int i = tid; i < HB * KP; i += blockDim.x) {
+        float hx = hyp_pts[(((size_t)io * hyp + h0) * KP + i) * 2], hy = hyp_pts[(((size_t)io * hyp + h0) * KP + i) * 2 + 1];
+        if (!(fabsf(hx + hy) > 1e-6f)) hx = hy = __builtin_nanf("");
+        hp[i] = make_float2(hx, hy);
+        cnt[i] = 0;
+    }
     __syncthreads();
     const int* pl = pixlist + (size_t)io * list_stride;
     const int per_chunk = (s.tn + px_chunks - 1) / px_chunks;
     const int t_begin = blockIdx.y * per_chunk, t_end = min(s.tn, t_begin + per_chunk);
-    int local[(HB * KP + 63) / 64 + 1];  // lane j keeps the count of pair j + 64*r
+    const bool exact_only = !(thresh >= 0.f);  // the squared form needs t >= 0
+    const float t2 = thresh * thresh;
+    int cntv[KP];  // lane hh: inliers of (hypothesis hh, keypoint v) seen by this wave
 #pragma unroll
-    for (int r = 0; r < (HB * KP + 63) / 64; ++r) local[r] = 0;
+    for (int v = 0; v < KP; ++v) cntv[v] = 0;
     for (int t0 = t_begin + (tid & ~63); t0 < t_end; t0 += blockDim.x) {
         const int t = t0 + lane;
         const bool act = t < t_end;
-        float cx = 0.f, cy = 0.f, dxv[KP], dyv[KP], ndv[KP];
+        float cx = 0.f, cy = 0.f, dxv[KP], dyv[KP], ndv[KP], qv[KP];
+#pragma unroll
+        for (int v = 0; v < KP; ++v) { dxv[v] = dyv[v] = 0.f; ndv[v] = 1.f; qv[v] = 1.f; }
         if (act) {
             const int pix = pl[t];
             const int y = pix / W, x = pix - y * W;
@@ -182,29 +197,35 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ ver
             const float* p = vertex + ((size_t)img * H * W + pix) * ld + dir_off;
 #pragma unroll
             for (int v = 0; v < KP; ++v) {
-                dyv[v] = p[2 * v];
-                dxv[v] = p[2 * v + 1];
-                ndv[v] = sqrtf(dxv[v] * dxv[v] + dyv[v] * dyv[v]);
+                const float dy = p[2 * v], dx = p[2 * v + 1];
+                const float nd = sqrtf(dx * dx + dy * dy);
+                if (nd > 1e-6f) { dxv[v] = dx; dyv[v] = dy; ndv[v] = nd; qv[v] = t2 * (nd * nd); }
             }
-        } else {
-#pragma unroll
-            for (int v = 0; v < KP; ++v) dxv[v] = dyv[v] = ndv[v] = 0.f;
         }
-#pragma unroll
+#pragma unroll 1
         for (int hh = 0; hh < HB; ++hh) {
+            const bool mine = lane == hh;
 #pragma unroll
             for (int v = 0; v < KP; ++v) {
-                const int pair = hh * KP + v;
-                const bool in = act && inlier_test(dxv[v], dyv[v], ndv[v], cx, cy, hp[pair * 2], hp[pair * 2 + 1], thresh);
-                const int c = __popcll(__ballot(in));  // wave-uniform
-                if (lane == (pair & 63)) local[pair >> 6] += c;
+                const float2 h = hp[hh * KP + v];
+                const float ex = h.x - cx, ey = h.y - cy;
+                const float e2 = ex * ex + ey * ey;
+                const float sd = dxv[v] * ex + dyv[v] * ey;
+                const float lhs = sd * sd, rhs = qv[v] * e2;
+                bool in = sd > 0.f && lhs > rhs && e2 > 0.9e-12f;
+                if (exact_only || fabsf(lhs - rhs) <= 1e-5f * rhs || e2 < 1.1e-12f) {  // borderline: the reference's expression
+                    const float nh = sqrtf(e2);
+                    in = nh > 1e-6f && (sd / (ndv[v] * nh)) > thresh && (dxv[v] != 0.f || dyv[v] != 0.f);
+                }
+                const int c = __popcll(__ballot(in && act));  // wave-uniform
+                cntv[v] += mine ? c : 0;
             }
         }
     }
+    if (lane < HB) {
 #pragma unroll
-    for (int r = 0; r < (HB * KP + 63) / 64; ++r) {
-        const int pair = r * 64 + lane;
-        if (pair < HB * KP && local[r]) atomicAdd(&cnt[pair], local[r]);
+        for (int v = 0; v < KP; ++v)
+            if (cntv[v]) atomicAdd(&cnt[lane * KP + v], cntv[v]);
     }
     __syncthreads();
     for (int i = tid; i < HB * KP; i += blockDim.x)
