@@ -63,6 +63,14 @@ def measured_traffic(tile):
     return round(tot / n) if n else None
 
 
+def _dtype_note():
+    """the arithmetic type of the MFMA kernels: exact fp32 MFMA by default; with the opt-in CASAPOSE_WINO_GEMM=split the Winograd GEMMs run as
+    exact three-way bf16 splits on the bf16 matrix pipe (fp32-equivalent results) and the line says so."""
+    if os.environ.get("CASAPOSE_WINO_GEMM", "") == "split":
+        return "f32 (OPT-IN: Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six products, fp32 accumulate)"
+    return "f32"
+
+
 def bench_train(args):
     """Secondary workload (BASELINE.json configs[2]/[3]): one data-parallel TRAINING step of casapose_c_gcu5 --
     forward with batch statistics (SyncBN all-reduced across ranks), mask/vertex/proxy/keypoint losses, hand-written
@@ -122,7 +130,7 @@ def bench_train(args):
     result = {
         "metric": "training images/sec at 448x448, 8-object (casapose_c_gcu5 forward + losses + backward + Adam)",
         "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _dtype_note(),
         "data": "synthetic (seed 1237: uniform images, 8 elliptical objects, he_uniform weights)",
         "config": {"workload": "config_8.ini training step: casapose_c_gcu5, K=9, ver_dim=27, bs=%d per GPU, %dx%d, fp32, GT-mask conditioning, "
                                "mask+vertex+proxy+keypoint losses, SyncBN, Adam" % (B, H, W),
@@ -317,7 +325,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": _dtype_note(),
         "data": "synthetic (seed 1237: uniform [-1,1) images, he_uniform weights, randomised BN/CLADE statistics)",
         "config": {"workload": "config_8.ini inference: casapose_c_gcu5, K=9 classes, ver_dim=27, bs=%d per GPU, %dx%d, fp32, estimated-mask conditioning, connected-component filter + LS voting" % (B, H, W),
                    "images_per_gpu_per_step": B, "parallelism": "replicas x%d (no collective)" % world},

@@ -1,0 +1,232 @@
+// Grouped GEMM of the Winograd path on the bf16 matrix pipe with fp32-equivalent accuracy (OPT-IN):
+//     M[p][t][n] = sum_k V[p][t][k] * U[p][n][k]
+// Every fp32 operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significand bits):
+//     hi = trunc_bf16(x),  mid = trunc_bf16(x - hi),  lo = x - hi - mid
+// and the six products  hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi  are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Each
+// product of two bf16 numbers is exact in fp32; the three dropped products (mid*lo, lo*mid, lo*lo) are <= 2^-24 of the full product,
+// i.e. the rounding an fp32 multiply makes anyway.  Six bf16 MFMAs of K = 16 cost 6 x 32 cycles against 8 x 64 for the fp32 MFMA.
+//
+// Sizing (why this is not wino_gemm.hip with another instruction): at this MFMA rate a 32x32 per-wave tile would need ~3x the LDS
+// bandwidth of a CU for its fragment reads, so a block is 128 x 128 with four consumer waves of 64 x 64 (12 fragment reads per 24 MFMAs
+// and K = 16), four producer waves that split fp32 -> 3 x bf16 while they stage (memory traffic stays fp32: no extra copies of V / U
+// in HBM), two LDS stages of 60 KB, one persistent block per CU.  Measured 175-180 TFLOP/s-equivalent against 115-120 for the fp32 MFMA
+// kernel; with the MFMAs or the splitting removed it still takes 80 % of its time (LDS traffic: 156 KB per chunk).  The alternative of
+// keeping fp32 in LDS and splitting in the consumers (each fragment split by two waves) was measured slower: 149 TFLOP/s-equivalent.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BK = 32;          // k per chunk
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 80;        // bytes per staged row of one split: 32 bf16 (64 B) + 16 B pad -> conflict-free 16-byte fragment reads
+constexpr int SPLIT_BYTES = BM * ROWB;          // one split plane of a 128-row tile
+constexpr int TILE_BYTES = 3 * SPLIT_BYTES;     // hi, mid, lo
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A and B
+
+struct SplitK {
+    const float* A;
+    const float* B;
+    float* C;
+    int rows, N, K, group_rows, nchunks, tiles_m, tiles_n;
+    unsigned a_bytes, b_bytes, b_group_stride_bytes;
+};
+
+// exact three-way split of four floats into packed bf16 pairs: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of
+// x - hi - mid (that last remainder has at most 8 significant bits, so taking its top half is exact).  v_perm_b32 packs the high halves.
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float r1 = x[e] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+        m[e] = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, m[e] & 0xffff0000u);
+        l[e] = __builtin_bit_cast(unsigned, r2);
+    }
+    // perm(src0, src1, sel): byte k of the result = byte sel[k] of {src0 (bytes 4-7), src1 (bytes 0-3)}; 0x07060302 = [hi16(src1), hi16(src0)]
+    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+
+__global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][A | B][3 splits][128 rows][80 B]
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255;
+    const int lane = tid & 63;
+
+    // tile sequence: XCD x owns a contiguous run of the (m-major, n-minor) tile list (same scheme as wino_gemm.hip)
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nx = 8;
+    const int xcd = blockIdx.x % nx, bidx = blockIdx.x / nx, nb = gridDim.x / nx;
+    const int q_ = ntiles / nx, r_ = ntiles % nx;
+    const int start = (xcd < r_) ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+    const int cnt = q_ + (xcd < r_ ? 1 : 0);
+    const int my_items = (cnt > bidx) ? (cnt - bidx + nb - 1) / nb : 0;
+    const int total_chunks = my_items * p.nchunks;
+    if (total_chunks == 0) return;
+
+#define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    if (producer) {
+        const int col4 = tid & 7, rbase = tid >> 3;  // 32 rows x 8 float4 per pass, four passes per operand
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+        float4 areg[4], breg[4];
+        unsigned aoff[4], boff[4];
+        int it = -1, q = p.nchunks;
+        auto advance = [&]() {
+            if (++q >= p.nchunks) {
+                q = 0;
+                ++it;
+                const int tile = start + bidx + it * nb;
+                const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+                const int m0 = tm * BM, n0 = tn * BN;
+                const unsigned gofs = (unsigned)(m0 / p.group_rows) * p.b_group_stride_bytes;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rbase + 32 * i;
+                    aoff[i] = ((unsigned)(m0 + r) * (unsigned)p.K + col4 * 4) * 4u;
+                    boff[i] = (n0 + r < p.N) ? gofs + ((unsigned)(n0 + r) * (unsigned)p.K + col4 * 4) * 4u : OOB;
+                }
+            }
+        };
+        auto issue = [&]() {
+            advance();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], q * (BK * 4), 0));
+                breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)boff[i], q * (BK * 4), 0));
+            }
+        };
+        auto store = [&](int buf) {
+            unsigned char* a = smem + buf * STAGE_BYTES + rbase * ROWB + col4 * 8;
+            unsigned char* b = a + TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint2 h, m, l;
+                split4(areg[i], h, m, l);
+                *reinterpret_cast<uint2*>(a + 32 * i * ROWB) = h;
+                *reinterpret_cast<uint2*>(a + 32 * i * ROWB + SPLIT_BYTES) = m;
+                *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
+                split4(breg[i], h, m, l);
+                *reinterpret_cast<uint2*>(b + 32 * i * ROWB) = h;
+                *reinterpret_cast<uint2*>(b + 32 * i * ROWB + SPLIT_BYTES) = m;
+                *reinterpret_cast<uint2*>(b + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
+            }
+        };
+        issue();
+        store(0);
+        if (total_chunks > 1) issue();
+        CP_BARRIER();
+        for (int c = 0; c < total_chunks; ++c) {
+            if (c + 1 < total_chunks) {
+                store((c + 1) & 1);
+                if (c + 2 < total_chunks) issue();
+            }
+            CP_BARRIER();
+        }
+        return;
+    }
+
+    // ---------------------------------- consumers: 2 x 2 waves of 64 x 64 ------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, kh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][2][3], fb[2][2][3];   // [slot][row / column block][split]
+    auto read_frags = [&](int buf, int ks, int slot) {
+        const unsigned char* a = smem + buf * STAGE_BYTES + (wm * 64 + lrow) * ROWB + ks * 32 + kh * 16;
+        const unsigned char* b = smem + buf * STAGE_BYTES + TILE_BYTES + (wn * 64 + lrow) * ROWB + ks * 32 + kh * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                fa[slot][i][s] = *reinterpret_cast<const bf16x8*>(a + i * 32 * ROWB + s * SPLIT_BYTES);
+                fb[slot][i][s] = *reinterpret_cast<const bf16x8*>(b + i * 32 * ROWB + s * SPLIT_BYTES);
+            }
+    };
+    auto mfma_step = [&](int slot) {
+        // smallest terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int sa = (t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0;   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            const int sb = (t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i][sa], fb[slot][j][sb], acc[i][j], 0, 0, 0);
+        }
+    };
+    CP_BARRIER();  // stage 0 ready
+    read_frags(0, 0, 0);
+    int it = 0, q = 0;
+    for (int c = 0; c < total_chunks; ++c) {
+        const int buf = c & 1;
+        read_frags(buf, 1, 1);
+        mfma_step(0);
+        mfma_step(1);
+        CP_BARRIER();
+        if (c + 1 < total_chunks) read_frags(buf ^ 1, 0, 0);
+        if (++q == p.nchunks) {
+            const int tile = start + bidx + it * nb;
+            const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = tn * BN + wn * 64 + j * 32 + lrow;
+                    float* dst = p.C + (size_t)(tm * BM + wm * 64 + i * 32 + kh * 4) * p.N + col;
+                    if (col < p.N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][j][r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            q = 0;
+            ++it;
+        }
+    }
+#undef CP_BARRIER
+}
+
+}  // namespace
+
+extern "C" int cp_wino_gemm_split_f32(const float* V, const float* U, float* M, int rows, int group_rows, int k, int n, void* stream) {
+    CP_REQUIRE(V && U && M, "cp_wino_gemm_split_f32: null pointer");
+    CP_REQUIRE(rows > 0 && group_rows > 0 && rows % group_rows == 0 && group_rows % 128 == 0, "cp_wino_gemm_split_f32: rows must be whole groups of a multiple of 128 rows");
+    CP_REQUIRE(k > 0 && k % 32 == 0 && n > 0, "cp_wino_gemm_split_f32: K must be a multiple of 32");
+    const long long ab = (long long)rows * k * 4, bb = (long long)(rows / group_rows) * n * k * 4, cb = (long long)rows * n * 4;
+    CP_REQUIRE(ab < (1LL << 31) && bb < (1LL << 31) && cb < (1LL << 33), "cp_wino_gemm_split_f32: operand spans >= 2 GiB");
+    CP_REQUIRE(((uintptr_t)V & 15) == 0 && ((uintptr_t)U & 15) == 0, "cp_wino_gemm_split_f32: operands must be 16-byte aligned");
+    SplitK g{};
+    g.A = V; g.B = U; g.C = M;
+    g.rows = rows; g.N = n; g.K = k; g.group_rows = group_rows; g.nchunks = k / BK;
+    g.tiles_m = rows / BM; g.tiles_n = (n + BN - 1) / BN;
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+    g.b_group_stride_bytes = (unsigned)((long long)n * k * 4);
+    const size_t lds = (size_t)2 * STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    CP_LAUNCH(wino_gemm_split_kernel, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
+    return cp::check_launch("cp_wino_gemm_split_f32");
+}

@@ -194,6 +194,8 @@ class FusedConv:
 
 
 WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
+# opt-in: the Winograd GEMM as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent; csrc/wino_gemm_split.hip)
+WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
 
 
 class WinoConv:
@@ -271,7 +273,8 @@ class WinoConv:
         if WINO_GROUPED_CONV:  # the grouped mode of the general conv kernel (kept for comparison)
             check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
         else:
-            check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+            gemm = lib.cp_wino_gemm_split_f32 if WINO_GEMM_SPLIT else lib.cp_wino_gemm_f32
+            check(gemm(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
                   "cp_wino_gemm_f32(%s)" % self.name)
 
     @property

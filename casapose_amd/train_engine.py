@@ -379,7 +379,10 @@ class ConvOp:
             check(lib.cp_wino_input_transform_f32(ptr, ld, ch, self.batch, self.in_h, self.in_w, self.dil, V.data_ptr(), w["ktot"], off, stream),
                   "cp_wino_input_transform_f32(%s)" % self.layer.name)
             off += ch
-        check(lib.cp_wino_gemm_f32(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
+        from .engine import WINO_GEMM_SPLIT
+
+        gemm = lib.cp_wino_gemm_split_f32 if WINO_GEMM_SPLIT else lib.cp_wino_gemm_f32
+        check(gemm(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
               "cp_wino_gemm_f32(%s)" % self.layer.name)
         check(lib.cp_wino_output_transform_f32(self._wM.data_ptr(), w["cout"], self.batch, self.in_h, self.in_w, self.dil, residual_ptr, w["cout"], None, None,
                                                None, 0, out_ptr, w["cout"], None, w["cout"], stream), "cp_wino_output_transform_f32(%s)" % self.layer.name)

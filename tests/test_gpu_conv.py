@@ -287,3 +287,29 @@ def test_winograd_conv(device, srcs, cout, dil, hw, epi):
         close(raw, ref)
     if ref_act is not None:
         close(act, ref_act)
+
+
+def test_split_bf16_gemm_is_fp32_equivalent(device):
+    """cp_wino_gemm_split_f32 (opt-in; csrc/wino_gemm_split.hip): the grouped GEMM with every operand split exactly into three bf16 terms
+    and six products accumulated in fp32.  Against an fp64 product its error must not exceed the exact-fp32 MFMA kernel's by more than
+    rounding noise, on well-scaled data and on data spanning 12 orders of magnitude (the split is exact for any exponent)."""
+    from casapose_amd import _lib
+    from casapose_amd._lib import check
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream(device).cuda_stream
+    g = torch.Generator().manual_seed(5)
+    for rows, group, n, k, spread in [(256, 128, 128, 64, 0.0), (3 * 384, 384, 256, 96, 6.0), (2 * 128, 128, 132, 32, 0.0)]:
+        V = torch.randn(rows, k, generator=g) * torch.pow(10.0, spread * (torch.rand(rows, 1, generator=g) - 0.5))
+        U = torch.randn(rows // group, n, k, generator=g) * torch.pow(10.0, spread * (torch.rand(rows // group, n, 1, generator=g) - 0.5))
+        Vd, Ud = V.to(device), U.to(device)
+        M1, M2 = torch.empty(rows, n, device=device), torch.empty(rows, n, device=device)
+        check(lib.cp_wino_gemm_f32(Vd.data_ptr(), Ud.data_ptr(), M1.data_ptr(), rows, group, k, n, st), "fp32")
+        check(lib.cp_wino_gemm_split_f32(Vd.data_ptr(), Ud.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+        ref = torch.cat([V[i * group:(i + 1) * group].double() @ U[i].double().T for i in range(rows // group)])
+        scale = (V.double().abs() @ torch.ones(k, 1, dtype=torch.float64)).clamp_min(1e-300)  # row-wise magnitude: errors are relative to sum |v||u|
+        bound = torch.cat([V[i * group:(i + 1) * group].double().abs() @ U[i].double().abs().T for i in range(rows // group)]).clamp_min(1e-300)
+        e1 = float(((M1.cpu().double() - ref).abs() / bound).max())
+        e2 = float(((M2.cpu().double() - ref).abs() / bound).max())
+        assert e2 < 2e-6 and e2 < 2.0 * e1 + 1e-7, (rows, n, k, e1, e2)
+        del scale

@@ -24,4 +24,17 @@ for name, rows, n, k in [("stage2 3x3", 76800, 128, 1152), ("stage3_unit1_conv1"
         check(lib.cp_wino_gemm_f32(V.data_ptr(), U.data_ptr(), M.data_ptr(), rows, group, k, n, st), "gemm")
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print("%-32s M=%7d N=%4d K=%5d  %7.3f ms  %6.1f TF/s" % (name, rows, n, k, ms, 2.0 * rows * n * k / ms / 1e9))
+    line = "%-32s M=%7d N=%4d K=%5d  %7.3f ms  %6.1f TF/s" % (name, rows, n, k, ms, 2.0 * rows * n * k / ms / 1e9)
+    if rows % 128 == 0:  # the split-bf16 kernel (fp32-equivalent) on the same problem, and its deviation from the fp32-MFMA result
+        M2 = torch.empty_like(M)
+        check(lib.cp_wino_gemm_split_f32(V.data_ptr(), U.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+        e0.record()
+        for _ in range(5):
+            check(lib.cp_wino_gemm_split_f32(V.data_ptr(), U.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+        e1.record(); e1.synchronize()
+        ms2 = e0.elapsed_time(e1) / 5
+        ref = (V[:4096].double() @ U.double().T)
+        e_f32 = float((M[:4096].double() - ref).abs().max() / ref.abs().max())
+        e_spl = float((M2[:4096].double() - ref).abs().max() / ref.abs().max())
+        line += "   | split-bf16: %7.3f ms %6.1f TF/s-eq   max err / range: fp32 MFMA %.2e, split %.2e" % (ms2, 2.0 * rows * n * k / ms2 / 1e9, e_f32, e_spl)
+    print(line)
