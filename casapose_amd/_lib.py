@@ -110,6 +110,8 @@ SYMBOLS = [
     ("cp_wino_tiles", _i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("cp_wino_gemm_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     ("cp_wino_gemm_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    ("cp_wino_split_weights_bytes", C.c_size_t, [_i, _i, _i]),
+    ("cp_wino_split_weights_f32", _i, [_vp, _i, _i, _i, _vp, _vp]),
     ("cp_wino_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_transform_weights_f32", _i, [_vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_wino_dy_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -7,13 +7,14 @@
 // i.e. the rounding an fp32 multiply makes anyway.  Six bf16 MFMAs of K = 16 cost 6 x 32 cycles against 8 x 64 for the fp32 MFMA.
 //
 // Sizing (why this is not wino_gemm.hip with another instruction): at this MFMA rate a 32x32 per-wave tile would need ~3x the LDS
-// bandwidth of a CU for its fragment reads, so a block is 128 x 128 with four consumer waves of 64 x 64 (12 fragment reads per 24 MFMAs
-// and K = 16), four producer waves that split fp32 -> 3 x bf16 while they stage (memory traffic stays fp32: no extra copies of V / U
-// in HBM), two LDS stages of 60 KB, one persistent block per CU.  Measured 175-180 TFLOP/s-equivalent against 115-120 for the fp32 MFMA
-// kernel; with the MFMAs or the splitting removed it still takes 80 % of its time (LDS traffic: 156 KB per chunk).  The alternative of
-// keeping fp32 in LDS and splitting in the consumers (each fragment split by two waves) was measured slower: 149 TFLOP/s-equivalent.
+// bandwidth of a CU for its fragment reads, so a block is 128 x 128 with four consumer waves of 64 x 64.  The activations (A) stay fp32 in
+// HBM and are split by the four producer waves while they stage them (two LDS stages of 30 KB); the weights (B) are pre-split once into
+// fragment-major bf16 planes (split_weights_kernel) and every consumer wave fetches its 12 fragments of a chunk straight from L2 one
+// chunk ahead.  One persistent block per CU.  Measured 176-185 TFLOP/s-equivalent against 115-120 for the fp32 MFMA kernel = ~1.1 PFLOP/s
+// of bf16 MFMA work.  Variants measured within 3 %: all six planes staged in LDS (182); fp32 in LDS, split in the consumers (149).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -26,15 +27,8 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 80;        // bytes per staged row of one split: 32 bf16 (64 B) + 16 B pad -> conflict-free 16-byte fragment reads
 constexpr int SPLIT_BYTES = BM * ROWB;          // one split plane of a 128-row tile
 constexpr int TILE_BYTES = 3 * SPLIT_BYTES;     // hi, mid, lo
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A and B
-
-struct SplitK {
-    const float* A;
-    const float* B;
-    float* C;
-    int rows, N, K, group_rows, nchunks, tiles_m, tiles_n;
-    unsigned a_bytes, b_bytes, b_group_stride_bytes;
-};
+constexpr int STAGE_BYTES = TILE_BYTES;         // only A is staged; B fragments come pre-split straight from L2
+constexpr int NSTAGE = 2;
 
 // exact three-way split of four floats into packed bf16 pairs: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of
 // x - hi - mid (that last remainder has at most 8 significant bits, so taking its top half is exact).  v_perm_b32 packs the high halves.
@@ -55,9 +49,44 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, ui
     lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
 }
 
+struct SplitK {
+    const float* A;
+    const unsigned char* B;   // pre-split weights: [group][n / 32][k / 16][hi, mid, lo][64 lanes][8 bf16] (cp_wino_split_weights_f32)
+    float* C;
+    int rows, N, K, group_rows, nchunks, tiles_m, tiles_n;
+    int nb32;                 // 32-column blocks per group (N rounded up to 128, / 32)
+    unsigned a_bytes, b_bytes;
+};
+
+// pre-split one weight row segment: thread = (group, 32-column block, k16 step, lane)
+__global__ void split_weights_kernel(const float* __restrict__ U, int groups, int n, int k, int nb32, unsigned char* __restrict__ out) {
+    const long long total = (long long)groups * nb32 * (k / 16) * 64;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long long t = i >> 6;
+        const int ks = (int)(t % (k / 16));
+        t /= (k / 16);
+        const int jb = (int)(t % nb32);
+        const int g = (int)(t / nb32);
+        const int col = jb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (col < n) {
+            const float* src = U + ((size_t)g * n + col) * k + k0;
+            v0 = *reinterpret_cast<const float4*>(src);
+            v1 = *reinterpret_cast<const float4*>(src + 4);
+        }
+        uint2 h0, m0, l0, h1, m1, l1;
+        split4(v0, h0, m0, l0);
+        split4(v1, h1, m1, l1);
+        unsigned char* dst = out + ((((size_t)g * nb32 + jb) * (k / 16) + ks) * 3) * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][A | B][3 splits][128 rows][80 B]
-    constexpr unsigned OOB = 0x80000000u;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool producer = wave >= 4;
@@ -80,9 +109,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
     if (producer) {
         const int col4 = tid & 7, rbase = tid >> 3;  // 32 rows x 8 float4 per pass, four passes per operand
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-        float4 areg[4], breg[4];
-        unsigned aoff[4], boff[4];
+        float4 areg[4];
+        unsigned aoff[4];
         int it = -1, q = p.nchunks;
         auto advance = [&]() {
             if (++q >= p.nchunks) {
@@ -90,27 +118,19 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                 ++it;
                 const int tile = start + bidx + it * nb;
                 const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-                const int m0 = tm * BM, n0 = tn * BN;
-                const unsigned gofs = (unsigned)(m0 / p.group_rows) * p.b_group_stride_bytes;
+                const int m0 = tm * BM;
+                (void)tn;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = rbase + 32 * i;
-                    aoff[i] = ((unsigned)(m0 + r) * (unsigned)p.K + col4 * 4) * 4u;
-                    boff[i] = (n0 + r < p.N) ? gofs + ((unsigned)(n0 + r) * (unsigned)p.K + col4 * 4) * 4u : OOB;
-                }
+                for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)(m0 + rbase + 32 * i) * (unsigned)p.K + col4 * 4) * 4u;
             }
         };
         auto issue = [&]() {
             advance();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], q * (BK * 4), 0));
-                breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)boff[i], q * (BK * 4), 0));
-            }
+            for (int i = 0; i < 4; ++i) areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], q * (BK * 4), 0));
         };
         auto store = [&](int buf) {
             unsigned char* a = smem + buf * STAGE_BYTES + rbase * ROWB + col4 * 8;
-            unsigned char* b = a + TILE_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 h, m, l;
@@ -118,10 +138,6 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB) = h;
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + SPLIT_BYTES) = m;
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
-                split4(breg[i], h, m, l);
-                *reinterpret_cast<uint2*>(b + 32 * i * ROWB) = h;
-                *reinterpret_cast<uint2*>(b + 32 * i * ROWB + SPLIT_BYTES) = m;
-                *reinterpret_cast<uint2*>(b + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
             }
         };
         issue();
@@ -148,19 +164,40 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[2][2][3], fb[2][2][3];   // [slot][row / column block][split]
-    auto read_frags = [&](int buf, int ks, int slot) {
+    bf16x8 fa[2][2][3];        // [slot][row block][split]: A fragments from LDS
+    bf16x8 fb[2][2][2][3];     // [chunk parity][k16 step][column block][split]: B fragments of a whole chunk, fetched one chunk ahead from L2
+    const __amdgpu_buffer_rsrc_t rbw = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+    const unsigned ks_total = (unsigned)(p.K / 16);
+    auto read_a = [&](int buf, int ks, int slot) {
         const unsigned char* a = smem + buf * STAGE_BYTES + (wm * 64 + lrow) * ROWB + ks * 32 + kh * 16;
-        const unsigned char* b = smem + buf * STAGE_BYTES + TILE_BYTES + (wn * 64 + lrow) * ROWB + ks * 32 + kh * 16;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                fa[slot][i][s] = *reinterpret_cast<const bf16x8*>(a + i * 32 * ROWB + s * SPLIT_BYTES);
-                fb[slot][i][s] = *reinterpret_cast<const bf16x8*>(b + i * 32 * ROWB + s * SPLIT_BYTES);
-            }
+            for (int s = 0; s < 3; ++s) fa[slot][i][s] = *reinterpret_cast<const bf16x8*>(a + i * 32 * ROWB + s * SPLIT_BYTES);
     };
-    auto mfma_step = [&](int slot) {
+    // B fragments of flattened chunk `cc` (tile cc / nchunks of this block, chunk cc % nchunks) into register set `par`
+    int f_it = -1, f_q = p.nchunks;
+    unsigned f_base[2] = {0u, 0u};
+    auto fetch_b = [&](int par) {
+        if (++f_q >= p.nchunks) {
+            f_q = 0;
+            ++f_it;
+            const int tile = start + bidx + f_it * nb;
+            const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+            const unsigned g = (unsigned)((tm * BM) / p.group_rows);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) f_base[j] = ((g * (unsigned)p.nb32 + (unsigned)(tn * 4 + wn * 2 + j)) * ks_total * 3u) * 1024u + (unsigned)lane * 16u;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    fb[par][ks][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rbw, (int)(f_base[j] + ((unsigned)(f_q * 2 + ks) * 3u + (unsigned)s) * 1024u), 0, 0));
+    };
+    auto mfma_step = [&](int slot, int par, int ks) {
         // smallest terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -170,19 +207,18 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i][sa], fb[slot][j][sb], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i][sa], fb[par][ks][j][sb], acc[i][j], 0, 0, 0);
         }
     };
-    CP_BARRIER();  // stage 0 ready
-    read_frags(0, 0, 0);
     int it = 0, q = 0;
-    for (int c = 0; c < total_chunks; ++c) {
+    auto chunk = [&](int c, int par) {
         const int buf = c & 1;
-        read_frags(buf, 1, 1);
-        mfma_step(0);
-        mfma_step(1);
+        if (c + 1 < total_chunks) fetch_b(par ^ 1);   // next chunk's weights: in flight during this chunk's 48 MFMAs
+        read_a(buf, 1, 1);
+        mfma_step(0, par, 0);
+        mfma_step(1, par, 1);
         CP_BARRIER();
-        if (c + 1 < total_chunks) read_frags(buf ^ 1, 0, 0);
+        if (c + 1 < total_chunks) read_a(buf ^ 1, 0, 0);
         if (++q == p.nchunks) {
             const int tile = start + bidx + it * nb;
             const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
@@ -202,26 +238,52 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             q = 0;
             ++it;
         }
+    };
+    fetch_b(0);
+    CP_BARRIER();  // stage 0 ready
+    read_a(0, 0, 0);
+    int c = 0;
+    for (; c + 1 < total_chunks; c += 2) {
+        chunk(c, 0);
+        chunk(c + 1, 1);
     }
+    if (c < total_chunks) chunk(c, 0);
 #undef CP_BARRIER
 }
 
 }  // namespace
 
-extern "C" int cp_wino_gemm_split_f32(const float* V, const float* U, float* M, int rows, int group_rows, int k, int n, void* stream) {
-    CP_REQUIRE(V && U && M, "cp_wino_gemm_split_f32: null pointer");
+extern "C" size_t cp_wino_split_weights_bytes(int groups, int n, int k) {
+    if (groups <= 0 || n <= 0 || k <= 0 || k % 16) return 0;
+    const size_t nb32 = (size_t)((n + 127) / 128) * 4;
+    return (size_t)groups * nb32 * (k / 16) * 3 * 1024;
+}
+
+extern "C" int cp_wino_split_weights_f32(const float* U, int groups, int n, int k, void* out, void* stream) {
+    CP_REQUIRE(U && out && groups > 0 && n > 0 && k > 0 && k % 32 == 0, "cp_wino_split_weights_f32: bad arguments (K must be a multiple of 32)");
+    CP_REQUIRE(((uintptr_t)U & 15) == 0 && ((uintptr_t)out & 15) == 0, "cp_wino_split_weights_f32: pointers must be 16-byte aligned");
+    const int nb32 = ((n + 127) / 128) * 4;
+    const long long total = (long long)groups * nb32 * (k / 16) * 64;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    CP_LAUNCH(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, groups, n, k, nb32, reinterpret_cast<unsigned char*>(out));
+    return cp::check_launch("cp_wino_split_weights_f32");
+}
+
+extern "C" int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream) {
+    CP_REQUIRE(V && Usplit && M, "cp_wino_gemm_split_f32: null pointer");
     CP_REQUIRE(rows > 0 && group_rows > 0 && rows % group_rows == 0 && group_rows % 128 == 0, "cp_wino_gemm_split_f32: rows must be whole groups of a multiple of 128 rows");
     CP_REQUIRE(k > 0 && k % 32 == 0 && n > 0, "cp_wino_gemm_split_f32: K must be a multiple of 32");
-    const long long ab = (long long)rows * k * 4, bb = (long long)(rows / group_rows) * n * k * 4, cb = (long long)rows * n * 4;
+    const long long ab = (long long)rows * k * 4, cb = (long long)rows * n * 4;
+    const long long bb = (long long)cp_wino_split_weights_bytes(rows / group_rows, n, k);
     CP_REQUIRE(ab < (1LL << 31) && bb < (1LL << 31) && cb < (1LL << 33), "cp_wino_gemm_split_f32: operand spans >= 2 GiB");
-    CP_REQUIRE(((uintptr_t)V & 15) == 0 && ((uintptr_t)U & 15) == 0, "cp_wino_gemm_split_f32: operands must be 16-byte aligned");
+    CP_REQUIRE(((uintptr_t)V & 15) == 0 && ((uintptr_t)Usplit & 15) == 0, "cp_wino_gemm_split_f32: operands must be 16-byte aligned");
     SplitK g{};
-    g.A = V; g.B = U; g.C = M;
+    g.A = V; g.B = reinterpret_cast<const unsigned char*>(Usplit); g.C = M;
     g.rows = rows; g.N = n; g.K = k; g.group_rows = group_rows; g.nchunks = k / BK;
     g.tiles_m = rows / BM; g.tiles_n = (n + BN - 1) / BN;
+    g.nb32 = g.tiles_n * 4;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
-    g.b_group_stride_bytes = (unsigned)((long long)n * k * 4);
-    const size_t lds = (size_t)2 * STAGE_BYTES;
+    const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -198,6 +198,16 @@ WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
 WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
 
 
+def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """cp_wino_split_weights_f32: [groups][n][k] fp32 -> the fragment-major hi / mid / lo bf16 planes cp_wino_gemm_split_f32 reads."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(lib.cp_wino_split_weights_bytes(groups, n, k), dtype=torch.uint8, device=U.device)
+    st = torch.cuda.current_stream(U.device).cuda_stream if stream is None else stream
+    check(lib.cp_wino_split_weights_f32(U.data_ptr(), groups, n, k, out.data_ptr(), st), "cp_wino_split_weights_f32")
+    return out
+
+
 class WinoConv:
     """A deep 3x3 / stride-1 convolution executed as Winograd F(4x4,3x3): input transform(s), ONE grouped 1x1 launch over
     the 36 planes, output transform with the fused epilogue (csrc/wino.hip).  Same interface as FusedConv.run()."""
@@ -220,6 +230,7 @@ class WinoConv:
             c0 += creal
             k0 += cpad
         self.U = torch.from_numpy(U).to(device)
+        self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if WINO_GEMM_SPLIT else None   # pre-split bf16 planes of the opt-in GEMM
         self.desc = ConvDesc()  # the grouped GEMM
         self._keep: List = []
 
@@ -273,9 +284,12 @@ class WinoConv:
         if WINO_GROUPED_CONV:  # the grouped mode of the general conv kernel (kept for comparison)
             check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
         else:
-            gemm = lib.cp_wino_gemm_split_f32 if WINO_GEMM_SPLIT else lib.cp_wino_gemm_f32
-            check(gemm(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
-                  "cp_wino_gemm_f32(%s)" % self.name)
+            if self.Us is not None:
+                check(lib.cp_wino_gemm_split_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+                      "cp_wino_gemm_split_f32(%s)" % self.name)
+            else:
+                check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+                      "cp_wino_gemm_f32(%s)" % self.name)
 
     @property
     def flops(self) -> float:

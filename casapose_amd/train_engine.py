@@ -349,6 +349,11 @@ class ConvOp:
         for s, w in self.wino_dgrad.items():  # flipped taps, K index = forward output channel, output = forward input channel
             check(lib.cp_wino_transform_weights_f32(m + 4 * w["c0"] * cout, 3 * cin * cout, cin * cout, 1, cout, 1, cout, w["cout"], w["ktot"], 0,
                                                     w["U"].data_ptr(), stream), "cp_wino_transform_weights_f32")
+        from .engine import WINO_GEMM_SPLIT, split_wino_weights
+
+        if WINO_GEMM_SPLIT:  # opt-in GEMM on the bf16 matrix pipe: its weights are the pre-split planes of U
+            for w in ([self.wino_fwd] if self.wino_fwd is not None else []) + list(self.wino_dgrad.values()):
+                w["Us"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us"), stream=stream)
 
     def bind_winograd(self, V: torch.Tensor, M: torch.Tensor):
         self._wV, self._wM = V, M
@@ -379,11 +384,12 @@ class ConvOp:
             check(lib.cp_wino_input_transform_f32(ptr, ld, ch, self.batch, self.in_h, self.in_w, self.dil, V.data_ptr(), w["ktot"], off, stream),
                   "cp_wino_input_transform_f32(%s)" % self.layer.name)
             off += ch
-        from .engine import WINO_GEMM_SPLIT
-
-        gemm = lib.cp_wino_gemm_split_f32 if WINO_GEMM_SPLIT else lib.cp_wino_gemm_f32
-        check(gemm(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
-              "cp_wino_gemm_f32(%s)" % self.layer.name)
+        if w.get("Us") is not None:
+            check(lib.cp_wino_gemm_split_f32(V.data_ptr(), w["Us"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
+                  "cp_wino_gemm_split_f32(%s)" % self.layer.name)
+        else:
+            check(lib.cp_wino_gemm_f32(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
+                  "cp_wino_gemm_f32(%s)" % self.layer.name)
         check(lib.cp_wino_output_transform_f32(self._wM.data_ptr(), w["cout"], self.batch, self.in_h, self.in_w, self.dil, residual_ptr, w["cout"], None, None,
                                                None, 0, out_ptr, w["cout"], None, w["cout"], stream), "cp_wino_output_transform_f32(%s)" % self.layer.name)
 

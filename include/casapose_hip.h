@@ -257,11 +257,14 @@ int cp_wino_tiles(int batch, int h, int w, int dilation, int* tiles, int* tiles_
  * k % 32 == 0.  Same arithmetic as the grouped mode of cp_conv2d_fwd_f32 (which remains available); the operand stream is
  * pipelined ACROSS tiles because a tile only lives for k/32 chunks. */
 int cp_wino_gemm_f32(const float* V, const float* U, float* M, int rows, int group_rows, int k, int n, void* stream);
-/* OPT-IN alternative with the same arguments and fp32-equivalent results on the bf16 matrix pipe: every operand is split exactly into
- * three bf16 terms while it is staged and six of the nine products (all but the three below 2^-24) are accumulated in fp32
- * (csrc/wino_gemm_split.hip).  group_rows must be a multiple of 128.  Selected by CASAPOSE_WINO_GEMM=split; never the
- * default of bench.py. */
-int cp_wino_gemm_split_f32(const float* V, const float* U, float* M, int rows, int group_rows, int k, int n, void* stream);
+/* OPT-IN alternative with fp32-equivalent results on the bf16 matrix pipe: every operand is split exactly into three bf16 terms and six
+ * of the nine products (all but the three below 2^-24) are accumulated in fp32 (csrc/wino_gemm_split.hip).  V is the same
+ * fp32 tensor (split while it is staged); the weights are pre-split ONCE into fragment-major bf16 planes by cp_wino_split_weights_f32
+ * (U as for cp_wino_gemm_f32: [groups][n][k] fp32; `out` of cp_wino_split_weights_bytes(groups, n, k) bytes, caller-owned).
+ * group_rows must be a multiple of 128.  Selected by CASAPOSE_WINO_GEMM=split; never the default of bench.py. */
+size_t cp_wino_split_weights_bytes(int groups, int n, int k);
+int cp_wino_split_weights_f32(const float* U, int groups, int n, int k, void* out, void* stream);
+int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream);
 int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
                               int k_off, float* dst);
 /* device version of the weight transform (training: after every optimizer step): g(ky,kx,c,o) is read at

@@ -295,6 +295,7 @@ def test_split_bf16_gemm_is_fp32_equivalent(device):
     rounding noise, on well-scaled data and on data spanning 12 orders of magnitude (the split is exact for any exponent)."""
     from casapose_amd import _lib
     from casapose_amd._lib import check
+    from casapose_amd.engine import split_wino_weights
 
     lib = _lib.load()
     st = torch.cuda.current_stream(device).cuda_stream
@@ -305,7 +306,8 @@ def test_split_bf16_gemm_is_fp32_equivalent(device):
         Vd, Ud = V.to(device), U.to(device)
         M1, M2 = torch.empty(rows, n, device=device), torch.empty(rows, n, device=device)
         check(lib.cp_wino_gemm_f32(Vd.data_ptr(), Ud.data_ptr(), M1.data_ptr(), rows, group, k, n, st), "fp32")
-        check(lib.cp_wino_gemm_split_f32(Vd.data_ptr(), Ud.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+        Us = split_wino_weights(Ud, rows // group, n, k)
+        check(lib.cp_wino_gemm_split_f32(Vd.data_ptr(), Us.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
         ref = torch.cat([V[i * group:(i + 1) * group].double() @ U[i].double().T for i in range(rows // group)])
         scale = (V.double().abs() @ torch.ones(k, 1, dtype=torch.float64)).clamp_min(1e-300)  # row-wise magnitude: errors are relative to sum |v||u|
         bound = torch.cat([V[i * group:(i + 1) * group].double().abs() @ U[i].double().abs().T for i in range(rows // group)]).clamp_min(1e-300)

@@ -27,10 +27,12 @@ for name, rows, n, k in [("stage2 3x3", 76800, 128, 1152), ("stage3_unit1_conv1"
     line = "%-32s M=%7d N=%4d K=%5d  %7.3f ms  %6.1f TF/s" % (name, rows, n, k, ms, 2.0 * rows * n * k / ms / 1e9)
     if rows % 128 == 0:  # the split-bf16 kernel (fp32-equivalent) on the same problem, and its deviation from the fp32-MFMA result
         M2 = torch.empty_like(M)
-        check(lib.cp_wino_gemm_split_f32(V.data_ptr(), U.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+        from casapose_amd.engine import split_wino_weights
+        Us = split_wino_weights(U, 1, n, k)
+        check(lib.cp_wino_gemm_split_f32(V.data_ptr(), Us.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
         e0.record()
         for _ in range(5):
-            check(lib.cp_wino_gemm_split_f32(V.data_ptr(), U.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
+            check(lib.cp_wino_gemm_split_f32(V.data_ptr(), Us.data_ptr(), M2.data_ptr(), rows, group, k, n, st), "split")
         e1.record(); e1.synchronize()
         ms2 = e0.elapsed_time(e1) / 5
         ref = (V[:4096].double() @ U.double().T)
