@@ -23,7 +23,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256
 TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1,2> (64x128)", 3: "conv_f32_kernel<2,2,2,1> (128x64)",
               4: "conv_f32_kernel<4,1,1,1> (128x32)", 5: "conv_f32_kernel<2,2,1,1> (64x64)", 6: "conv_f32_kernel<4,1,2,1> (256x32)",
               7: "conv_halo_kernel (LDS-resident 4-row halo tile, cout <= 64)",
-              8: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)"}
+              8: "conv_stem_kernel (7x7/s2 stem, LDS-resident input halo)",
+              100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)"}
 
 
 def cpu_baseline(h, w, seg_dim, ver_dim):
@@ -46,7 +47,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim):
 
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
-                   5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "wino_gemm_kernel"}
+                   5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel"}
 
 
 def measured_traffic(tile):
@@ -353,7 +354,7 @@ def main():
         wino = {"layers": 0, "ms": 0.0, "gemm_ms": 0.0, "replaced_flops": 0.0}
         direct_flops = 0.0
         for conv in plan.convs:
-            tile = 8 if hasattr(conv, "gemm_flops") else lib.cp_conv_selected_tile(conv.desc)
+            tile = 100 if hasattr(conv, "gemm_flops") else lib.cp_conv_selected_tile(conv.desc)
             d_ = conv.desc
             t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
             direct_flops += conv.flops

@@ -77,7 +77,7 @@ class ConvDesc(C.Structure):
 
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
-TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO = range(8)
+TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO, TILE_STEM = range(9)
 
 # every symbol include/casapose_hip.h declares: (name, restype, argtypes)
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -89,6 +89,7 @@ SYMBOLS = [
     ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     ("cp_conv_halo_weight_floats", _i, [_i, _i, C.POINTER(_i)]),
     ("cp_conv_pack_weights_halo_host", _i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    ("cp_conv_pack_weights_stem_host", _i, [_vp, _i, _i, _vp]),
     ("cp_conv_pack_head_weights_host", _i, [_vp, _i, _vp]),
     ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
     ("cp_conv_selected_tile", _i, [C.POINTER(ConvDesc)]),

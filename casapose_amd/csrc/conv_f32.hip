@@ -26,6 +26,8 @@ int halo_weight_floats(int cout, int num_sources, const int* channels);
 int halo_pack_weights(const float* w, int layout, int cout, int num_sources, const int* channels, const int* real_channels, float* dst);
 bool halo_applicable(const cp_conv_desc* d);
 int launch_halo_conv(const cp_conv_desc* d, hipStream_t st);
+bool stem_applicable(const cp_conv_desc* d);
+int launch_stem_conv(const cp_conv_desc* d, hipStream_t st);
 }  // namespace cp
 
 namespace {
@@ -536,6 +538,7 @@ extern "C" int cp_conv_pack_weights_host(const float* w, int layout, int kh, int
 extern "C" int cp_conv_selected_tile(const cp_conv_desc* d) {
     if (!d) return CP_ERR_INVALID;
     if (d->tile_hint) return d->tile_hint;
+    if (cp::stem_applicable(d)) return CP_TILE_STEM;
     if (cp::halo_applicable(d)) return CP_TILE_HALO;
     return pick_tile((long long)d->batch * d->out_h * d->out_w, d->cout);
 }
@@ -657,6 +660,10 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
     }
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->tile_hint == CP_TILE_STEM || (d->tile_hint == 0 && cp::stem_applicable(d))) {
+        CP_REQUIRE(cp::stem_applicable(d), "cp_conv2d_fwd_f32: CP_TILE_STEM requested but the layer is not the 7x7/s2/p3 4->64 stem with stem-packed weights");
+        return cp::launch_stem_conv(d, st);
+    }
     if (d->tile_hint == CP_TILE_HALO || (d->tile_hint == 0 && cp::halo_applicable(d))) {
         CP_REQUIRE(cp::halo_applicable(d), "cp_conv2d_fwd_f32: CP_TILE_HALO requested but the layer does not qualify (3x3/s1/p1, cout<=64, weights_halo)");
         return cp::launch_halo_conv(d, st);

@@ -119,6 +119,10 @@ class FusedConv:
             check(lib.cp_conv_pack_weights_halo_host(w.ctypes.data, layout, cout, ns, chans, real, ph.ctypes.data),
                   "cp_conv_pack_weights_halo_host(%s)" % name)
             self.wp_halo = torch.from_numpy(ph).to(device)
+        if kh == 7 and kw == 7 and cout == 64 and ns == 1 and sources[0][0] == 4:  # the ResNet stem: packing of csrc/conv_stem.hip (used at stride 2 / pad 3)
+            ph = np.empty(25 * 2 * 64 * 4, dtype=np.float32)
+            check(lib.cp_conv_pack_weights_stem_host(w.ctypes.data, layout, sources[0][1], ph.ctypes.data), "cp_conv_pack_weights_stem_host(%s)" % name)
+            self.wp_halo = torch.from_numpy(ph).to(device)
         self.desc = ConvDesc()
         self._keep: List[torch.Tensor] = []
         self.head_w: Optional[torch.Tensor] = None

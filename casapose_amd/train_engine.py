@@ -181,6 +181,14 @@ class TrainConv:
 
             self.idx_halo = torch.from_numpy(_index_map(pack_halo, hwio, nfl)).to(dev)
             self.wp_halo = torch.empty(nfl, dtype=torch.float32, device=dev)
+        elif k == 7 and cout == 64 and ns == 1 and sources[0][0] == 4:  # the stem (csrc/conv_stem.hip): its packing travels in weights_halo
+            nfl = 25 * 2 * 64 * 4
+
+            def pack_stem(src, dst):
+                check(lib.cp_conv_pack_weights_stem_host(src.ctypes.data, 0, sources[0][1], dst.ctypes.data), "pack stem " + key)
+
+            self.idx_halo = torch.from_numpy(_index_map(pack_stem, hwio, nfl)).to(dev)
+            self.wp_halo = torch.empty(nfl, dtype=torch.float32, device=dev)
         # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
         self.dgrad: List[Optional[dict]] = []
         cpad = (cout + 31) // 32 * 32

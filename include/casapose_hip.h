@@ -124,7 +124,8 @@ typedef struct cp_conv_desc {
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
-       CP_TILE_64x64 = 5, CP_TILE_256x32 = 6, CP_TILE_HALO = 7 /* halo-tile kernel (needs weights_halo) */ };
+       CP_TILE_64x64 = 5, CP_TILE_256x32 = 6, CP_TILE_HALO = 7 /* halo-tile kernel (needs weights_halo) */,
+       CP_TILE_STEM = 8 /* 7x7/s2 4->64 stem kernel (weights_halo = cp_conv_pack_weights_stem_host packing) */ };
 
 /* K extent (multiple of 32) of the packed weight rows for a conv with the given sources */
 int cp_conv_ktot(int kh, int kw, int num_sources, const int* channels);
@@ -139,6 +140,9 @@ int cp_conv_pack_weights_host(const float* w_host, int layout, int kh, int kw, i
 int cp_conv_halo_weight_floats(int cout, int num_sources, const int* channels);
 int cp_conv_pack_weights_halo_host(const float* w_host, int layout, int cout, int num_sources, const int* channels,
                                    const int* real_channels, float* dst_host);
+/* packing for the stem kernel (csrc/conv_stem.hip: 7x7 / stride 2 / pad 3, one 4-channel source, cout = 64), passed in
+ * cp_conv_desc.weights_halo: 12800 floats [25 two-tap steps][2][64][4]; layout as for cp_conv_pack_weights_host */
+int cp_conv_pack_weights_stem_host(const float* w_host, int layout, int real_channels, float* dst);
 /* HOST: pack a [1][1][32][head_cout] (HWIO) 1x1 kernel for the fused head: 1024 floats */
 int cp_conv_pack_head_weights_host(const float* w_host, int head_cout, float* dst_host);
 int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);

@@ -78,6 +78,32 @@ def test_conv0_c4_source_with_input_affine(device):
     close(act, ref)
 
 
+@pytest.mark.parametrize("hw", [(30, 44), (64, 96), (38, 130)])
+def test_stem_kernel_matches_oracle_and_generic_route(device, hw):
+    """csrc/conv_stem.hip (the 7x7 / stride 2 / pad 3 stem with the input halo resident in LDS) is what an automatic launch picks for
+    conv0; it must agree with the fp64 oracle and with the implicit-GEMM kernel (tile hint) on ragged sizes, raw and activated outputs,
+    with and without the input affine."""
+    from casapose_amd import _lib, ops
+
+    rng = np.random.default_rng(hw[0])
+    img = rng.uniform(-1, 1, (3, hw[0], hw[1], 3))
+    w = rng.standard_normal((7, 7, 3, 64)) / 12.0
+    ps, pb = rng.uniform(0.5, 1.5, 3), rng.standard_normal(3) * 0.3
+    es, eb = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.3
+    raw_ref = O.conv2d(img * ps + pb, w, stride=2, pad=3)
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    pre = (dev(np.append(ps, 0.0), device), dev(np.append(pb, 0.0), device))
+    kw = dict(stride=2, pad=3, pre=[pre], real_channels=[3], scale=dev(es, device), shift=dev(eb, device), act=1, want_raw=True, want_act=True)
+    raw, act = ops.conv2d_fused([img4], w.astype(np.float32), tile_hint=_lib.TILE_STEM, **kw)
+    close(raw, raw_ref)
+    close(act, O.relu(raw_ref * es + eb))
+    raw_g, act_g = ops.conv2d_fused([img4], w.astype(np.float32), tile_hint=_lib.TILE_64x64, **kw)
+    close(raw, raw_g.cpu().numpy().astype(np.float64), rtol=2e-6)
+    close(act, act_g.cpu().numpy().astype(np.float64), rtol=2e-6)
+    plain, _ = ops.conv2d_fused([img4], w.astype(np.float32), stride=2, pad=3, real_channels=[3])  # automatic: the stem kernel, no affine
+    close(plain, O.conv2d(img, w, stride=2, pad=3))
+
+
 def test_two_sources_residual_dual_output(device):
     from casapose_amd import ops
 
