@@ -24,6 +24,14 @@ constexpr int ROWS = 16;        // rows per strip
 constexpr int MAXKP = 9;        // compile-time bound for the private accumulators
 constexpr int WAVES = 4;
 
+// softplus = max(x,0) + log1p(exp(-|x|)) on the hardware exp2 / log2 units: with t = exp(-|x|) in (0,1] and u = fl(1 + t),
+// log1p(t) = log(u) + (t - (u - 1)) / u restores the bits the addition drops (error ~1e-7 of the result)
+__device__ __forceinline__ float softplus_fast(float x) {
+    const float t = __expf(-fabsf(x));
+    const float u = 1.0f + t;
+    return fmaxf(x, 0.f) + (__logf(u) + (t - (u - 1.0f)) * __frcp_rn(u));
+}
+
 template <int KP>
 __global__ __launch_bounds__(256) void ls_accumulate_kernel(const float* __restrict__ field, int ld, int seg_off,
                                                             int dir_off, int conf_off, const uint8_t* __restrict__ labels,
@@ -248,9 +256,7 @@ __global__ __launch_bounds__(256) void ls_accumulate36_kernel(const float* __res
                     // softplus (:35) = max(x,0) + log1p(exp(-|x|)) on the hardware exp2 / log2 units: t = exp(-|x|) in (0,1], and
                     // log1p(t) = log(u) + (t - (u - 1)) / u with u = fl(1 + t) restores the bits the addition drops (error ~1e-7 of w;
                     // the libm calls of the generic kernel cost as much as the whole memory stream)
-                    const float t = __expf(-fabsf(cf));
-                    const float u = 1.0f + t;
-                    const float w = fmaxf(cf, 0.f) + (__logf(u) + (t - (u - 1.0f)) * __frcp_rn(u));
+                    const float w = softplus_fast(cf);
                     const float n2 = dy * dy + dx * dx;
                     const float inv = (n2 > 0.f) ? __frsqrt_rn(n2) : 0.f;  // divide_no_nan (:90); one reciprocal square root for both components
                     const float ny = dy * inv, nx = dx * inv;
@@ -371,7 +377,7 @@ __global__ void ls_bwd_kernel(const float* __restrict__ field, int ld, int dir_o
             float gdy = 0.f, gdx = 0.f, gcf = 0.f;
             if (lab > 0) {
                 const float dy = px[dir_off + 2 * j], dx = px[dir_off + 2 * j + 1];
-                const float w = fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf)));
+                const float w = softplus_fast(cf);
                 const float nrm = sqrtf(dy * dy + dx * dx);
                 const float p0 = tab[4 * j], p1 = tab[4 * j + 1], u0 = tab[4 * j + 2], u1 = tab[4 * j + 3];
                 const float e0 = cy - p0, e1 = cx - p1;
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void kp_stats_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < KP; ++j) {
                 const float cf = px[j];
-                cs[j] += (double)(fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf))));
+                cs[j] += (double)softplus_fast(cf);
             }
         }
     }
