@@ -96,6 +96,38 @@ class ParamStore:
         self.v = torch.zeros_like(self.theta)
         self.step_count = 0
 
+    # ---- packed-weight arena: every kernel layout of every layer lives in ONE buffer refreshed by ONE gather of the master parameters
+    def pack_reset(self):
+        self._pack_parts: List[np.ndarray] = []
+        self._pack_used = 0
+        self._pack_cap = 8 * self.size
+        self.pack_arena = torch.empty(self._pack_cap, dtype=torch.float32, device=self.device)
+        self.pack_idx: Optional[torch.Tensor] = None
+
+    def pack_alloc(self, idx_rel: np.ndarray, master_off: int) -> torch.Tensor:
+        """A packed-layout buffer of len(idx_rel) floats whose element i is theta[master_off + idx_rel[i]] (0 where idx_rel[i] < 0)."""
+        n = int(idx_rel.size)
+        if getattr(self, "_pack_parts", None) is None or self.pack_idx is not None:
+            self.pack_reset()
+        npad = n + ((-n) % 4)
+        if self._pack_used + npad > self._pack_cap:
+            raise RuntimeError("packed-weight arena exhausted (%d + %d > %d floats)" % (self._pack_used, npad, self._pack_cap))
+        part = np.full(npad, -1, np.int32)
+        part[:n] = np.where(idx_rel >= 0, idx_rel.astype(np.int64) + master_off, -1).astype(np.int32)
+        self._pack_parts.append(part)
+        view = self.pack_arena[self._pack_used:self._pack_used + n]
+        self._pack_used += npad
+        return view
+
+    def pack_finalize(self):
+        self.pack_idx = torch.from_numpy(np.concatenate(self._pack_parts)).to(self.device) if self._pack_parts else None
+
+    def pack_refresh(self, stream: int):
+        """arena[i] = theta[pack_idx[i]]: all layers' kernel layouts in one launch"""
+        if self.pack_idx is not None:
+            check(_lib.load().cp_gather_f32(self.theta.data_ptr(), self.pack_idx.data_ptr(), self.pack_idx.numel(), self.pack_arena.data_ptr(), stream),
+                  "cp_gather_f32(arena)")
+
     def view(self, name: str, of: Optional[torch.Tensor] = None) -> torch.Tensor:
         off, shape = self.offsets[name]
         n = int(np.prod(shape))
@@ -169,8 +201,10 @@ class TrainConv:
         def pack_fwd(src, dst):
             check(lib.cp_conv_pack_weights_host(src.ctypes.data, 0, k, k, cout, ns, chans, real, dst.ctypes.data), "pack " + key)
 
-        self.idx_fwd = torch.from_numpy(_index_map(pack_fwd, hwio, cout * self.ktot)).to(dev)
-        self.wp = torch.empty(cout * self.ktot, dtype=torch.float32, device=dev)
+        self._off = off
+        imap = _index_map(pack_fwd, hwio, cout * self.ktot)
+        self.idx_fwd = torch.from_numpy(imap).to(dev)
+        self.wp = store.pack_alloc(imap, off)
         self.dwp = torch.empty(cout * self.ktot, dtype=torch.float32, device=dev)
         self.idx_halo = self.wp_halo = None
         if k == 3 and cout <= 64 and sources[0][0] % 32 == 0 and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 32 == 0):
@@ -179,16 +213,18 @@ class TrainConv:
             def pack_halo(src, dst):
                 check(lib.cp_conv_pack_weights_halo_host(src.ctypes.data, 0, cout, ns, chans, real, dst.ctypes.data), "pack halo " + key)
 
-            self.idx_halo = torch.from_numpy(_index_map(pack_halo, hwio, nfl)).to(dev)
-            self.wp_halo = torch.empty(nfl, dtype=torch.float32, device=dev)
+            imap = _index_map(pack_halo, hwio, nfl)
+            self.idx_halo = torch.from_numpy(imap).to(dev)
+            self.wp_halo = store.pack_alloc(imap, off)
         elif k == 7 and cout == 64 and ns == 1 and sources[0][0] == 4:  # the stem (csrc/conv_stem.hip): its packing travels in weights_halo
             nfl = 25 * 2 * 64 * 4
 
             def pack_stem(src, dst):
                 check(lib.cp_conv_pack_weights_stem_host(src.ctypes.data, 0, sources[0][1], dst.ctypes.data), "pack stem " + key)
 
-            self.idx_halo = torch.from_numpy(_index_map(pack_stem, hwio, nfl)).to(dev)
-            self.wp_halo = torch.empty(nfl, dtype=torch.float32, device=dev)
+            imap = _index_map(pack_stem, hwio, nfl)
+            self.idx_halo = torch.from_numpy(imap).to(dev)
+            self.wp_halo = store.pack_alloc(imap, off)
         # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
         self.dgrad: List[Optional[dict]] = []
         cpad = (cout + 31) // 32 * 32
@@ -206,8 +242,8 @@ class TrainConv:
             def pack_d(src, dst, dch=dch, dre=dre, cr=cr):
                 check(lib.cp_conv_pack_weights_host(src.ctypes.data, 0, k, k, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad " + key)
 
-            ent = dict(idx=torch.from_numpy(_index_map(pack_d, np.ascontiguousarray(sub), cr * kt)).to(dev),
-                       w=torch.empty(cr * kt, dtype=torch.float32, device=dev), cout=cr, cin=cpad, idx_halo=None, w_halo=None,
+            imap = _index_map(pack_d, np.ascontiguousarray(sub), cr * kt)
+            ent = dict(idx=torch.from_numpy(imap).to(dev), w=store.pack_alloc(imap, off), cout=cr, cin=cpad, idx_halo=None, w_halo=None,
                        desc=ConvDesc())
             if k == 3 and cr <= 64:
                 nfl = lib.cp_conv_halo_weight_floats(cr, 1, dch)
@@ -215,8 +251,9 @@ class TrainConv:
                 def pack_dh(src, dst, dch=dch, dre=dre, cr=cr):
                     check(lib.cp_conv_pack_weights_halo_host(src.ctypes.data, 0, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad halo " + key)
 
-                ent["idx_halo"] = torch.from_numpy(_index_map(pack_dh, np.ascontiguousarray(sub), nfl)).to(dev)
-                ent["w_halo"] = torch.empty(nfl, dtype=torch.float32, device=dev)
+                imap = _index_map(pack_dh, np.ascontiguousarray(sub), nfl)
+                ent["idx_halo"] = torch.from_numpy(imap).to(dev)
+                ent["w_halo"] = store.pack_alloc(imap, off)
             self.dgrad.append(ent)
             c0 += cr
         self.desc = ConvDesc()
@@ -225,12 +262,15 @@ class TrainConv:
         self.master_shape = tuple(shape)
         self.refresh_hooks: List[Callable[[int], None]] = []  # extra weight layouts owned by the ops (Winograd planes)
 
-    def refresh(self, stream: int):
-        """Re-pack the kernel layouts from the master weights (after an optimizer step / at start)."""
+    def refresh(self, stream: int, hooks_only: bool = False):
+        """Re-pack the kernel layouts from the master weights (after an optimizer step / at start).  hooks_only: the plan refreshes the
+        gather-type layouts of all layers with one launch over the packed-weight arena (ParamStore.pack_refresh)."""
         lib = _lib.load()
         m = self.master.data_ptr()
         for hook in self.refresh_hooks:
             hook(stream)
+        if hooks_only:
+            return
         check(lib.cp_gather_f32(m, self.idx_fwd.data_ptr(), self.idx_fwd.numel(), self.wp.data_ptr(), stream), "cp_gather_f32")
         if self.idx_halo is not None:
             check(lib.cp_gather_f32(m, self.idx_halo.data_ptr(), self.idx_halo.numel(), self.wp_halo.data_ptr(), stream), "cp_gather_f32")
@@ -576,6 +616,7 @@ class TrainPlan:
         ws = [w, w // 2, w // 4, w // 8]
         self.ops: List = []
         self.convs: List[TrainConv] = []
+        store.pack_reset()  # this plan's kernel layouts share one arena (one gather per weight refresh)
         dims = tuple(decoder_dims)
 
         def new(hh, ww, c, grad=True, name=""):
@@ -792,6 +833,7 @@ class TrainPlan:
     def _finish_plan(self, f32):
         dev = self.store.device
         c0 = self.conv0
+        self.store.pack_finalize()
         # two convolutions on one weight set: the op that runs LAST in the backward (first in the forward) adds to the master gradient
         seen = set()
         for op in reversed(self.ops):
@@ -841,8 +883,9 @@ class TrainPlan:
 
     # ---- one step ------------------------------------------------------------------------------------
     def refresh_weights(self, stream: int):
+        self.store.pack_refresh(stream)
         for L in self.convs:
-            L.refresh(stream)
+            L.refresh(stream, hooks_only=True)
 
     def forward(self, img: torch.Tensor, cond_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
         lib = _lib.load()
