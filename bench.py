@@ -64,6 +64,12 @@ def measured_traffic(tile):
     return round(tot / n) if n else None
 
 
+def _dtype_note_train():
+    if os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split":
+        return "f32 (Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)"
+    return "f32"
+
+
 def _dtype_note():
     """the arithmetic type of the MFMA kernels: exact fp32 MFMA by default; with the opt-in CASAPOSE_WINO_GEMM=split the Winograd GEMMs run as
     exact three-way bf16 splits on the bf16 matrix pipe (fp32-equivalent results) and the line says so."""
@@ -131,7 +137,7 @@ def bench_train(args):
     result = {
         "metric": "training images/sec at 448x448, 8-object (casapose_c_gcu5 forward + losses + backward + Adam)",
         "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _dtype_note(),
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _dtype_note_train(),
         "data": "synthetic (seed 1237: uniform images, 8 elliptical objects, he_uniform weights)",
         "config": {"workload": "config_8.ini training step: casapose_c_gcu5, K=9, ver_dim=27, bs=%d per GPU, %dx%d, fp32, GT-mask conditioning, "
                                "mask+vertex+proxy+keypoint losses, SyncBN, Adam" % (B, H, W),

@@ -200,6 +200,9 @@ class FusedConv:
 WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
 # opt-in: the Winograd GEMM as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent; csrc/wino_gemm_split.hip)
 WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
+# The TRAINING plan uses it by default (BASELINE configs[2] asks for bf16 convolutions; this is the fp32-equivalent way to use that pipe);
+# CASAPOSE_WINO_GEMM=f32 restores the fp32 MFMA there.  Inference (the headline metric, fp32) stays on the fp32 MFMA unless asked.
+TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
 
 
 def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:

@@ -397,9 +397,9 @@ class ConvOp:
         for s, w in self.wino_dgrad.items():  # flipped taps, K index = forward output channel, output = forward input channel
             check(lib.cp_wino_transform_weights_f32(m + 4 * w["c0"] * cout, 3 * cin * cout, cin * cout, 1, cout, 1, cout, w["cout"], w["ktot"], 0,
                                                     w["U"].data_ptr(), stream), "cp_wino_transform_weights_f32")
-        from .engine import WINO_GEMM_SPLIT, split_wino_weights
+        from .engine import TRAIN_WINO_GEMM_SPLIT, split_wino_weights
 
-        if WINO_GEMM_SPLIT:  # opt-in GEMM on the bf16 matrix pipe: its weights are the pre-split planes of U
+        if TRAIN_WINO_GEMM_SPLIT:  # GEMM on the bf16 matrix pipe (exact 3-way splits, fp32-equivalent): its weights are the pre-split planes of U
             for w in ([self.wino_fwd] if self.wino_fwd is not None else []) + list(self.wino_dgrad.values()):
                 w["Us"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us"), stream=stream)
 
