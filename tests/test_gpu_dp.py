@@ -85,3 +85,33 @@ def test_two_rank_dp_equals_whole_batch(device, tmp_path):
     err = np.linalg.norm(g_dp - g_ref) / np.linalg.norm(g_ref)
     assert err < 2e-3, "summed replica gradients / world_size differ from the whole-batch gradient: %g" % err
     assert np.allclose(r0["mm"], plan.store.state["bn0.moving_mean"].cpu().numpy(), atol=1e-6)   # global statistics feed the moving averages
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_multi_rank_contract(mode, tmp_path):
+    """bench.py with WORLD_SIZE = 2 (the driver launches it with torch.distributed.run over RCCL on 2/4/8 GPUs; here both ranks share
+    cuda:0 over gloo): rank 0 prints ONE JSON line with the whole-job aggregate, n_gpus = 2, weak scaling; rank 1 prints none."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", LOCAL_RANK="0", CASAPOSE_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    if mode == "train":
+        cmd += ["--mode", "train", "--batch", "4", "--height", "64", "--width", "96"]
+    else:
+        cmd += ["--batch", "2", "--height", "64", "--width", "96"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines0 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    lines1 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not lines1
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    per_step = (2 if mode == "infer" else 4) * 2
+    assert abs(d["value"] - per_step / (d["ms_per_step"] / 1e3)) < 0.02 * d["value"]
