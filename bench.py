@@ -27,23 +27,81 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)"}
 
 
-def cpu_baseline(h, w, seg_dim, ver_dim):
-    """The NumPy oracle (fp32 arithmetic, BLAS threads = all host cores) on ONE image of the same
-    workload: forward + LS voting.  A reported baseline, not the optimisation target; the
-    reference's TF-CPU path cannot run here."""
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_rate(fn, images, warmup=3, timed=10, budget_s=12.0):
+    """images/s of fn(): `warmup` untimed calls, then up to `timed` calls (at least 3, stopping once `budget_s` is spent) -- median."""
+    t_start = time.perf_counter()
+    for i in range(warmup):
+        fn()
+        if time.perf_counter() - t_start > budget_s / 2 and i >= 0:
+            break
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < timed and (len(ts) < 3 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return images / ts[len(ts) // 2], len(ts)
+
+
+def cpu_baseline(h, w, seg_dim, ver_dim, batch):
+    """CPU restatement (PyTorch-CPU, oneDNN), NOT TensorFlow: the reference's TF-CPU path cannot run here, so the
+    number beside the GPU is the oracle's torch restatement of the same inference graph (oracle/torch_train_ref.forward_train with
+    training=False and the estimated mask) in fp32 on all host cores, as BASELINE.md 3 / SURVEY 8(d) prescribe: warm-up, then the
+    median of the timed iterations, at bs 1 and at the bench batch; legs: forward, forward + component filter + LS voter.  Bounded
+    to about 30 s.  A reported baseline, not the optimisation target."""
     import numpy as np
+    import torch
+    from scipy import ndimage
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import casapose_oracle as O
+    import torch_train_ref as R
 
-    p = O.init_params(seg_dim, ver_dim, seed=1237, dtype=np.float32)
-    img = np.random.default_rng(1237).uniform(-1, 1, (1, h, w, 3)).astype(np.float32)
-    t0 = time.perf_counter()
-    out = O.casapose_c_gcu5(p, img).astype(np.float32)
-    O.ls_voting(out[..., :seg_dim], out[..., seg_dim : seg_dim + 18], out[..., seg_dim + 18 :])
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 image 480x640 forward + LS voting, NumPy oracle in fp32 (%.1f s)" % dt}
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    p = R.to_torch(O.init_params(seg_dim, ver_dim, seed=1237, dtype=np.float32), dtype=torch.float32, requires_grad=False)
+    gen = torch.Generator().manual_seed(1237)
+    objects, kp = seg_dim - 1, (ver_dim // 3)
+
+    def forward(img):
+        with torch.no_grad():
+            return R.forward_train(p, img, None, training=False)
+
+    def vote(out):
+        lab = out[..., :seg_dim].argmax(-1).numpy()
+        keep = np.zeros_like(lab)
+        for bi in range(lab.shape[0]):  # largest 4-connected component of >= 50 px per object (voting_layers_2d.py:43-79)
+            for o in range(1, seg_dim):
+                cc, n = ndimage.label(lab[bi] == o)
+                if n:
+                    sizes = np.bincount(cc.ravel())[1:]
+                    if sizes.max() >= 50:
+                        keep[bi][cc == 1 + int(sizes.argmax())] = o
+        with torch.no_grad():
+            return R.ls_voting(torch.from_numpy(keep), out[..., seg_dim:seg_dim + 2 * kp], out[..., seg_dim + 2 * kp:], objects)
+
+    legs = {}
+    for bs, budget in ((1, 5.0), (batch, 10.0)):
+        img = 2.0 * torch.rand(bs, h, w, 3, generator=gen) - 1.0
+        fwd, n1 = _median_rate(lambda: forward(img), bs, budget_s=budget)
+        both, n2 = _median_rate(lambda: vote(forward(img)), bs, warmup=1, budget_s=budget)
+        legs["bs%d" % bs] = {"forward_images_per_s": round(fwd, 3), "forward_plus_filter_plus_ls_images_per_s": round(both, 3), "timed_iterations": [n1, n2]}
+    best = max(v["forward_plus_filter_plus_ls_images_per_s"] for v in legs.values())
+    return {"value": round(best, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "what": "CPU restatement (PyTorch-CPU fp32, oneDNN, %d threads), not TensorFlow" % cores, "cpu": _cpu_model_name(),
+            "sample": "%dx%d, bs 1 and bs %d: 3 warm-up + median of <= 10 timed iterations per leg (time-boxed); value = best forward + "
+                      "component filter + LS voting rate" % (h, w, batch), "legs": legs}
 
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
@@ -249,6 +307,40 @@ def bench_vote(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start N fresh rank processes, one per GPU,
+    before anything here touches the GPU, and return their worst exit code.  Under torch.distributed.run (the driver's way) the
+    ranks already exist: only check that --gpus matches WORLD_SIZE.  Returns None when this process is itself a rank."""
+    import subprocess
+
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, world), file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+
+    import torch  # device_count() does not initialise the GPU runtime
+
+    ndev = torch.cuda.device_count()
+    shared = os.environ.get("CASAPOSE_DIST_BACKEND", "nccl") == "gloo"  # tests: several ranks on one GPU over gloo
+    if args.gpus > ndev and not (shared and ndev > 0):
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, ndev), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:  # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["infer", "train", "vote"], default="infer",
@@ -262,6 +354,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    launched = launch_ranks(args)
+    if launched is not None:
+        sys.exit(launched)
     if args.mode == "train":
         if args.batch == 16 and args.height == 480 and args.width == 640:  # training defaults (config_8.ini:18, BASELINE configs[2])
             args.batch, args.height, args.width = 32, 448, 448
@@ -299,10 +394,9 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1237 + rank)
     img = (2.0 * torch.rand(B, H, W, 3, generator=gen) - 1.0).to(dev)
     voter = CoordLSVotingWeighted(name="coords_ls_voting", num_classes=seg_dim, num_points=kp, filter_estimates=True)
-    out_buf = torch.empty(B, H, W, seg_dim + ver_dim, dtype=torch.float32, device=dev)
 
-    def step():
-        out = net._net.forward(img, None, out_buf)
+    def step():  # the reference's own call sequence (test_casapose.py:299-312): model call, split, voting layer
+        out = net([img], training=False)
         s, d, c = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
         return voter([s, d, c])
 
@@ -326,6 +420,7 @@ def main():
         "value": round(world * B * args.steps / dt, 3),
         "unit": "images/s",
         "n_gpus": world,
+        "gpus_requested": args.gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -393,24 +488,30 @@ def main():
         d = per_tile[dom]
         conv_ms = sum(t["ms"] for t in per_tile.values()) + (wino["ms"] - wino["gemm_ms"])   # MFMA launches + Winograd transform passes
         conv_fl = sum(t["flops"] for t in per_tile.values())
+        ach_all = conv_fl / (conv_ms * 1e-3) / 1e12
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # headline = EXECUTED FLOPs of every convolution launch of the forward (Winograd layers count the grouped GEMM they run, not the
+        # direct convolution they replace) over the summed HIP-event durations of those launches incl. the Winograd transform passes;
+        # the north-star target (>= 0.70 of the fp32-MFMA peak) is quoted on the whole encoder-decoder forward, so that is `frac`
         result["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(dom),
-            "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command; memory-side requests, Infinity-Cache hits included)",
-            "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"]),
-            "kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "launches_per_step": d["launches"],
-            "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-            "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 3), "ms_per_step": round(conv_ms, 3),
-                                 "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
-                                 "note": "executed FLOPs (Winograd layers count their grouped GEMM) over all convolution launches incl. the transform passes",
-                                 "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
-                                 "direct_equivalent_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 3)},
+            "bound": "mfma", "achieved": round(ach_all, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_all / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel": "all convolution launches of the forward (conv_halo / wino_gemm / conv_f32 / conv_stem kernels + Winograd transform passes)",
+            "ms_per_step": round(conv_ms, 3), "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
+            "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
+            "traffic": measured_traffic(dom),
+            "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r01_pmc_traffic.json "
+                            "(separate rocprofv3 --pmc passes of this command in round 1), not measured by this run",
+            "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                                "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"])},
+            "families": {TILE_NAMES.get(k, str(k)).split(" ")[0] + ("" if k != 5 else "<64x64>"): {"ms": round(t["ms"], 3), "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2), "launches": t["launches"]}
+                         for k, t in sorted(per_tile.items())},
             "winograd": {"layers": wino["layers"], "ms_per_step": round(wino["ms"], 3), "gemm_ms": round(wino["gemm_ms"], 3),
                          "transform_ms": round(wino["ms"] - wino["gemm_ms"], 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim)
+        result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -25,19 +25,21 @@ BN_EPS = 2e-5  # resnet.py:44; _normalization_layers.py:108
 
 # Hard label maps the forward already computed (arg-max of its own logits), keyed by the storage
 # address of the network output: the voting layer receives `torch.split` views of that output and
-# can reuse the map instead of re-reading 708 MB of logits.  Entries hold a weak reference to the
-# output tensor and are refreshed by every forward that writes into the same buffer.
+# can reuse the map instead of re-reading 708 MB of logits.  An entry owns a COPY of the map (the
+# plan's own label buffer is overwritten by the next forward), holds a weak reference to the output
+# tensor and remembers its version counter: an in-place edit of the output (views share the counter)
+# or a dead / re-used storage is a miss, and the voter recomputes the arg-max from the logits.
 import weakref
 
-_LABEL_CACHE: Dict[int, Tuple["weakref.ReferenceType", torch.Tensor]] = {}
+_LABEL_CACHE: Dict[int, Tuple["weakref.ReferenceType", torch.Tensor, int]] = {}
 
 
-def cached_labels(storage_ptr: int, shape: Tuple[int, int, int]) -> Optional[torch.Tensor]:
+def cached_labels(storage_ptr: int, shape: Tuple[int, int, int], version: Optional[int] = None) -> Optional[torch.Tensor]:
     hit = _LABEL_CACHE.get(storage_ptr)
     if hit is None:
         return None
-    ref, labels = hit
-    if ref() is None or tuple(labels.shape) != tuple(shape):
+    ref, labels, ver = hit
+    if ref() is None or tuple(labels.shape) != tuple(shape) or (version is not None and version != ver) or ref()._version != ver:
         _LABEL_CACHE.pop(storage_ptr, None)
         return None
     return labels
@@ -623,7 +625,7 @@ class ForwardPlan:
         if seg_input is None:  # labels[0] is the arg-max of THIS output's logits
             if len(_LABEL_CACHE) > 8:
                 _LABEL_CACHE.clear()
-            _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), self.labels[0])
+            _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), self.labels[0].clone(), out._version)
         else:
             _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
         return out

@@ -62,7 +62,7 @@ class CoordLSVotingWeighted:
 
             lab0 = None
             if so == 0 and rec.storage_offset() == 0:
-                lab0 = cached_labels(rec.untyped_storage().data_ptr(), (b, h, w))  # the forward's own arg-max map
+                lab0 = cached_labels(rec.untyped_storage().data_ptr(), (b, h, w), seg._version)  # the forward's own arg-max map
             if lab0 is None:
                 lab0 = ops.argmax_labels(rec, classes=objects + 1, offset=so)
             ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objects), dtype=torch.uint8, device=rec.device)

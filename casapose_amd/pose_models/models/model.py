@@ -13,6 +13,7 @@ import torch
 
 from ... import engine
 from ... import train_engine
+from ...utils import h5_weights
 
 
 def _he_uniform(rng, shape, fan_in):
@@ -89,9 +90,11 @@ class Layer:
         self.trainable = True
 
     def get_weights(self) -> List[np.ndarray]:
+        self._model._sync_from_store()  # after a train_step the flat device store holds the current weights
         return [self._model._params[k].copy() for k in self._keys]
 
     def set_weights(self, weights: Sequence[np.ndarray]):
+        self._model._sync_from_store()
         if len(weights) != len(self._keys):
             raise ValueError("layer %s expects %d arrays, got %d" % (self.name, len(self._keys), len(weights)))
         new = dict(self._model._params)
@@ -132,12 +135,12 @@ class CasaposeModel:
         self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial, self._pvnet, **self._sharing)
         self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
                                        self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet, **self._sharing)
-        if isinstance(weights, str):
-            self.load_weights(weights)
-        self._layers = self._build_layers()
         self._store: Optional[train_engine.ParamStore] = None   # training state (flat master weights + Adam moments)
         self._plan: Optional[train_engine.TrainPlan] = None
         self._params_stale = False                               # the store holds newer weights than self._params
+        if isinstance(weights, str):
+            self.load_weights(weights)
+        self._layers = self._build_layers()
 
     # ---- training state --------------------------------------------------------------------------
     def training_plan(self, batch: int, h: int, w: int, group=None, world_size: int = 1):
@@ -166,8 +169,11 @@ class CasaposeModel:
         groups: Dict[str, List[str]] = {}
         for k in self._params:
             groups.setdefault(k.split(".")[0], []).append(k)
-        order = {"kernel": 0, "weights": 0, "gamma": 1, "beta": 2, "moving_mean": 3, "moving_variance": 4}
-        return [Layer(self, n, sorted(ks, key=lambda k: order[k.split(".")[1]])) for n, ks in groups.items()]
+        # Keras `layer.get_weights()` order: BatchNormalization gamma, beta, moving statistics; the CLADE layers add beta before
+        # gamma (_normalization_layers.py:96-107), so positional set_weights() from reference-ordered lists lines up
+        order = h5_weights.KERAS_FIELD_ORDER
+        clade = dict(order, beta=1, gamma=2)
+        return [Layer(self, n, sorted(ks, key=lambda k: (clade if n.endswith("_clade") else order)[k.split(".")[1]])) for n, ks in groups.items()]
 
     @property
     def layers(self) -> List[Layer]:
@@ -217,17 +223,21 @@ class CasaposeModel:
             self._params_stale = False
 
     def save_weights(self, path: str):
-        """Reference writes Keras .h5 (train_casapose.py:903); here the same name->array mapping is stored as .npz (any
-        extension is kept as given).  load_weights() reads both this format and real Keras HDF5 files (utils/h5_weights.py)."""
+        """`net.save_weights(frozen_path + "/result_w.h5")` (train_casapose.py:903): a path ending in .h5 / .hdf5 / .keras gets a
+        real HDF5 file with Keras' group tree, dataset names and `layer_names` / `weight_names` attributes
+        (utils/h5_weights.write_keras_h5), readable by Keras' load_weights(by_name=True) and by load_weights() below; any other
+        extension stores the '<layer>.<field>' -> array mapping as .npz."""
         self._sync_from_store()
+        if str(path).lower().endswith((".h5", ".hdf5", ".keras")):
+            h5_weights.write_keras_h5(path, self._params)
+            return
         with open(path, "wb") as f:
             np.savez(f, **self._params)
 
     def load_weights(self, path: str, by_name: bool = True, skip_mismatch: bool = True):
         """by_name / skip_mismatch follow test_casapose.py:225-228: unknown names are ignored and
         shape mismatches are skipped (with a warning) instead of raising."""
-        from ...utils import h5_weights
-
+        self._sync_from_store()
         if h5_weights.is_hdf5(path):  # a Keras save_weights file (the reference's result_w_8.h5 / result_w_13.h5)
             found = h5_weights.keras_weights_from_h5(path, {k.split(".")[0] for k in self._params})
 

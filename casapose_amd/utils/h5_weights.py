@@ -1,4 +1,4 @@
-"""Minimal HDF5 reader (and a test-only writer) for Keras weight files -- h5py is not available in this environment.
+"""Minimal HDF5 reader and writer for Keras weight files -- h5py is not available in this environment.
 
 `model.load_weights("result_w_8.h5", by_name=True, skip_mismatch=True)` (test_casapose.py:225-228) needs the float32 datasets
 of a Keras `save_weights` file: every layer is a group, every weight a contiguous little-endian float dataset whose path ends in
@@ -10,8 +10,11 @@ the subset of the HDF5 1.8 file format such files use when written with the defa
   a fixed- or floating-point datatype and a contiguous or compact layout (v1-v3).
 
 Anything else (superblock v2/v3, new-style groups with link messages / fractal heaps, chunked or filtered datasets, variable-
-length types) raises `H5FormatError` with the feature named -- never a silent partial read.  Attributes are not needed: the
-weights are addressed by their path.  Format reference: "HDF5 File Format Specification Version 2.0" (The HDF Group); parity
+length types) raises `H5FormatError` with the feature named -- never a silent partial read.  Attributes are not needed to
+read weights (they are addressed by their path); attribute messages are skipped by the dataset reader and parsed by
+`read_attrs()` when they hold fixed-length strings (`layer_names`, `weight_names`, `backend`, `keras_version`).
+`write_keras_h5()` is what `model.save_weights("*.h5")` calls (train_casapose.py:903): the group tree, dataset names and
+attributes of Keras' `save_weights_to_hdf5_group`.  Format reference: "HDF5 File Format Specification Version 2.0" (The HDF Group); parity
 with libhdf5 is untested here (no h5py, no Keras file on this machine): the reader is pinned against `write_h5()` below, which
 emits the same structures from the specification.
 """
@@ -179,6 +182,60 @@ class _File:
             raise H5FormatError("dataset extends past the end of the file")
         return np.frombuffer(self.buf, dtype=dtype, count=count, offset=start).reshape(shape).astype(dtype.newbyteorder("="))
 
+    # ---- attributes ---------------------------------------------------------------------------------------------
+    def read_attributes(self, msgs) -> Dict[str, object]:
+        """Fixed-length-string attributes of an object header ({name: bytes | [bytes]}); other types map to None."""
+        out: Dict[str, object] = {}
+        for mtype, d, size in msgs:
+            if mtype != 0x000C:
+                continue
+            ver = self.buf[d]
+            if ver not in (1, 2, 3):
+                raise H5FormatError("attribute message version %d" % ver)
+            nsz, tsz, ssz = self.u16(d + 2), self.u16(d + 4), self.u16(d + 6)
+            p = d + (9 if ver == 3 else 8)
+            pad = (lambda n: (n + 7) & ~7) if ver == 1 else (lambda n: n)
+            name = self.buf[p:p + nsz].split(b"\x00")[0].decode("utf-8")
+            t = p + pad(nsz)
+            sp = t + pad(tsz)
+            data = sp + pad(ssz)
+            cls, tsize = self.buf[t] & 0x0F, self.u32(t + 4)
+            sver, rank = self.buf[sp], self.buf[sp + 1]
+            dims = tuple(self.u64(sp + (8 if sver == 1 else 4) + 8 * i) for i in range(rank))
+            if cls != 3:
+                out[name] = None
+                continue
+            n = int(np.prod(dims)) if dims else 1
+            vals = [bytes(self.buf[data + i * tsize:data + (i + 1) * tsize]).rstrip(b"\x00") for i in range(n)]
+            out[name] = vals if dims else vals[0]
+        return out
+
+
+def read_attrs(path: str) -> Dict[str, Dict[str, object]]:
+    """{'/group/path': {attribute: value}} for every GROUP of the file that carries fixed-length-string attributes."""
+    f = _File(path)
+    out: Dict[str, Dict[str, object]] = {}
+    seen = set()
+
+    def visit(prefix: str, header_addr: int, btree=None, heap=None):
+        if header_addr in seen:
+            return
+        seen.add(header_addr)
+        msgs = f.messages(header_addr)
+        types = {m[0] for m in msgs}
+        if 0x0011 in types:
+            d = [m for m in msgs if m[0] == 0x0011][0][1]
+            btree, heap = f.u64(d), f.u64(d + 8)
+        if btree is not None and 0x0008 not in types:
+            a = f.read_attributes(msgs)
+            if a:
+                out[prefix or "/"] = a
+            for name, child in f.group_entries(btree, heap):
+                visit(prefix + "/" + name, child)
+
+    visit("", f.root_header, f.root_btree, f.root_heap)
+    return out
+
 
 def read_h5(path: str) -> Dict[str, np.ndarray]:
     """{'/group/.../dataset': array} for every dataset of the file."""
@@ -230,10 +287,13 @@ def keras_weights_from_h5(path: str, layer_names) -> Dict[str, np.ndarray]:
 
 
 # ------------------------------------------------------------------------------------------------
-# test-only writer: the same structures, straight from the specification
+# writer: the same structures, straight from the specification
 # ------------------------------------------------------------------------------------------------
-def write_h5(path: str, datasets: Dict[str, np.ndarray]):
-    """Write {'a/b/name': float32 array} as superblock v0 + old-style groups + contiguous datasets."""
+def write_h5(path: str, datasets: Dict[str, np.ndarray], attrs: Dict[str, Dict[str, object]] = None):
+    """Write {'a/b/name': float32 array} as superblock v0 + old-style groups + contiguous datasets.  `attrs` maps a group path
+    ('' = root) to {attribute name: bytes | [bytes]}, stored as fixed-length null-padded ASCII strings (what h5py stores for the
+    numpy 'S' arrays Keras passes for `layer_names` / `weight_names`)."""
+    attrs = {"/".join(c for c in k.split("/") if c): v for k, v in (attrs or {}).items()}
     tree: dict = {}
     for p, a in datasets.items():
         node = tree
@@ -268,9 +328,27 @@ def write_h5(path: str, datasets: Dict[str, np.ndarray]):
         layout = struct.pack("<BBQQ", 3, 1, data_addr, a.nbytes)
         return object_header([message(0x0001, space), message(0x0003, dtype), message(0x0008, layout)])
 
-    def write_group(node: dict) -> Tuple[int, int, int]:
+    def attribute(name: str, value) -> bytes:
+        vals = [value] if isinstance(value, (bytes, str)) else list(value)
+        vals = [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in vals]
+        width = max([len(v) for v in vals] + [1])
+        nm = name.encode("utf-8") + b"\x00"
+        dtype = struct.pack("<BBBBI", 0x13, 0x01, 0, 0, width)  # class 3 (string) v1, null-padded, ASCII
+        if isinstance(value, (bytes, str)):
+            space = struct.pack("<BBB5x", 1, 0, 0)              # scalar
+        else:
+            space = struct.pack("<BBB5x", 1, 1, 0) + struct.pack("<Q", len(vals))
+        pad8 = lambda b: b + b"\x00" * ((-len(b)) % 8)
+        body = struct.pack("<BxHHH", 1, len(nm), len(dtype), len(space)) + pad8(nm) + pad8(dtype) + pad8(space)
+        body += b"".join(v.ljust(width, b"\x00") for v in vals)
+        if len(body) > 65000:
+            raise H5FormatError("attribute %s does not fit an object-header message (%d bytes)" % (name, len(body)))
+        return message(0x000C, body)
+
+    def write_group(node: dict, path: str = "") -> Tuple[int, int, int]:
         names = sorted(node)
-        children = [(n, write_group(node[n])[0] if isinstance(node[n], dict) else write_dataset(node[n])) for n in names]
+        children = [(n, write_group(node[n], (path + "/" + n).strip("/"))[0] if isinstance(node[n], dict) else write_dataset(node[n]))
+                    for n in names]
         heap_data = bytearray(b"\x00" * 8)
         offs = []
         for n, _ in children:
@@ -292,7 +370,7 @@ def write_h5(path: str, datasets: Dict[str, np.ndarray]):
         for addr, last_key in snods:
             node_b += struct.pack("<QQ", addr, last_key)
         btree = put(node_b)
-        hdr = object_header([message(0x0011, struct.pack("<QQ", btree, heap))])
+        hdr = object_header([message(0x0011, struct.pack("<QQ", btree, heap))] + [attribute(k, v) for k, v in attrs.get(path, {}).items()])
         return hdr, btree, heap
 
     root_hdr, root_btree, root_heap = write_group(tree)
@@ -302,3 +380,59 @@ def write_h5(path: str, datasets: Dict[str, np.ndarray]):
     buf[0:len(sb)] = sb
     with open(path, "wb") as f:
         f.write(bytes(buf))
+
+
+# Keras names of the weights of one layer, in Keras' own `layer.weights` order (Conv2D: kernel; BatchNormalization: gamma, beta,
+# moving_mean, moving_variance; ClassAdaptiveWeightedNormalization: its add_weight order beta, gamma, then the inner
+# SyncBatchNormalization's moving statistics -- _normalization_layers.py:96-108; PartialConvolution: <name>_weights, :314-319)
+KERAS_FIELD_ORDER = {"kernel": 0, "weights": 0, "gamma": 1, "beta": 2, "moving_mean": 3, "moving_variance": 4}
+BACKBONE_GROUP = "model"  # resnet.py:319 builds the backbone as an unnamed `models.Model` -> Keras names it "model"
+
+
+def is_backbone_layer(layer: str) -> bool:
+    return layer == "conv0" or layer.startswith(("bn_data", "bn0", "bn1", "stage"))
+
+
+def keras_layout(params: Dict[str, np.ndarray], backbone_group: str = BACKBONE_GROUP):
+    """(datasets, attrs) of the file Keras' `save_weights` writes for a model holding `params` ('<layer>.<field>' keys):
+    top-level layers are groups `<layer>` whose datasets are named by the variable (`<layer>/<field>:0`, custom layers prefixing
+    the field with the layer name), the nested backbone model is ONE top-level layer whose variables keep their own layer scope
+    (`model/conv0/kernel:0`), the CLADE layer's moving statistics live in its inner `sync_batch_normalization_<n>` scope."""
+    layers: Dict[str, List[str]] = {}
+    for k in params:
+        layers.setdefault(k.split(".")[0], []).append(k)
+    datasets: Dict[str, np.ndarray] = {}
+    weight_names: Dict[str, List[bytes]] = {}
+    top_order: List[str] = []
+    inner_bn = 0
+    for layer, keys in layers.items():
+        clade = layer.endswith("_clade")
+        order = dict(KERAS_FIELD_ORDER, **({"beta": 1, "gamma": 2} if clade else {}))
+        keys = sorted(keys, key=lambda k: order[k.split(".")[1]])
+        top = backbone_group if is_backbone_layer(layer) else layer
+        if top not in top_order:
+            top_order.append(top)
+        if clade:
+            inner_bn += 1
+        for k in keys:
+            field = k.split(".")[1]
+            if clade and field in ("gamma", "beta"):
+                var = "%s/%s_%s:0" % (layer, layer, field)
+            elif clade:
+                var = "%s/sync_batch_normalization_%d/%s:0" % (layer, inner_bn, field)
+            elif field == "weights":
+                var = "%s/%s_weights:0" % (layer, layer)
+            else:
+                var = "%s/%s:0" % (layer, field)
+            weight_names.setdefault(top, []).append(var.encode())
+            datasets["%s/%s" % (top, var)] = params[k]
+    attrs: Dict[str, Dict[str, object]] = {"": {"layer_names": [t.encode() for t in top_order], "backend": b"tensorflow",
+                                                "keras_version": b"2.9.0"}}
+    for top, names in weight_names.items():
+        attrs[top] = {"weight_names": names}
+    return datasets, attrs
+
+
+def write_keras_h5(path: str, params: Dict[str, np.ndarray], backbone_group: str = BACKBONE_GROUP):
+    datasets, attrs = keras_layout(params, backbone_group)
+    write_h5(path, datasets, attrs)

@@ -141,14 +141,29 @@ def guided_bilinear_upsample(x, lab_lo, lab_hi):
     return (filled * wts[None, :, :, :, None]).sum(3)
 
 
-def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.Tensor, stats_out: Optional[dict] = None,
+def batchnorm_inference(x, gamma, beta, mean, var):
+    """(Sync)BatchNormalization, training=False: the moving statistics (resnet.py:39-49, eps 2e-5)."""
+    y = (x - mean) / torch.sqrt(var + BN_EPS)
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    return y
+
+
+def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optional[torch.Tensor], stats_out: Optional[dict] = None,
                   partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, pvnet: bool = False,
-                  shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True):
+                  shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True, training: bool = True):
     """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
     convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
-    hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim]."""
+    hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim].
+    training=False normalises with the moving statistics (the inference graph); labels=None conditions decoder 2 on the arg-max of
+    the network's own logits (the estimated mask of pose_models.py:548-549, README.md:74-80).  That combination, in fp32 on all
+    host cores, is the CPU baseline `bench.py` times beside the GPU."""
 
     def bn(name, x):
+        if not training:
+            return batchnorm_inference(x, p.get(name + ".gamma"), p.get(name + ".beta"), p[name + ".moving_mean"], p[name + ".moving_variance"])
         return batchnorm_train(x, p.get(name + ".gamma"), p.get(name + ".beta"), stats_out, name)
 
     x = bn("bn_data", img)
@@ -190,6 +205,8 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
     if pvnet:  # PVNet: one merged head (pose_models.py:678)
         return conv_nhwc(d1, p["pv_final_conv.kernel"])
     logits = conv_nhwc(d1, p["pv_final_conv_segmentation.kernel"])
+    if labels is None:
+        labels = torch.argmax(logits.detach(), dim=-1)  # softmax(1e6 * logits) is one-hot at the first maximum
     labs = labels_pyramid(labels)
     lvl = [3, 3, 2, 1, 0]
     d2 = None
@@ -206,7 +223,11 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: torch.T
             y = partial_conv(inp, p[n + "_prepare_conv2d.weights"], lab)
         else:
             y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
-        y = clade_train(y, lab, p[n + "_clade.gamma"], p[n + "_clade.beta"], stats_out, n + "_clade")
+        if training:
+            y = clade_train(y, lab, p[n + "_clade.gamma"], p[n + "_clade.beta"], stats_out, n + "_clade")
+        else:
+            y = batchnorm_inference(y, None, None, p[n + "_clade.moving_mean"], p[n + "_clade.moving_variance"])
+            y = p[n + "_clade.gamma"][lab.to(torch.int64)] * y + p[n + "_clade.beta"][lab.to(torch.int64)]
         y = F.relu(y) if i == 0 else leaky_pair(y)
         if 0 < i < 4:
             if guided[i] and bilinear[i]:
@@ -332,6 +353,24 @@ def ls_voting(labels: torch.Tensor, dirs: torch.Tensor, conf: torch.Tensor, obje
         t = (q * m).sum(dim=(1, 2))                                    # [b,kp,2]
         out.append((torch.linalg.pinv(A) @ t[..., None])[..., 0] * h)
     return torch.stack(out, dim=1)
+
+
+def ransac_round_counts(direct: torch.Tensor, coords: torch.Tensor, idxs: torch.Tensor, thresh: float = 0.99) -> torch.Tensor:
+    """One RANSAC round of ransac_voting_batch for one object (ransac_voting.py:197-249,319-329): hypotheses from the drawn pixel
+    pairs, then the [hn,tn,vn] cosine tests and their inlier counts [hn,vn].  direct [tn,vn,2] (dx,dy), coords [tn,2] (x,y),
+    idxs [hn,vn,2] int64.  The broadcast form of the reference, on torch-CPU threads: the CPU-baseline leg of `bench.py --mode vote`."""
+    hn, vn, _ = idxs.shape
+    vi = torch.arange(vn)[None, :, None]
+    c_s, d_s = coords[idxs], direct[idxs, vi]                                                     # [hn,vn,2,2]
+    det = d_s[:, :, 1, 0] * d_s[:, :, 0, 1] - d_s[:, :, 1, 1] * d_s[:, :, 0, 0]
+    u = ((c_s[:, :, 1, 1] - c_s[:, :, 0, 1]) * d_s[:, :, 1, 0] - (c_s[:, :, 1, 0] - c_s[:, :, 0, 0]) * d_s[:, :, 1, 1]) / det
+    hyp = torch.where((det.abs() > 1e-6)[..., None], c_s[:, :, 0] + d_s[:, :, 0] * u[..., None], torch.zeros_like(c_s[:, :, 0]))
+    hd = hyp[:, None] - coords[None, :, None]                                                     # [hn,tn,vn,2]
+    nd = torch.sqrt((direct * direct).sum(-1))[None]
+    nh = torch.sqrt((hd * hd).sum(-1))
+    valid = (nd > 1e-6) & (nh > 1e-6) & (hyp.sum(-1).abs() > 1e-6)[:, None, :]
+    ang = (direct[None] * hd).sum(-1) / (nd * nh)
+    return (valid & (ang > thresh)).sum(dim=1)
 
 
 def crop_to_image_affine(offsets: np.ndarray) -> np.ndarray:

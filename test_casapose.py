@@ -7,7 +7,7 @@
 
 `--datatest <folder>` reads an NDDS / converted-BOP tree; `--datatest synthetic[:N]` selects the built-in scene generator
 (no dataset on this machine).  Writes <evalf>/loss_test_eval.csv and <evalf>/test_summary_eval.csv with the reference's columns and, with
---write_poses, BOP-style per-object pose lines under <evalf>/poses_out/.
+--write_poses, <evalf>/poses_out/bop_evaluation.csv plus the per-object pose text files (casapose_amd/utils/io_utils.py).
 """
 import glob
 import os
@@ -23,18 +23,8 @@ from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset  # n
 from casapose_amd.pose_models.tfkeras import Classifiers  # noqa: E402
 from casapose_amd.training import test_step  # noqa: E402
 from casapose_amd.utils.config_parser import parse_config  # noqa: E402
+from casapose_amd.utils.io_utils import latest_checkpoint, write_poses  # noqa: E402
 from casapose_amd.utils.learning_rate_schedules import LossWeightHandler  # noqa: E402
-
-
-def write_poses(poses_gt, poses_est, objects, index, path_out):
-    """one line per image and object: index, 12 numbers of the estimated [R|t], 12 of the ground truth (io_utils.py:54-138 keeps
-    the same information in per-object text files)."""
-    for o, name in enumerate(objects):
-        d = os.path.join(path_out, name)
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "poses.txt"), "a") as f:
-            f.write("%d %s %s\n" % (index, " ".join("%.6f" % v for v in np.asarray(poses_est[o]).reshape(-1)),
-                                    " ".join("%.6f" % v for v in np.asarray(poses_gt[o]).reshape(-1))))
 
 
 def main(argv=None):
@@ -71,9 +61,9 @@ def main(argv=None):
         print(net_path)
         net.load_weights(net_path, by_name=True, skip_mismatch=True)
     elif opt.net != "":
-        ckpts = sorted(glob.glob(checkpoint_path + "/ckpt-*.npz"), key=lambda p: int(p.rsplit("-", 1)[1].split(".")[0]))
-        if ckpts:
-            net.load_weights(ckpts[-1])
+        latest = latest_checkpoint(checkpoint_path)
+        if latest is not None:
+            net.load_weights(latest[0])
     for layer in net.layers:
         layer.trainable = False
     net.summary()
@@ -121,7 +111,8 @@ def main(argv=None):
         print("Err 2D: {}".format(err_2d))
         print("Err 3D: {}".format(err_3d))
         if opt.write_poses:
-            write_poses(batch["poses_gt"][0, :, 0].numpy(), np.asarray(poses)[0], objectsofinterest, batch_idx, opt.evalf + "/poses_out/")
+            image_id = batch.get("image_id", ["synthetic_%06d_%06d" % (0, batch_idx)])  # batch tuple entry 12 (vectorfield_dataset.py:309)
+            write_poses(batch["poses_gt"][0], np.asarray(poses)[0], objectsofinterest, image_id, opt.evalf + "/poses_out/", seconds)
     test_loss /= max(test_batches, 1)
     gt = acc["gt"]
     div = lambda a, b: np.divide(a, b, out=np.zeros_like(a), where=b != 0)  # noqa: E731  (divide_no_nan)

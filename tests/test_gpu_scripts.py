@@ -71,7 +71,23 @@ def test_train_and_test_scripts_end_to_end(device, tmp_path):
     assert ev[0][:6] == ["loss", "mask_loss", "vertex_loss", "proxy_loss", "kp_loss", "time"] and len(ev) == 2 and len(ev[1]) == 5 + 9 + 9
     assert len(list(csv.reader(open(out + "/loss_test_eval.csv")))) == 3
     assert np.all(np.isfinite(res["loss"])) and res["valid_3d"].shape == (8,)
-    assert os.path.exists(out + "/poses_out/obj_000001/poses.txt")
+    bop = list(csv.reader(open(out + "/poses_out/bop_evaluation.csv")))       # io_utils.py:54-138
+    assert bop[0] == ["scene_id", "im_id", "obj_id", "score", "R", "t", "time"] and len(bop) > 1
+    assert all(len(r) == 7 and len(r[4].split()) == 9 and len(r[5].split()) == 3 and float(r[3]) in (0.0, 1.0) for r in bop[1:])
+    assert os.path.exists(out + "/poses_out/all_poses/poses_init_obj_000001.txt") and os.path.exists(out + "/poses_out/filtered_poses/poses_gt_obj_000001.txt")
+    # frozen_model/result_w.h5 is real HDF5 in Keras' layout (train_casapose.py:903); resuming on --net continues the checkpoint numbering
+    from casapose_amd.utils import h5_weights
+
+    assert h5_weights.is_hdf5(out + "/frozen_model/result_w.h5")
+    attrs = h5_weights.read_attrs(out + "/frozen_model/result_w.h5")
+    assert b"model" in attrs["/"]["layer_names"] and b"conv0/kernel:0" in attrs["/model"]["weight_names"]
+    before = dict(np.load(out + "/training_checkpoints/ckpt-3.npz"))
+    train_casapose.main(common + ["--data", "synthetic:4", "--datatest", "", "--epochs", "1", "--batchsize", "4", "--imagesize", "128", "160",
+                                  "--saveinterval", "1", "--lr", "0.0"])
+    assert os.path.exists(out + "/training_checkpoints/ckpt-5.npz")            # restored ckpt-3, saved 4 (epoch) and 5 (end of run)
+    after = dict(np.load(out + "/training_checkpoints/ckpt-5.npz"))
+    trained = [k for k in before if not k.endswith(("moving_mean", "moving_variance"))]
+    assert all(np.array_equal(before[k], after[k]) for k in trained)            # lr 0: the restored weights, not a fresh initialisation
 
 
 def test_test_script_on_an_ndds_folder(device, tmp_path):

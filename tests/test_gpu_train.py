@@ -508,6 +508,19 @@ def test_model_api_train_step(device, k, bpnp):
     assert np.abs(after - before).max() > 1e-3, "inference must see the trained weights"
     p = net.get_parameters()
     assert np.abs(p["conv0.kernel"] - net._store.view("conv0.kernel").cpu().numpy()).max() == 0
+    # layer surgery after training has started (round-1 ADVICE): get_weights must return the TRAINED values and set_weights on one
+    # layer must not revert the others to their pre-training state
+    trained = net.get_parameters()
+    lay = net.get_layer("pv_block_6_clade")
+    wts = lay.get_weights()
+    assert [a.shape for a in wts[:2]] == [(k, 256), (k, 256)] and np.array_equal(wts[0], trained["pv_block_6_clade.beta"])   # Keras order: beta, gamma
+    assert np.array_equal(net.get_layer("stage1_unit1_conv1").get_weights()[0], trained["stage1_unit1_conv1.kernel"])
+    train_step(net, batch, lf, optim, opt)
+    trained = net.get_parameters()
+    lay.set_weights(lay.get_weights())
+    again = net.get_parameters()
+    assert all(np.array_equal(trained[n], again[n]) for n in trained)
+    assert np.abs(again["conv0.kernel"] - net._store.view("conv0.kernel").cpu().numpy()).max() == 0
     # frozen layers (layer.trainable = False) keep their weights
     net.get_layer("conv0").trainable = False
     w0 = net.get_parameters()["conv0.kernel"].copy()

@@ -62,3 +62,45 @@ def test_unsupported_features_are_refused(tmp_path):
     assert not H.is_hdf5(str(q))
     with pytest.raises(H.H5FormatError):
         H.read_h5(str(q))
+
+
+def test_keras_save_layout_round_trip(tmp_path):
+    """write_keras_h5 = what `net.save_weights("result_w.h5")` writes (train_casapose.py:903): Keras' group tree (nested backbone
+    model as ONE top-level layer), variable names, `layer_names` / `weight_names` / `backend` / `keras_version` attributes; the
+    reader maps it back to every parameter."""
+    import casapose_oracle as O
+
+    params = O.init_params(9, 27, seed=5, dtype=np.float32)
+    p = str(tmp_path / "result_w.h5")
+    H.write_keras_h5(p, params)
+    assert H.is_hdf5(p)
+    found = H.keras_weights_from_h5(p, {k.split(".")[0] for k in params})
+    assert set(found) == set(params) and all(np.array_equal(found[k], params[k]) for k in params)
+    attrs = H.read_attrs(p)
+    root = attrs["/"]
+    assert root["backend"] == b"tensorflow" and root["keras_version"].startswith(b"2.")
+    names = root["layer_names"]
+    assert names.count(b"model") == 1 and b"conv0" not in names and b"pv_block_6_clade" in names and b"pv_final_conv_vertex" in names
+    # every name listed in weight_names resolves to a dataset below its layer group, in Keras' variable order
+    paths = set(H.read_h5(p))
+    for layer in names:
+        wn = attrs["/" + layer.decode()]["weight_names"]
+        assert wn and all("/%s/%s" % (layer.decode(), w.decode()) in paths for w in wn)
+    m = [w.decode() for w in attrs["/model"]["weight_names"]]
+    i = m.index("bn0/gamma:0")
+    assert m[i:i + 4] == ["bn0/gamma:0", "bn0/beta:0", "bn0/moving_mean:0", "bn0/moving_variance:0"]
+    c = [w.decode() for w in attrs["/pv_block_6_clade"]["weight_names"]]
+    assert c[:2] == ["pv_block_6_clade/pv_block_6_clade_beta:0", "pv_block_6_clade/pv_block_6_clade_gamma:0"]   # add_weight order
+    assert c[2].startswith("pv_block_6_clade/sync_batch_normalization_") and c[2].endswith("/moving_mean:0")
+    assert [w.decode() for w in attrs["/pv_block_6_prepare_conv2d"]["weight_names"]] == ["pv_block_6_prepare_conv2d/pv_block_6_prepare_conv2d_weights:0"]
+
+
+def test_attribute_messages_do_not_disturb_the_dataset_reader(tmp_path):
+    rng = np.random.default_rng(1)
+    data = {"a/b/w:0": rng.standard_normal((3, 4)).astype(np.float32), "a/c:0": rng.standard_normal(5).astype(np.float32)}
+    p = str(tmp_path / "t.h5")
+    H.write_h5(p, data, attrs={"": {"layer_names": [b"a"], "note": "x" * 300}, "a": {"weight_names": [b"b/w:0", b"c:0"]}, "a/b": {"k": b"v"}})
+    got = H.read_h5(p)
+    assert all(np.array_equal(got["/" + k], v) for k, v in data.items())
+    at = H.read_attrs(p)
+    assert at["/"]["layer_names"] == [b"a"] and at["/"]["note"] == b"x" * 300 and at["/a"]["weight_names"] == [b"b/w:0", b"c:0"] and at["/a/b"]["k"] == b"v"

@@ -1,0 +1,52 @@
+"""The two CPU oracles agree with each other: the training-mode restatement (oracle/torch_train_ref.py, torch fp64 + autograd) run
+with batch statistics equals the inference-mode NumPy restatement (oracle/casapose_oracle.py) once those batch statistics are
+written into the moving mean / variance -- for casapose_c_gcu5 and for two registry siblings.  Neither oracle is pinned by
+TensorFlow (parity unpinned); this test only guarantees that the GPU's inference and training gates measure against ONE
+restatement of the graph, not two."""
+import numpy as np
+import pytest
+import torch
+
+import casapose_oracle as O
+import torch_train_ref as R
+
+
+@pytest.mark.parametrize("variant", ["casapose_c_gcu5", "casapose_c_gcu4_bilat", "casapose_c_gu", "casapose_c_gcu4_sw2"])
+def test_training_forward_equals_inference_forward_with_batch_statistics(variant):
+    k, v, b, h, w = 4, 27, 2, 32, 32
+    partial, guided = O.VARIANTS[variant]
+    sharing = O.SHARED.get(variant, O.NOT_SHARED)
+    kw = dict(partial=partial, guided=guided, bilinear=O.BILINEAR_GUIDED.get(variant, (False,) * 5), **sharing)
+    params = O.init_params(k, v, seed=11, dtype=np.float64, partial=partial, **sharing)
+    rng = np.random.default_rng(2)
+    img = rng.uniform(-1, 1, (b, h, w, 3))
+    lab = np.zeros((b, h, w), np.int64)
+    lab[:, 4:20, 6:22] = 1
+    lab[0, 14:30, 12:30] = 2
+    lab[1, 2:12, 20:31] = 3
+    stats = {}
+    with torch.no_grad():
+        out_t = R.forward_train(R.to_torch(params, requires_grad=False), torch.from_numpy(img), torch.from_numpy(lab), stats_out=stats, **kw).numpy()
+    p2 = dict(params)
+    for name, (mean, var) in stats.items():
+        p2[name + ".moving_mean"], p2[name + ".moving_variance"] = mean.numpy(), var.numpy()
+    assert len(stats) >= 29                                              # every normalisation layer of the graph reported
+    out_n = O.casapose_c_gcu5(p2, img, seg_input=O.onehot_from_labels(lab, k, np.float64), variant=variant)
+    assert out_t.shape == out_n.shape == (b, h, w, k + v)
+    assert np.abs(out_t - out_n).max() < 1e-9 * max(1.0, np.abs(out_n).max())
+
+
+def test_inference_mode_of_the_torch_restatement_equals_the_numpy_oracle():
+    """The graph `bench.py`'s cpu_baseline times (forward_train(training=False, labels=None), there in fp32) is the NumPy oracle's
+    inference forward with the estimated mask."""
+    k, v, b, h, w = 9, 27, 1, 32, 48
+    params = O.init_params(k, v, seed=1237, dtype=np.float64)
+    img = np.random.default_rng(5).uniform(-1, 1, (b, h, w, 3))
+    with torch.no_grad():
+        out_t = R.forward_train(R.to_torch(params, requires_grad=False), torch.from_numpy(img), None, training=False).numpy()
+    out_n = O.casapose_c_gcu5(params, img)
+    assert np.abs(out_t - out_n).max() < 1e-9 * max(1.0, np.abs(out_n).max())
+    # and its LS voter equals the NumPy voter on the same record
+    seg, direct, conf, labels, _ = O.synthetic_voting_inputs(1, 40, 60, num_obj=8, seed=3)
+    got = R.ls_voting(torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(direct.astype(np.float64)), torch.from_numpy(conf.astype(np.float64)), 8).numpy()
+    assert np.abs(got - O.ls_voting(seg, direct, conf)).max() < 1e-3

@@ -2,7 +2,7 @@
 # usage: [FILES="conv_f32 conv_halo"] tools/build_variant.sh <name> <extra hipcc -D flags...>   -> variants/lib_<name>.so
 # (the listed sources -- default conv_f32.hip and conv_halo.hip -- rebuilt with the flags; every other object of the regular build linked unchanged)
 set -e
-R=/root/repo; C=$R/casapose_amd/csrc; name=$1; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; C=$R/casapose_amd/csrc; name=$1; shift
 FILES=${FILES:-"conv_f32 conv_halo"}
 mkdir -p $R/variants
 make -C $C -s

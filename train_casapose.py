@@ -10,7 +10,9 @@ Differences that are forced by this environment and documented in DESIGN.md:
     semantics of MirroredStrategy) instead of one process driving all GPUs; `--batchsize` stays the GLOBAL batch;
   * `--data <folder>` reads an NDDS / converted-BOP tree like the reference (casapose_amd/data_handler/vectorfield_dataset.py);
     `--data synthetic[:N]` selects the built-in ray-cast scene generator (synthetic_scene.py) -- there is no dataset here;
-  * weights are stored as .npz under the reference's file names (no h5py here).
+  * checkpoints (`training_checkpoints/ckpt-<n>`, tf.train.Checkpoint in the reference) are .npz files holding the network only,
+    like the reference's Checkpoint(network=net); `frozen_model/result_w.h5` is real HDF5 in Keras' save_weights layout
+    (casapose_amd/utils/h5_weights.py).
 """
 import datetime
 import os
@@ -30,6 +32,7 @@ from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted 
 from casapose_amd.pose_models.tfkeras import Classifiers  # noqa: E402
 from casapose_amd.training import Adam, copy_weights_add_confidence_maps, copy_weights_from_backup_network, train_step  # noqa: E402
 from casapose_amd.utils.config_parser import parse_config  # noqa: E402
+from casapose_amd.utils.io_utils import latest_checkpoint  # noqa: E402
 from casapose_amd.utils.learning_rate_schedules import ExponentialDecayLateStart, LossWeightHandler, PiecewiseConstantDecay  # noqa: E402
 
 
@@ -136,8 +139,17 @@ def main(argv=None):
     if net_backup is not None:
         net_backup.load_weights(frozen_path + "/" + opt.load_h5_filename + ".h5", by_name=True, skip_mismatch=True)
         print("loaded backup network")
+    save_count = [0]
     if opt.load_h5_weights:
         net.load_weights(frozen_path + "/" + opt.load_h5_filename + ".h5", by_name=True, skip_mismatch=True)
+    elif opt.net != "":  # resume: checkpoint.restore(tf.train.latest_checkpoint(checkpoint_path)) (train_casapose.py:379-393)
+        latest = latest_checkpoint(checkpoint_path)
+        if latest is not None:
+            net.load_weights(latest[0])
+            save_count[0] = latest[1]  # tf.train.Checkpoint restores its save_counter: numbering continues
+            print("restored {}".format(latest[0]))
+        else:
+            print("no checkpoint under {}: starting from the initial weights".format(checkpoint_path))
     if opt.copy_weights_add_confidence_maps and opt.estimate_confidence:
         copy_weights_add_confidence_maps(net, net_backup, ver_dim - opt.no_points)
     elif opt.copy_weights_from_backup_network:
@@ -160,7 +172,6 @@ def main(argv=None):
             s += "".join(",2d_{}".format(o) for o in objectsofinterest) + "".join(",3d_{}".format(o) for o in objectsofinterest)
             f.write(s + "\n")
     group = torch.distributed.group.WORLD if world > 1 else None
-    save_count = [0]
 
     def shard(batch):
         b, e = parallel.shard_range(opt.batchsize, rank, world)
