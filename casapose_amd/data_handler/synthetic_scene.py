@@ -120,13 +120,18 @@ class SyntheticSceneDataset:
         return dict(img=img.astype(np.float32), label=label, poses=poses, kp2=kp2, counts=counts,
                     offsets=np.array([hc, wc, 0, 0, 0, 0, 0, 1, FULL_W, FULL_H], np.float32))
 
-    def batch(self, index: int, batchsize: int) -> Dict[str, torch.Tensor]:
-        """Deterministic batch `index` (images index*batchsize ... of the endless stream seeded by `seed`)."""
-        items = [self._render(np.random.default_rng([self.seed, index * batchsize + i])) for i in range(batchsize)]
+    def batch(self, index: int, batchsize: int, shard: Tuple[int, int] = (0, 1)) -> Dict[str, torch.Tensor]:
+        """Deterministic batch `index` (images index*batchsize ... of the endless stream seeded by `seed`).  `shard = (rank, world)`
+        renders only that replica's contiguous slice of the global batch (casapose_amd.parallel.shard_range) -- image i of the
+        stream is the same picture whichever replica draws it."""
+        from ..parallel import shard_range
+
+        begin, end = shard_range(batchsize, shard[0], shard[1])
+        items = [self._render(np.random.default_rng([self.seed, index * batchsize + i])) for i in range(begin, end)]
         K1 = self.oc + 1
         lab = np.stack([it["label"] for it in items])
         seg = np.eye(K1, dtype=np.float32)[lab]
-        b = batchsize
+        b = end - begin
         return dict(
             img=torch.from_numpy(np.stack([it["img"] for it in items])),
             target_seg=torch.from_numpy(seg),
@@ -144,14 +149,15 @@ class SyntheticSceneDataset:
         """(vertex_array [oc,V,3], vertex_count [oc,1]) like VectorfieldDataset.generate_object_vertex_array."""
         return self.mesh_vertex_array.astype(np.float32), self.mesh_vertex_count
 
-    def generate_dataset(self, batchsize: int, epochs: int = 1, *_unused, **_unused_kw) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
+    def generate_dataset(self, batchsize: int, epochs: int = 1, *_unused, shard: Tuple[int, int] = (0, 1), **_unused_kw) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
         """(iterator over epochs*batches batches, batches per epoch) -- the shape of VectorfieldDataset.generate_dataset
-        (vectorfield_dataset.py:905-1013).  The same `length` images are revisited every epoch."""
+        (vectorfield_dataset.py:905-1013).  The same `length` images are revisited every epoch.  `batchsize` is the GLOBAL batch
+        (vectorfield_dataset.py:923,1002); with shard = (rank, world) every replica produces only its own slice of each batch."""
         n = self.length // batchsize
 
         def it():
             for _ in range(max(epochs, 1) + 1):
                 for i in range(n):
-                    yield self.batch(i, batchsize)
+                    yield self.batch(i, batchsize, shard)
 
         return it(), n

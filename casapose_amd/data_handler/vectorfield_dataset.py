@@ -161,6 +161,7 @@ class VectorfieldDataset:
         self.use_train_split, self.use_validation_split, self.train_validation_split = use_train_split, use_validation_split, train_validation_split
         self.visibility_filter, self.wxyz_quaterion_input = visibility_filter, wxyz_quaterion_input
         self.rng = np.random.default_rng(seed)
+        self.order_rng = np.random.default_rng([seed if seed is not None else 0, 1])  # epoch permutations only: identical on every replica
         self.meshes = self.load_meshes(path_meshes)
         self.imgs: List[Tuple[str, str, str, str, str]] = []
         self.class_labels: Dict[str, Dict[str, int]] = {}
@@ -327,16 +328,22 @@ class VectorfieldDataset:
 
     # ---- batches ---------------------------------------------------------------------------------------
     def generate_dataset(self, batchsize, epochs, prefetch=0, imagesize=(448, 448), cropratio=1.0, worker=1, no_objects=None, shuffle=True,
-                         mirrored_strategy=None) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
+                         mirrored_strategy=None, shard: Tuple[int, int] = (0, 1)) -> Tuple[Iterator[Dict[str, torch.Tensor]], int]:
+        """`batchsize` is the GLOBAL batch (vectorfield_dataset.py:923; `experimental_distribute_dataset` splits it, :1000-1002).  Here every
+        replica owns a process: shard = (rank, world) makes it read, decode and augment only its contiguous slice of each global batch
+        (the epoch permutation comes from a generator of its own, seeded alike on all replicas, so the slices partition the batch)."""
+        from ..parallel import shard_range
+
         data_size = len(self.imgs) - (len(self.imgs) % batchsize)
         epoch_batches = data_size // batchsize
         oc = len(self.objectsofinterest)
+        begin, end = shard_range(batchsize, shard[0], shard[1])
 
         def it():
             for _ in range(max(int(epochs), 1)):
-                order = self.rng.permutation(data_size) if shuffle else np.arange(data_size)
+                order = self.order_rng.permutation(data_size) if shuffle else np.arange(data_size)
                 for b in range(epoch_batches):
-                    items = [self.apply_preprocessing(self.imgs[i], imagesize, cropratio) for i in order[b * batchsize:(b + 1) * batchsize]]
+                    items = [self.apply_preprocessing(self.imgs[i], imagesize, cropratio) for i in order[b * batchsize + begin:b * batchsize + end]]
                     lab = np.stack([x["label"] for x in items])
                     st = lambda k: torch.from_numpy(np.stack([x[k] for x in items]))  # noqa: E731
                     yield dict(img=st("img"), target_seg=torch.from_numpy(np.eye(oc + 1, dtype=np.float32)[lab]), target_vert=st("target_vert"),

@@ -75,3 +75,20 @@ def all_reduce_sum_async(t: torch.Tensor, group=None):
     """Start a SUM all-reduce of `t` and return the work handle (`.wait()` makes the current stream wait for it).  RCCL runs it on its
     own stream after the work already queued on the current stream, so it overlaps whatever is launched next."""
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def reduce_step_log(losses, pose_stats, world_size: int, device=None):
+    """The per-step logging exchange of the training driver as ONE collective: `losses` (5 python floats) become their MEAN over the
+    replicas (strategy.reduce(MEAN), train_casapose.py:690-694), `pose_stats` (a sequence of >= 6 per-object vectors, or None) its first
+    six vectors SUMMED over the replicas (:732-737).  Returns (list of floats, [6, objects] float64 array or None)."""
+    import numpy as np
+
+    st = None if pose_stats is None else np.stack([np.asarray(pose_stats[j], np.float64).reshape(-1) for j in range(6)])
+    if world_size <= 1 or not dist.is_initialized():
+        return [float(v) for v in losses], st
+    flat = np.concatenate([np.asarray(losses, np.float64) / world_size] + ([st.reshape(-1)] if st is not None else []))
+    t = torch.from_numpy(flat).to(device if device is not None and dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    flat = t.cpu().numpy()
+    n = len(losses)
+    return [float(v) for v in flat[:n]], (flat[n:].reshape(st.shape) if st is not None else None)

@@ -75,10 +75,53 @@ def voting_case():
                         ransac_draws=draws, ransac_keypoints=rs, ransac_rounds=rounds, true_keypoints=kps.astype(np.float32))
 
 
+def ellipse_labels(h, w, objects, seed):
+    """objects non-overlapping ellipses on a grid, one per class, rest background (SURVEY 8d training inputs)."""
+    rng = np.random.default_rng(seed)
+    cols = int(np.ceil(np.sqrt(objects * w / h)))
+    rows = int(np.ceil(objects / cols))
+    yy, xx = np.mgrid[0:h, 0:w]
+    lab = np.zeros((h, w), np.uint8)
+    for o in range(objects):
+        cy, cx = (o // cols + 0.5) * h / rows, (o % cols + 0.5) * w / cols
+        ry, rx = rng.uniform(0.25, 0.45) * h / rows, rng.uniform(0.25, 0.45) * w / cols
+        lab[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = o + 1
+    return lab
+
+
+def fullsize_case(name, k, h, w, seed, samples=8192):
+    """ONE image at a BASELINE.json size through the fp64 oracle (minutes on this machine, once): the GPU tests cannot afford the
+    oracle at that size, so the fixture keeps (a) the oracle's own arg-max label map, (b) a sample of complete output records of the
+    estimated-mask forward, (c) the same sample of the forward conditioned on a GIVEN synthetic label map (ellipses), (d) the logits'
+    top-2 margin at every pixel (uint8-quantised flag: margin < 1e-3 of the range) so that label disagreements can be attributed
+    to near-ties.  Inputs are regenerated from the seeds by the test; checksums guard that."""
+    v = 27
+    p = O.init_params(k, v, seed=seed, dtype=np.float64)
+    img = np.random.default_rng(seed).uniform(-1, 1, (1, h, w, 3)).astype(np.float32)
+    given = ellipse_labels(h, w, k - 1, seed)[None]
+    out_est = O.casapose_c_gcu5(p, img.astype(np.float64))
+    out_giv = O.casapose_c_gcu5(p, img.astype(np.float64), seg_input=O.onehot_from_labels(given.astype(np.int64), k))
+    logits = out_est[0, ..., :k]
+    top2 = np.sort(logits, -1)[..., -2:]
+    near_tie = ((top2[..., 1] - top2[..., 0]) < 1e-3 * np.abs(logits).max()).astype(np.uint8)
+    rng = np.random.default_rng(seed + 1)
+    ys, xs = rng.integers(0, h, samples), rng.integers(0, w, samples)
+    np.savez_compressed(os.path.join(HERE, name), seed=seed, classes=k, height=h, width=w,
+                        image_abs_sum=float(np.abs(img.astype(np.float64)).sum()), param_abs_sum=float(sum(np.abs(a).sum() for a in p.values())),
+                        labels_estimated=logits.argmax(-1).astype(np.uint8), near_tie=np.packbits(near_tie), labels_given=given[0],
+                        sample_y=ys.astype(np.int16), sample_x=xs.astype(np.int16),
+                        records_estimated=out_est[0, ys, xs].astype(np.float32), records_given=out_giv[0, ys, xs].astype(np.float32),
+                        logit_range=float(np.abs(logits).max()), field_range=float(np.abs(out_giv[0, ..., k:]).max()))
+
+
 if __name__ == "__main__":
-    forward_case()
-    layer_cases()
-    voting_case()
+    if "--fullsize" in sys.argv:  # minutes per image: run on demand, the small cases below are not touched
+        fullsize_case("fullsize_gcu5_k9_480x640.npz", 9, 480, 640, 1237)       # BASELINE configs[1]: 8-object LMO inference size
+        fullsize_case("fullsize_gcu5_k14_448x448.npz", 14, 448, 448, 1313)     # configs[4]: 13-object network at the training size
+    else:
+        forward_case()
+        layer_cases()
+        voting_case()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

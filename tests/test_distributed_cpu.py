@@ -123,3 +123,60 @@ def test_two_rank_syncbn_protocol_matches_whole_batch():
     assert np.allclose(res[0][3], mean.detach().numpy(), atol=1e-12) and np.allclose(res[1][4], var.detach().numpy(), atol=1e-10)
     assert np.allclose(dx, x.grad.numpy(), atol=1e-10)
     assert np.allclose(res[0][6], gamma.grad.numpy(), atol=1e-10) and np.allclose(res[1][6], gamma.grad.numpy(), atol=1e-10)
+
+
+def _log_worker(rank, world, port, q):
+    import numpy as np
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from casapose_amd import parallel
+    from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
+
+    parallel.init_from_env("gloo")
+    calls = {"n": 0}
+    real = torch.distributed.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    torch.distributed.all_reduce = counting
+    losses = [1.0 + rank, 2.0 * rank, 0.5, 3.0, rank * rank]
+    stats = [np.arange(8, dtype=np.float64) * (j + 1) + rank for j in range(8)]
+    mean, st = parallel.reduce_step_log(losses, stats, world, None)
+    mean2, st2 = parallel.reduce_step_log(losses, None, world, None)
+    torch.distributed.all_reduce = real
+    # every replica renders only its slice of the GLOBAL batch (ragged: 7 images over 3 replicas), and the slices partition it
+    ds = SyntheticSceneDataset(3, (64, 64), length=7, seed=5, random_crop=False)
+    it, n = ds.generate_dataset(7, 1, shard=(rank, world))
+    mine = next(it)
+    q.put((rank, mean, st, mean2, st2 is None, calls["n"], mine["img"].numpy(), n))
+    torch.distributed.destroy_process_group()
+
+
+def test_three_rank_packed_logging_and_source_sharding():
+    """ONE collective per step for the logged quantities (5 losses as MEAN, 6 pose-statistic vectors as SUM; train_casapose.py:690-694,
+    732-737) and per-replica data sharding at the source, world size 3 with a ragged global batch."""
+    import numpy as np
+
+    from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_log_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_mean = [np.mean([1.0 + r for r in range(3)]), np.mean([2.0 * r for r in range(3)]), 0.5, 3.0, np.mean([r * r for r in range(3)])]
+    want_st = np.stack([sum(np.arange(8, dtype=np.float64) * (j + 1) + r for r in range(3)) for j in range(6)])
+    whole = SyntheticSceneDataset(3, (64, 64), length=7, seed=5, random_crop=False).batch(0, 7)["img"].numpy()
+    got = np.concatenate([r[6] for r in res])
+    assert [r[6].shape[0] for r in res] == [3, 2, 2] and np.array_equal(got, whole)
+    for rank, mean, st, mean2, none2, ncalls, _, n in res:
+        assert np.allclose(mean, want_mean) and np.allclose(mean2, want_mean) and np.allclose(st, want_st) and none2
+        assert ncalls == 2 and n == 1                     # exactly one all-reduce per logged step

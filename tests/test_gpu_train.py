@@ -556,3 +556,88 @@ def test_weight_surgery_helpers(device):
     copy_weights_add_confidence_maps(conf, noconf, 18, print_fn=lambda *_: None)
     k2 = conf.get_parameters()["pv_final_conv_vertex.kernel"]
     assert np.array_equal(k2[..., :18], noconf.get_parameters()["pv_final_conv_vertex.kernel"]) and np.array_equal(k2[..., 18:], b2[..., 18:])
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: the 13-object network (config_13.ini) with use_bpnp_reprojection_loss = 1, at the training size
+# --------------------------------------------------------------------------------------------------
+def test_config13_bpnp_step_at_448_matches_autograd(device):
+    """K = 14, 448x448, one image of the ray-cast 13-object scene: forward with batch statistics, mask / vertex / proxy losses and the
+    keypoint loss in its BPnP form (host PnP + implicit-function gradient, loss_functions.py:264-323, config_13.ini) TOGETHER, then
+    the whole backward.  Reference: oracle/torch_train_ref.py in fp64 -- autograd through the network and the differentiable LS
+    voter, with d loss / d keypoints of the BPnP term supplied by the same host routine evaluated on the REFERENCE's voted
+    keypoints (that routine's implicit gradient is itself checked against finite differences below, at this configuration).
+    Gates: outputs <= 1e-3 of range, loss values <= 1e-3 relative, every trainable variable's gradient <= 2e-2 relative L2."""
+    from casapose_amd import training as T
+    from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
+    from casapose_amd.train_engine import ParamStore, TrainPlan, crop_to_image_affine, project_keypoints
+
+    b, h, w, k, kp, v = 1, 448, 448, 14, 9, 27
+    ds = SyntheticSceneDataset(k - 1, (h, w), length=1, seed=6)
+    batch = ds.batch(0, b)
+    img = batch["img"].numpy().astype(np.float32)
+    lab = batch["filtered_seg"][..., 0].numpy().astype(np.uint8)
+    kpts = batch["target_vert"][:, :, 0].numpy().astype(np.float32)                                  # [b,oc,kp,2] (y,x) crop pixels
+    params = O.init_params(k, v, seed=13, dtype=np.float32)
+    store = ParamStore(params, device)
+    plan = TrainPlan(store, k, v, b, h, w)
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    labd, kd = torch.from_numpy(lab).to(device), torch.from_numpy(kpts).to(device)
+    out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd).cpu().numpy()
+    # ---- reference forward ----
+    p64 = R.to_torch(params)
+    labt = torch.from_numpy(lab.astype(np.int64))
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), labt)
+    assert rel(out[..., :k], ref.detach().numpy()[..., :k]) < 1e-3 and rel(out[..., k:], ref.detach().numpy()[..., k:]) < 1e-3
+    # ---- losses: mask + vertex + proxy on both sides ----
+    wts, kp_w, cap = (1.0, 0.5, 0.015), 0.007, 12.5
+    sums = plan.loss_and_grad(labd, labd, kd, *wts, filter_with_segmentation=True).cpu().numpy()
+    ml, vl, pl = R.losses(ref, labt, torch.from_numpy(kpts.astype(np.float64)), k, kp, True)
+    for got, want in zip(sums[:3], (ml, vl, pl)):
+        assert abs(got - want.item()) < 1e-3 * abs(want.item())
+    # ---- keypoint loss, BPnP form ----
+    cam = batch["cam_mat"].numpy().astype(np.float64)
+    cam = cam[0] if cam.ndim == 3 else cam
+    p3d = batch["keypoints3d"].numpy().astype(np.float64).reshape(b, k - 1, kp, 3)
+    gt_xy_np = project_keypoints(p3d, cam, batch["poses_gt"].numpy().astype(np.float64).reshape(b, k - 1, 3, 4))
+    aff_np = crop_to_image_affine(batch["offsets"].numpy().astype(np.float64))
+    gt_xy, aff = torch.from_numpy(gt_xy_np).to(device).contiguous(), torch.from_numpy(aff_np).to(device).contiguous()
+    seen = {}
+
+    def host_loss(c, av):
+        lv, g, _ = T.bpnp_reprojection_loss_host(c, gt_xy, aff, av, p3d, cam, cap, kp_w)
+        seen["coords"], seen["avail"], seen["loss"], seen["g"] = T._host(c).copy(), T._host(av).copy(), lv, g
+        return lv, g
+
+    val = plan.kp_loss_and_grad(labd, gt_xy, aff, kp_w, max_pixel_error=cap, min_num=50, confidence_regularization=True, vote_with_gt=True, host_loss=host_loss)
+    coords_ref = R.ls_voting(labt, ref[..., k:k + 2 * kp], ref[..., k + 2 * kp:], k - 1)
+    avail = seen["avail"]
+    assert avail.sum() >= 6, "the scene must show enough objects for the test to mean something"
+    big = avail[0] > 0
+    assert np.abs(seen["coords"][0][big] - coords_ref.detach().numpy()[0][big]).max() < 0.05 + 1e-3 * np.abs(coords_ref.detach().numpy()[0][big]).max()
+    lv_ref, g_ref, _ = T.bpnp_reprojection_loss_host(coords_ref.detach().numpy(), gt_xy_np, aff_np, avail, p3d, cam, cap, kp_w)
+    # confidence regulariser |mean_fg softplus(conf) - 0.7| (loss_functions.py:325-342) in torch
+    fg = (labt > 0).double()
+    cl = (F.softplus(ref[..., k + 2 * kp:]) * fg[..., None]).sum((1, 2)) / fg.sum((1, 2))[:, None]
+    reg = (cl - 0.7).abs().mean()
+    assert abs(val.item() - (lv_ref + reg.item())) < 2e-3 * abs(lv_ref + reg.item())
+    total = wts[0] * ml + wts[1] * vl + wts[2] * pl + kp_w * reg + (coords_ref * torch.from_numpy(g_ref.astype(np.float64))).sum()
+    total.backward()
+    plan.backward()
+    torch.cuda.synchronize()
+    worst = {name: rel_l2(store.grad_view(name).cpu().numpy(), p64[name].grad.numpy()) for name in store.offsets}
+    bad = {n: e for n, e in worst.items() if e > 2e-2}
+    assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
+    # ---- the host BPnP gradient itself, by central differences on two visible objects of THIS scene ----
+    c0 = coords_ref.detach().numpy().copy()
+    one = np.zeros_like(avail)
+    for o in np.nonzero(big)[0][:2]:
+        one[:] = 0
+        one[0, o] = 1
+        _, g, _ = T.bpnp_reprojection_loss_host(c0, gt_xy_np, aff_np, one, p3d, cam, cap, 1.0)
+        for j, a in ((0, 0), (4, 1), (8, 0)):
+            cp, cm = c0.copy(), c0.copy()
+            cp[0, o, j, a] += 1e-3
+            cm[0, o, j, a] -= 1e-3
+            fd = (T.bpnp_reprojection_loss_host(cp, gt_xy_np, aff_np, one, p3d, cam, cap, 1.0)[0] - T.bpnp_reprojection_loss_host(cm, gt_xy_np, aff_np, one, p3d, cam, cap, 1.0)[0]) / 2e-3
+            assert abs(fd - g[0, o, j, a]) < 2e-3 * max(1.0, np.abs(g[0, o]).max()) + 2e-2 * abs(fd), (o, j, a, fd, g[0, o, j, a])

@@ -218,3 +218,26 @@ def test_flat_parameter_buffer_follows_forward_order_for_gradient_buckets():
     assert [rank[b] for b in BUCKET_STARTS] == sorted(rank[b] for b in BUCKET_STARTS) and rank[BUCKET_STARTS[0]] == 0
     assert all(st.offsets[n][0] % 4 == 0 for n in names)
     np.testing.assert_array_equal(st.view("conv0.kernel").numpy(), params["conv0.kernel"])
+
+
+def test_casapose_alias_package_serves_the_reference_import_surface():
+    """`from casapose... import ...` as the reference's scripts write it (tfkeras.py:17; train_casapose.py:12-31; test_casapose.py:10-21)
+    resolves to the SAME module objects as casapose_amd (one copy of every module, shared library handle and caches)."""
+    import importlib
+
+    import casapose
+    import casapose_amd
+
+    pairs = ["pose_models.tfkeras", "pose_models.models_factory", "pose_models.model_factory", "pose_estimation.voting_layers_2d", "pose_estimation.ransac_voting",
+             "pose_estimation.pose_evaluation", "utils.config_parser", "utils.io_utils", "utils.learning_rate_schedules", "data_handler.vectorfield_dataset"]
+    for name in pairs:
+        assert importlib.import_module("casapose." + name) is importlib.import_module("casapose_amd." + name), name
+    from casapose.pose_models.tfkeras import Classifiers
+    from casapose_amd.pose_models.tfkeras import Classifiers as C2
+
+    assert Classifiers is C2 and "casapose_c_gcu5" in Classifiers.models_names()
+    import pytest
+
+    with pytest.raises(ModuleNotFoundError, match="casapose_amd.utils.draw_utils"):
+        importlib.import_module("casapose.utils.draw_utils")
+    assert casapose.__path__ == [] and casapose_amd.__name__ == "casapose_amd"

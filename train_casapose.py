@@ -108,7 +108,9 @@ def main(argv=None):
     local_bs = opt.batchsize // world
     train_ds = open_dataset(opt.data, opt, no_objects, opt.imagesize, True, opt.manualseed)
     test_ds = open_dataset(opt.datatest, opt, no_objects, opt.imagesize, False, opt.manualseed + 1)
-    gen = lambda ds: ds.generate_dataset(opt.batchsize, opt.epochs, opt.prefetch, opt.imagesize, opt.crop_factor, opt.workers, no_objects)  # noqa: E731
+    # per-replica sharding AT THE SOURCE: each rank renders / reads only its slice of the global batch
+    gen = lambda ds: ds.generate_dataset(opt.batchsize, opt.epochs, opt.prefetch, opt.imagesize, opt.crop_factor, opt.workers, no_objects,  # noqa: E731
+                                         shard=(rank, world))
     trainingdata, train_batches = gen(train_ds) if train_ds else (None, 0)
     testingdata, test_batches = gen(test_ds) if test_ds else (None, 0)
     print("training data: {} batches".format(train_batches))
@@ -173,26 +175,20 @@ def main(argv=None):
             f.write(s + "\n")
     group = torch.distributed.group.WORLD if world > 1 else None
 
-    def shard(batch):
-        b, e = parallel.shard_range(opt.batchsize, rank, world)
-        return {k: v[b:e] for k, v in batch.items()}
-
     def runnetwork(iterator, batches_per_epoch, epoch, train=True, pose_validation=False):
         lr = optimizer.lr
         epoch_loss = np.zeros(5)
         pose_acc = np.zeros((6, no_objects))
         start = time.time()
         for batch_idx in range(batches_per_epoch):
-            batch = shard(next(iterator))
+            batch = next(iterator)
             loss = train_step(net, batch, loss_factors, optimizer, opt, group, world, train=train)
-            loss = [parallel.sum_over_ranks(v, device) / world for v in loss] if world > 1 else loss      # MEAN over replicas (:690-694)
-            if pose_validation and not train:
-                st = pose_statistics(net, batch, opt, no_objects, device)
-                for i, j in enumerate((0, 1, 2, 3, 4, 5)):
-                    v = torch.as_tensor(np.asarray(st[j], np.float64), device=device)
-                    if world > 1:
-                        torch.distributed.all_reduce(v)                                                  # SUM over replicas (:732-737)
-                    pose_acc[i] += v.cpu().numpy()
+            st = pose_statistics(net, batch, opt, no_objects, device) if (pose_validation and not train) else None
+            # ONE packed collective per step for everything that is logged: the 5 loss scalars (MEAN over replicas, :690-694) and the
+            # 6 per-object pose-statistic vectors (SUM over replicas, :732-737)
+            loss, st = parallel.reduce_step_log(loss, st, world, device)
+            if st is not None:
+                pose_acc += st
             epoch_loss += np.array(loss[:5])
             if rank == 0:
                 with open(opt.outf + ("/loss_train.csv" if train else "/loss_test.csv"), "a") as f:
