@@ -78,6 +78,8 @@ class ConvDesc(C.Structure):
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO, TILE_STEM = range(9)
+# host-side selectors (never passed to the library): the bf16-pipe kernel of csrc/conv_hsplit.hip with 3 planes (exact fp32 split) / 1 plane (bf16)
+TILE_SPLIT3, TILE_BF16 = 100, 101
 
 # every symbol include/casapose_hip.h declares: (name, restype, argtypes)
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -93,6 +95,12 @@ SYMBOLS = [
     ("cp_conv_pack_head_weights_host", _i, [_vp, _i, _vp]),
     ("cp_conv2d_fwd_f32", _i, [C.POINTER(ConvDesc), _vp]),
     ("cp_conv_selected_tile", _i, [C.POINTER(ConvDesc)]),
+    ("cp_conv_split_applicable", _i, [C.POINTER(ConvDesc)]),
+    ("cp_conv_split_weight_floats", _i, [_i, _i, C.POINTER(_i)]),
+    ("cp_conv_split_weight_bytes", C.c_size_t, [_i, _i, C.POINTER(_i), _i]),
+    ("cp_conv_pack_weights_split_host", _i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    ("cp_conv_split_weights_f32", _i, [_vp, _ll, _i, _vp, _vp]),
+    ("cp_conv2d_fwd_split", _i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),
     ("cp_maxpool3x3s2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     ("cp_upsample_bilinear_x2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -1,0 +1,639 @@
+// 3x3 / stride 1 / pad 1 convolution for the shallow, high-resolution layers (cout <= 64) on the bf16 matrix pipe:
+//   NP = 3  fp32-EQUIVALENT: every fp32 operand is split exactly into three bf16 terms (hi, mid, lo: 8 + 8 + 8 significand bits) and the
+//           six products lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (the scheme of
+//           wino_gemm_split.hip; the three dropped products are <= 2^-24 of the full product -- the rounding an fp32 multiply makes anyway);
+//   NP = 1  plain bf16 operands (round to nearest even), fp32 accumulation -- "bf16 convolutions" of BASELINE.json configs[2].
+// Activations and outputs stay fp32 in HBM; the split / conversion happens once per staged halo pixel.
+//
+// Why not conv_halo.hip with another instruction: six bf16 MFMAs of K = 16 take 6 x 32 cycles where the fp32 MFMA needs 8 x 64, so at the
+// old tile shape the weight fragments (1.5x the bytes per k, 2.7x less time) would need ~64 B/clk/CU from L1.  Here
+//   * a block owns 16 rows x 32 columns of output; each of its 8 waves computes TWO rows, so every weight fragment fetched from L2 feeds
+//     two pixel fragments (31 B/clk/CU), and every pixel fragment read from LDS feeds TN cout blocks;
+//   * there are no producer waves: all 8 waves issue the next 16-channel slice's halo loads (18 x 34 pixels) before their MFMAs, and split +
+//     store them into the other LDS stage afterwards -- one barrier per slice, ~5 % of a slice's MFMA time;
+//   * halo planes are [pixel][16 bf16] = 32-byte rows with the two 16-byte slots swapped for pixels with bit 3 set: the 16 lanes of a
+//     ds_read_b128 group hit 16 different slots at any tap offset (no padding: 3 planes x 2 stages = 117.5 KB, + 29 KB image halo);
+//   * the 4-channel image source is three K = 16 steps with k = tap * 4 + channel.
+// Accumulators are transposed as in conv_halo.hip (MFMA A = weights, B = pixels): lane = pixel, so the partial-conv tap mask, 9/count,
+// the CLADE table row, residual and stores are per lane with four consecutive channels in four consecutive registers.
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int COLS = 34;             // 32 output columns + 2 halo columns
+constexpr int TH = 16;               // output rows per tile (2 per wave)
+constexpr int HR = TH + 2;
+constexpr int HP = HR * COLS;        // 612 halo pixels
+constexpr int PLANE_B = HP * 32;     // bytes of one halo plane (16 bf16 per pixel)
+constexpr int IPLANE_B = HP * 8;     // bytes of one image-halo plane (4 bf16 per pixel)
+constexpr int NIT = (HP * 4 + 511) / 512;   // float4 halo elements per thread and slice
+
+struct SSrc {
+    const float* data;
+    int C, ld;
+    unsigned bytes;
+};
+
+struct HSplitK {
+    SSrc s[2];
+    const float* img;
+    unsigned img_bytes;
+    const unsigned char* W;   // [step][cout block][plane][64 lanes][8 bf16]; steps = 9 per 16-channel slice, then 3 image steps
+    unsigned w_bytes;
+    int B, H, Wd, Cout;
+    int nch0, nch;            // 16-channel slices of source 0 / of both sources
+    int tiles_y, tiles_x, ntiles;
+    const uint8_t* label;
+    unsigned lab_bytes;
+    const float* residual;
+    int res_ld;
+    const float* scale;
+    const float* shift;
+    int clade, norm, act;
+    float* out_raw;
+    int raw_ld;
+    float* out_act;
+    int act_ld;
+};
+
+#define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ unsigned pack_hi16(unsigned a_lo, unsigned b_hi) { return __builtin_amdgcn_perm(b_hi, a_lo, 0x07060302u); }
+
+// exact three-way split of four floats into packed bf16 pairs (see wino_gemm_split.hip)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float r1 = x[e] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+        m[e] = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, m[e] & 0xffff0000u);
+        l[e] = __builtin_bit_cast(unsigned, r2);
+    }
+    hi = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    mid = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    lo = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+}
+
+// round-to-nearest-even bf16 of four floats (finite inputs; NaN payloads are not preserved bit for bit, which no caller needs)
+__device__ __forceinline__ uint2 round4(const float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[e]);
+        r[e] = u + 0x7fffu + ((u >> 16) & 1u);
+    }
+    return make_uint2(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]));
+}
+
+template <int NP>
+__global__ void hsplit_weights_kernel(const float* __restrict__ src, long long nfrag, unsigned char* __restrict__ dst) {
+    // src: [fragment][64 lanes][8 floats] -> dst: [fragment][plane][64 lanes][8 bf16]
+    const long long total = nfrag * 64;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i >> 6;
+        const int lane = (int)(i & 63);
+        const float4 v0 = *reinterpret_cast<const float4*>(src + i * 8), v1 = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        unsigned char* d = dst + (f * NP) * 1024 + lane * 16;
+        if constexpr (NP == 3) {
+            uint2 h0, m0, l0, h1, m1, l1;
+            split4(v0, h0, m0, l0);
+            split4(v1, h1, m1, l1);
+            *reinterpret_cast<uint4*>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(d + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+            *reinterpret_cast<uint4*>(d + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+            const uint2 a = round4(v0), b = round4(v1);
+            *reinterpret_cast<uint4*>(d) = make_uint4(a.x, a.y, b.x, b.y);
+        }
+    }
+}
+
+template <int TN, int NP, bool PARTIAL>
+__global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NPROD = (NP == 3) ? 6 : 1;
+    constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
+    constexpr int RING = 3;                          // weight prefetch ring over sub-steps (tap, cout block); divides 9 * TN and 3 * TN
+    constexpr int RD = RING - 1;
+    static_assert((9 * TN) % RING == 0 && (3 * TN) % RING == 0, "ring must divide the sub-steps of a slice and of the image block");
+
+    const bool has_img = p.img != nullptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;                              // [2 stages][NP][HP][32 B]
+    unsigned char* imgh = smem + 2 * NP * PLANE_B;           // [2 tile parities][NP][HP][8 B]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lrow = lane & 31, kh = lane >> 5;
+
+    const int bid = cp::xcd_remap(blockIdx.x, gridDim.x);
+    const int g = (int)gridDim.x;
+    const int my_tiles = (p.ntiles - bid + g - 1) / g;
+    if (my_tiles <= 0) return;
+    struct TilePos { int tx, ty, n; };
+    TilePos first;
+    {
+        int t = bid;
+        first.tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        first.ty = t % p.tiles_y;
+        first.n = t / p.tiles_y;
+    }
+    const int d_tx = g % p.tiles_x, d_ty = (g / p.tiles_x) % p.tiles_y, d_n = g / (p.tiles_x * p.tiles_y);
+    auto next_tile = [&](TilePos& t) {
+        t.tx += d_tx;
+        int cy = 0;
+        if (t.tx >= p.tiles_x) { t.tx -= p.tiles_x; cy = 1; }
+        t.ty += d_ty + cy;
+        int cn = 0;
+        if (t.ty >= p.tiles_y) { t.ty -= p.tiles_y; cn = 1; }
+        t.n += d_n + cn;
+    };
+
+    // ------------------------------------------------------------------ loader side (every thread) ------------------------------------
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
+                                                                          p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(has_img ? p.img : p.s[0].data), 0, has_img ? p.img_bytes : 0u, 0x00020000);
+    // halo element `it` of a thread: float4 number it*512 + tid = (pixel, channel quad)
+    int e_hy[NIT], e_hx[NIT];
+    unsigned e_lds[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 512 + tid, pix = idx >> 2, q = idx & 3;
+        e_hy[it] = pix < HP ? pix / COLS : 0x4000;
+        e_hx[it] = pix % COLS;
+        e_lds[it] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
+    }
+    const int q4 = (tid & 3) * 4;
+    float4 lv[NIT];
+    float4 liv[2];
+    auto issue_slice = [&](const TilePos& tp, int c) {
+        const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
+        const int si = c >= p.nch0 ? 1 : 0;
+        const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
+        const int sld = si ? p.s[1].ld : p.s[0].ld;
+        const int cb = ((c - (si ? p.nch0 : 0)) * 16 + q4) * 4;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
+            const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+            lv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB), 0, 0));
+        }
+    };
+    auto store_slice = [&](int stage) {
+        unsigned char* h = halo + stage * (NP * PLANE_B);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (e_hy[it] >= 0x4000) continue;
+            if constexpr (NP == 3) {
+                uint2 a, b, c;
+                split4(lv[it], a, b, c);
+                *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
+                *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
+                *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
+            } else {
+                *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(lv[it]);
+            }
+        }
+    };
+    auto issue_img = [&](const TilePos& tp) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pix = it * 512 + tid;
+            const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
+            const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+            liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)(((tp.n * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
+        }
+    };
+    auto store_img = [&](int parity) {
+        unsigned char* h = imgh + parity * (NP * IPLANE_B);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pix = it * 512 + tid;
+            if (pix >= HP) continue;
+            if constexpr (NP == 3) {
+                uint2 a, b, c;
+                split4(liv[it], a, b, c);
+                *reinterpret_cast<uint2*>(h + pix * 8) = a;
+                *reinterpret_cast<uint2*>(h + IPLANE_B + pix * 8) = b;
+                *reinterpret_cast<uint2*>(h + 2 * IPLANE_B + pix * 8) = c;
+            } else {
+                *reinterpret_cast<uint2*>(h + pix * 8) = round4(liv[it]);
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ MFMA side ------------------------------------------------------
+    const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
+    const bool has_lab = PARTIAL || p.clade;
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(has_lab ? (const void*)p.label : (const void*)p.W), 0, has_lab ? p.lab_bytes : 0u, 0x00020000);
+    const unsigned tab_b = p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t r_tab_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.scale : (const void*)p.W), 0, tab_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tab_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.shift : (const void*)p.W), 0, tab_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? (const void*)p.residual : (const void*)p.W), 0,
+                                                                            p.residual ? npix * (unsigned)p.res_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_raw ? (void*)p.out_raw : (void*)p.W), 0,
+                                                                            p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
+                                                                            p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+    const int nsub_tile = (p.nch * 9 + (has_img ? 3 : 0)) * TN;   // weight sub-steps (step, cout block) of one tile
+    const unsigned wlane = (unsigned)lane * 16u;
+    bf16x8 fw[RING][NP];
+    auto ldw = [&](int sub, int slot) {   // sub-step index within the tile, wrapped: the next tile reads the same stream again
+        if (sub >= nsub_tile) sub -= nsub_tile;
+#pragma unroll
+        for (int s = 0; s < NP; ++s)
+            fw[slot][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)((unsigned)sub * FRAG_B + (unsigned)s * 1024u + wlane), 0, 0));
+    };
+    // LDS byte offsets of this lane's pixel fragments: rows 2*wave + r, tap (ky, kx)
+    unsigned aoff[2][9], ioff[2][9];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pix = (2 * wave + r + t / 3) * COLS + lrow + t % 3;
+            aoff[r][t] = (unsigned)(pix * 32 + ((kh ^ ((pix >> 3) & 1)) * 16));
+            ioff[r][t] = (unsigned)(pix * 8);
+        }
+    f32x16 acc[2][TN];
+    bf16x8 fa[2][2][NP];   // [slot][row][plane]
+    int pmask[2] = {0x1ff, 0x1ff}, clab[2] = {0, 0};
+
+    auto load_labels = [&](const TilePos& t) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = t.ty * TH + 2 * wave + r, x = t.tx * 32 + lrow;
+            if constexpr (PARTIAL) {
+                int lb[9];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+                    lb[tp] = __builtin_amdgcn_raw_buffer_load_b8(rsl, ok ? ((t.n * p.H + yy) * p.Wd + xx) : (int)OOB, 0, 0) | (ok ? 0 : 0xff00);
+                }
+                int m = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) m |= (lb[tp] == lb[4]) ? (1 << tp) : 0;
+                pmask[r] = (lb[4] & 0xff00) ? 0 : m;
+                clab[r] = lb[4] & 0xff;
+            } else {
+                const bool ok = y < p.H && x < p.Wd;
+                clab[r] = __builtin_amdgcn_raw_buffer_load_b8(rsl, (ok && p.clade) ? ((t.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) & 0xff;
+            }
+        }
+    };
+
+    auto epilogue = [&](int n, int y0, int x0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + 2 * wave + r, x = x0 + lrow;
+            const bool pok = y < p.H && x < p.Wd;
+            const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
+            float f = 1.f;
+            if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 res[4], esc[4], esh[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ch = j * 32 + g4 * 8 + kh * 4;
+                    const unsigned o = (pok && ch < p.Cout) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB;
+                    res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)o, 0, 0));
+                    const unsigned to = (ch < p.Cout) ? (unsigned)((clab[r] * (p.clade ? p.Cout : 0) + ch) * 4) : OOB;
+                    esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+                    esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ch = j * 32 + g4 * 8 + kh * 4;
+                    const bool ok = pok && ch < p.Cout;
+                    float4 v;
+                    v.x = acc[r][j][g4 * 4 + 0] * f + res[g4].x;
+                    v.y = acc[r][j][g4 * 4 + 1] * f + res[g4].y;
+                    v.z = acc[r][j][g4 * 4 + 2] * f + res[g4].z;
+                    v.w = acc[r][j][g4 * 4 + 3] * f + res[g4].w;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    float4 t = v;
+                    if (p.scale) {
+                        t.x = v.x * esc[g4].x + esh[g4].x;
+                        t.y = v.y * esc[g4].y + esh[g4].y;
+                        t.z = v.z * esc[g4].z + esh[g4].z;
+                        t.w = v.w * esc[g4].w + esh[g4].w;
+                    }
+                    if (p.act == CP_ACT_RELU) {
+                        t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                    } else if (p.act == CP_ACT_LEAKY01) {
+                        t.x = fmaxf(t.x, 0.f) - fmaxf(-0.1f * t.x, 0.f);
+                        t.y = fmaxf(t.y, 0.f) - fmaxf(-0.1f * t.y, 0.f);
+                        t.z = fmaxf(t.z, 0.f) - fmaxf(-0.1f * t.z, 0.f);
+                        t.w = fmaxf(t.w, 0.f) - fmaxf(-0.1f * t.w, 0.f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                }
+            }
+        }
+    };
+
+    // one (tap, cout block) sub-step: NPROD x 2 MFMAs; smallest terms first
+    auto mfma_sub = [&](int aslot, int wslot, int j) {
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+            // (weight plane, pixel plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            const int sw = (NP == 1) ? 0 : ((t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0);
+            const int sp = (NP == 1) ? 0 : ((t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[wslot][sw], fa[aslot][r][sp], acc[r][j], 0, 0, 0);
+        }
+    };
+
+    // ------------------------------------------------------------------ pipeline ---------------------------------------------------------
+    const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
+    const int total_slices = my_tiles * nslices;
+    TilePos ftile = first;   // tile of the slice being FETCHED
+    int fc = 0, fk = 0;      // its slice index / tile counter
+    issue_slice(ftile, 0);
+    if (has_img) issue_img(ftile);
+    store_slice(0);
+    if (has_img) store_img(0);
+#pragma unroll
+    for (int u = 0; u < RD; ++u) ldw(u, u);
+    CP_BARRIER();
+
+    TilePos ctile = first;
+    int gs = 0;  // global slice counter
+    for (int k = 0; k < my_tiles; ++k) {
+        const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        if (has_lab) load_labels(ctile);
+        next_tile(ctile);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
+        for (int c = 0; c < nslices; ++c, ++gs) {
+            // fetch the next slice (of this tile or the next) while this one is multiplied
+            bool fetched = false, fetched_img = false;
+            if (gs + 1 < total_slices) {
+                if (++fc == nslices) {
+                    fc = 0;
+                    ++fk;
+                    next_tile(ftile);
+                    if (has_img) {
+                        issue_img(ftile);
+                        fetched_img = true;
+                    }
+                }
+                issue_slice(ftile, fc);
+                fetched = true;
+            }
+            const unsigned char* hb = halo + (gs & 1) * (NP * PLANE_B);
+            const int sub0 = c * 9 * TN;
+            auto read_a = [&](int t, int slot) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) {
+                        bf16x8 v = *reinterpret_cast<const bf16x8*>(hb + s * PLANE_B + aoff[r][t]);
+                        if constexpr (PARTIAL) {
+                            if (!((pmask[r] >> t) & 1)) v = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+                        }
+                        fa[slot][r][s] = v;
+                    }
+            };
+            read_a(0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) read_a(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int sub = t * TN + j;   // compile-time within the slice
+                    ldw(sub0 + sub + RD, (sub + RD) % RING);
+                    mfma_sub(t & 1, sub % RING, j);
+                }
+            }
+            // ---- image steps after the last staged slice: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1
+            if (has_img && c + 1 == nslices) {
+                const unsigned char* ib = imgh + (k & 1) * (NP * IPLANE_B);
+                const int isub0 = nslices * 9 * TN;
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int s = 0; s < NP; ++s) {
+                            uint2 lo2 = make_uint2(0u, 0u), hi2 = make_uint2(0u, 0u);
+                            // taps of the two halves (compile-time per half): kh = 0 -> 4*s3, 4*s3+1; kh = 1 -> 4*s3+2, 4*s3+3
+                            const int ta = 4 * s3, tb = 4 * s3 + 2;
+                            if (ta < 9 || tb < 9) {
+                                const int t0 = kh ? tb : ta;
+                                if (t0 < 9) {
+                                    const unsigned o0 = kh ? ioff[r][tb < 9 ? tb : 0] : ioff[r][ta < 9 ? ta : 0];
+                                    lo2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o0);
+                                    if constexpr (PARTIAL) {
+                                        if (!((pmask[r] >> t0) & 1)) lo2 = make_uint2(0u, 0u);
+                                    }
+                                }
+                                const int t1 = t0 + 1;
+                                if (t1 < 9) {
+                                    const unsigned o1 = kh ? ioff[r][tb + 1 < 9 ? tb + 1 : 0] : ioff[r][ta + 1 < 9 ? ta + 1 : 0];
+                                    hi2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o1);
+                                    if constexpr (PARTIAL) {
+                                        if (!((pmask[r] >> t1) & 1)) hi2 = make_uint2(0u, 0u);
+                                    }
+                                }
+                            }
+                            fa[s3 & 1][r][s] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
+                        }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int sub = s3 * TN + j;
+                        ldw(isub0 + sub + RD, (sub + RD) % RING);
+                        mfma_sub(s3 & 1, sub % RING, j);
+                    }
+                }
+            }
+            // ---- the fetched slice goes into the other stage (read last during slice gs - 1, a barrier ago) ----
+            if (fetched) store_slice((gs + 1) & 1);
+            if (fetched_img) store_img(fk & 1);
+            CP_BARRIER();
+        }
+        epilogue(n, y0, x0);
+    }
+}
+
+template <int TN, int NP, bool PARTIAL>
+int launch_hsplit(HSplitK k, hipStream_t st) {
+    k.tiles_y = (k.H + TH - 1) / TH;
+    k.tiles_x = (k.Wd + 31) / 32;
+    k.ntiles = k.B * k.tiles_y * k.tiles_x;
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = std::min(256, k.ntiles);
+    CP_LAUNCH((conv_hsplit_kernel<TN, NP, PARTIAL>), dim3(grid), dim3(512), lds, st, k);
+    return cp::check_launch("cp_conv2d_fwd_split");
+}
+
+int split_fragments(int cout, int num_sources, const int* channels) {
+    const int tn = cout <= 32 ? 1 : 2;
+    int steps = 0;
+    for (int s = 0; s < num_sources; ++s) steps += (channels[s] == 4) ? 3 : (channels[s] / 16) * 9;
+    return steps * tn;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------------------------
+extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
+    if (!d) return 0;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return 0;
+    if (d->cout > 64 || d->cout % 4 != 0 || d->group_rows || d->head_out) return 0;
+    if ((d->out_raw && d->out_raw_ld % 4) || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return 0;
+    if ((((uintptr_t)d->out_raw) | ((uintptr_t)d->out_act) | ((uintptr_t)d->residual)) & 15) return 0;
+    if (d->num_sources < 1 || d->num_sources > 2) return 0;
+    for (int s = 0; s < d->num_sources; ++s) {
+        const cp_conv_source& in = d->src[s];
+        if (in.mode != CP_SRC_DIRECT || in.pre_scale || in.pre_shift) return 0;
+        if (in.channels == 4) {
+            if (s != d->num_sources - 1 || s == 0 || in.ld != 4) return 0;   // the image source comes last, after a 16-multiple source
+        } else if (in.channels % 16 != 0 || in.ld % 4 != 0 || (((uintptr_t)in.data) & 15)) {
+            return 0;
+        }
+    }
+    if (d->src[0].channels == 4) return 0;
+    if (d->tap_label && d->epi_label && d->tap_label != d->epi_label) return 0;
+    if (!d->tap_label && d->row_scale) return 0;
+    return 1;
+}
+
+extern "C" int cp_conv_split_weight_floats(int cout, int num_sources, const int* channels) {
+    return split_fragments(cout, num_sources, channels) * 64 * 8;
+}
+
+extern "C" size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels, int planes) {
+    return (size_t)split_fragments(cout, num_sources, channels) * (size_t)planes * 1024;
+}
+
+// HOST: Keras-layout kernel -> the fp32 image of the fragment stream, [step][cout block][64 lanes][8 k]:
+//   16-channel slice c of a source, tap t: lane (i = l & 31, kh = l >> 5), element e  <-  W[co = 32*j + i][channel 16*c + 8*kh + e] at tap t
+//   image source, step s3:                                                             <-  W[co][channel e & 3] at tap 4*s3 + 2*kh + (e >> 2)
+// (channels / taps / output channels that do not exist: zero).  cp_conv_split_weights_f32 turns this image into the bf16 planes on the
+// device, so a training step re-packs with one gather + one split launch.
+extern "C" int cp_conv_pack_weights_split_host(const float* w, int layout, int cout, int num_sources, const int* channels, const int* real_channels,
+                                               float* dst) {
+    CP_REQUIRE(w && dst && cout > 0 && cout <= 64 && num_sources >= 1 && num_sources <= 2, "cp_conv_pack_weights_split_host: bad arguments");
+    const int tn = cout <= 32 ? 1 : 2;
+    int cin = 0;
+    for (int s = 0; s < num_sources; ++s) cin += real_channels[s];
+    const int total = cp_conv_split_weight_floats(cout, num_sources, channels);
+    for (int i = 0; i < total; ++i) dst[i] = 0.f;
+    auto src_index = [&](int ci, int t, int co) {
+        const int ky = t / 3, kx = t % 3;
+        return (layout == 0) ? ((((size_t)ky * 3 + kx) * cin + ci) * cout + co) : ((((size_t)ci * 3 + ky) * 3 + kx) * cout + co);
+    };
+    size_t step = 0;
+    int cbase = 0;
+    for (int s = 0; s < num_sources; ++s) {
+        const int C = channels[s], Cr = real_channels[s];
+        if (C == 4) {
+            for (int s3 = 0; s3 < 3; ++s3, ++step)
+                for (int j = 0; j < tn; ++j)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = 32 * j + (l & 31), t = 4 * s3 + 2 * (l >> 5) + (e >> 2), ch = e & 3;
+                            if (co < cout && t < 9 && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
+                        }
+        } else {
+            for (int c = 0; c < C / 16; ++c)
+                for (int t = 0; t < 9; ++t, ++step)
+                    for (int j = 0; j < tn; ++j)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = 32 * j + (l & 31), ch = 16 * c + 8 * (l >> 5) + e;
+                                if (co < cout && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
+                            }
+        }
+        cbase += Cr;
+    }
+    return CP_OK;
+}
+
+extern "C" int cp_conv_split_weights_f32(const float* packed, long long floats, int planes, void* out, void* stream) {
+    CP_REQUIRE(packed && out && floats > 0 && floats % 512 == 0 && (planes == 1 || planes == 3), "cp_conv_split_weights_f32: bad arguments");
+    CP_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0, "cp_conv_split_weights_f32: pointers must be 16-byte aligned");
+    const long long nfrag = floats / 512;
+    const int blocks = (int)std::min<long long>((nfrag * 64 + 255) / 256, 4096);
+    if (planes == 3)
+        CP_LAUNCH(hsplit_weights_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, reinterpret_cast<unsigned char*>(out));
+    else
+        CP_LAUNCH(hsplit_weights_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, reinterpret_cast<unsigned char*>(out));
+    return cp::check_launch("cp_conv_split_weights_f32");
+}
+
+extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_split, int planes, void* stream) {
+    CP_REQUIRE(d && weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_split: bad arguments");
+    CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 64, direct sources "
+                                            "of 16-multiple channels + optional trailing 4-channel source)");
+    CP_REQUIRE(d->out_raw || d->out_act, "cp_conv2d_fwd_split: no output");
+    HSplitK k{};
+    int nch = 0;
+    for (int s = 0; s < d->num_sources; ++s) {
+        const cp_conv_source& in = d->src[s];
+        const long long nbytes = (long long)d->batch * d->in_h * d->in_w * in.ld * 4;
+        CP_REQUIRE(nbytes < (1LL << 31), "cp_conv2d_fwd_split: source %d spans %lld bytes; 32-bit range-checked addressing needs < 2 GiB", s, nbytes);
+        if (in.channels == 4) {
+            k.img = in.data;
+            k.img_bytes = (unsigned)nbytes;
+            continue;
+        }
+        k.s[s].data = in.data;
+        k.s[s].C = in.channels;
+        k.s[s].ld = in.ld;
+        k.s[s].bytes = (unsigned)nbytes;
+        if (s == 0) k.nch0 = in.channels / 16;
+        nch += in.channels / 16;
+    }
+    k.nch = nch;
+    int chans[2] = {d->src[0].channels, d->num_sources > 1 ? d->src[1].channels : 0};
+    k.W = reinterpret_cast<const unsigned char*>(weights_split);
+    k.w_bytes = (unsigned)cp_conv_split_weight_bytes(d->cout, d->num_sources, chans, planes);
+    k.B = d->batch; k.H = d->in_h; k.Wd = d->in_w; k.Cout = d->cout;
+    const long long out_bytes = (long long)d->batch * d->in_h * d->in_w * std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0) * 4;
+    CP_REQUIRE(out_bytes < (1LL << 32), "cp_conv2d_fwd_split: output spans >= 4 GiB");
+    k.label = d->tap_label ? d->tap_label : d->epi_label;
+    k.lab_bytes = (unsigned)((size_t)d->batch * d->in_h * d->in_w);
+    k.residual = d->residual; k.res_ld = d->residual_ld;
+    k.scale = d->scale; k.shift = d->shift; k.clade = d->epi_label != nullptr; k.act = d->act;
+    k.norm = d->row_scale != nullptr;
+    k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
+    const bool partial = d->tap_label != nullptr;
+    const int tn = d->cout <= 32 ? 1 : 2;
+    hipStream_t st = (hipStream_t)stream;
+#define CP_HS(TN_, NP_)                                                                   \
+    if (tn == TN_ && planes == NP_) return partial ? launch_hsplit<TN_, NP_, true>(k, st) : launch_hsplit<TN_, NP_, false>(k, st);
+    CP_HS(1, 3)
+    CP_HS(2, 3)
+    CP_HS(1, 1)
+    CP_HS(2, 1)
+#undef CP_HS
+    return CP_ERR_INVALID;
+}

@@ -125,10 +125,32 @@ class FusedConv:
             ph = np.empty(25 * 2 * 64 * 4, dtype=np.float32)
             check(lib.cp_conv_pack_weights_stem_host(w.ctypes.data, layout, sources[0][1], ph.ctypes.data), "cp_conv_pack_weights_stem_host(%s)" % name)
             self.wp_halo = torch.from_numpy(ph).to(device)
+        # third packing: the fp32 image of the fragment stream of csrc/conv_hsplit.hip (3x3 / cout <= 64 / 16-multiple sources [+ image]);
+        # its bf16 planes (3 = exact split, 1 = plain bf16) are made on the device when a mode asks for them
+        self.wp_split_f32 = None
+        self._split_planes: Dict[int, torch.Tensor] = {}
+        self.split_mode = 0
+        split_ok = (kh == 3 and kw == 3 and cout <= 64 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4
+                    and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 16 == 0))
+        if split_ok:
+            nfl = lib.cp_conv_split_weight_floats(cout, ns, chans)
+            ps = np.empty(nfl, dtype=np.float32)
+            check(lib.cp_conv_pack_weights_split_host(w.ctypes.data, layout, cout, ns, chans, real, ps.ctypes.data), "cp_conv_pack_weights_split_host(%s)" % name)
+            self.wp_split_f32 = torch.from_numpy(ps).to(device)
         self.desc = ConvDesc()
         self._keep: List[torch.Tensor] = []
         self.head_w: Optional[torch.Tensor] = None
         self.head_cout = 0
+
+    def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
+        """bf16 planes of the weights for cp_conv2d_fwd_split (made once per mode; refresh=True after the fp32 image changed)."""
+        if planes not in self._split_planes:
+            lib = _lib.load()
+            out = torch.empty(self.wp_split_f32.numel() // 512 * planes * 1024, dtype=torch.uint8, device=self.wp_split_f32.device)
+            st = torch.cuda.current_stream(out.device).cuda_stream if stream is None else stream
+            check(lib.cp_conv_split_weights_f32(self.wp_split_f32.data_ptr(), self.wp_split_f32.numel(), planes, out.data_ptr(), st), "cp_conv_split_weights_f32")
+            self._split_planes[planes] = out
+        return self._split_planes[planes]
 
     def attach_head(self, kernel_1x1: np.ndarray):
         """Fuse a following 1x1 convolution (HWIO [1,1,32,q], no bias / activation) into this layer's epilogue."""
@@ -179,6 +201,13 @@ class FusedConv:
         d.out_raw_ld = out_raw_ld if out_raw_ld is not None else self.cout
         d.out_act = _ptr(out_act)
         d.out_act_ld = out_act_ld if out_act_ld is not None else self.cout
+        # tile_hint TILE_SPLIT3 / TILE_BF16 (Python-side values): run on csrc/conv_hsplit.hip when the layer is in its range
+        self.split_mode = 0
+        if tile_hint in (_lib.TILE_SPLIT3, _lib.TILE_BF16):
+            if self.wp_split_f32 is None:
+                raise _lib.CasaposeHipError("%s: the bf16-pipe kernel covers 3x3 / cout <= 64 / 16-multiple sources only" % self.name)
+            self.split_mode = 3 if tile_hint == _lib.TILE_SPLIT3 else 1
+            tile_hint = 0
         d.tile_hint = tile_hint
         d.head_weights = _ptr(self.head_w) if head_out is not None else None
         d.head_out = _ptr(head_out)
@@ -189,7 +218,14 @@ class FusedConv:
         return d.out_h, d.out_w
 
     def run(self, stream: int):
-        check(_lib.load().cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)
+        lib = _lib.load()
+        if self.split_mode:
+            if not lib.cp_conv_split_applicable(C.byref(self.desc)):
+                raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
+            check(lib.cp_conv2d_fwd_split(C.byref(self.desc), self.split_weights(self.split_mode, stream).data_ptr(), self.split_mode, stream),
+                  "cp_conv2d_fwd_split(%s)" % self.name)
+            return
+        check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)
 
     @property
     def flops(self) -> float:
@@ -205,6 +241,8 @@ WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
 # The TRAINING plan uses it by default (BASELINE configs[2] asks for bf16 convolutions; this is the fp32-equivalent way to use that pipe);
 # CASAPOSE_WINO_GEMM=f32 restores the fp32 MFMA there.  Inference (the headline metric, fp32) stays on the fp32 MFMA unless asked.
 TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
+# images per Winograd batch group (0 = the whole batch in one go)
+WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 
 
 def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
@@ -275,29 +313,43 @@ class WinoConv:
         self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
         return in_h, in_w
 
+    def chunks(self) -> List[Tuple[int, int, int]]:
+        """[(first image, images, padded tiles)]: the batch is processed in groups of WINO_CHUNK images so that the two scratch tensors
+        of a group (V: 36*Tp*K, M: 36*Tp*Cout floats -- 2.25x the layer's input and output) stay resident in the 256 MiB Infinity Cache
+        between the input transform, the GEMM and the output transform instead of making two round trips to HBM each."""
+        n = WINO_CHUNK if 0 < WINO_CHUNK < self.batch else self.batch
+        return [(b0, min(n, self.batch - b0), self.tiles(min(n, self.batch - b0), self.h, self.w, self.dil)[1]) for b0 in range(0, self.batch, n)]
+
     def run(self, stream: int):
         lib = _lib.load()
-        off = 0
-        for (cpad, _), s in zip(self.sources, self.srcs):
-            check(lib.cp_wino_input_transform_f32(s["data"].data_ptr(), s["ld"], cpad, self.batch, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
-                                                  stream), "cp_wino_input_transform_f32(%s)" % self.name)
-            off += cpad
-        self.run_gemm(stream)
         e = self.epi
-        check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
-                                               _ptr(e["scale"]), _ptr(e["shift"]), _ptr(e["epi_label"]), e["act"], _ptr(e["out_raw"]), self.cout,
-                                               _ptr(e["out_act"]), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
+        px = self.h * self.w
+        at = lambda t, b0, ld, size=4: (t.data_ptr() + b0 * px * ld * size) if t is not None else None  # noqa: E731
+        for b0, nb, tp in self.chunks():
+            off = 0
+            for (cpad, _), s in zip(self.sources, self.srcs):
+                check(lib.cp_wino_input_transform_f32(at(s["data"], b0, s["ld"]), s["ld"], cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
+                                                      stream), "cp_wino_input_transform_f32(%s)" % self.name)
+                off += cpad
+            self.run_gemm(stream, tp)
+            check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
+                                                   _ptr(e["scale"]), _ptr(e["shift"]), at(e["epi_label"], b0, 1, 1), e["act"], at(e["out_raw"], b0, self.cout),
+                                                   self.cout, at(e["out_act"], b0, self.cout), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
 
-    def run_gemm(self, stream: int):
+    def run_gemm(self, stream: int, tp: Optional[int] = None):
         lib = _lib.load()
-        if WINO_GROUPED_CONV:  # the grouped mode of the general conv kernel (kept for comparison)
+        if tp is None:  # stand-alone timing of the GEMM (bench.py): every chunk's GEMM back to back on the same scratch
+            for _, _, tpc in self.chunks():
+                self.run_gemm(stream, tpc)
+            return
+        if WINO_GROUPED_CONV:  # the grouped mode of the general conv kernel (kept for comparison; whole batch only)
             check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
         else:
             if self.Us is not None:
-                check(lib.cp_wino_gemm_split_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+                check(lib.cp_wino_gemm_split_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
                       "cp_wino_gemm_split_f32(%s)" % self.name)
             else:
-                check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * self.Tp, self.Tp, self.ktot, self.cout, stream),
+                check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
                       "cp_wino_gemm_f32(%s)" % self.name)
 
     @property
@@ -308,8 +360,8 @@ class WinoConv:
 
     @property
     def gemm_flops(self) -> float:
-        """FLOPs the grouped GEMM actually executes (36 planes x padded tiles)."""
-        return 2.0 * 36 * self.Tp * self.ktot * self.cout
+        """FLOPs the grouped GEMMs actually execute (36 planes x padded tiles, summed over the batch groups)."""
+        return sum(2.0 * 36 * tp * self.ktot * self.cout for _, _, tp in self.chunks())
 
 
 def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int) -> bool:

@@ -150,6 +150,27 @@ int cp_conv2d_fwd_f32(const cp_conv_desc* desc, void* stream);
 int cp_conv_selected_tile(const cp_conv_desc* desc);
 
 /* ------------------------------------------------------------------------------------
+ * The same convolution on the bf16 matrix pipe (csrc/conv_hsplit.hip), for the shallow high-resolution layers: 3x3 / stride 1 /
+ * pad 1, cout <= 64, sources CP_SRC_DIRECT with 16-multiple channels plus an optional trailing 4-channel source (the image).
+ * Replaces the same reference call sites as cp_conv2d_fwd_f32 for those layers (models/casapose.py:61-82, resnet.py:97-103 stage 1).
+ *   planes = 3: fp32-EQUIVALENT -- every fp32 operand is split exactly into three bf16 terms and six bf16 products are accumulated in fp32
+ *               (error <= that of the fp32 MFMA); the default of the training plan, opt-in for inference
+ *   planes = 1: operands rounded to bf16 (nearest even), fp32 accumulation -- "bf16 convolutions" (BASELINE.json configs[2]); 3e-2 gates
+ * The descriptor is the one of cp_conv2d_fwd_f32 (tensors stay fp32 in HBM; desc->weights / weights_halo are ignored); epilogue:
+ * row_scale (partial-conv 9/count, computed from tap_label), residual, out_raw, affine / CLADE table + activation -> out_act.
+ * Weights: cp_conv_pack_weights_split_host lays a Keras kernel out as the fp32 image of the kernel's fragment stream
+ * (cp_conv_split_weight_floats floats); cp_conv_split_weights_f32 turns that image into the bf16 planes
+ * (cp_conv_split_weight_bytes bytes) on the device -- one gather + one launch re-packs after an optimizer step.
+ * ---------------------------------------------------------------------------------- */
+int cp_conv_split_applicable(const cp_conv_desc* desc);   /* 1 if cp_conv2d_fwd_split covers this descriptor */
+int cp_conv_split_weight_floats(int cout, int num_sources, const int* channels);
+size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels, int planes);
+int cp_conv_pack_weights_split_host(const float* w_host, int layout, int cout, int num_sources, const int* channels,
+                                    const int* real_channels, float* dst_host);
+int cp_conv_split_weights_f32(const float* packed, long long floats, int planes, void* out, void* stream);
+int cp_conv2d_fwd_split(const cp_conv_desc* desc, const void* weights_split, int planes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Small streaming kernels around the convolutions
  * ---------------------------------------------------------------------------------- */
 

@@ -105,8 +105,18 @@ def test_two_forwards_then_filtered_vote_uses_the_right_labels(device):
     assert hit is not None and (hit.cpu().numpy() == got_a[..., :k].argmax(-1)).all()
     ka, kb = vote(out_a), vote(out_b)
     ra, rb = oracle_vote(got_a), oracle_vote(got_b)
-    tol = lambda r: 0.05 + 1e-4 * np.abs(r).max()  # random weights: ill-conditioned systems far outside the image
-    assert np.abs(ka - ra).max() < tol(ra) and np.abs(kb - rb).max() < tol(rb)
+
+    def close(kp, ref, arr):
+        # objects whose kept component has >= 50 pixels: well-posed systems, the 0.05 px gate.  (The reference's top-k rule keeps a LONE
+        # component of fewer than 50 pixels -- voting_layers_2d.py:64-76 -- and one or two pixels give a rank-one system whose
+        # pseudo-inverse amplifies the last bits of the fp64 sums: those keypoints only have to be finite.)
+        lab = arr[0, ..., :k].argmax(-1)
+        big = np.array([O.largest_component_filter((lab == o).astype(np.int32)).sum() >= 50 for o in range(1, k)])
+        assert big.any() and np.isfinite(kp).all()
+        return np.abs(kp[0][big] - ref[0][big]).max() < 0.05 + 1e-4 * np.abs(ref[0][big]).max()
+
+    assert close(ka, ra, got_a) and close(kb, rb, got_b)
+    assert not close(ka, rb, got_b)  # and they are different images: a vote on a's output with b's labels would not pass
     # in-place edit of the logits: the cached map is stale and must not be used
     out_a[..., 0] += 100.0  # everything becomes background
     assert engine.cached_labels(out_a.untyped_storage().data_ptr(), (b, h, w)) is None

@@ -1,0 +1,123 @@
+"""GPU parity of the bf16-pipe 3x3 kernel (csrc/conv_hsplit.hip) against the fp64 oracle:
+  planes = 3 (exact three-way bf16 split, six products): the SAME gate as the fp32-MFMA kernels (1e-4 of the tensor's range; measured
+             error is at the fp32 round-off level), over 12 orders of magnitude of operand scale;
+  planes = 1 (operands rounded to bf16): the bf16 gate of SURVEY 8(d), 3e-2 relative.
+Every operand / epilogue mode the kernel covers: one and two sources, the 4-channel image source, ragged tiles (16-row x 32-column
+tiles), partial-convolution tap mask with 9/count, CLADE table + leaky pair, residual, dual outputs."""
+import numpy as np
+import pytest
+import torch
+
+import casapose_oracle as O
+from test_gpu_conv import _labels, close, dev
+
+pytestmark = pytest.mark.gpu
+SPLIT3, BF16 = 100, 101
+MODES = [(SPLIT3, 1e-4), (BF16, 3e-2)]
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("cin,cout,hw", [(16, 32, (16, 32)), (32, 32, (8, 32)), (64, 32, (13, 45)), (64, 64, (21, 70)), (128, 48, (37, 33)), (96, 12, (4, 31)),
+                                         (48, 64, (33, 65))])
+def test_plain_and_ragged(device, mode, tol, cin, cout, hw):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(cin + cout + hw[0])
+    x = rng.standard_normal((2, hw[0], hw[1], cin))
+    w = rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)
+    raw, _ = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=mode)
+    close(raw, O.conv2d(x, w, pad=1), rtol=tol)
+
+
+def test_exact_split_is_fp32_equivalent_over_operand_scales(device):
+    """the three-way split is exact for any finite fp32 operand, so the error stays at the fp32 level when the operands are scaled by
+    1e-6 ... 1e6 and when they are ill-scaled against each other; it is compared with the error of the fp32-MFMA halo kernel."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 32, 64, 64))
+    w = rng.standard_normal((3, 3, 64, 64)) / 24.0
+    for sx, sw in ((1.0, 1.0), (1e-6, 1.0), (1e6, 1e-6), (1e3, 1e3)):
+        ref = O.conv2d(x * sx, w * sw, pad=1)
+        scale = np.abs(ref).max()
+        got = ops.conv2d_fused([dev(x * sx, device)], (w * sw).astype(np.float32), pad=1, tile_hint=SPLIT3)[0].cpu().numpy().astype(np.float64)
+        f32 = ops.conv2d_fused([dev(x * sx, device)], (w * sw).astype(np.float32), pad=1, tile_hint=7)[0].cpu().numpy().astype(np.float64)
+        ref32 = O.conv2d((x * sx).astype(np.float32).astype(np.float64), (w * sw).astype(np.float32).astype(np.float64), pad=1)
+        e_split, e_f32 = np.abs(got - ref32).max() / scale, np.abs(f32 - ref32).max() / scale
+        assert e_split < 2e-6 and e_split <= 2.0 * e_f32 + 2e-7, (sx, sw, e_split, e_f32)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_two_sources_residual_dual_output(device, mode, tol):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(6)
+    a, b = rng.standard_normal((2, 30, 40, 64)), rng.standard_normal((2, 30, 40, 32))
+    w = rng.standard_normal((3, 3, 96, 64)) / 30.0
+    res = rng.standard_normal((2, 30, 40, 64))
+    sc, sh = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.2
+    raw_ref = O.conv2d(np.concatenate([a, b], 3), w, pad=1) + res
+    raw, act = ops.conv2d_fused([dev(a, device), dev(b, device)], w.astype(np.float32), pad=1, residual=dev(res, device),
+                                scale=dev(sc, device), shift=dev(sh, device), act=2, want_raw=True, want_act=True, tile_hint=mode)
+    close(raw, raw_ref, rtol=tol)
+    close(act, O.leaky_as_relu_pair(raw_ref * sc + sh), rtol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_feature_plus_image(device, mode, tol):
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(7)
+    f = rng.standard_normal((2, 35, 40, 32))
+    img = rng.uniform(-1, 1, (2, 35, 40, 3))
+    w = rng.standard_normal((3, 3, 35, 32)) / 18.0
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    raw, _ = ops.conv2d_fused([dev(f, device), img4], w.astype(np.float32), pad=1, real_channels=[32, 3], tile_hint=mode)
+    close(raw, O.conv2d(np.concatenate([f, img], 3), w, pad=1), rtol=tol)
+    # only the image part non-zero / only the feature part non-zero: the two K segments are wired to the right weights
+    w_img = w.copy()
+    w_img[:, :, :32] = 0
+    raw, _ = ops.conv2d_fused([dev(f, device), img4], w_img.astype(np.float32), pad=1, real_channels=[32, 3], tile_hint=mode)
+    close(raw, O.conv2d(img, w[:, :, 32:], pad=1), rtol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("hw", [(24, 32), (38, 50)])
+def test_partial_clade(device, mode, tol, hw):
+    from casapose_amd import ops
+    from casapose_amd.engine import fold_clade
+
+    rng = np.random.default_rng(8 + hw[1])
+    b, (h, w), k = 2, hw, 5
+    lab = _labels(rng, b, h, w, k)
+    mask = O.onehot_from_labels(lab, k)
+    labels, pnorm, sel = ops.label_pyramid(dev(lab, device, torch.uint8))
+    p = {"c.gamma": rng.uniform(0.5, 1.5, (k, 32)), "c.beta": rng.standard_normal((k, 32)) * 0.2,
+         "c.moving_mean": rng.standard_normal(32) * 0.1, "c.moving_variance": rng.uniform(0.5, 1.5, 32)}
+    ts, tb = fold_clade(p, "c")
+    x = rng.standard_normal((b, h, w, 64))
+    wt = rng.standard_normal((64, 3, 3, 32)) / 24.0
+    y = O.clade_weighted(O.partial_convolution(x, wt, mask), mask, p["c.gamma"], p["c.beta"], p["c.moving_mean"], p["c.moving_variance"])
+    _, act = ops.conv2d_fused([dev(x, device)], wt.astype(np.float32), layout=1, pad=1, tap_label=labels[0], row_scale=pnorm[0],
+                              scale=dev(ts, device), shift=dev(tb, device), epi_label=labels[0], act=2, want_raw=False, want_act=True, tile_hint=mode)
+    close(act, O.leaky_as_relu_pair(y), rtol=tol)
+    # feature + image, partial conv (decoder block 10 with a materialised upsampling)
+    f = rng.standard_normal((b, h, w, 32))
+    img = rng.uniform(-1, 1, (b, h, w, 3))
+    wt2 = rng.standard_normal((35, 3, 3, 32)) / 18.0
+    ref = O.partial_convolution(np.concatenate([f, img], 3), wt2, mask)
+    raw, _ = ops.conv2d_fused([dev(f, device), ops.pad_channels_3to4(dev(img, device))], wt2.astype(np.float32), layout=1, pad=1,
+                              real_channels=[32, 3], tap_label=labels[0], row_scale=pnorm[0], tile_hint=mode)
+    close(raw, ref, rtol=tol)
+
+
+def test_out_of_range_layers_are_refused(device):
+    from casapose_amd import _lib, ops
+
+    rng = np.random.default_rng(5)
+    x, w = rng.standard_normal((1, 8, 32, 64)), rng.standard_normal((3, 3, 64, 128)) * 0.1
+    with pytest.raises(_lib.CasaposeHipError):
+        ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=SPLIT3)        # cout > 64
+    w2 = rng.standard_normal((3, 3, 64, 32)) * 0.1
+    with pytest.raises(_lib.CasaposeHipError):
+        ops.conv2d_fused([dev(x, device)], w2.astype(np.float32), pad=2, dilation=2, tile_hint=SPLIT3)   # dilated
