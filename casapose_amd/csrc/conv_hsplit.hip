@@ -7,12 +7,13 @@
 //
 // Why not conv_halo.hip with another instruction: six bf16 MFMAs of K = 16 take 6 x 32 cycles where the fp32 MFMA needs 8 x 64, so at the
 // old tile shape the weight fragments (1.5x the bytes per k, 2.7x less time) would need ~64 B/clk/CU from L1.  Here
-//   * a block owns 16 rows x 32 columns of output; each of its 8 waves computes TWO rows, so every weight fragment fetched from L2 feeds
-//     two pixel fragments (31 B/clk/CU), and every pixel fragment read from LDS feeds TN cout blocks;
-//   * there are no producer waves: all 8 waves issue the next 16-channel slice's halo loads (18 x 34 pixels) before their MFMAs, and split +
-//     store them into the other LDS stage afterwards -- one barrier per slice, ~5 % of a slice's MFMA time;
+//   * a block owns 8 rows x 32 columns of output; each of its 4 consumer waves (one per SIMD) computes TWO rows, so every weight fragment
+//     fetched from L2 feeds two pixel fragments (31 B/clk/CU), and every pixel fragment read from LDS feeds TN cout blocks;
+//   * 4 loader waves fetch the next 16-channel slice's halo (10 x 34 pixels), split it and store it into the other LDS stage -- one barrier
+//     per slice.  (A first version let all 8 waves load AND multiply: the vmcnt counter retires loads in order, so every wait for a weight
+//     fragment also waited for the halo loads issued before it and the HBM latency was exposed once per slice: 2.5x the MFMA time.)
 //   * halo planes are [pixel][16 bf16] = 32-byte rows with the two 16-byte slots swapped for pixels with bit 3 set: the 16 lanes of a
-//     ds_read_b128 group hit 16 different slots at any tap offset (no padding: 3 planes x 2 stages = 117.5 KB, + 29 KB image halo);
+//     ds_read_b128 group hit 16 different slots at any tap offset (no padding: 3 planes x 2 stages = 65 KB, + 16 KB image halo);
 //   * the 4-channel image source is three K = 16 steps with k = tap * 4 + channel.
 // Accumulators are transposed as in conv_halo.hip (MFMA A = weights, B = pixels): lane = pixel, so the partial-conv tap mask, 9/count,
 // the CLADE table row, residual and stores are per lane with four consecutive channels in four consecutive registers.
@@ -27,12 +28,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int COLS = 34;             // 32 output columns + 2 halo columns
-constexpr int TH = 16;               // output rows per tile (2 per wave)
+constexpr int TH = 8;                // output rows per tile (2 per consumer wave)
 constexpr int HR = TH + 2;
-constexpr int HP = HR * COLS;        // 612 halo pixels
+constexpr int HP = HR * COLS;        // 340 halo pixels
 constexpr int PLANE_B = HP * 32;     // bytes of one halo plane (16 bf16 per pixel)
 constexpr int IPLANE_B = HP * 8;     // bytes of one image-halo plane (4 bf16 per pixel)
-constexpr int NIT = (HP * 4 + 511) / 512;   // float4 halo elements per thread and slice
+constexpr int NIT = (HP * 4 + 255) / 256;   // float4 halo elements per loader thread and slice
+constexpr int NIMG = (HP + 255) / 256;      // image-halo pixels per loader thread
 
 struct SSrc {
     const float* data;
@@ -131,9 +133,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;                              // [2 stages][NP][HP][32 B]
     unsigned char* imgh = smem + 2 * NP * PLANE_B;           // [2 tile parities][NP][HP][8 B]
+    unsigned short* labh = reinterpret_cast<unsigned short*>(smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B);   // [2 tile parities][HP]: label | 0xff00 outside the image
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 4;
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int lrow = lane & 31, kh = lane >> 5;
 
@@ -160,85 +164,157 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         if (t.ty >= p.tiles_y) { t.ty -= p.tiles_y; cn = 1; }
         t.n += d_n + cn;
     };
+    const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
+    const int total_slices = my_tiles * nslices;
 
-    // ------------------------------------------------------------------ loader side (every thread) ------------------------------------
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
-                                                                          p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(has_img ? p.img : p.s[0].data), 0, has_img ? p.img_bytes : 0u, 0x00020000);
-    // halo element `it` of a thread: float4 number it*512 + tid = (pixel, channel quad)
-    int e_hy[NIT], e_hx[NIT];
-    unsigned e_lds[NIT];
+    if (loader) {
+        // ------------------------------------------------------------------ loaders ------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
+                                                                              p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(has_img ? p.img : p.s[0].data), 0, has_img ? p.img_bytes : 0u, 0x00020000);
+        // halo element `it` of a thread: float4 number it*256 + tid = (pixel, channel quad)
+        int e_hy[NIT], e_hx[NIT];
+        unsigned e_lds[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 512 + tid, pix = idx >> 2, q = idx & 3;
-        e_hy[it] = pix < HP ? pix / COLS : 0x4000;
-        e_hx[it] = pix % COLS;
-        e_lds[it] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid, pix = idx >> 2, q = idx & 3;
+            e_hy[it] = pix < HP ? pix / COLS : 0x4000;
+            e_hx[it] = pix % COLS;
+            e_lds[it] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
+        }
+        const int q4 = (tid & 3) * 4;
+        float4 lv[NIT];
+        float4 liv[NIMG];
+        auto issue_slice = [&](const TilePos& tp, int c) {
+            const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
+            const int si = c >= p.nch0 ? 1 : 0;
+            const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
+            const int sld = si ? p.s[1].ld : p.s[0].ld;
+            const int cb = ((c - (si ? p.nch0 : 0)) * 16 + q4) * 4;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
+                const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                lv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB), 0, 0));
+            }
+        };
+        auto store_slice = [&](int stage) {
+            unsigned char* h = halo + stage * (NP * PLANE_B);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (e_hy[it] >= 0x4000) continue;
+                if constexpr (NP == 3) {
+                    uint2 a, b, c;
+                    split4(lv[it], a, b, c);
+                    *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
+                    *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
+                    *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
+                } else {
+                    *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(lv[it]);
+                }
+            }
+        };
+        auto issue_img = [&](const TilePos& tp) {
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int pix = it * 256 + tid;
+                const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
+                const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)(((tp.n * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
+            }
+        };
+        auto store_img = [&](int parity) {
+            unsigned char* h = imgh + parity * (NP * IPLANE_B);
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int pix = it * 256 + tid;
+                if (pix >= HP) continue;
+                if constexpr (NP == 3) {
+                    uint2 a, b, c;
+                    split4(liv[it], a, b, c);
+                    *reinterpret_cast<uint2*>(h + pix * 8) = a;
+                    *reinterpret_cast<uint2*>(h + IPLANE_B + pix * 8) = b;
+                    *reinterpret_cast<uint2*>(h + 2 * IPLANE_B + pix * 8) = c;
+                } else {
+                    *reinterpret_cast<uint2*>(h + pix * 8) = round4(liv[it]);
+                }
+            }
+        };
+        const bool has_lab_l = PARTIAL || p.clade;
+        const __amdgpu_buffer_rsrc_t rsl_l = __builtin_amdgcn_make_buffer_rsrc((void*)(has_lab_l ? (const void*)p.label : (const void*)p.W), 0,
+                                                                                has_lab_l ? p.lab_bytes : 0u, 0x00020000);
+        int llab[NIMG];
+        auto issue_lab = [&](const TilePos& tp) {
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int pix = it * 256 + tid;
+                const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
+                const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? ((tp.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
+            }
+        };
+        auto store_lab = [&](int parity) {
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int pix = it * 256 + tid;
+                if (pix < HP) labh[parity * HP + pix] = (unsigned short)llab[it];
+            }
+        };
+        // slice gs+1 is stored (and slice gs+2 requested) while the consumers multiply slice gs
+        TilePos ftile = first;
+        int fc = 0, fk = 0;
+        bool img_pending = false;
+        auto advance = [&]() {      // move the fetch cursor to the next slice; returns false past the end
+            if (++fc == nslices) {
+                fc = 0;
+                ++fk;
+                next_tile(ftile);
+            }
+        };
+        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its image halo and its label halo
+            if (fc != 0) return;
+            if (has_img) issue_img(ftile);
+            if (has_lab_l) issue_lab(ftile);
+            img_pending = true;
+        };
+        auto store_tile_extras = [&]() {   // stages of tile fk: read last during tile fk - 2
+            if (!img_pending) return;
+            if (has_img) store_img(fk & 1);
+            if (has_lab_l) store_lab(fk & 1);
+            img_pending = false;
+        };
+        issue_tile_extras();
+        issue_slice(ftile, 0);
+        store_slice(0);
+        store_tile_extras();
+        int issued = 1;
+        if (total_slices > 1) {
+            advance();
+            issue_tile_extras();
+            issue_slice(ftile, fc);
+            issued = 2;
+        }
+        CP_BARRIER();
+        for (int gs = 0; gs < total_slices; ++gs) {
+            if (gs + 1 < total_slices) {
+                store_slice((gs + 1) & 1);                     // stage read last during slice gs - 1
+                store_tile_extras();
+                if (issued < total_slices) {
+                    advance();
+                    issue_tile_extras();
+                    issue_slice(ftile, fc);
+                    ++issued;
+                }
+            }
+            CP_BARRIER();
+        }
+        return;
     }
-    const int q4 = (tid & 3) * 4;
-    float4 lv[NIT];
-    float4 liv[2];
-    auto issue_slice = [&](const TilePos& tp, int c) {
-        const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
-        const int si = c >= p.nch0 ? 1 : 0;
-        const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
-        const int sld = si ? p.s[1].ld : p.s[0].ld;
-        const int cb = ((c - (si ? p.nch0 : 0)) * 16 + q4) * 4;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
-            const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-            lv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB), 0, 0));
-        }
-    };
-    auto store_slice = [&](int stage) {
-        unsigned char* h = halo + stage * (NP * PLANE_B);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (e_hy[it] >= 0x4000) continue;
-            if constexpr (NP == 3) {
-                uint2 a, b, c;
-                split4(lv[it], a, b, c);
-                *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
-                *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
-                *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
-            } else {
-                *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(lv[it]);
-            }
-        }
-    };
-    auto issue_img = [&](const TilePos& tp) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int pix = it * 512 + tid;
-            const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
-            const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-            liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)(((tp.n * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
-        }
-    };
-    auto store_img = [&](int parity) {
-        unsigned char* h = imgh + parity * (NP * IPLANE_B);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int pix = it * 512 + tid;
-            if (pix >= HP) continue;
-            if constexpr (NP == 3) {
-                uint2 a, b, c;
-                split4(liv[it], a, b, c);
-                *reinterpret_cast<uint2*>(h + pix * 8) = a;
-                *reinterpret_cast<uint2*>(h + IPLANE_B + pix * 8) = b;
-                *reinterpret_cast<uint2*>(h + 2 * IPLANE_B + pix * 8) = c;
-            } else {
-                *reinterpret_cast<uint2*>(h + pix * 8) = round4(liv[it]);
-            }
-        }
-    };
 
-    // ------------------------------------------------------------------ MFMA side ------------------------------------------------------
+    // ------------------------------------------------------------------ consumers: 4 waves x 2 rows --------------------------------------
     const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
     const bool has_lab = PARTIAL || p.clade;
-    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(has_lab ? (const void*)p.label : (const void*)p.W), 0, has_lab ? p.lab_bytes : 0u, 0x00020000);
     const unsigned tab_b = p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u;
     const __amdgpu_buffer_rsrc_t r_tab_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.scale : (const void*)p.W), 0, tab_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_tab_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.shift : (const void*)p.W), 0, tab_b, 0x00020000);
@@ -259,40 +335,31 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             fw[slot][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)((unsigned)sub * FRAG_B + (unsigned)s * 1024u + wlane), 0, 0));
     };
     // LDS byte offsets of this lane's pixel fragments: rows 2*wave + r, tap (ky, kx)
-    unsigned aoff[2][9], ioff[2][9];
+    unsigned aoff[2][9];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int pix = (2 * wave + r + t / 3) * COLS + lrow + t % 3;
             aoff[r][t] = (unsigned)(pix * 32 + ((kh ^ ((pix >> 3) & 1)) * 16));
-            ioff[r][t] = (unsigned)(pix * 8);
         }
     f32x16 acc[2][TN];
     bf16x8 fa[2][2][NP];   // [slot][row][plane]
     int pmask[2] = {0x1ff, 0x1ff}, clab[2] = {0, 0};
-
-    auto load_labels = [&](const TilePos& t) {
+    // labels of a tile come from the label halo the loaders staged with the tile's first slice: no global latency, no registers held
+    auto read_labels = [&](int parity) {
+        const unsigned short* lh = labh + parity * HP;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int y = t.ty * TH + 2 * wave + r, x = t.tx * 32 + lrow;
+            const int centre = (2 * wave + r + 1) * COLS + lrow + 1;
+            const int lc = lh[centre];
             if constexpr (PARTIAL) {
-                int lb[9];
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
-                    lb[tp] = __builtin_amdgcn_raw_buffer_load_b8(rsl, ok ? ((t.n * p.H + yy) * p.Wd + xx) : (int)OOB, 0, 0) | (ok ? 0 : 0xff00);
-                }
                 int m = 0;
 #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) m |= (lb[tp] == lb[4]) ? (1 << tp) : 0;
-                pmask[r] = (lb[4] & 0xff00) ? 0 : m;
-                clab[r] = lb[4] & 0xff;
-            } else {
-                const bool ok = y < p.H && x < p.Wd;
-                clab[r] = __builtin_amdgcn_raw_buffer_load_b8(rsl, (ok && p.clade) ? ((t.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) & 0xff;
+                for (int tp = 0; tp < 9; ++tp) m |= ((int)lh[centre + (tp / 3 - 1) * COLS + (tp % 3 - 1)] == lc) ? (1 << tp) : 0;
+                pmask[r] = (lc & 0xff00) ? 0 : m;
             }
+            clab[r] = lc & 0xff;
         }
     };
 
@@ -360,24 +427,15 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     };
 
     // ------------------------------------------------------------------ pipeline ---------------------------------------------------------
-    const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
-    const int total_slices = my_tiles * nslices;
-    TilePos ftile = first;   // tile of the slice being FETCHED
-    int fc = 0, fk = 0;      // its slice index / tile counter
-    issue_slice(ftile, 0);
-    if (has_img) issue_img(ftile);
-    store_slice(0);
-    if (has_img) store_img(0);
 #pragma unroll
     for (int u = 0; u < RD; ++u) ldw(u, u);
-    CP_BARRIER();
-
     TilePos ctile = first;
-    int gs = 0;  // global slice counter
+    CP_BARRIER();   // slice 0 (and the first tile's image / label halo) is in LDS
+    int gs = 0;     // global slice counter
     for (int k = 0; k < my_tiles; ++k) {
         const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
-        if (has_lab) load_labels(ctile);
         next_tile(ctile);
+        if (has_lab) read_labels(k & 1);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -385,21 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
         for (int c = 0; c < nslices; ++c, ++gs) {
-            // fetch the next slice (of this tile or the next) while this one is multiplied
-            bool fetched = false, fetched_img = false;
-            if (gs + 1 < total_slices) {
-                if (++fc == nslices) {
-                    fc = 0;
-                    ++fk;
-                    next_tile(ftile);
-                    if (has_img) {
-                        issue_img(ftile);
-                        fetched_img = true;
-                    }
-                }
-                issue_slice(ftile, fc);
-                fetched = true;
-            }
+            const bool last = c + 1 == nslices;
             const unsigned char* hb = halo + (gs & 1) * (NP * PLANE_B);
             const int sub0 = c * 9 * TN;
             auto read_a = [&](int t, int slot) {
@@ -426,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
             }
             // ---- image steps after the last staged slice: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1
-            if (has_img && c + 1 == nslices) {
+            if (has_img && last) {
                 const unsigned char* ib = imgh + (k & 1) * (NP * IPLANE_B);
                 const int isub0 = nslices * 9 * TN;
 #pragma unroll
@@ -436,24 +480,20 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                         for (int s = 0; s < NP; ++s) {
                             uint2 lo2 = make_uint2(0u, 0u), hi2 = make_uint2(0u, 0u);
-                            // taps of the two halves (compile-time per half): kh = 0 -> 4*s3, 4*s3+1; kh = 1 -> 4*s3+2, 4*s3+3
-                            const int ta = 4 * s3, tb = 4 * s3 + 2;
-                            if (ta < 9 || tb < 9) {
-                                const int t0 = kh ? tb : ta;
-                                if (t0 < 9) {
-                                    const unsigned o0 = kh ? ioff[r][tb < 9 ? tb : 0] : ioff[r][ta < 9 ? ta : 0];
-                                    lo2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o0);
-                                    if constexpr (PARTIAL) {
-                                        if (!((pmask[r] >> t0) & 1)) lo2 = make_uint2(0u, 0u);
-                                    }
+                            const int ta = 4 * s3, tb = 4 * s3 + 2;   // first tap of the lower / upper lane half (compile-time)
+                            const int t0 = kh ? tb : ta;
+                            if (t0 < 9) {
+                                const unsigned o0 = ((kh ? aoff[r][tb < 9 ? tb : 0] : aoff[r][ta < 9 ? ta : 0]) & ~31u) >> 2;   // pixel * 8
+                                lo2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o0);
+                                if constexpr (PARTIAL) {
+                                    if (!((pmask[r] >> t0) & 1)) lo2 = make_uint2(0u, 0u);
                                 }
-                                const int t1 = t0 + 1;
-                                if (t1 < 9) {
-                                    const unsigned o1 = kh ? ioff[r][tb + 1 < 9 ? tb + 1 : 0] : ioff[r][ta + 1 < 9 ? ta + 1 : 0];
-                                    hi2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o1);
-                                    if constexpr (PARTIAL) {
-                                        if (!((pmask[r] >> t1) & 1)) hi2 = make_uint2(0u, 0u);
-                                    }
+                            }
+                            if (t0 + 1 < 9) {
+                                const unsigned o1 = ((kh ? aoff[r][tb + 1 < 9 ? tb + 1 : 0] : aoff[r][ta + 1 < 9 ? ta + 1 : 0]) & ~31u) >> 2;
+                                hi2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o1);
+                                if constexpr (PARTIAL) {
+                                    if (!((pmask[r] >> (t0 + 1)) & 1)) hi2 = make_uint2(0u, 0u);
                                 }
                             }
                             fa[s3 & 1][r][s] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
@@ -466,12 +506,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     }
                 }
             }
-            // ---- the fetched slice goes into the other stage (read last during slice gs - 1, a barrier ago) ----
-            if (fetched) store_slice((gs + 1) & 1);
-            if (fetched_img) store_img(fk & 1);
+            if (last) epilogue(n, y0, x0);
             CP_BARRIER();
         }
-        epilogue(n, y0, x0);
     }
 }
 
@@ -480,7 +517,7 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.Wd + 31) / 32;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B;
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2;   // 83 KB with three planes: one block of 8 waves per CU
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

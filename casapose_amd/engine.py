@@ -108,10 +108,12 @@ class FusedConv:
         expect = (kh, kw, cin, cout) if layout == 0 else (cin, kh, kw, cout)
         if tuple(w.shape) != expect:
             raise ValueError("%s: kernel shape %s, expected %s" % (name, w.shape, expect))
-        packed = np.empty((cout, self.ktot), dtype=np.float32)
-        check(lib.cp_conv_pack_weights_host(w.ctypes.data, layout, kh, kw, cout, ns, chans, real, packed.ctypes.data),
-              "cp_conv_pack_weights_host(%s)" % name)
-        self.wp = torch.from_numpy(packed).to(device)
+        self.wp = None
+        if all(s[0] == 4 or s[0] % 32 == 0 for s in sources):   # (16-multiple sources exist only for the bf16-pipe kernel below)
+            packed = np.empty((cout, self.ktot), dtype=np.float32)
+            check(lib.cp_conv_pack_weights_host(w.ctypes.data, layout, kh, kw, cout, ns, chans, real, packed.ctypes.data),
+                  "cp_conv_pack_weights_host(%s)" % name)
+            self.wp = torch.from_numpy(packed).to(device)
         # second packing for the LDS-resident halo-tile kernel (3x3, cout <= 64, 32-multiple sources [+ image])
         self.wp_halo = None
         halo_ok = kh == 3 and kw == 3 and cout <= 64 and sources[0][0] % 32 == 0 and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 32 == 0)
@@ -160,7 +162,7 @@ class FusedConv:
             raise ValueError("%s: a fused head needs a 3x3 halo-kernel layer with 32 output channels" % self.name)
         packed = np.empty(1024, dtype=np.float32)
         check(lib.cp_conv_pack_head_weights_host(w.ctypes.data, w.shape[1], packed.ctypes.data), "cp_conv_pack_head_weights_host")
-        self.head_w = torch.from_numpy(packed).to(self.wp.device)
+        self.head_w = torch.from_numpy(packed).to(self.wp_halo.device)
         self.head_cout = int(w.shape[1])
 
     def bind(self, *, batch, in_h, in_w, stride=1, dilation=1, pad=0, srcs, tap_label=None, row_scale=None,
@@ -176,7 +178,7 @@ class FusedConv:
         d.cout, d.kh, d.kw = self.cout, self.kh, self.kw
         d.stride, d.dilation, d.pad = stride, dilation, pad
         d.num_sources = len(srcs)
-        keep = [self.wp]
+        keep = [self.wp] if self.wp is not None else []
         for i, s in enumerate(srcs):
             cs = d.src[i]
             cs.data = _ptr(s["data"])

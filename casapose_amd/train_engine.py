@@ -67,6 +67,16 @@ def forward_order() -> List[str]:
 BUCKET_STARTS = ("bn_data", "stage4_unit1_bn1", "pv_block_1_conv2d", "pv_block_6_prepare_conv2d")
 
 
+def conv_split_planes() -> int:
+    """bf16-pipe mode of the shallow 3x3 convolutions of the TRAINING plan (csrc/conv_hsplit.hip), read from CASAPOSE_CONV_MODE:
+    "split" (default) = 3 planes, exact three-way bf16 split, fp32-equivalent; "bf16" = 1 plane, operands rounded to bf16 (BASELINE configs[2]);
+    "f32" = 0, the fp32-MFMA kernels."""
+    mode = os.environ.get("CASAPOSE_CONV_MODE", "split")
+    if mode not in ("split", "bf16", "f32"):
+        raise ValueError("CASAPOSE_CONV_MODE must be split, bf16 or f32 (got %r)" % mode)
+    return {"split": 3, "bf16": 1, "f32": 0}[mode]
+
+
 class ParamStore:
     """Flat master parameters / gradients / Adam moments with named views."""
 
@@ -225,6 +235,18 @@ class TrainConv:
             imap = _index_map(pack_stem, hwio, nfl)
             self.idx_halo = torch.from_numpy(imap).to(dev)
             self.wp_halo = store.pack_alloc(imap, off)
+        # bf16-pipe kernel (csrc/conv_hsplit.hip) for the shallow 3x3 layers: fp32 image of its fragment stream in the arena, bf16 planes beside it
+        self.split = None
+        planes = conv_split_planes()
+        if planes and k == 3 and cout <= 64 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4 and (
+                ns == 1 or sources[1][0] == 4 or sources[1][0] % 16 == 0):
+            nfl = lib.cp_conv_split_weight_floats(cout, ns, chans)
+
+            def pack_split(src, dst):
+                check(lib.cp_conv_pack_weights_split_host(src.ctypes.data, 0, cout, ns, chans, real, dst.ctypes.data), "pack split " + key)
+
+            imap = _index_map(pack_split, hwio, nfl)
+            self.split = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes)
         # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
         self.dgrad: List[Optional[dict]] = []
         cpad = (cout + 31) // 32 * 32
@@ -254,6 +276,15 @@ class TrainConv:
                 imap = _index_map(pack_dh, np.ascontiguousarray(sub), nfl)
                 ent["idx_halo"] = torch.from_numpy(imap).to(dev)
                 ent["w_halo"] = store.pack_alloc(imap, off)
+            ent["split"] = None
+            if planes and k == 3 and cr <= 64 and cr % 4 == 0:
+                nfl = lib.cp_conv_split_weight_floats(cr, 1, dch)
+
+                def pack_ds(src, dst, dch=dch, dre=dre, cr=cr):
+                    check(lib.cp_conv_pack_weights_split_host(src.ctypes.data, 0, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad split " + key)
+
+                imap = _index_map(pack_ds, np.ascontiguousarray(sub), nfl)
+                ent["split"] = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes)
             self.dgrad.append(ent)
             c0 += cr
         self.desc = ConvDesc()
@@ -261,16 +292,28 @@ class TrainConv:
         self.layout = layout
         self.master_shape = tuple(shape)
         self.refresh_hooks: List[Callable[[int], None]] = []  # extra weight layouts owned by the ops (Winograd planes)
+        if self.split is not None or any(e is not None and e["split"] is not None for e in self.dgrad):
+            self.refresh_hooks.append(self._refresh_split)
+
+    def _refresh_split(self, stream: int):
+        """fp32 fragment images (just re-gathered from the master weights) -> bf16 planes of the bf16-pipe kernel"""
+        lib = _lib.load()
+        for sp in [self.split] + [e["split"] for e in self.dgrad if e is not None]:
+            if sp is not None:
+                check(lib.cp_conv_split_weights_f32(sp["f32"].data_ptr(), sp["f32"].numel(), sp["np"], sp["planes"].data_ptr(), stream), "cp_conv_split_weights_f32")
 
     def refresh(self, stream: int, hooks_only: bool = False):
         """Re-pack the kernel layouts from the master weights (after an optimizer step / at start).  hooks_only: the plan refreshes the
         gather-type layouts of all layers with one launch over the packed-weight arena (ParamStore.pack_refresh)."""
         lib = _lib.load()
         m = self.master.data_ptr()
+        if hooks_only:
+            for hook in self.refresh_hooks:
+                hook(stream)
+            return
+        self.store.pack_refresh(stream)   # every gather-type layout of the arena (idempotent)
         for hook in self.refresh_hooks:
             hook(stream)
-        if hooks_only:
-            return
         check(lib.cp_gather_f32(m, self.idx_fwd.data_ptr(), self.idx_fwd.numel(), self.wp.data_ptr(), stream), "cp_gather_f32")
         if self.idx_halo is not None:
             check(lib.cp_gather_f32(m, self.idx_halo.data_ptr(), self.idx_halo.numel(), self.wp_halo.data_ptr(), stream), "cp_gather_f32")
@@ -447,7 +490,15 @@ class ConvOp:
             self._wino_run(self.wino_fwd, [(t.data.data_ptr(), ld, c[0]) for (t, ld), c in zip(self.srcs, self.layer.sources)],
                            self.residual.data.data_ptr() if self.residual is not None else None, d.out_raw, stream)
             return
-        check(_lib.load().cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
+        lib = _lib.load()
+        sp = self.layer.split
+        if sp is not None:
+            if getattr(self, "_split_fwd", None) is None:
+                self._split_fwd = bool(lib.cp_conv_split_applicable(C.byref(self.layer.desc)))
+            if self._split_fwd:
+                check(lib.cp_conv2d_fwd_split(C.byref(self.layer.desc), sp["planes"].data_ptr(), sp["np"], stream), "cp_conv2d_fwd_split(%s)" % self.layer.name)
+                return
+        check(lib.cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
 
     def _dy(self):
         if self.dy_ptr_ld is not None:
@@ -490,7 +541,11 @@ class ConvOp:
             g = ent["desc"]
             g.src[0].data, g.src[0].ld = dy, dy_ld
             g.residual = t.grad.data_ptr() if t.has_grad else None
-            check(lib.cp_conv2d_fwd_f32(C.byref(g), stream), "dgrad(%s)" % L.name)
+            sp = ent["split"]
+            if sp is not None and lib.cp_conv_split_applicable(C.byref(g)):
+                check(lib.cp_conv2d_fwd_split(C.byref(g), sp["planes"].data_ptr(), sp["np"], stream), "dgrad split(%s)" % L.name)
+            else:
+                check(lib.cp_conv2d_fwd_f32(C.byref(g), stream), "dgrad(%s)" % L.name)
             t.has_grad = True
         if self.residual is not None:
             add_grad(self.residual, dy, self.out.pixels * self.out.c, stream)
