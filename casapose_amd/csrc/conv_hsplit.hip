@@ -125,15 +125,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NPROD = (NP == 3) ? 6 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
-    constexpr int RING = 3;                          // weight prefetch ring over sub-steps (tap, cout block); divides 9 * TN and 3 * TN
-    constexpr int RD = RING - 1;
-    static_assert((9 * TN) % RING == 0 && (3 * TN) % RING == 0, "ring must divide the sub-steps of a slice and of the image block");
+    constexpr int GSUB = 3 * TN;                     // (step, cout block) sub-steps of one weight group: 3 taps, or the 3 image steps
+    constexpr unsigned GROUP_B = GSUB * FRAG_B;      // bytes of a weight group: 9 KB (TN = 1) / 18 KB (TN = 2) with three planes
+    constexpr int NWL = (int)((GROUP_B / 16 + 255) / 256);   // 16-byte pieces of a group per loader thread
 
     const bool has_img = p.img != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;                              // [2 stages][NP][HP][32 B]
     unsigned char* imgh = smem + 2 * NP * PLANE_B;           // [2 tile parities][NP][HP][8 B]
     unsigned short* labh = reinterpret_cast<unsigned short*>(smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B);   // [2 tile parities][HP]: label | 0xff00 outside the image
+    unsigned char* wst = smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B + 4 * HP;                                // [2 stages][GROUP_B] weight groups
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= 4;
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     };
     const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
     const int total_slices = my_tiles * nslices;
+    const int ngroups_tile = nslices * 3 + (has_img ? 1 : 0);   // weight groups per tile: 3 per slice (3 taps each) + the image block
+    const int total_groups = my_tiles * ngroups_tile;
 
     if (loader) {
         // ------------------------------------------------------------------ loaders ------------------------------------------------------
@@ -261,11 +264,30 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 if (pix < HP) labh[parity * HP + pix] = (unsigned short)llab[it];
             }
         };
-        // slice gs+1 is stored (and slice gs+2 requested) while the consumers multiply slice gs
+        // weight groups: the tile's fragment stream is contiguous in memory, GROUP_B bytes per group; every tile reads the same stream
+        const __amdgpu_buffer_rsrc_t rsw_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+        u32x4 lw[NWL];
+        auto issue_w = [&](int gg) {   // global group index -> group of the tile
+            const unsigned base = (unsigned)(gg % ngroups_tile) * GROUP_B;
+#pragma unroll
+            for (int it = 0; it < NWL; ++it) {
+                const unsigned o = (unsigned)(it * 256 + tid) * 16u;
+                lw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw_l, (int)(o < GROUP_B ? base + o : OOB), 0, 0);
+            }
+        };
+        auto store_w = [&](int stage) {
+#pragma unroll
+            for (int it = 0; it < NWL; ++it) {
+                const unsigned o = (unsigned)(it * 256 + tid) * 16u;
+                if (o < GROUP_B) *reinterpret_cast<u32x4*>(wst + stage * GROUP_B + o) = lw[it];
+            }
+        };
+        // While the consumers multiply group gg: the weights of group gg+1 go into the other weight stage (and group gg+2 is requested);
+        // during the FIRST group of a slice the halo of the next slice goes into the other halo stage (and the slice after it is requested).
         TilePos ftile = first;
         int fc = 0, fk = 0;
         bool img_pending = false;
-        auto advance = [&]() {      // move the fetch cursor to the next slice; returns false past the end
+        auto advance = [&]() {      // move the fetch cursor to the next slice
             if (++fc == nslices) {
                 fc = 0;
                 ++fk;
@@ -286,8 +308,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         };
         issue_tile_extras();
         issue_slice(ftile, 0);
+        issue_w(0);
         store_slice(0);
         store_tile_extras();
+        store_w(0);
         int issued = 1;
         if (total_slices > 1) {
             advance();
@@ -295,18 +319,28 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             issue_slice(ftile, fc);
             issued = 2;
         }
+        if (total_groups > 1) issue_w(1);
         CP_BARRIER();
-        for (int gs = 0; gs < total_slices; ++gs) {
-            if (gs + 1 < total_slices) {
-                store_slice((gs + 1) & 1);                     // stage read last during slice gs - 1
-                store_tile_extras();
-                if (issued < total_slices) {
-                    advance();
-                    issue_tile_extras();
-                    issue_slice(ftile, fc);
-                    ++issued;
-                }
+        int gs = 0, lg = 0;   // global slice counter / group index within the tile of the group being multiplied
+        for (int gg = 0; gg < total_groups; ++gg) {
+            if (gg + 1 < total_groups) {
+                store_w((gg + 1) & 1);                             // weight stage read last during group gg - 1
+                if (gg + 2 < total_groups) issue_w(gg + 2);
             }
+            if (lg < nslices * 3 && lg % 3 == 0) {                 // first group of slice gs
+                if (gs + 1 < total_slices) {
+                    store_slice((gs + 1) & 1);                     // halo stage read last during slice gs - 1
+                    store_tile_extras();
+                    if (issued < total_slices) {
+                        advance();
+                        issue_tile_extras();
+                        issue_slice(ftile, fc);
+                        ++issued;
+                    }
+                }
+                ++gs;
+            }
+            if (++lg == ngroups_tile) lg = 0;
             CP_BARRIER();
         }
         return;
@@ -324,15 +358,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                                                                             p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
                                                                             p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
-    const int nsub_tile = (p.nch * 9 + (has_img ? 3 : 0)) * TN;   // weight sub-steps (step, cout block) of one tile
     const unsigned wlane = (unsigned)lane * 16u;
-    bf16x8 fw[RING][NP];
-    auto ldw = [&](int sub, int slot) {   // sub-step index within the tile, wrapped: the next tile reads the same stream again
-        if (sub >= nsub_tile) sub -= nsub_tile;
+    bf16x8 fw[2][NP];   // [slot][plane] weight fragments of one sub-step, read from the staged group
+    auto ldw = [&](const unsigned char* wg, int sub, int slot) {
 #pragma unroll
-        for (int s = 0; s < NP; ++s)
-            fw[slot][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)((unsigned)sub * FRAG_B + (unsigned)s * 1024u + wlane), 0, 0));
+        for (int s = 0; s < NP; ++s) fw[slot][s] = *reinterpret_cast<const bf16x8*>(wg + (unsigned)(sub * NP + s) * 1024u + wlane);
     };
     // LDS byte offsets of this lane's pixel fragments: rows 2*wave + r, tap (ky, kx)
     unsigned aoff[2][9];
@@ -427,11 +457,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     };
 
     // ------------------------------------------------------------------ pipeline ---------------------------------------------------------
-#pragma unroll
-    for (int u = 0; u < RD; ++u) ldw(u, u);
     TilePos ctile = first;
-    CP_BARRIER();   // slice 0 (and the first tile's image / label halo) is in LDS
-    int gs = 0;     // global slice counter
+    CP_BARRIER();   // slice 0, the first weight group (and the first tile's image / label halo) are in LDS
+    int gs = 0, gg = 0;   // global slice / group counters
     for (int k = 0; k < my_tiles; ++k) {
         const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
         next_tile(ctile);
@@ -443,9 +471,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
         for (int c = 0; c < nslices; ++c, ++gs) {
-            const bool last = c + 1 == nslices;
             const unsigned char* hb = halo + (gs & 1) * (NP * PLANE_B);
-            const int sub0 = c * 9 * TN;
             auto read_a = [&](int t, int slot) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -458,55 +484,64 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         fa[slot][r][s] = v;
                     }
             };
-            read_a(0, 0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) read_a(t + 1, (t + 1) & 1);
+            for (int g3 = 0; g3 < 3; ++g3, ++gg) {   // three groups of three taps, a barrier after each (the weight stage flips)
+                const unsigned char* wg = wst + (gg & 1) * GROUP_B;
+                read_a(g3 * 3, 0);
+                ldw(wg, 0, 0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int sub = t * TN + j;   // compile-time within the slice
-                    ldw(sub0 + sub + RD, (sub + RD) % RING);
-                    mfma_sub(t & 1, sub % RING, j);
-                }
-            }
-            // ---- image steps after the last staged slice: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1
-            if (has_img && last) {
-                const unsigned char* ib = imgh + (k & 1) * (NP * IPLANE_B);
-                const int isub0 = nslices * 9 * TN;
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int s = 0; s < NP; ++s) {
-                            uint2 lo2 = make_uint2(0u, 0u), hi2 = make_uint2(0u, 0u);
-                            const int ta = 4 * s3, tb = 4 * s3 + 2;   // first tap of the lower / upper lane half (compile-time)
-                            const int t0 = kh ? tb : ta;
-                            if (t0 < 9) {
-                                const unsigned o0 = ((kh ? aoff[r][tb < 9 ? tb : 0] : aoff[r][ta < 9 ? ta : 0]) & ~31u) >> 2;   // pixel * 8
-                                lo2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o0);
-                                if constexpr (PARTIAL) {
-                                    if (!((pmask[r] >> t0) & 1)) lo2 = make_uint2(0u, 0u);
-                                }
-                            }
-                            if (t0 + 1 < 9) {
-                                const unsigned o1 = ((kh ? aoff[r][tb + 1 < 9 ? tb + 1 : 0] : aoff[r][ta + 1 < 9 ? ta + 1 : 0]) & ~31u) >> 2;
-                                hi2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o1);
-                                if constexpr (PARTIAL) {
-                                    if (!((pmask[r] >> (t0 + 1)) & 1)) hi2 = make_uint2(0u, 0u);
-                                }
-                            }
-                            fa[s3 & 1][r][s] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
-                        }
+                for (int st = 0; st < 3; ++st) {
+                    if (st + 1 < 3) read_a(g3 * 3 + st + 1, (st + 1) & 1);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int sub = s3 * TN + j;
-                        ldw(isub0 + sub + RD, (sub + RD) % RING);
-                        mfma_sub(s3 & 1, sub % RING, j);
+                        const int sub = st * TN + j;
+                        if (sub + 1 < GSUB) ldw(wg, sub + 1, (sub + 1) & 1);
+                        mfma_sub(st & 1, sub & 1, j);
                     }
                 }
+                if (g3 == 2 && c + 1 == nslices && !has_img) epilogue(n, y0, x0);
+                CP_BARRIER();
             }
-            if (last) epilogue(n, y0, x0);
+        }
+        // ---- image block: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1 ----
+        if (has_img) {
+            const unsigned char* ib = imgh + (k & 1) * (NP * IPLANE_B);
+            const unsigned char* wg = wst + (gg & 1) * GROUP_B;
+            ldw(wg, 0, 0);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) {
+                        uint2 lo2 = make_uint2(0u, 0u), hi2 = make_uint2(0u, 0u);
+                        const int ta = 4 * s3, tb = 4 * s3 + 2;   // first tap of the lower / upper lane half (compile-time)
+                        const int t0 = kh ? tb : ta;
+                        if (t0 < 9) {
+                            const unsigned o0 = ((kh ? aoff[r][tb < 9 ? tb : 0] : aoff[r][ta < 9 ? ta : 0]) & ~31u) >> 2;   // pixel * 8
+                            lo2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o0);
+                            if constexpr (PARTIAL) {
+                                if (!((pmask[r] >> t0) & 1)) lo2 = make_uint2(0u, 0u);
+                            }
+                        }
+                        if (t0 + 1 < 9) {
+                            const unsigned o1 = ((kh ? aoff[r][tb + 1 < 9 ? tb + 1 : 0] : aoff[r][ta + 1 < 9 ? ta + 1 : 0]) & ~31u) >> 2;
+                            hi2 = *reinterpret_cast<const uint2*>(ib + s * IPLANE_B + o1);
+                            if constexpr (PARTIAL) {
+                                if (!((pmask[r] >> (t0 + 1)) & 1)) hi2 = make_uint2(0u, 0u);
+                            }
+                        }
+                        fa[s3 & 1][r][s] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int sub = s3 * TN + j;
+                    if (sub + 1 < GSUB) ldw(wg, sub + 1, (sub + 1) & 1);
+                    mfma_sub(s3 & 1, sub & 1, j);
+                }
+            }
+            epilogue(n, y0, x0);
+            ++gg;
             CP_BARRIER();
         }
     }
@@ -517,7 +552,8 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.Wd + 31) / 32;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2;   // 83 KB with three planes: one block of 8 waves per CU
+    // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 18 / 36 KB (three planes): one block of 8 waves per CU
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * 3 * TN * NP * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -246,7 +246,8 @@ class TrainConv:
                 check(lib.cp_conv_pack_weights_split_host(src.ctypes.data, 0, cout, ns, chans, real, dst.ctypes.data), "pack split " + key)
 
             imap = _index_map(pack_split, hwio, nfl)
-            self.split = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes)
+            self.split = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes,
+                              idx=torch.from_numpy(imap).to(dev))
         # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
         self.dgrad: List[Optional[dict]] = []
         cpad = (cout + 31) // 32 * 32
@@ -284,7 +285,8 @@ class TrainConv:
                     check(lib.cp_conv_pack_weights_split_host(src.ctypes.data, 0, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad split " + key)
 
                 imap = _index_map(pack_ds, np.ascontiguousarray(sub), nfl)
-                ent["split"] = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes)
+                ent["split"] = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes,
+                                    idx=torch.from_numpy(imap).to(dev))
             self.dgrad.append(ent)
             c0 += cr
         self.desc = ConvDesc()
@@ -311,7 +313,9 @@ class TrainConv:
             for hook in self.refresh_hooks:
                 hook(stream)
             return
-        self.store.pack_refresh(stream)   # every gather-type layout of the arena (idempotent)
+        for sp in [self.split] + [e["split"] for e in self.dgrad if e is not None]:   # fp32 fragment images of the bf16-pipe kernel, then their planes
+            if sp is not None:
+                check(lib.cp_gather_f32(m, sp["idx"].data_ptr(), sp["idx"].numel(), sp["f32"].data_ptr(), stream), "cp_gather_f32")
         for hook in self.refresh_hooks:
             hook(stream)
         check(lib.cp_gather_f32(m, self.idx_fwd.data_ptr(), self.idx_fwd.numel(), self.wp.data_ptr(), stream), "cp_gather_f32")
