@@ -125,8 +125,12 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NPROD = (NP == 3) ? 6 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
-    constexpr int GSUB = 3 * TN;                     // (step, cout block) sub-steps of one weight group: 3 taps, or the 3 image steps
-    constexpr unsigned GROUP_B = GSUB * FRAG_B;      // bytes of a weight group: 9 KB (TN = 1) / 18 KB (TN = 2) with three planes
+    constexpr int GT = (TN == 1) ? 9 : 3;            // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice), a
+                                                     // third of it for the 64-channel ones (their groups would not fit the LDS otherwise)
+    constexpr int GPS = 9 / GT;                      // groups per slice
+    constexpr int GSUB = GT * TN;                    // (tap, cout block) sub-steps of a group; the image block is a group of 3 * TN sub-steps
+    constexpr unsigned GROUP_B = GSUB * FRAG_B;      // bytes of a weight group: 27 KB (TN = 1) / 18 KB (TN = 2) with three planes
+    constexpr unsigned IGROUP_B = 3 * TN * FRAG_B;   // bytes of the image block's group
     constexpr int NWL = (int)((GROUP_B / 16 + 255) / 256);   // 16-byte pieces of a group per loader thread
 
     const bool has_img = p.img != nullptr;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     };
     const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
     const int total_slices = my_tiles * nslices;
-    const int ngroups_tile = nslices * 3 + (has_img ? 1 : 0);   // weight groups per tile: 3 per slice (3 taps each) + the image block
+    const int ngroups_tile = nslices * GPS + (has_img ? 1 : 0);   // weight groups per tile: GPS per slice + the image block
     const int total_groups = my_tiles * ngroups_tile;
 
     if (loader) {
@@ -267,12 +271,14 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // weight groups: the tile's fragment stream is contiguous in memory, GROUP_B bytes per group; every tile reads the same stream
         const __amdgpu_buffer_rsrc_t rsw_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
         u32x4 lw[NWL];
-        auto issue_w = [&](int gg) {   // global group index -> group of the tile
-            const unsigned base = (unsigned)(gg % ngroups_tile) * GROUP_B;
+        auto issue_w = [&](int gg) {   // global group index -> group of the tile (wide groups first, the image block's group last)
+            const int lgw = gg % ngroups_tile;
+            const unsigned base = (unsigned)lgw * GROUP_B;
+            const unsigned len = (lgw < nslices * GPS) ? GROUP_B : IGROUP_B;
 #pragma unroll
             for (int it = 0; it < NWL; ++it) {
                 const unsigned o = (unsigned)(it * 256 + tid) * 16u;
-                lw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw_l, (int)(o < GROUP_B ? base + o : OOB), 0, 0);
+                lw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw_l, (int)(o < len ? base + o : OOB), 0, 0);
             }
         };
         auto store_w = [&](int stage) {
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 store_w((gg + 1) & 1);                             // weight stage read last during group gg - 1
                 if (gg + 2 < total_groups) issue_w(gg + 2);
             }
-            if (lg < nslices * 3 && lg % 3 == 0) {                 // first group of slice gs
+            if (lg < nslices * GPS && lg % GPS == 0) {             // first group of slice gs
                 if (gs + 1 < total_slices) {
                     store_slice((gs + 1) & 1);                     // halo stage read last during slice gs - 1
                     store_tile_extras();
@@ -408,10 +414,15 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int ch = j * 32 + g4 * 8 + kh * 4;
                     const unsigned o = (pok && ch < p.Cout) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB;
-                    res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)o, 0, 0));
-                    const unsigned to = (ch < p.Cout) ? (unsigned)((clab[r] * (p.clade ? p.Cout : 0) + ch) * 4) : OOB;
-                    esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
-                    esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                    res[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    esc[g4] = res[g4];
+                    esh[g4] = res[g4];
+                    if (p.residual) res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)o, 0, 0));
+                    if (p.scale) {   // uniform branches: a layer without these operands issues no loads and waits for none
+                        const unsigned to = (ch < p.Cout) ? (unsigned)((clab[r] * (p.clade ? p.Cout : 0) + ch) * 4) : OOB;
+                        esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+                        esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                    }
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -485,13 +496,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     }
             };
 #pragma unroll
-            for (int g3 = 0; g3 < 3; ++g3, ++gg) {   // three groups of three taps, a barrier after each (the weight stage flips)
+            for (int g3 = 0; g3 < GPS; ++g3, ++gg) {   // GPS groups of GT taps, a barrier after each (the weight stage flips)
                 const unsigned char* wg = wst + (gg & 1) * GROUP_B;
-                read_a(g3 * 3, 0);
+                read_a(g3 * GT, 0);
                 ldw(wg, 0, 0);
 #pragma unroll
-                for (int st = 0; st < 3; ++st) {
-                    if (st + 1 < 3) read_a(g3 * 3 + st + 1, (st + 1) & 1);
+                for (int st = 0; st < GT; ++st) {
+                    if (st + 1 < GT) read_a(g3 * GT + st + 1, (st + 1) & 1);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int sub = st * TN + j;
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         mfma_sub(st & 1, sub & 1, j);
                     }
                 }
-                if (g3 == 2 && c + 1 == nslices && !has_img) epilogue(n, y0, x0);
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) epilogue(n, y0, x0);
                 CP_BARRIER();
             }
         }
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int sub = s3 * TN + j;
-                    if (sub + 1 < GSUB) ldw(wg, sub + 1, (sub + 1) & 1);
+                    if (sub + 1 < 3 * TN) ldw(wg, sub + 1, (sub + 1) & 1);
                     mfma_sub(s3 & 1, sub & 1, j);
                 }
             }
@@ -552,8 +563,8 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.Wd + 31) / 32;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
-    // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 18 / 36 KB (three planes): one block of 8 waves per CU
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * 3 * TN * NP * 1024;
+    // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : 3) * TN * NP * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -427,6 +427,10 @@ class ForwardPlan:
                 self.steps.append(wl.run)
                 return
             layer.bind(batch=B, **kw)
+            # opt-in (CASAPOSE_CONV_MODE / CasaposeNet(conv_mode=...)): the shallow 3x3 layers on the bf16 matrix pipe (csrc/conv_hsplit.hip),
+            # 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside its range keep the fp32-MFMA kernels
+            if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
+                layer.split_mode = net.conv_planes
             self.convs.append(layer)
             self.steps.append(layer.run)
 
@@ -692,7 +696,7 @@ class CasaposeNet:
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
                  partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True,
                  bilinear: Sequence[bool] = BILINEAR_DEFAULT, pvnet: bool = False, shared: Sequence[bool] = (False,) * 5,
-                 reuse_first: bool = False, skips2: bool = True):
+                 reuse_first: bool = False, skips2: bool = True, conv_mode: Optional[str] = None):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -710,6 +714,11 @@ class CasaposeNet:
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
+        mode = conv_mode if conv_mode is not None else os.environ.get("CASAPOSE_INFER_CONV_MODE", "f32")
+        if mode not in ("f32", "split", "bf16"):
+            raise ValueError("conv_mode must be f32, split or bf16 (got %r)" % mode)
+        self.conv_mode = mode
+        self.conv_planes = {"f32": 0, "split": 3, "bf16": 1}[mode]
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self.set_params(params)
 

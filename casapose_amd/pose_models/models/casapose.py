@@ -37,7 +37,7 @@ def CASAPose(layer_params, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2d
         raise NotImplementedError("backbone %s is not built for MI355X yet" % base_model)
     return CasaposeModel("casapose_custom", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights, output_lablemap=output_lablemap,
-                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True),
+                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True), conv_mode=kwargs.get("conv_mode"),
                          partial=[p.partial_conv for p in params], guided=[p.guided_upsampling for p in params],
                          bilinear=[p.bilinear_upsampling for p in params])
 

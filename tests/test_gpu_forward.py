@@ -271,3 +271,29 @@ def test_load_weights_from_keras_h5(device, tmp_path):
         net.load_weights(path2)
     got = net.get_parameters()
     assert np.array_equal(got["conv0.kernel"], other["conv0.kernel"]) and np.array_equal(got["pv_block_6_clade.gamma"], params["pv_block_6_clade.gamma"])
+
+
+@pytest.mark.parametrize("mode,tol", [("split", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_forward_on_the_bf16_matrix_pipe(device, mode, tol, fuse):
+    """conv_mode="split": the shallow 3x3 layers run as exact three-way bf16 splits (csrc/conv_hsplit.hip) -- the SAME 1e-3 gate as the
+    fp32-MFMA forward; conv_mode="bf16": their operands are rounded to bf16 -- the 3e-2 gate of SURVEY 8(d).  fuse=False materialises the
+    upsampled tensors and the 32-channel head inputs, which puts EVERY shallow layer in the kernel's range."""
+    from casapose_amd import _lib
+
+    b, h, w, k, v = 2, 64, 96, 5, 27
+    net, p64 = build(device, k, v, h, w, seg_input=True, fuse_upsample=fuse, fuse_heads=fuse, conv_mode=mode)
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    lab = np.zeros((b, h, w), np.int64)
+    lab[:, 8:40, 10:50] = 1
+    lab[:, 30:60, 40:90] = 2
+    lab[0, 5:20, 60:80] = 3
+    lab[1, 44:62, 4:30] = 4
+    seg = O.onehot_from_labels(lab, k, np.float32)
+    ref = O.casapose_c_gcu5(p64, img.astype(np.float64), seg_input=seg.astype(np.float64))
+    got = net([img, seg], training=False).cpu().numpy().astype(np.float64)
+    assert rel_err(got[..., :k], ref[..., :k]) < tol and rel_err(got[..., k:], ref[..., k:]) < tol
+    on_pipe = [c.name for c in net._net.plan(b, h, w).convs if getattr(c, "split_mode", 0)]
+    assert len(on_pipe) >= (10 if not fuse else 4), on_pipe     # stage 1 (4 layers) always; decoder blocks 3-5 / 8-10 when their sources are direct
+    assert all(getattr(c, "split_mode", 0) in (0, 3 if mode == "split" else 1) for c in net._net.plan(b, h, w).convs)
