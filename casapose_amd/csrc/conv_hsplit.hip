@@ -26,6 +26,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int COLS = 34;             // 32 output columns + 2 halo columns
 constexpr int TH = 8;                // output rows per tile (2 per consumer wave)
@@ -36,9 +38,12 @@ constexpr int IPLANE_B = HP * 8;     // bytes of one image-halo plane (4 bf16 pe
 constexpr int NIT = (HP * 4 + 255) / 256;   // float4 halo elements per loader thread and slice
 constexpr int NIMG = (HP + 255) / 256;      // image-halo pixels per loader thread
 
+enum : int { HS_BILINEAR = 2, HS_PARTIAL = 4, HS_SEL = 8 };
+
 struct SSrc {
     const float* data;
-    int C, ld;
+    const uint8_t* sel;
+    int C, ld, Hs, Ws;
     unsigned bytes;
 };
 
@@ -62,6 +67,9 @@ struct HSplitK {
     int raw_ld;
     float* out_act;
     int act_ld;
+    const unsigned char* head_w;   // fused 1x1 head (cout == 32): [2 steps][plane][64 lanes][8 bf16], cp_conv_pack_head_split_host
+    float* head_out;
+    int head_cout, head_ld;
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -120,8 +128,12 @@ __global__ void hsplit_weights_kernel(const float* __restrict__ src, long long n
     }
 }
 
-template <int TN, int NP, bool PARTIAL>
+template <int TN, int NP, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
+    constexpr bool PARTIAL = (MODE & HS_PARTIAL) != 0;
+    constexpr bool BILINEAR = (MODE & HS_BILINEAR) != 0;   // source 0 is read at half resolution through a x2 half-pixel bilinear filter
+    constexpr bool SEL = (MODE & HS_SEL) != 0;             // source 0 is read at half resolution through the guided-upsampling selection map
+    constexpr int NV = BILINEAR ? 4 : 1;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NPROD = (NP == 3) ? 6 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
@@ -139,6 +151,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     unsigned char* imgh = smem + 2 * NP * PLANE_B;           // [2 tile parities][NP][HP][8 B]
     unsigned short* labh = reinterpret_cast<unsigned short*>(smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B);   // [2 tile parities][HP]: label | 0xff00 outside the image
     unsigned char* wst = smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B + 4 * HP;                                // [2 stages][GROUP_B] weight groups
+    unsigned char* hwl = wst + 2 * GROUP_B;                                                                   // [2 steps][NP][1 KB] fused-head weights
+    const bool head = (TN == 1) && p.head_out != nullptr;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= 4;
@@ -191,8 +205,22 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             e_lds[it] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
         }
         const int q4 = (tid & 3) * 4;
-        float4 lv[NIT];
+        float4 lv[NIT][NV];
         float4 liv[NIMG];
+        int selb[NIT];       // SEL: the selection byte of this element's pixel (constant over the slices of a tile)
+        int lpar[NIT];       // BILINEAR: parity bits of the element's pixel of the slice in flight, 0x100 = "this slice is source 0"
+        const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
+                                                                              SEL ? p.lab_bytes : 0u, 0x00020000);
+        auto issue_sel = [&](const TilePos& tp) {
+            if constexpr (SEL) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int y = tp.ty * TH - 1 + e_hy[it], x = tp.tx * 32 - 1 + e_hx[it];
+                    const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                    selb[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? ((tp.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
+                }
+            }
+        };
         auto issue_slice = [&](const TilePos& tp, int c) {
             const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
             const int si = c >= p.nch0 ? 1 : 0;
@@ -203,7 +231,38 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             for (int it = 0; it < NIT; ++it) {
                 const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
                 const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                lv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB), 0, 0));
+                const unsigned direct = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
+                if constexpr (BILINEAR) {
+                    lpar[it] = ((y & 1) << 1) | ((x & 1) << 2) | (si == 0 ? 0x100 : 0);
+                    unsigned o00 = direct, o01 = direct, o10 = direct, o11 = direct;
+                    if (si == 0) {   // half-pixel centres: output pixel y reads source rows (y-1)/2 and (y+1)/2 (clamped), weights 0.75 / 0.25
+                        const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
+                        int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
+                        const int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
+                        ys = max(ys, 0);
+                        xs = max(xs, 0);
+                        const int nb = n * Hs * Ws;
+                        o00 = inb ? (unsigned)(((nb + ys * Ws + xs) * sld) * 4 + cb) : OOB;
+                        o01 = inb ? (unsigned)(((nb + ys * Ws + x1) * sld) * 4 + cb) : OOB;
+                        o10 = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld) * 4 + cb) : OOB;
+                        o11 = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld) * 4 + cb) : OOB;
+                    }
+                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o00, 0, 0));
+                    if (si == 0) {
+                        lv[it][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o01, 0, 0));
+                        lv[it][2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o10, 0, 0));
+                        lv[it][3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o11, 0, 0));
+                    }
+                } else if constexpr (SEL) {
+                    unsigned o = direct;
+                    if (si == 0) {
+                        const int sl = selb[it];
+                        o = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * sld) * 4 + cb) : OOB;
+                    }
+                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0));
+                } else {
+                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)direct, 0, 0));
+                }
             }
         };
         auto store_slice = [&](int stage) {
@@ -211,14 +270,26 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (e_hy[it] >= 0x4000) continue;
+                float4 val = lv[it][0];
+                if constexpr (BILINEAR) {
+                    if (lpar[it] & 0x100) {
+                        const float fy = (lpar[it] & 2) ? 0.25f : 0.75f, fx = (lpar[it] & 4) ? 0.25f : 0.75f;
+                        const float gy = 1.f - fy, gx = 1.f - fx;
+                        const float4 v01 = lv[it][1], v10 = lv[it][2], v11 = lv[it][3];
+                        val.x = (val.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
+                        val.y = (val.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
+                        val.z = (val.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
+                        val.w = (val.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
+                    }
+                }
                 if constexpr (NP == 3) {
                     uint2 a, b, c;
-                    split4(lv[it], a, b, c);
+                    split4(val, a, b, c);
                     *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
                     *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
                     *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
                 } else {
-                    *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(lv[it]);
+                    *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(val);
                 }
             }
         };
@@ -300,8 +371,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 next_tile(ftile);
             }
         };
-        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its image halo and its label halo
+        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its image halo, its label halo, its selection bytes
             if (fc != 0) return;
+            issue_sel(ftile);
             if (has_img) issue_img(ftile);
             if (has_lab_l) issue_lab(ftile);
             img_pending = true;
@@ -312,6 +384,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             if (has_lab_l) store_lab(fk & 1);
             img_pending = false;
         };
+        if (head) {   // the fused head's weights: 2 steps x NP KB, staged once
+            const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 2u * NP * 1024u, 0x00020000);
+            for (unsigned o = (unsigned)tid * 16u; o < 2u * NP * 1024u; o += 256u * 16u)
+                *reinterpret_cast<u32x4*>(hwl + o) = __builtin_amdgcn_raw_buffer_load_b128(rsh, (int)o, 0, 0);
+        }
         issue_tile_extras();
         issue_slice(ftile, 0);
         issue_w(0);
@@ -364,6 +441,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                                                                             p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
                                                                             p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc((void*)(head ? (void*)p.head_out : (void*)p.W), 0,
+                                                                             head ? npix * (unsigned)p.head_ld * 4u : 0u, 0x00020000);
     const unsigned wlane = (unsigned)lane * 16u;
     bf16x8 fw[2][NP];   // [slot][plane] weight fragments of one sub-step, read from the staged group
     auto ldw = [&](const unsigned char* wg, int sub, int slot) {
@@ -407,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
             float f = 1.f;
             if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
+            float4 keep[4];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float4 res[4], esc[4], esh[4];
@@ -450,6 +530,53 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         t.w = fmaxf(t.w, 0.f) - fmaxf(-0.1f * t.w, 0.f);
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    if (j == 0) keep[g4] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if constexpr (TN == 1) {
+                if (head) {
+                    // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel] on the same matrix pipe.  The order of K is free, so step m
+                    // takes, from lane half kh, the eight channels this lane already holds: 8*(2m) + 4*kh + 0..3 and 8*(2m+1) + 4*kh + 0..3
+                    // (the head weights are packed in that order); the activated values are split / rounded in registers.
+                    f32x16 a2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a2[e] = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        bf16x8 px[NP];
+                        if constexpr (NP == 3) {
+                            uint2 h0, m0, l0, h1, m1, l1;
+                            split4(keep[2 * m], h0, m0, l0);
+                            split4(keep[2 * m + 1], h1, m1, l1);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+                            px[2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                        } else {
+                            const uint2 a = round4(keep[2 * m]), b = round4(keep[2 * m + 1]);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+                        }
+                        bf16x8 hw[NP];
+#pragma unroll
+                        for (int sidx = 0; sidx < NP; ++sidx) hw[sidx] = *reinterpret_cast<const bf16x8*>(hwl + (unsigned)(m * NP + sidx) * 1024u + wlane);
+#pragma unroll
+                        for (int t6 = 0; t6 < NPROD; ++t6) {
+                            const int sw = (NP == 1) ? 0 : ((t6 == 0) ? 2 : (t6 == 1) ? 0 : (t6 == 2) ? 1 : (t6 == 3) ? 1 : 0);
+                            const int sp = (NP == 1) ? 0 : ((t6 == 0) ? 0 : (t6 == 1) ? 2 : (t6 == 2) ? 1 : (t6 == 3) ? 0 : (t6 == 4) ? 1 : 0);
+                            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw[sw], px[sp], a2, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int q0 = g4 * 8 + kh * 4;
+                        const int nq = pok ? p.head_cout - q0 : 0;
+                        const unsigned o = (pix * (unsigned)p.head_ld + (unsigned)q0) * 4u;
+                        const unsigned v0 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), v1 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]);
+                        const unsigned v2 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), v3 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3]);
+                        if (nq >= 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, v1, v2, v3}, r_head, (int)o, 0, 0);
+                        else if (nq == 3) __builtin_amdgcn_raw_buffer_store_b96(u32x3{v0, v1, v2}, r_head, (int)o, 0, 0);
+                        else if (nq == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v0, v1}, r_head, (int)o, 0, 0);
+                        else if (nq == 1) __builtin_amdgcn_raw_buffer_store_b32(v0, r_head, (int)o, 0, 0);
+                    }
                 }
             }
         }
@@ -558,20 +685,21 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     }
 }
 
-template <int TN, int NP, bool PARTIAL>
+template <int TN, int NP, int MODE>
 int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.Wd + 31) / 32;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
     // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : 3) * TN * NP * 1024;
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : 3) * TN * NP * 1024 +
+                       (size_t)2 * NP * 1024;   // + the fused head's weights
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = std::min(256, k.ntiles);
-    CP_LAUNCH((conv_hsplit_kernel<TN, NP, PARTIAL>), dim3(grid), dim3(512), lds, st, k);
+    CP_LAUNCH((conv_hsplit_kernel<TN, NP, MODE>), dim3(grid), dim3(512), lds, st, k);
     return cp::check_launch("cp_conv2d_fwd_split");
 }
 
@@ -590,13 +718,16 @@ int split_fragments(int cout, int num_sources, const int* channels) {
 extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
     if (!d) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return 0;
-    if (d->cout > 64 || d->cout % 4 != 0 || d->group_rows || d->head_out) return 0;
+    if (d->cout > 64 || d->cout % 4 != 0 || d->group_rows) return 0;
+    if (d->head_out && (d->cout != 32 || !d->head_weights || d->head_cout < 1 || d->head_cout > 32)) return 0;
     if ((d->out_raw && d->out_raw_ld % 4) || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return 0;
     if ((((uintptr_t)d->out_raw) | ((uintptr_t)d->out_act) | ((uintptr_t)d->residual)) & 15) return 0;
     if (d->num_sources < 1 || d->num_sources > 2) return 0;
     for (int s = 0; s < d->num_sources; ++s) {
         const cp_conv_source& in = d->src[s];
-        if (in.mode != CP_SRC_DIRECT || in.pre_scale || in.pre_shift) return 0;
+        if (in.pre_scale || in.pre_shift) return 0;
+        if (s == 0 ? (in.mode != CP_SRC_DIRECT && in.mode != CP_SRC_BILINEAR_X2 && in.mode != CP_SRC_NEAREST_SEL) : in.mode != CP_SRC_DIRECT) return 0;
+        if (in.mode != CP_SRC_DIRECT && ((d->in_h | d->in_w) & 1)) return 0;
         if (in.channels == 4) {
             if (s != d->num_sources - 1 || s == 0 || in.ld != 4) return 0;   // the image source comes last, after a 16-multiple source
         } else if (in.channels % 16 != 0 || in.ld % 4 != 0 || (((uintptr_t)in.data) & 15)) {
@@ -606,6 +737,8 @@ extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
     if (d->src[0].channels == 4) return 0;
     if (d->tap_label && d->epi_label && d->tap_label != d->epi_label) return 0;
     if (!d->tap_label && d->row_scale) return 0;
+    if (d->src[0].mode == CP_SRC_BILINEAR_X2 && d->tap_label) return 0;   // the instantiated combinations: those the network uses
+    if (d->src[0].mode == CP_SRC_NEAREST_SEL && (!d->tap_label || !d->src[0].sel)) return 0;
     return 1;
 }
 
@@ -673,16 +806,32 @@ extern "C" int cp_conv_split_weights_f32(const float* packed, long long floats, 
     return cp::check_launch("cp_conv_split_weights_f32");
 }
 
-extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_split, int planes, void* stream) {
+// HOST: [1][1][32][head_cout] (HWIO) 1x1 kernel -> the fp32 image of the fused head's two fragments, [2 steps][64 lanes][8]:
+//   step m, lane (q = l & 31, kh = l >> 5), element e  <-  Wh[channel 8*(2m + (e >> 2)) + 4*kh + (e & 3)][q]   (the K order the epilogue uses)
+// 1024 floats; cp_conv_split_weights_f32 turns it into the bf16 planes.
+extern "C" int cp_conv_pack_head_split_host(const float* w, int head_cout, float* dst) {
+    CP_REQUIRE(w && dst && head_cout >= 1 && head_cout <= 32, "cp_conv_pack_head_split_host: bad arguments");
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                const int q = l & 31, c = 8 * (2 * m + (e >> 2)) + 4 * (l >> 5) + (e & 3);
+                dst[(m * 64 + l) * 8 + e] = q < head_cout ? w[c * head_cout + q] : 0.f;
+            }
+    return CP_OK;
+}
+
+extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_split, const void* head_weights_split, int planes, void* stream) {
     CP_REQUIRE(d && weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_split: bad arguments");
-    CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 64, direct sources "
-                                            "of 16-multiple channels + optional trailing 4-channel source)");
-    CP_REQUIRE(d->out_raw || d->out_act, "cp_conv2d_fwd_split: no output");
+    CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 64, sources "
+                                            "of 16-multiple channels + optional trailing 4-channel source; source 0 direct, bilinear x2 or guided x2)");
+    CP_REQUIRE(d->out_raw || d->out_act || d->head_out, "cp_conv2d_fwd_split: no output");
+    CP_REQUIRE(!d->head_out || head_weights_split, "cp_conv2d_fwd_split: a fused head needs its split weights");
     HSplitK k{};
     int nch = 0;
     for (int s = 0; s < d->num_sources; ++s) {
         const cp_conv_source& in = d->src[s];
-        const long long nbytes = (long long)d->batch * d->in_h * d->in_w * in.ld * 4;
+        const int Hs = (in.mode == CP_SRC_DIRECT) ? d->in_h : d->in_h / 2, Ws = (in.mode == CP_SRC_DIRECT) ? d->in_w : d->in_w / 2;
+        const long long nbytes = (long long)d->batch * Hs * Ws * in.ld * 4;
         CP_REQUIRE(nbytes < (1LL << 31), "cp_conv2d_fwd_split: source %d spans %lld bytes; 32-bit range-checked addressing needs < 2 GiB", s, nbytes);
         if (in.channels == 4) {
             k.img = in.data;
@@ -690,8 +839,11 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
             continue;
         }
         k.s[s].data = in.data;
+        k.s[s].sel = in.sel;
         k.s[s].C = in.channels;
         k.s[s].ld = in.ld;
+        k.s[s].Hs = Hs;
+        k.s[s].Ws = Ws;
         k.s[s].bytes = (unsigned)nbytes;
         if (s == 0) k.nch0 = in.channels / 16;
         nch += in.channels / 16;
@@ -701,7 +853,8 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
     k.W = reinterpret_cast<const unsigned char*>(weights_split);
     k.w_bytes = (unsigned)cp_conv_split_weight_bytes(d->cout, d->num_sources, chans, planes);
     k.B = d->batch; k.H = d->in_h; k.Wd = d->in_w; k.Cout = d->cout;
-    const long long out_bytes = (long long)d->batch * d->in_h * d->in_w * std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0) * 4;
+    const int max_ld = std::max(std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0), d->head_out ? d->head_out_ld : 0);
+    const long long out_bytes = (long long)d->batch * d->in_h * d->in_w * max_ld * 4;
     CP_REQUIRE(out_bytes < (1LL << 32), "cp_conv2d_fwd_split: output spans >= 4 GiB");
     k.label = d->tap_label ? d->tap_label : d->epi_label;
     k.lab_bytes = (unsigned)((size_t)d->batch * d->in_h * d->in_w);
@@ -709,15 +862,19 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
     k.scale = d->scale; k.shift = d->shift; k.clade = d->epi_label != nullptr; k.act = d->act;
     k.norm = d->row_scale != nullptr;
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
-    const bool partial = d->tap_label != nullptr;
+    k.head_w = d->head_out ? reinterpret_cast<const unsigned char*>(head_weights_split) : nullptr;
+    k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
+    const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0);
     const int tn = d->cout <= 32 ? 1 : 2;
     hipStream_t st = (hipStream_t)stream;
-#define CP_HS(TN_, NP_)                                                                   \
-    if (tn == TN_ && planes == NP_) return partial ? launch_hsplit<TN_, NP_, true>(k, st) : launch_hsplit<TN_, NP_, false>(k, st);
-    CP_HS(1, 3)
-    CP_HS(2, 3)
-    CP_HS(1, 1)
-    CP_HS(2, 1)
+#define CP_HS(TN_, NP_, M_) if (tn == TN_ && planes == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
+#define CP_HS4(TN_, NP_) CP_HS(TN_, NP_, 0) CP_HS(TN_, NP_, HS_BILINEAR) CP_HS(TN_, NP_, HS_PARTIAL) CP_HS(TN_, NP_, HS_PARTIAL | HS_SEL)
+    CP_HS4(1, 3)
+    CP_HS4(2, 3)
+    CP_HS4(1, 1)
+    CP_HS4(2, 1)
+#undef CP_HS4
 #undef CP_HS
+    cp::set_error("cp_conv2d_fwd_split: operand mode %d is not instantiated", mode);
     return CP_ERR_INVALID;
 }

@@ -154,6 +154,16 @@ class FusedConv:
             self._split_planes[planes] = out
         return self._split_planes[planes]
 
+    def head_split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
+        key = -planes
+        if key not in self._split_planes:
+            lib = _lib.load()
+            out = torch.empty(2 * planes * 1024, dtype=torch.uint8, device=self.head_w_split_f32.device)
+            st = torch.cuda.current_stream(out.device).cuda_stream if stream is None else stream
+            check(lib.cp_conv_split_weights_f32(self.head_w_split_f32.data_ptr(), 1024, planes, out.data_ptr(), st), "cp_conv_split_weights_f32(head)")
+            self._split_planes[key] = out
+        return self._split_planes[key]
+
     def attach_head(self, kernel_1x1: np.ndarray):
         """Fuse a following 1x1 convolution (HWIO [1,1,32,q], no bias / activation) into this layer's epilogue."""
         lib = _lib.load()
@@ -164,6 +174,9 @@ class FusedConv:
         check(lib.cp_conv_pack_head_weights_host(w.ctypes.data, w.shape[1], packed.ctypes.data), "cp_conv_pack_head_weights_host")
         self.head_w = torch.from_numpy(packed).to(self.wp_halo.device)
         self.head_cout = int(w.shape[1])
+        ps = np.empty(1024, dtype=np.float32)   # the same head for the bf16-pipe kernel
+        check(lib.cp_conv_pack_head_split_host(w.ctypes.data, w.shape[1], ps.ctypes.data), "cp_conv_pack_head_split_host")
+        self.head_w_split_f32 = torch.from_numpy(ps).to(self.wp_halo.device)
 
     def bind(self, *, batch, in_h, in_w, stride=1, dilation=1, pad=0, srcs, tap_label=None, row_scale=None,
              residual=None, scale=None, shift=None, epi_label=None, act=0, out_raw=None, out_raw_ld=None,
@@ -224,7 +237,8 @@ class FusedConv:
         if self.split_mode:
             if not lib.cp_conv_split_applicable(C.byref(self.desc)):
                 raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
-            check(lib.cp_conv2d_fwd_split(C.byref(self.desc), self.split_weights(self.split_mode, stream).data_ptr(), self.split_mode, stream),
+            head = self.head_split_weights(self.split_mode, stream).data_ptr() if self.desc.head_out else None
+            check(lib.cp_conv2d_fwd_split(C.byref(self.desc), self.split_weights(self.split_mode, stream).data_ptr(), head, self.split_mode, stream),
                   "cp_conv2d_fwd_split(%s)" % self.name)
             return
         check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)

@@ -500,7 +500,7 @@ class ConvOp:
             if getattr(self, "_split_fwd", None) is None:
                 self._split_fwd = bool(lib.cp_conv_split_applicable(C.byref(self.layer.desc)))
             if self._split_fwd:
-                check(lib.cp_conv2d_fwd_split(C.byref(self.layer.desc), sp["planes"].data_ptr(), sp["np"], stream), "cp_conv2d_fwd_split(%s)" % self.layer.name)
+                check(lib.cp_conv2d_fwd_split(C.byref(self.layer.desc), sp["planes"].data_ptr(), None, sp["np"], stream), "cp_conv2d_fwd_split(%s)" % self.layer.name)
                 return
         check(lib.cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
 
@@ -547,7 +547,7 @@ class ConvOp:
             g.residual = t.grad.data_ptr() if t.has_grad else None
             sp = ent["split"]
             if sp is not None and lib.cp_conv_split_applicable(C.byref(g)):
-                check(lib.cp_conv2d_fwd_split(C.byref(g), sp["planes"].data_ptr(), sp["np"], stream), "dgrad split(%s)" % L.name)
+                check(lib.cp_conv2d_fwd_split(C.byref(g), sp["planes"].data_ptr(), None, sp["np"], stream), "dgrad split(%s)" % L.name)
             else:
                 check(lib.cp_conv2d_fwd_f32(C.byref(g), stream), "dgrad(%s)" % L.name)
             t.has_grad = True

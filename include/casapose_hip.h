@@ -151,7 +151,8 @@ int cp_conv_selected_tile(const cp_conv_desc* desc);
 
 /* ------------------------------------------------------------------------------------
  * The same convolution on the bf16 matrix pipe (csrc/conv_hsplit.hip), for the shallow high-resolution layers: 3x3 / stride 1 /
- * pad 1, cout <= 64, sources CP_SRC_DIRECT with 16-multiple channels plus an optional trailing 4-channel source (the image).
+ * pad 1, cout <= 64, sources with 16-multiple channels plus an optional trailing 4-channel source (the image); source 0 may be
+ * CP_SRC_BILINEAR_X2 or (with tap_label) CP_SRC_NEAREST_SEL, the fused upsamplings of the decoders; a fused 1x1 head as in cp_conv2d_fwd_f32.
  * Replaces the same reference call sites as cp_conv2d_fwd_f32 for those layers (models/casapose.py:61-82, resnet.py:97-103 stage 1).
  *   planes = 3: fp32-EQUIVALENT -- every fp32 operand is split exactly into three bf16 terms and six bf16 products are accumulated in fp32
  *               (error <= that of the fp32 MFMA); the default of the training plan, opt-in for inference
@@ -168,7 +169,10 @@ size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels
 int cp_conv_pack_weights_split_host(const float* w_host, int layout, int cout, int num_sources, const int* channels,
                                     const int* real_channels, float* dst_host);
 int cp_conv_split_weights_f32(const float* packed, long long floats, int planes, void* out, void* stream);
-int cp_conv2d_fwd_split(const cp_conv_desc* desc, const void* weights_split, int planes, void* stream);
+/* HOST: a [1][1][32][head_cout] 1x1 kernel as the fp32 image (1024 floats) of the fused head's fragments; cp_conv_split_weights_f32
+ * makes its planes.  head_weights_split may be NULL when desc->head_out is NULL. */
+int cp_conv_pack_head_split_host(const float* w_host, int head_cout, float* dst_host);
+int cp_conv2d_fwd_split(const cp_conv_desc* desc, const void* weights_split, const void* head_weights_split, int planes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Small streaming kernels around the convolutions

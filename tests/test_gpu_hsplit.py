@@ -111,6 +111,70 @@ def test_partial_clade(device, mode, tol, hw):
     close(raw, ref, rtol=tol)
 
 
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_fused_upsampling_sources(device, mode, tol):
+    """source 0 read through the x2 bilinear filter (decoder blocks 3-5) or through the guided-upsampling selection map (blocks 8-10)"""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(17)
+    f = rng.standard_normal((2, 13, 20, 32))
+    img = rng.uniform(-1, 1, (2, 26, 40, 3))
+    w = rng.standard_normal((3, 3, 35, 32)) / 18.0
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    raw, _ = ops.conv2d_fused([dev(f, device), img4], w.astype(np.float32), pad=1, real_channels=[32, 3], modes=[2, 0], tile_hint=mode)
+    close(raw, O.conv2d(np.concatenate([O.upsample_bilinear_x2(f), img], 3), w, pad=1), rtol=tol)
+    low2, skip = rng.standard_normal((1, 10, 24, 64)), rng.standard_normal((1, 20, 48, 64))
+    w2 = rng.standard_normal((3, 3, 128, 64)) / 34.0
+    raw3, _ = ops.conv2d_fused([dev(low2, device), dev(skip, device)], w2.astype(np.float32), pad=1, modes=[2, 0], tile_hint=mode)
+    close(raw3, O.conv2d(np.concatenate([O.upsample_bilinear_x2(low2), skip], 3), w2, pad=1), rtol=tol)
+    # guided x2 source + image / + skip, partial conv (decoder blocks 10 and 8)
+    b, h, wd, k = 2, 24, 48, 5
+    lab = _labels(rng, b, h, wd, k)
+    mask = O.onehot_from_labels(lab, k)
+    labels, pnorm, sel = ops.label_pyramid(dev(lab, device, torch.uint8))
+    low = rng.standard_normal((b, h // 2, wd // 2, 32))
+    imgp = rng.uniform(-1, 1, (b, h, wd, 3))
+    wt = rng.standard_normal((35, 3, 3, 32)) / 18.0
+    up = O.guided_upsampling(low, O.half_size(mask), mask)
+    raw4, _ = ops.conv2d_fused([dev(low, device), ops.pad_channels_3to4(dev(imgp, device))], wt.astype(np.float32), layout=1, pad=1, real_channels=[32, 3],
+                               modes=[1, 0], sels=[sel[0], None], tap_label=labels[0], row_scale=pnorm[0], tile_hint=mode)
+    close(raw4, O.partial_convolution(np.concatenate([up, imgp], 3), wt, mask), rtol=tol)
+    low64, skip64 = rng.standard_normal((b, h // 2, wd // 2, 64)), rng.standard_normal((b, h, wd, 64))
+    wt2 = rng.standard_normal((128, 3, 3, 64)) / 34.0
+    up64 = O.guided_upsampling(low64, O.half_size(mask), mask)
+    raw5, _ = ops.conv2d_fused([dev(low64, device), dev(skip64, device)], wt2.astype(np.float32), layout=1, pad=1, modes=[1, 0], sels=[sel[0], None],
+                               tap_label=labels[0], row_scale=pnorm[0], tile_hint=mode)
+    close(raw5, O.partial_convolution(np.concatenate([up64, skip64], 3), wt2, mask), rtol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("q", [9, 27, 32])
+def test_fused_head(device, mode, tol, q):
+    """the 1x1 head (pv_final_conv_segmentation / _vertex) fused into the epilogue of a 32-channel layer, on the same matrix pipe"""
+    from casapose_amd import _lib
+    from casapose_amd.engine import FusedConv
+
+    rng = np.random.default_rng(23 + q)
+    b, h, w = 2, 19, 45
+    f, img = rng.standard_normal((b, h, w, 32)), rng.uniform(-1, 1, (b, h, w, 3))
+    wk = rng.standard_normal((3, 3, 35, 32)) / 18.0
+    wh = rng.standard_normal((1, 1, 32, q)) / 6.0
+    sc, sh = rng.uniform(0.5, 1.5, 32), rng.standard_normal(32) * 0.2
+    from casapose_amd import ops
+
+    layer = FusedConv("t", wk.astype(np.float32), 0, 3, 3, 32, [(32, 32), (4, 3)], device)
+    layer.attach_head(wh.astype(np.float32))
+    out = torch.zeros(b, h, w, 36, device=device)
+    layer.bind(batch=b, in_h=h, in_w=w, pad=1, srcs=[dict(data=dev(f, device), ld=32), dict(data=ops.pad_channels_3to4(dev(img, device)), ld=4)],
+               scale=dev(sc, device), shift=dev(sh, device), act=2, head_out=out, head_out_ld=36, tile_hint=mode)
+    layer.run(torch.cuda.current_stream(device).cuda_stream)
+    act = O.leaky_as_relu_pair(O.conv2d(np.concatenate([f, img], 3), wk, pad=1) * sc + sh)
+    ref = O.conv2d(act, wh)
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.abs(got[..., :q] - ref).max() <= tol * np.abs(ref).max()
+    assert (got[..., q:] == 0).all()        # channels beyond the head stay untouched
+
+
 def test_out_of_range_layers_are_refused(device):
     from casapose_amd import _lib, ops
 
