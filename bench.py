@@ -24,7 +24,10 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               4: "conv_f32_kernel<4,1,1,1> (128x32)", 5: "conv_f32_kernel<2,2,1,1> (64x64)", 6: "conv_f32_kernel<4,1,2,1> (256x32)",
               7: "conv_halo_kernel (LDS-resident 4-row halo tile, cout <= 64)",
               8: "conv_stem_kernel (7x7/s2 stem, LDS-resident input halo)",
-              100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)"}
+              100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)",
+              203: "conv_hsplit_kernel<3> (bf16 pipe, exact three-way split: six bf16 products per fp32 product; FLOPs counted as executed bf16 FLOPs)",
+              201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)"}
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
 def _log(msg):
@@ -153,17 +156,36 @@ def measured_traffic(tile):
 
 
 def _dtype_note_train():
+    """the training plan's defaults put two kernel groups on the bf16 matrix pipe with fp32-EQUIVALENT arithmetic (exact three-way splits, six
+    products, fp32 accumulate): the Winograd GEMMs (CASAPOSE_WINO_GEMM) and the forward / data-gradient of the shallow 3x3 layers
+    (CASAPOSE_CONV_MODE); CASAPOSE_CONV_MODE=bf16 rounds the latter's operands to bf16 (BASELINE configs[2])."""
+    parts = []
     if os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split":
-        return "f32 (Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)"
-    return "f32"
+        parts.append("Winograd GEMMs")
+    conv = os.environ.get("CASAPOSE_CONV_MODE", "split")
+    if conv == "split":
+        parts.append("forward / data gradient of the shallow 3x3 layers")
+    note = "f32"
+    if parts:
+        note += " (%s as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)" % " and ".join(parts)
+    if conv == "bf16":
+        note = "bf16 operands / f32 accumulate in the forward / data gradient of the shallow 3x3 layers; " + note + " elsewhere"
+    return note
 
 
 def _dtype_note():
-    """the arithmetic type of the MFMA kernels: exact fp32 MFMA by default; with the opt-in CASAPOSE_WINO_GEMM=split the Winograd GEMMs run as
-    exact three-way bf16 splits on the bf16 matrix pipe (fp32-equivalent results) and the line says so."""
+    """the arithmetic type of the MFMA kernels: exact fp32 MFMA by default; the opt-ins (CASAPOSE_WINO_GEMM=split: Winograd GEMMs,
+    CASAPOSE_INFER_CONV_MODE=split: shallow 3x3 layers, as exact three-way bf16 splits on the bf16 matrix pipe -- fp32-equivalent results,
+    DESIGN.md 8; CASAPOSE_INFER_CONV_MODE=bf16: those layers with bf16 operands) are named in the line when set."""
+    notes = []
     if os.environ.get("CASAPOSE_WINO_GEMM", "") == "split":
-        return "f32 (OPT-IN: Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six products, fp32 accumulate)"
-    return "f32"
+        notes.append("Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six products, fp32 accumulate")
+    mode = os.environ.get("CASAPOSE_INFER_CONV_MODE", "f32")
+    if mode == "split":
+        notes.append("shallow 3x3 layers (stage 1, decoder blocks 3-5 / 8-10) as exact 3-way bf16 splits, fp32-equivalent")
+    elif mode == "bf16":
+        return "bf16 operands / f32 accumulate in the shallow 3x3 layers (stage 1, decoder blocks 3-5 / 8-10), f32 elsewhere (OPT-IN)"
+    return "f32" + (" (OPT-IN: %s)" % "; ".join(notes) if notes else "")
 
 
 def bench_train(args):
@@ -488,9 +510,10 @@ def main():
         wino = {"layers": 0, "ms": 0.0, "gemm_ms": 0.0, "replaced_flops": 0.0}
         direct_flops = 0.0
         for conv in plan.convs:
-            tile = 100 if hasattr(conv, "gemm_flops") else lib.cp_conv_selected_tile(conv.desc)
+            pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe (opt-in conv mode), csrc/conv_hsplit.hip
+            tile = 100 if hasattr(conv, "gemm_flops") else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
             d_ = conv.desc
-            t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
+            t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS if pipe else PEAK_F32_MFMA_TFLOPS})
             direct_flops += conv.flops
             if hasattr(conv, "gemm_flops"):
                 # Winograd layer: the grouped GEMM is an MFMA kernel of its own family, accounted with the FLOPs it EXECUTES;
@@ -507,10 +530,10 @@ def main():
                 wino["replaced_flops"] += conv.flops
                 continue
             t["ms"] += timed(lambda: conv.run(stream))
-            t["flops"] += conv.flops
+            t["flops"] += conv.flops * (6.0 if pipe == 3 else 1.0)   # the exact split executes six bf16 products per fp32 product
             t["launches"] += 1
             # algorithmic HBM bytes: every operand once (sources at their stored resolution, packed weights, outputs)
-            byt = 4.0 * conv.wp.numel()
+            byt = 4.0 * (conv.wp.numel() if conv.wp is not None else 0)
             for si in range(d_.num_sources):
                 sc = d_.src[si]
                 byt += 4.0 * d_.batch * d_.in_h * d_.in_w * sc.channels / (1 if sc.mode == 0 else 4)
@@ -521,8 +544,13 @@ def main():
         d = per_tile[dom]
         conv_ms = sum(t["ms"] for t in per_tile.values()) + (wino["ms"] - wino["gemm_ms"])   # MFMA launches + Winograd transform passes
         conv_fl = sum(t["flops"] for t in per_tile.values())
-        ach_all = conv_fl / (conv_ms * 1e-3) / 1e12
+        f32_ms = sum(t["ms"] for t in per_tile.values() if t["peak"] == PEAK_F32_MFMA_TFLOPS) + (wino["ms"] - wino["gemm_ms"])
+        conv_fl = sum(t["flops"] for t in per_tile.values() if t["peak"] == PEAK_F32_MFMA_TFLOPS)   # headline: the fp32-MFMA launches (all of them by default)
+        ach_all = conv_fl / (f32_ms * 1e-3) / 1e12
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # with an opt-in conv mode some layers run on the bf16 pipe: each family is priced against ITS pipe's peak, and the time-weighted
+        # mean of those fractions over all convolution time is reported beside the fp32 figure
+        weighted = sum(t["ms"] * (t["flops"] / (t["ms"] * 1e-3) / 1e12 / t["peak"]) for t in per_tile.values()) / conv_ms
         # headline = EXECUTED FLOPs of every convolution launch of the forward (Winograd layers count the grouped GEMM they run, not the
         # direct convolution they replace) over the summed HIP-event durations of those launches incl. the Winograd transform passes;
         # the north-star target (>= 0.70 of the fp32-MFMA peak) is quoted on the whole encoder-decoder forward, so that is `frac`
@@ -530,15 +558,17 @@ def main():
             "bound": "mfma", "achieved": round(ach_all, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_all / PEAK_F32_MFMA_TFLOPS, 4),
             "kernel": "all convolution launches of the forward (conv_halo / wino_gemm / conv_f32 / conv_stem kernels + Winograd transform passes)",
-            "ms_per_step": round(conv_ms, 3), "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
+            "ms_per_step": round(f32_ms, 3), "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
+            "all_conv_ms_per_step": round(conv_ms, 3), "time_weighted_frac_of_each_family_s_own_peak": round(weighted, 4),
             "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
             "traffic": measured_traffic(dom),
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r01_pmc_traffic.json "
                             "(separate rocprofv3 --pmc passes of this command in round 1), not measured by this run",
-            "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / d["peak"], 4), "peak": d["peak"],
                                 "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                                 "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"])},
-            "families": {TILE_NAMES.get(k, str(k)).split(" ")[0] + ("" if k != 5 else "<64x64>"): {"ms": round(t["ms"], 3), "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2), "launches": t["launches"]}
+            "families": {TILE_NAMES.get(k, str(k)).split(" ")[0] + ("" if k != 5 else "<64x64>"): {"ms": round(t["ms"], 3), "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2), "launches": t["launches"],
+                                                                                                  "peak": t["peak"]}
                          for k, t in sorted(per_tile.items())},
             "winograd": {"layers": wino["layers"], "ms_per_step": round(wino["ms"], 3), "gemm_ms": round(wino["gemm_ms"], 3),
                          "transform_ms": round(wino["ms"] - wino["gemm_ms"], 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
