@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         float4 lv[NIT][NV];
         float4 liv[NIMG];
         int selb[NIT];       // SEL: the selection byte of this element's pixel (constant over the slices of a tile)
-        int lpar[NIT];       // BILINEAR: parity bits of the element's pixel of the slice in flight, 0x100 = "this slice is source 0"
+        int lpar[NIT];       // BILINEAR: parity bits (y & 1) << 1 | (x & 1) << 2 of the element's pixel in the tile being fetched
         const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
                                                                               SEL ? p.lab_bytes : 0u, 0x00020000);
         auto issue_sel = [&](const TilePos& tp) {
@@ -221,48 +221,51 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
             }
         };
-        auto issue_slice = [&](const TilePos& tp, int c) {
+        // byte offsets of this thread's halo elements for the tile being fetched (channel 0 of the slice's 16; OOB outside the image), computed
+        // once per tile: a slice only adds its uniform channel offset through the load's scalar offset -- no per-slice address arithmetic
+        unsigned eo0[NIT][NV], eo1[NIT];
+        auto tile_offsets = [&](const TilePos& tp) {
             const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
-            const int si = c >= p.nch0 ? 1 : 0;
-            const __amdgpu_buffer_rsrc_t rs = si ? rs1 : rs0;
-            const int sld = si ? p.s[1].ld : p.s[0].ld;
-            const int cb = ((c - (si ? p.nch0 : 0)) * 16 + q4) * 4;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
                 const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                const unsigned direct = inb ? (unsigned)((((n * p.H + y) * p.Wd + x) * sld) * 4 + cb) : OOB;
-                if constexpr (BILINEAR) {
-                    lpar[it] = ((y & 1) << 1) | ((x & 1) << 2) | (si == 0 ? 0x100 : 0);
-                    unsigned o00 = direct, o01 = direct, o10 = direct, o11 = direct;
-                    if (si == 0) {   // half-pixel centres: output pixel y reads source rows (y-1)/2 and (y+1)/2 (clamped), weights 0.75 / 0.25
-                        const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
-                        int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
-                        const int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
-                        ys = max(ys, 0);
-                        xs = max(xs, 0);
-                        const int nb = n * Hs * Ws;
-                        o00 = inb ? (unsigned)(((nb + ys * Ws + xs) * sld) * 4 + cb) : OOB;
-                        o01 = inb ? (unsigned)(((nb + ys * Ws + x1) * sld) * 4 + cb) : OOB;
-                        o10 = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld) * 4 + cb) : OOB;
-                        o11 = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld) * 4 + cb) : OOB;
-                    }
-                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o00, 0, 0));
-                    if (si == 0) {
-                        lv[it][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o01, 0, 0));
-                        lv[it][2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o10, 0, 0));
-                        lv[it][3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o11, 0, 0));
-                    }
+                const unsigned pixel = (unsigned)((n * p.H + y) * p.Wd + x);
+                eo1[it] = inb ? (pixel * (unsigned)p.s[1].ld + (unsigned)q4) * 4u : OOB;
+                if constexpr (BILINEAR) {   // half-pixel centres: output row y reads source rows (y-1)/2 and (y+1)/2 (clamped), weights 0.75 / 0.25
+                    lpar[it] = ((y & 1) << 1) | ((x & 1) << 2);
+                    const int Hs = p.s[0].Hs, Ws = p.s[0].Ws, sld = p.s[0].ld;
+                    int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
+                    const int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
+                    ys = max(ys, 0);
+                    xs = max(xs, 0);
+                    const int nb = n * Hs * Ws;
+                    eo0[it][0] = inb ? (unsigned)(((nb + ys * Ws + xs) * sld + q4) * 4) : OOB;
+                    eo0[it][1] = inb ? (unsigned)(((nb + ys * Ws + x1) * sld + q4) * 4) : OOB;
+                    eo0[it][2] = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld + q4) * 4) : OOB;
+                    eo0[it][3] = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld + q4) * 4) : OOB;
                 } else if constexpr (SEL) {
-                    unsigned o = direct;
-                    if (si == 0) {
-                        const int sl = selb[it];
-                        o = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * sld) * 4 + cb) : OOB;
-                    }
-                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0));
+                    const int sl = selb[it];
+                    eo0[it][0] = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * p.s[0].ld + q4) * 4) : OOB;
                 } else {
-                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)direct, 0, 0));
+                    eo0[it][0] = inb ? (pixel * (unsigned)p.s[0].ld + (unsigned)q4) * 4u : OOB;
                 }
+            }
+        };
+        bool slice_src0 = true;   // BILINEAR: the slice in flight belongs to source 0 (needs the interpolation)
+        auto issue_slice = [&](const TilePos& tp, int c) {
+            (void)tp;
+            const int si = c >= p.nch0 ? 1 : 0;
+            const int cs = (c - (si ? p.nch0 : 0)) * 64;   // uniform byte offset of the slice's first channel
+            slice_src0 = si == 0;
+            if (si == 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) lv[it][v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)eo0[it][v], cs, 0));
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)eo1[it], cs, 0));
             }
         };
         auto store_slice = [&](int stage) {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 if (e_hy[it] >= 0x4000) continue;
                 float4 val = lv[it][0];
                 if constexpr (BILINEAR) {
-                    if (lpar[it] & 0x100) {
+                    if (slice_src0) {
                         const float fy = (lpar[it] & 2) ? 0.25f : 0.75f, fx = (lpar[it] & 4) ? 0.25f : 0.75f;
                         const float gy = 1.f - fy, gx = 1.f - fx;
                         const float4 v01 = lv[it][1], v10 = lv[it][2], v11 = lv[it][3];
@@ -371,9 +374,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 next_tile(ftile);
             }
         };
-        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its image halo, its label halo, its selection bytes
+        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its element offsets, image halo, label halo, selection bytes
             if (fc != 0) return;
             issue_sel(ftile);
+            tile_offsets(ftile);
             if (has_img) issue_img(ftile);
             if (has_lab_l) issue_lab(ftile);
             img_pending = true;

@@ -519,7 +519,10 @@ class ForwardPlan:
                 src0 = prev
                 mode = _lib.SRC_DIRECT
                 if up:
-                    if fuse_upsample:
+                    # on the bf16 pipe the 32-output-channel layers (blocks 4, 5) are too short on MFMA work per loaded element to hide a
+                    # four-tap interpolation in the loader waves (measured: 0.77 / 1.29 ms fused against 0.46 / 0.63 ms direct), so the x2
+                    # bilinear tensor is materialised for them (one streaming pass, 0.12 / 0.25 ms)
+                    if fuse_upsample and not (net.conv_planes and dims[i] <= 32):
                         mode = _lib.SRC_BILINEAR_X2
                     else:
                         big = new(B, hs[l], ws[l], prev_c)
