@@ -138,13 +138,14 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
 
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
-                   5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel"}
+                   5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel",
+                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<"}
 
 
 def measured_traffic(tile):
     """Average HBM bytes per launch of the instantiation family `tile`, from the committed PMC passes (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or tile not in TILE_PMC_PREFIX:
+    path = next((q for q in (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    if path is None or tile not in TILE_PMC_PREFIX:
         return None
     tab = json.load(open(path))
     tot = n = 0.0
@@ -562,8 +563,8 @@ def main():
             "all_conv_ms_per_step": round(conv_ms, 3), "time_weighted_frac_of_each_family_s_own_peak": round(weighted, 4),
             "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
             "traffic": measured_traffic(dom),
-            "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r01_pmc_traffic.json "
-                            "(separate rocprofv3 --pmc passes of this command in round 1), not measured by this run",
+            "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
+                            "(separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.sh), not measured by this run",
             "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / d["peak"], 4), "peak": d["peak"],
                                 "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                                 "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"])},
