@@ -109,6 +109,7 @@ SYMBOLS = [
     ("cp_argmax_labels", _i, [_vp, _i, _i, _ll, _vp, _vp]),
     ("cp_label_pyramid", _i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     ("cp_ls_vote_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_ls_vote_w_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ls_vote_workspace_bytes", C.c_size_t, [_i, _i, _i]),
     ("cp_ccl_filter_labels", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),

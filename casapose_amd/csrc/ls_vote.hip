@@ -36,7 +36,7 @@ template <int KP>
 __global__ __launch_bounds__(256) void ls_accumulate_kernel(const float* __restrict__ field, int ld, int seg_off,
                                                             int dir_off, int conf_off, const uint8_t* __restrict__ labels,
                                                             int B, int H, int W, int objects, double* __restrict__ sums,
-                                                            int strips_x, int strips_y) {
+                                                            int strips_x, int strips_y, int sigmoid) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* acc_lds = reinterpret_cast<double*>(smem_raw);                         // [objects][KP][5]
     float* stage = reinterpret_cast<float*>(smem_raw + sizeof(double) * objects * KP * 5);  // [WAVES][64*ld]
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void ls_accumulate_kernel(const float* __restr
 #ifdef LS_NOSOFTPLUS
                     float w = fmaxf(cf, 0.f);
 #else
-                    float w = fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf)));  // softplus (:35)
+                    float w = sigmoid ? 1.0f / (1.0f + expf(-cf))                    // sigmoid_weights=True (:32-33, sigmoid_scale = 1)
+                                      : fmaxf(cf, 0.f) + log1pf(expf(-fabsf(cf)));   // softplus (:35)
 #endif
                     float nrm = sqrtf(dy * dy + dx * dx);
                     float ny = (nrm > 0.f) ? dy / nrm : 0.f;  // divide_no_nan (:90)
@@ -507,9 +508,19 @@ extern "C" size_t cp_ls_vote_workspace_bytes(int batch, int objects, int kp) {
     return (size_t)batch * objects * kp * 5 * sizeof(double);
 }
 
+extern "C" int cp_ls_vote_w_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels, int batch, int h, int w,
+                                int objects, int kp, int sigmoid_weights, double* sums_ws, float* keypoints, void* stream);
+
 extern "C" int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels,
                               int batch, int h, int w, int objects, int kp, double* sums_ws, float* keypoints,
                               void* stream) {
+    return cp_ls_vote_w_f32(field, ld, seg_off, dir_off, conf_off, labels, batch, h, w, objects, kp, 0, sums_ws, keypoints, stream);
+}
+
+// the same voter with the pixel weight selectable: sigmoid_weights = 0 softplus(conf) (the configs' choice), 1 sigmoid(conf)
+// (CoordLSVotingWeighted(sigmoid_weights=True), voting_layers_2d.py:32-33)
+extern "C" int cp_ls_vote_w_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels, int batch, int h, int w,
+                                int objects, int kp, int sigmoid_weights, double* sums_ws, float* keypoints, void* stream) {
     CP_REQUIRE(field && sums_ws && keypoints, "cp_ls_vote_f32: null pointer");
     CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ls_vote_f32: bad sizes");
     CP_REQUIRE(kp == MAXKP, "cp_ls_vote_f32: built for %d keypoints (got %d)", MAXKP, kp);
@@ -522,11 +533,11 @@ extern "C" int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_o
     int strips_x = (w + 63) / 64, strips_y = (h + ROWS - 1) / ROWS;
     int blocks_per_img = (strips_x * strips_y + WAVES - 1) / WAVES;
     size_t lds = sizeof(double) * objects * kp * 5 + sizeof(float) * WAVES * 64 * ld;
-    if (ld == 36 && seg_off == 0 && dir_off == 9 && conf_off == 27 && objects == 8 && !getenv("CP_LS_GENERIC")) {  // the production record
+    if (!sigmoid_weights && ld == 36 && seg_off == 0 && dir_off == 9 && conf_off == 27 && objects == 8 && !getenv("CP_LS_GENERIC")) {  // the production record
         CP_LAUNCH(ls_accumulate36_kernel, dim3(batch * blocks_per_img), dim3(256), lds, st, field, labels, batch, h, w, sums_ws, strips_x, strips_y);
     } else {
         CP_LAUNCH((ls_accumulate_kernel<MAXKP>), dim3(batch * blocks_per_img), dim3(256), lds, st, field, ld, seg_off,
-                  dir_off, conf_off, labels, batch, h, w, objects, sums_ws, strips_x, strips_y);
+                  dir_off, conf_off, labels, batch, h, w, objects, sums_ws, strips_x, strips_y, sigmoid_weights ? 1 : 0);
     }
     int total = batch * objects * kp;
     CP_LAUNCH(ls_solve_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums_ws, total, h, keypoints);

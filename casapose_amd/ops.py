@@ -127,13 +127,13 @@ def label_pyramid(labels0: torch.Tensor):
 
 
 def ls_vote(field: torch.Tensor, seg_off: int, dir_off: int, conf_off: int, objects: int, kp: int = 9,
-            labels: Optional[torch.Tensor] = None, return_sums: bool = False):
+            labels: Optional[torch.Tensor] = None, return_sums: bool = False, sigmoid_weights: bool = False):
     """cp_ls_vote_f32 on a [B,H,W,ld] record tensor.  Returns keypoints [B,objects,kp,2] (y,x)."""
     _need_cuda(field, labels)
     b, h, w, ld = field.shape
     lib = _lib.load()
     sums = torch.empty(b, objects, kp, 5, dtype=torch.float64, device=field.device)
     out = torch.empty(b, objects, kp, 2, dtype=torch.float32, device=field.device)
-    check(lib.cp_ls_vote_f32(field.data_ptr(), ld, seg_off, dir_off, conf_off, labels.data_ptr() if labels is not None else None,
-                             b, h, w, objects, kp, sums.data_ptr(), out.data_ptr(), _stream(field)), "cp_ls_vote_f32")
+    check(lib.cp_ls_vote_w_f32(field.data_ptr(), ld, seg_off, dir_off, conf_off, labels.data_ptr() if labels is not None else None,
+                               b, h, w, objects, kp, 1 if sigmoid_weights else 0, sums.data_ptr(), out.data_ptr(), _stream(field)), "cp_ls_vote_w_f32")
     return (out, sums) if return_sums else out

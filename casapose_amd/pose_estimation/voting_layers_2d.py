@@ -38,14 +38,13 @@ def _as_record(seg: torch.Tensor, direct: torch.Tensor, conf: torch.Tensor):
 class CoordLSVotingWeighted:
     def __init__(self, name, num_classes, num_points=9, sigmoid_weights=False, filter_estimates=False,
                  output_second_largest_component=False):
-        if sigmoid_weights:
-            raise NotImplementedError("sigmoid_weights=True (voting_layers_2d.py:32-33) is not built; the configs use softplus")
         if output_second_largest_component:
             raise NotImplementedError("output_second_largest_component is a reference debugging switch and is not built")
         self.name = name
         self.num_classes = num_classes
         self.num_points = num_points
         self.filter_estimates = filter_estimates
+        self.sigmoid_weights = bool(sigmoid_weights)   # w = sigmoid(sigmoid_scale * conf), sigmoid_scale = 1 (voting_layers_2d.py:20,32-33); default softplus
         self.min_component = 50  # voting_layers_2d.py:66
 
     def __call__(self, inp: Sequence[torch.Tensor], **kwargs) -> torch.Tensor:
@@ -70,4 +69,4 @@ class CoordLSVotingWeighted:
             check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, objects, self.min_component, ws.data_ptr(),
                                            labels.data_ptr(), torch.cuda.current_stream(rec.device).cuda_stream),
                   "cp_ccl_filter_labels")
-        return ops.ls_vote(rec, so, do, co, objects, self.num_points, labels=labels)
+        return ops.ls_vote(rec, so, do, co, objects, self.num_points, labels=labels, sigmoid_weights=self.sigmoid_weights)

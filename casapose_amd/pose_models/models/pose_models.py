@@ -90,14 +90,14 @@ def CASAPoseConditional5(*args, **kwargs):
 def PVNet(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32, input_shape=None, input_tensor=None, weights=None,
           base_model="resnet18", backbone=None, output_lablemap=False, **kwargs):
     """pvnet_combined (pose_models.py:645-696): the baseline without the class-adaptive decoder -- ResNet-18 + decoder 1 + one 1x1 head
-    `pv_final_conv` with seg_dim + ver_dim output channels.  (The registry key `pvnet` is the same graph with per-object vector
-    fields, ver_dim = 2*points*objects; its separated-field losses are not built, so only the merged-output use is supported.)"""
+    `pv_final_conv` with seg_dim + ver_dim output channels.  The registry key `pvnet` is the same graph with per-object ("separated")
+    vector fields, ver_dim = 2*points*objects (train_casapose.py:221,313-320): its forward (inference) is built for any head width; the
+    training step covers the merged-output form only (seg_dim + ver_dim <= 64: the separated-field losses of compute_loss,
+    train_casapose.py:57,97-125, are not built) and says so when asked."""
     if base_model != "resnet18":
         raise NotImplementedError("backbone %s is not built for MI355X yet (resnet18 is)" % base_model)
     if backbone is not None or input_tensor is not None:
         raise NotImplementedError("external backbone / input_tensor are Keras-graph features without an equivalent here")
-    if seg_dim + ver_dim > 64:
-        raise NotImplementedError("PVNet with more than 64 output channels (separated vector fields) is not built")
     return CasaposeModel("pvnet_combined", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
                          fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=False, pvnet=True)

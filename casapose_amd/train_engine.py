@@ -504,6 +504,52 @@ class ConvOp:
                 return
         check(lib.cp_conv2d_fwd_f32(C.byref(self.layer.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.layer.name)
 
+    def executed_flops(self) -> Dict[str, float]:
+        """FLOPs this op's launches EXECUTE per step, by matrix pipe: {"f32": fp32-MFMA FLOPs, "bf16": bf16-MFMA FLOPs} -- a Winograd layer counts
+        its grouped GEMMs (36 planes x padded tiles), an exact three-way split counts six bf16 products per fp32 product; forward + weight
+        gradient + every data gradient.  (bench.py --mode train prices the step against the two pipes' peaks with it.)"""
+        from .engine import TRAIN_WINO_GEMM_SPLIT
+
+        L = self.layer
+        lib = _lib.load()
+        out = {"f32": 0.0, "bf16": 0.0}
+        m_out = float(self.batch * self.out_h * self.out_w)
+        cin = sum(s[1] for s in L.sources)
+        direct = 2.0 * m_out * L.k * L.k * cin * L.cout
+        wino_pipe, wino_mult = ("bf16", 6.0) if TRAIN_WINO_GEMM_SPLIT else ("f32", 1.0)
+
+        def split_pipe(sp):
+            return ("bf16", 6.0 if sp["np"] == 3 else 1.0)
+
+        if getattr(self, "wino_fwd", None) is not None:
+            w = self.wino_fwd
+            g = 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
+            out[wino_pipe] += wino_mult * g      # forward GEMM
+            out["f32"] += g                      # weight gradient: grouped fp32 GEMM over the 36 planes
+        else:
+            if L.split is not None and lib.cp_conv_split_applicable(C.byref(L.desc)):
+                pipe, mult = split_pipe(L.split)
+                out[pipe] += mult * direct
+            else:
+                out["f32"] += direct
+            out["f32"] += direct                 # weight gradient (conv_wgrad_kernel, fp32 MFMA)
+        c0 = 0
+        for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
+            if ent is None:
+                continue
+            if s in getattr(self, "wino_dgrad", {}):
+                w = self.wino_dgrad[s]
+                out[wino_pipe] += wino_mult * 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
+            else:
+                m_in = float(self.batch * self.in_h * self.in_w)
+                d = 2.0 * m_in * L.k * L.k * ent["cin"] * cr
+                if ent["split"] is not None and self.stride == 1 and self.dil == 1 and L.k == 3:
+                    pipe, mult = split_pipe(ent["split"])
+                    out[pipe] += mult * d
+                else:
+                    out["f32"] += d
+        return out
+
     def _dy(self):
         if self.dy_ptr_ld is not None:
             st, off, ld = self.dy_ptr_ld
@@ -660,7 +706,8 @@ class TrainPlan:
         self.pvnet = bool(pvnet)
         if self.pvnet:  # one merged head: its gradient row is the contiguous [seg | vertex] record
             if seg_dim + ver_dim > self.GRAD_LD:
-                raise ValueError("pvnet_combined: seg_dim + ver_dim must be <= %d" % self.GRAD_LD)
+                raise NotImplementedError("PVNet training covers the merged-output model (seg_dim + ver_dim <= %d); the separated-vector-field losses of "
+                                          "the `pvnet` registry entry (train_casapose.py:57,97-125) are not built -- its forward is" % self.GRAD_LD)
             self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
         self._buckets = None

@@ -230,6 +230,11 @@ int cp_label_pyramid(const uint8_t* labels0, int batch, int h, int w, uint8_t* c
 int cp_ls_vote_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels,
                    int batch, int h, int w, int objects, int kp, double* sums_ws, float* keypoints,
                    void* stream);
+/* the same with the pixel weight selectable: sigmoid_weights = 0 -> softplus(conf) (cp_ls_vote_f32), 1 -> sigmoid(conf)
+ * (CoordLSVotingWeighted(sigmoid_weights=True), voting_layers_2d.py:32-33; sigmoid_scale is 1 in the reference) */
+int cp_ls_vote_w_f32(const float* field, int ld, int seg_off, int dir_off, int conf_off, const uint8_t* labels,
+                     int batch, int h, int w, int objects, int kp, int sigmoid_weights, double* sums_ws, float* keypoints,
+                     void* stream);
 size_t cp_ls_vote_workspace_bytes(int batch, int objects, int kp);
 
 /* Largest-connected-component filter of voting_layers_2d.py:43-79 (tfa.image.connected_components,

@@ -593,12 +593,15 @@ def largest_component_filter(hot: np.ndarray, min_size: int = 50) -> np.ndarray:
     return ((comp == keep_id) & (hot > 0)).astype(hot.dtype)
 
 
-def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_override=None):
+def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_override=None, sigmoid_weights=False):
     """CoordLSVotingWeighted.call/calc (voting_layers_2d.py:28-122).
     seg [B,H,W,K] logits, direct [B,H,W,2*kp] (dy,dx pairs), conf [B,H,W,kp].
     Returns [B,K-1,kp,2] keypoints in (y,x) pixels; accumulation in fp64."""
     b, h, w, k = seg.shape
-    wgt = softplus(conf.astype(np.float32)).astype(np.float32)
+    if sigmoid_weights:  # voting_layers_2d.py:32-33 with sigmoid_scale = 1
+        wgt = (1.0 / (1.0 + np.exp(-conf.astype(np.float64)))).astype(np.float32)
+    else:
+        wgt = softplus(conf.astype(np.float32)).astype(np.float32)
     hot = saturated_softmax(seg.astype(np.float32))[..., 1:]
     if hot_override is not None:
         hot = hot_override

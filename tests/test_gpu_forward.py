@@ -138,6 +138,10 @@ def test_ls_voting_matches_oracle(device):
     # separate (non-view) tensors take the packing path
     got2 = CoordLSVotingWeighted("v", objs + 1)([s.contiguous(), d.contiguous(), c.contiguous()]).cpu().numpy()
     assert np.abs(got2 - ref).max() < 0.05
+    # sigmoid_weights=True (voting_layers_2d.py:32-33): another pixel weight, same machinery
+    got3 = CoordLSVotingWeighted("v", objs + 1, sigmoid_weights=True)([s, d, c]).cpu().numpy()
+    ref3 = O.ls_voting(seg, direct, conf, sigmoid_weights=True)
+    assert np.abs(got3 - ref3).max() < 0.05 and np.abs(ref3 - ref).max() > 1e-3
 
 
 def test_ls_voting_sums_and_empty_objects(device):
@@ -196,6 +200,24 @@ def test_custom_decoder_params(device):
     with pytest.raises(NotImplementedError):
         CASAPose([DecoderParams(True, True, False, True, False)] * 5, ver_dim=27, seg_dim=3, input_shape=(32, 32, 3), device=device)
     assert [tuple(p) for p in CASAPOSE_PARAMS["clade"]][1] == (True, True, True, False, False)
+
+
+def test_pvnet_with_separated_vector_fields_forward(device):
+    """the `pvnet` registry entry (models_factory.py:31): per-object vector fields, ver_dim = 2 * points * objects -> a 1x1 head with
+    seg_dim + 144 output channels for 8 objects; inference forward vs the oracle; the training step refuses the separated-field losses."""
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    b, h, w, k = 1, 32, 48, 9
+    v = 2 * 9 * (k - 1)
+    params = O.init_params(k, v, seed=33, dtype=np.float32, pvnet=True)
+    net = Classifiers.get("pvnet")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, device=device)
+    net.set_parameters(params)
+    img = np.random.default_rng(4).uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    ref = O.casapose_c_gcu5({n: a.astype(np.float64) for n, a in params.items()}, img.astype(np.float64), variant="pvnet_combined")
+    got = net([img], training=False).cpu().numpy().astype(np.float64)
+    assert got.shape == (b, h, w, k + v) and rel_err(got, ref) < 1e-3
+    with pytest.raises(NotImplementedError, match="separated"):
+        net([img], training=True)
 
 
 def test_pvnet_combined_forward_and_training(device):
