@@ -698,6 +698,9 @@ class TrainPlan:
                  pvnet: bool = False, shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
+        if pvnet and seg_dim + ver_dim > self.GRAD_LD:
+            raise NotImplementedError("PVNet training covers the merged-output model (seg_dim + ver_dim <= %d); the separated-vector-field losses of "
+                                      "the `pvnet` registry entry (train_casapose.py:57,97-125) are not built -- its forward is" % self.GRAD_LD)
         if seg_dim > 32 or ver_dim > 32:
             raise ValueError("the training plan supports up to 32 classes / 32 vertex channels")
         lib = _lib.load()
