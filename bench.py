@@ -25,6 +25,7 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               7: "conv_halo_kernel (LDS-resident 4-row halo tile, cout <= 64)",
               8: "conv_stem_kernel (7x7/s2 stem, LDS-resident input halo)",
               100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)",
+              103: "wino_gemm_split_kernel (bf16 pipe, exact three-way split of the Winograd planes' GEMM; FLOPs counted as executed bf16 FLOPs)",
               203: "conv_hsplit_kernel<3> (bf16 pipe, exact three-way split: six bf16 products per fp32 product; FLOPs counted as executed bf16 FLOPs)",
               201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)"}
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
@@ -139,7 +140,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
                    5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel",
-                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<"}
+                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel"}
 
 
 def measured_traffic(tile):
@@ -418,6 +419,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-optin", action="store_true", help="skip the extra fp32-equivalent opt-in line (exact bf16 splits) reported beside the headline")
     args = ap.parse_args()
     launched = launch_ranks(args)
     if launched is not None:
@@ -524,7 +526,9 @@ def main():
         direct_flops = 0.0
         for conv in plan.convs:
             pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe (opt-in conv mode), csrc/conv_hsplit.hip
-            tile = 100 if hasattr(conv, "gemm_flops") else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
+            if hasattr(conv, "gemm_flops") and getattr(conv, "Us", None) is not None:
+                pipe = 3                                # Winograd GEMM as exact three-way splits (opt-in CASAPOSE_WINO_GEMM=split)
+            tile = (103 if pipe else 100) if hasattr(conv, "gemm_flops") else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
             d_ = conv.desc
             t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS if pipe else PEAK_F32_MFMA_TFLOPS})
             direct_flops += conv.flops
@@ -534,7 +538,7 @@ def main():
                 gemm_ms = timed(lambda: conv.run_gemm(stream))
                 whole_ms = timed(lambda: conv.run(stream))
                 t["ms"] += gemm_ms
-                t["flops"] += conv.gemm_flops
+                t["flops"] += conv.gemm_flops * (6.0 if pipe == 3 else 1.0)
                 t["launches"] += 1
                 t["bytes"] += 4.0 * (36.0 * conv.Tp * (conv.ktot + conv.cout) + conv.U.numel())
                 wino["layers"] += 1
@@ -587,6 +591,40 @@ def main():
                          "transform_ms": round(wino["ms"] - wino["gemm_ms"], 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
         }
     _log("roofline section done")
+    if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode == "f32" and os.environ.get("CASAPOSE_WINO_GEMM", "") != "split":
+        # the same workload with the two fp32-EQUIVALENT opt-ins switched on (exact three-way bf16 splits on the bf16 matrix pipe: the shallow
+        # 3x3 layers, csrc/conv_hsplit.hip, and the Winograd GEMMs, csrc/wino_gemm_split.hip) -- reported BESIDE the headline, never as it
+        from casapose_amd import engine as _engine
+
+        del net
+        torch.cuda.empty_cache()
+        _engine.WINO_GEMM_SPLIT = True
+        try:
+            net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None, base_model="resnet18", device=dev,
+                                                      seed=1237, conv_mode="split")
+            net2.set_parameters(params)
+
+            def step2():
+                out = net2([img], training=False)
+                s_, d_, c_ = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
+                return voter([s_, d_, c_])
+
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                k2 = step2()
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t1
+            result["optin_fp32_equivalent"] = {
+                "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
+                "max_keypoint_difference_vs_headline_px": round(float((k2 - kpts).abs().max()), 4),
+                "what": "CASAPOSE_INFER_CONV_MODE=split + CASAPOSE_WINO_GEMM=split: shallow 3x3 layers and Winograd GEMMs as exact 3-way bf16 splits "
+                        "(six bf16 products per fp32 product, fp32 accumulate; error <= the fp32 MFMA's, tests/test_gpu_hsplit.py, test_gpu_conv.py); NOT the headline"}
+            _log("opt-in line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
+        finally:
+            _engine.WINO_GEMM_SPLIT = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)
     if rank == 0:
