@@ -596,6 +596,7 @@ def main():
         # 3x3 layers, csrc/conv_hsplit.hip, and the Winograd GEMMs, csrc/wino_gemm_split.hip) -- reported BESIDE the headline, never as it
         from casapose_amd import engine as _engine
 
+        ref_logits = net([img], training=False)[..., :seg_dim].clone()
         del net
         torch.cuda.empty_cache()
         _engine.WINO_GEMM_SPLIT = True
@@ -614,12 +615,13 @@ def main():
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                k2 = step2()
+                step2()
             torch.cuda.synchronize(dev)
             dt2 = time.perf_counter() - t1
             result["optin_fp32_equivalent"] = {
                 "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
-                "max_keypoint_difference_vs_headline_px": round(float((k2 - kpts).abs().max()), 4),
+                # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)
+                "max_logit_difference_vs_headline_rel": float("%.3g" % float((net2([img], training=False)[..., :seg_dim] - ref_logits).abs().max() / ref_logits.abs().max())),
                 "what": "CASAPOSE_INFER_CONV_MODE=split + CASAPOSE_WINO_GEMM=split: shallow 3x3 layers and Winograd GEMMs as exact 3-way bf16 splits "
                         "(six bf16 products per fp32 product, fp32 accumulate; error <= the fp32 MFMA's, tests/test_gpu_hsplit.py, test_gpu_conv.py); NOT the headline"}
             _log("opt-in line done: %.3f ms/step" % (1e3 * dt2 / args.steps))

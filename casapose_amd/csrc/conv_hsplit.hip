@@ -51,11 +51,12 @@ struct HSplitK {
     SSrc s[2];
     const float* img;
     unsigned img_bytes;
-    const unsigned char* W;   // [step][cout block][plane][64 lanes][8 bf16]; steps = 9 per 16-channel slice, then 3 image steps
+    const unsigned char* W;   // [pass][step][cout block][plane][64 lanes][8 bf16]; steps = 9 per 16-channel slice, then 3 image steps
     unsigned w_bytes;
     int B, H, Wd, Cout;
     int nch0, nch;            // 16-channel slices of source 0 / of both sources
-    int tiles_y, tiles_x, ntiles;
+    int tiles_y, tiles_x, ntiles;   // ntiles = passes * B * tiles_y * tiles_x: the tile list is walked once per pass of 32*TN output channels
+    int passes, tiles_per_pass;
     const uint8_t* label;
     unsigned lab_bytes;
     const float* residual;
@@ -137,12 +138,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NPROD = (NP == 3) ? 6 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
-    constexpr int GT = (TN == 1) ? 9 : 3;            // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice), a
-                                                     // third of it for the 64-channel ones (their groups would not fit the LDS otherwise)
+    constexpr int GT = (TN == 1) ? 9 : (TN == 2) ? 3 : 1;   // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice),
+                                                            // a third of it for the 64-channel ones, one tap for 128 channels per pass (LDS budget)
     constexpr int GPS = 9 / GT;                      // groups per slice
     constexpr int GSUB = GT * TN;                    // (tap, cout block) sub-steps of a group; the image block is a group of 3 * TN sub-steps
     constexpr unsigned GROUP_B = GSUB * FRAG_B;      // bytes of a weight group: 27 KB (TN = 1) / 18 KB (TN = 2) with three planes
-    constexpr unsigned IGROUP_B = 3 * TN * FRAG_B;   // bytes of the image block's group
+    constexpr unsigned IGROUP_B = 3 * TN * FRAG_B;   // bytes of the image block's group (layers with the image source have TN = 1)
+    static_assert(TN == 1 || TN == 2 || TN == 4, "32, 64 or 128 output channels per pass");
     constexpr int NWL = (int)((GROUP_B / 16 + 255) / 256);   // 16-byte pieces of a group per loader thread
 
     const bool has_img = p.img != nullptr;
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         if (t.ty >= p.tiles_y) { t.ty -= p.tiles_y; cn = 1; }
         t.n += d_n + cn;
     };
+    // TilePos.n runs over passes * B: pass = n / B selects 32*TN output channels (and their weight stream), n % B the image
+    const int tile_w_bytes = (p.nch * 9 + (has_img ? 3 : 0)) * TN * (int)FRAG_B;   // one pass's weight stream
     const int nslices = p.nch;                       // LDS-staged slices per tile (the image halo rides with slice 0)
     const int total_slices = my_tiles * nslices;
     const int ngroups_tile = nslices * GPS + (has_img ? 1 : 0);   // weight groups per tile: GPS per slice + the image block
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 for (int it = 0; it < NIT; ++it) {
                     const int y = tp.ty * TH - 1 + e_hy[it], x = tp.tx * 32 - 1 + e_hx[it];
                     const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                    selb[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? ((tp.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
+                    selb[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? (((tp.n % p.B) * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
                 }
             }
         };
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // once per tile: a slice only adds its uniform channel offset through the load's scalar offset -- no per-slice address arithmetic
         unsigned eo0[NIT][NV], eo1[NIT];
         auto tile_offsets = [&](const TilePos& tp) {
-            const int n = tp.n, y0 = tp.ty * TH, x0 = tp.tx * 32;
+            const int n = tp.n % p.B, y0 = tp.ty * TH, x0 = tp.tx * 32;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 const int pix = it * 256 + tid;
                 const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
                 const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)(((tp.n * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
+                liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)((((tp.n % p.B) * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
             }
         };
         auto store_img = [&](int parity) {
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 const int pix = it * 256 + tid;
                 const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
                 const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? ((tp.n * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
+                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? (((tp.n % p.B) * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
             }
         };
         auto store_lab = [&](int parity) {
@@ -352,8 +356,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         const __amdgpu_buffer_rsrc_t rsw_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
         u32x4 lw[NWL];
         auto issue_w = [&](int gg) {   // global group index -> group of the tile (wide groups first, the image block's group last)
-            const int lgw = gg % ngroups_tile;
-            const unsigned base = (unsigned)lgw * GROUP_B;
+            const int kt = gg / ngroups_tile, lgw = gg - kt * ngroups_tile;
+            const int pass = (bid + kt * g) / p.tiles_per_pass;   // this block's kt-th tile belongs to that pass of output channels
+            const unsigned base = (unsigned)(pass * tile_w_bytes) + (unsigned)lgw * GROUP_B;
             const unsigned len = (lgw < nslices * GPS) ? GROUP_B : IGROUP_B;
 #pragma unroll
             for (int it = 0; it < NWL; ++it) {
@@ -469,7 +474,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             aoff[r][t] = (unsigned)(pix * 32 + ((kh ^ ((pix >> 3) & 1)) * 16));
         }
     f32x16 acc[2][TN];
-    bf16x8 fa[2][2][NP];   // [slot][row][plane]
+    constexpr int FAS = (TN == 4) ? 1 : 2;   // pixel-fragment slots: double-buffered except in the 128-channel kernels (register budget)
+    bf16x8 fa[FAS][2][NP];   // [slot][row][plane]
     int pmask[2] = {0x1ff, 0x1ff}, clab[2] = {0, 0};
     // labels of a tile come from the label halo the loaders staged with the tile's first slice: no global latency, no registers held
     auto read_labels = [&](int parity) {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         }
     };
 
-    auto epilogue = [&](int n, int y0, int x0) {
+    auto epilogue = [&](int n, int y0, int x0, int cbase) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = y0 + 2 * wave + r, x = x0 + lrow;
@@ -500,9 +506,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float4 res[4], esc[4], esh[4];
+                // the 128-channel kernels have no registers to park a whole row's operands: they fetch per group of four channels
+                constexpr int PRE = (TN == 4) ? 1 : 4;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int ch = j * 32 + g4 * 8 + kh * 4;
+                for (int g0 = 0; g0 < 4; g0 += PRE) {
+#pragma unroll
+                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
+                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
                     const unsigned o = (pok && ch < p.Cout) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB;
                     res[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
                     esc[g4] = res[g4];
@@ -515,8 +525,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     }
                 }
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int ch = j * 32 + g4 * 8 + kh * 4;
+                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
+                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
                     const bool ok = pok && ch < p.Cout;
                     float4 v;
                     v.x = acc[r][j][g4 * 4 + 0] * f + res[g4].x;
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
                     if (j == 0) keep[g4] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 }
             }
             if constexpr (TN == 1) {
@@ -609,7 +620,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     CP_BARRIER();   // slice 0, the first weight group (and the first tile's image / label halo) are in LDS
     int gs = 0, gg = 0;   // global slice / group counters
     for (int k = 0; k < my_tiles; ++k) {
-        const int n = ctile.n, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        const int pass = ctile.n / p.B;
+        const int n = ctile.n - pass * p.B, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        const int cbase = pass * 32 * TN;   // first output channel of this pass
         next_tile(ctile);
         if (has_lab) read_labels(k & 1);
 #pragma unroll
@@ -639,18 +652,19 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 ldw(wg, 0, 0);
 #pragma unroll
                 for (int st = 0; st < GT; ++st) {
-                    if (st + 1 < GT) read_a(g3 * GT + st + 1, (st + 1) & 1);
+                    if (FAS == 2 && st + 1 < GT) read_a(g3 * GT + st + 1, (st + 1) & 1);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int sub = st * TN + j;
                         if (sub + 1 < GSUB) ldw(wg, sub + 1, (sub + 1) & 1);
-                        mfma_sub(st & 1, sub & 1, j);
+                        mfma_sub(st & (FAS - 1), sub & 1, j);
                     }
+                    if (FAS == 1 && st + 1 < GT) read_a(g3 * GT + st + 1, 0);
                 }
 #ifdef HS_NOEPI
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) epilogue(n, y0, x0);   // timing experiment: never true, keeps the accumulators alive
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) epilogue(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
 #else
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) epilogue(n, y0, x0);
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) epilogue(n, y0, x0, cbase);
 #endif
                 CP_BARRIER();
             }
@@ -689,13 +703,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 for (int j = 0; j < TN; ++j) {
                     const int sub = s3 * TN + j;
                     if (sub + 1 < 3 * TN) ldw(wg, sub + 1, (sub + 1) & 1);
-                    mfma_sub(s3 & 1, sub & 1, j);
+                    mfma_sub(s3 & (FAS - 1), sub & 1, j);
                 }
             }
 #ifdef HS_NOEPI
             if (p.B < 0)
 #endif
-            epilogue(n, y0, x0);
+            epilogue(n, y0, x0, cbase);
             ++gg;
             CP_BARRIER();
         }
@@ -706,9 +720,11 @@ template <int TN, int NP, int MODE>
 int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.Wd + 31) / 32;
-    k.ntiles = k.B * k.tiles_y * k.tiles_x;
+    k.passes = (k.Cout + 32 * TN - 1) / (32 * TN);
+    k.tiles_per_pass = k.B * k.tiles_y * k.tiles_x;
+    k.ntiles = k.passes * k.tiles_per_pass;
     // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : 3) * TN * NP * 1024 +
+    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : TN == 2 ? 3 : 1) * TN * NP * 1024 +
                        (size_t)2 * NP * 1024;   // + the fused head's weights
     static bool attr_set = false;
     if (!attr_set) {
@@ -720,11 +736,15 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     return cp::check_launch("cp_conv2d_fwd_split");
 }
 
+// output channels per pass: 32 or 64.  (A 128-channel pass -- TN = 4, 128 accumulator registers -- was compiled and spills ~75 registers at the
+// 256-register budget of two waves per SIMD; wider layers simply take more passes over the tile list, re-staging the halo each time.)
+inline int split_tn(int cout) { return cout <= 32 ? 1 : 2; }
+
 int split_fragments(int cout, int num_sources, const int* channels) {
-    const int tn = cout <= 32 ? 1 : 2;
+    const int tn = split_tn(cout), passes = (cout + 32 * tn - 1) / (32 * tn);
     int steps = 0;
     for (int s = 0; s < num_sources; ++s) steps += (channels[s] == 4) ? 3 : (channels[s] / 16) * 9;
-    return steps * tn;
+    return steps * tn * passes;
 }
 
 }  // namespace
@@ -735,7 +755,7 @@ int split_fragments(int cout, int num_sources, const int* channels) {
 extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
     if (!d) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return 0;
-    if (d->cout > 64 || d->cout % 4 != 0 || d->group_rows) return 0;
+    if (d->cout > 512 || d->cout % 4 != 0 || d->group_rows) return 0;
     if (d->head_out && (d->cout != 32 || !d->head_weights || d->head_cout < 1 || d->head_cout > 32)) return 0;
     if ((d->out_raw && d->out_raw_ld % 4) || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return 0;
     if ((((uintptr_t)d->out_raw) | ((uintptr_t)d->out_act) | ((uintptr_t)d->residual)) & 15) return 0;
@@ -746,7 +766,7 @@ extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
         if (s == 0 ? (in.mode != CP_SRC_DIRECT && in.mode != CP_SRC_BILINEAR_X2 && in.mode != CP_SRC_NEAREST_SEL) : in.mode != CP_SRC_DIRECT) return 0;
         if (in.mode != CP_SRC_DIRECT && ((d->in_h | d->in_w) & 1)) return 0;
         if (in.channels == 4) {
-            if (s != d->num_sources - 1 || s == 0 || in.ld != 4) return 0;   // the image source comes last, after a 16-multiple source
+            if (s != d->num_sources - 1 || s == 0 || in.ld != 4 || d->cout > 32) return 0;   // the image source comes last, after a 16-multiple source (32-channel layers)
         } else if (in.channels % 16 != 0 || in.ld % 4 != 0 || (((uintptr_t)in.data) & 15)) {
             return 0;
         }
@@ -774,8 +794,8 @@ extern "C" size_t cp_conv_split_weight_bytes(int cout, int num_sources, const in
 // device, so a training step re-packs with one gather + one split launch.
 extern "C" int cp_conv_pack_weights_split_host(const float* w, int layout, int cout, int num_sources, const int* channels, const int* real_channels,
                                                float* dst) {
-    CP_REQUIRE(w && dst && cout > 0 && cout <= 64 && num_sources >= 1 && num_sources <= 2, "cp_conv_pack_weights_split_host: bad arguments");
-    const int tn = cout <= 32 ? 1 : 2;
+    CP_REQUIRE(w && dst && cout > 0 && cout <= 512 && num_sources >= 1 && num_sources <= 2, "cp_conv_pack_weights_split_host: bad arguments");
+    const int tn = split_tn(cout), passes = (cout + 32 * tn - 1) / (32 * tn);
     int cin = 0;
     for (int s = 0; s < num_sources; ++s) cin += real_channels[s];
     const int total = cp_conv_split_weight_floats(cout, num_sources, channels);
@@ -784,29 +804,33 @@ extern "C" int cp_conv_pack_weights_split_host(const float* w, int layout, int c
         const int ky = t / 3, kx = t % 3;
         return (layout == 0) ? ((((size_t)ky * 3 + kx) * cin + ci) * cout + co) : ((((size_t)ci * 3 + ky) * 3 + kx) * cout + co);
     };
-    size_t step = 0;
-    int cbase = 0;
-    for (int s = 0; s < num_sources; ++s) {
-        const int C = channels[s], Cr = real_channels[s];
-        if (C == 4) {
-            for (int s3 = 0; s3 < 3; ++s3, ++step)
-                for (int j = 0; j < tn; ++j)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e) {
-                            const int co = 32 * j + (l & 31), t = 4 * s3 + 2 * (l >> 5) + (e >> 2), ch = e & 3;
-                            if (co < cout && t < 9 && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
-                        }
-        } else {
-            for (int c = 0; c < C / 16; ++c)
-                for (int t = 0; t < 9; ++t, ++step)
+    int steps_pass = 0;
+    for (int s = 0; s < num_sources; ++s) steps_pass += (channels[s] == 4) ? 3 : (channels[s] / 16) * 9;
+    for (int ps = 0; ps < passes; ++ps) {   // one complete fragment stream per pass of 32 * tn output channels
+        size_t step = (size_t)ps * steps_pass;
+        int cbase = 0;
+        for (int s = 0; s < num_sources; ++s) {
+            const int C = channels[s], Cr = real_channels[s];
+            if (C == 4) {
+                for (int s3 = 0; s3 < 3; ++s3, ++step)
                     for (int j = 0; j < tn; ++j)
                         for (int l = 0; l < 64; ++l)
                             for (int e = 0; e < 8; ++e) {
-                                const int co = 32 * j + (l & 31), ch = 16 * c + 8 * (l >> 5) + e;
-                                if (co < cout && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
+                                const int co = 32 * (ps * tn + j) + (l & 31), t = 4 * s3 + 2 * (l >> 5) + (e >> 2), ch = e & 3;
+                                if (co < cout && t < 9 && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
                             }
+            } else {
+                for (int c = 0; c < C / 16; ++c)
+                    for (int t = 0; t < 9; ++t, ++step)
+                        for (int j = 0; j < tn; ++j)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int co = 32 * (ps * tn + j) + (l & 31), ch = 16 * c + 8 * (l >> 5) + e;
+                                    if (co < cout && ch < Cr) dst[((step * tn + j) * 64 + l) * 8 + e] = w[src_index(cbase + ch, t, co)];
+                                }
+            }
+            cbase += Cr;
         }
-        cbase += Cr;
     }
     return CP_OK;
 }
@@ -882,7 +906,7 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
     k.head_w = d->head_out ? reinterpret_cast<const unsigned char*>(head_weights_split) : nullptr;
     k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0);
-    const int tn = d->cout <= 32 ? 1 : 2;
+    const int tn = split_tn(d->cout);
     hipStream_t st = (hipStream_t)stream;
 #define CP_HS(TN_, NP_, M_) if (tn == TN_ && planes == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
 #define CP_HS4(TN_, NP_) CP_HS(TN_, NP_, 0) CP_HS(TN_, NP_, HS_BILINEAR) CP_HS(TN_, NP_, HS_PARTIAL) CP_HS(TN_, NP_, HS_PARTIAL | HS_SEL)

@@ -94,7 +94,7 @@ class FusedConv:
     """One cp_conv2d_fwd_f32 launch with its packed weights and descriptor."""
 
     def __init__(self, name: str, kernel: np.ndarray, layout: int, kh: int, kw: int, cout: int,
-                 sources: Sequence[Tuple[int, int]], device: torch.device):
+                 sources: Sequence[Tuple[int, int]], device: torch.device, want_split: bool = True):
         lib = _lib.load()
         self.name = name
         self.kh, self.kw, self.cout = kh, kw, cout
@@ -127,14 +127,14 @@ class FusedConv:
             ph = np.empty(25 * 2 * 64 * 4, dtype=np.float32)
             check(lib.cp_conv_pack_weights_stem_host(w.ctypes.data, layout, sources[0][1], ph.ctypes.data), "cp_conv_pack_weights_stem_host(%s)" % name)
             self.wp_halo = torch.from_numpy(ph).to(device)
-        # third packing: the fp32 image of the fragment stream of csrc/conv_hsplit.hip (3x3 / cout <= 64 / 16-multiple sources [+ image]);
+        # third packing: the fp32 image of the fragment stream of csrc/conv_hsplit.hip (3x3 / cout <= 512 in passes of 64 / 16-multiple sources [+ image]);
         # its bf16 planes (3 = exact split, 1 = plain bf16) are made on the device when a mode asks for them
         self.wp_split_f32 = None
         self._split_planes: Dict[int, torch.Tensor] = {}
         self.split_mode = 0
-        split_ok = (kh == 3 and kw == 3 and cout <= 64 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4
-                    and (ns == 1 or sources[1][0] == 4 or sources[1][0] % 16 == 0))
-        if split_ok:
+        split_ok = (kh == 3 and kw == 3 and cout <= 512 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4
+                    and (ns == 1 or (sources[1][0] == 4 and cout <= 32) or sources[1][0] % 16 == 0))
+        if split_ok and want_split:
             nfl = lib.cp_conv_split_weight_floats(cout, ns, chans)
             ps = np.empty(nfl, dtype=np.float32)
             check(lib.cp_conv_pack_weights_split_host(w.ctypes.data, layout, cout, ns, chans, real, ps.ctypes.data), "cp_conv_pack_weights_split_host(%s)" % name)
@@ -220,7 +220,7 @@ class FusedConv:
         self.split_mode = 0
         if tile_hint in (_lib.TILE_SPLIT3, _lib.TILE_BF16):
             if self.wp_split_f32 is None:
-                raise _lib.CasaposeHipError("%s: the bf16-pipe kernel covers 3x3 / cout <= 64 / 16-multiple sources only" % self.name)
+                raise _lib.CasaposeHipError("%s: the bf16-pipe kernel covers 3x3 / cout <= 512 / 16-multiple sources only" % self.name)
             self.split_mode = 3 if tile_hint == _lib.TILE_SPLIT3 else 1
             tile_hint = 0
         d.tile_hint = tile_hint
@@ -766,7 +766,7 @@ class CasaposeNet:
         Wn: Dict[str, WinoConv] = {}
 
         def add(name, key, layout, k, cout, sources, stride=1, dil=1, pad=None, partial=False):
-            L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev)
+            L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev, want_split=bool(self.conv_planes))
             pad = dil * (k // 2) if pad is None else pad
             if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout):
                 Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev)

@@ -238,8 +238,10 @@ class TrainConv:
         # bf16-pipe kernel (csrc/conv_hsplit.hip) for the shallow 3x3 layers: fp32 image of its fragment stream in the arena, bf16 planes beside it
         self.split = None
         planes = conv_split_planes()
-        if planes and k == 3 and cout <= 64 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4 and (
-                ns == 1 or sources[1][0] == 4 or sources[1][0] % 16 == 0):
+        if layout == 0 and sum(s_[0] for s_ in sources) >= 256 and cout >= 128:
+            planes = 0   # the deep ordinary 3x3 layers run as Winograd (engine.wino_eligible); partial convolutions (layout 1) of that size do not
+        if planes and k == 3 and cout <= 512 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4 and (
+                ns == 1 or (sources[1][0] == 4 and cout <= 32) or sources[1][0] % 16 == 0):
             nfl = lib.cp_conv_split_weight_floats(cout, ns, chans)
 
             def pack_split(src, dst):
@@ -278,7 +280,7 @@ class TrainConv:
                 ent["idx_halo"] = torch.from_numpy(imap).to(dev)
                 ent["w_halo"] = store.pack_alloc(imap, off)
             ent["split"] = None
-            if planes and k == 3 and cr <= 64 and cr % 4 == 0:
+            if planes and k == 3 and cr <= 512 and cr % 4 == 0:
                 nfl = lib.cp_conv_split_weight_floats(cr, 1, dch)
 
                 def pack_ds(src, dst, dch=dch, dre=dre, cr=cr):

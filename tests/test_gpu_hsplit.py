@@ -18,7 +18,7 @@ MODES = [(SPLIT3, 1e-4), (BF16, 3e-2)]
 
 @pytest.mark.parametrize("mode,tol", MODES)
 @pytest.mark.parametrize("cin,cout,hw", [(16, 32, (16, 32)), (32, 32, (8, 32)), (64, 32, (13, 45)), (64, 64, (21, 70)), (128, 48, (37, 33)), (96, 12, (4, 31)),
-                                         (48, 64, (33, 65))])
+                                         (48, 64, (33, 65)), (64, 128, (19, 40)), (96, 256, (9, 33)), (32, 72, (12, 31))])
 def test_plain_and_ragged(device, mode, tol, cin, cout, hw):
     from casapose_amd import ops
 
@@ -175,13 +175,36 @@ def test_fused_head(device, mode, tol, q):
     assert (got[..., q:] == 0).all()        # channels beyond the head stay untouched
 
 
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_wide_partial_layer_in_passes(device, mode, tol):
+    """more than 64 output channels = several passes of 64 over the tile list (decoder blocks 6 / 7: 512 -> 256, 384 -> 128, partial)"""
+    from casapose_amd import ops
+    from casapose_amd.engine import fold_clade
+
+    rng = np.random.default_rng(41)
+    b, h, w, k, cin, cout = 2, 15, 20, 4, 128, 160
+    lab = _labels(rng, b, h, w, k)
+    mask = O.onehot_from_labels(lab, k)
+    labels, pnorm, _ = ops.label_pyramid(dev(lab, device, torch.uint8))
+    p = {"c.gamma": rng.uniform(0.5, 1.5, (k, cout)), "c.beta": rng.standard_normal((k, cout)) * 0.2,
+         "c.moving_mean": rng.standard_normal(cout) * 0.1, "c.moving_variance": rng.uniform(0.5, 1.5, cout)}
+    ts, tb = fold_clade(p, "c")
+    x = rng.standard_normal((b, h, w, cin))
+    wt = rng.standard_normal((cin, 3, 3, cout)) / 34.0
+    y = O.clade_weighted(O.partial_convolution(x, wt, mask), mask, p["c.gamma"], p["c.beta"], p["c.moving_mean"], p["c.moving_variance"])
+    raw, act = ops.conv2d_fused([dev(x, device)], wt.astype(np.float32), layout=1, pad=1, tap_label=labels[0], row_scale=pnorm[0],
+                                scale=dev(ts, device), shift=dev(tb, device), epi_label=labels[0], act=1, want_raw=True, want_act=True, tile_hint=mode)
+    close(raw, O.partial_convolution(x, wt, mask), rtol=tol)
+    close(act, O.relu(y), rtol=tol)
+
+
 def test_out_of_range_layers_are_refused(device):
     from casapose_amd import _lib, ops
 
     rng = np.random.default_rng(5)
-    x, w = rng.standard_normal((1, 8, 32, 64)), rng.standard_normal((3, 3, 64, 128)) * 0.1
+    x, w = rng.standard_normal((1, 8, 32, 64)), rng.standard_normal((3, 3, 64, 520)) * 0.1
     with pytest.raises(_lib.CasaposeHipError):
-        ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=SPLIT3)        # cout > 64
+        ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=SPLIT3)        # cout > 512
     w2 = rng.standard_normal((3, 3, 64, 32)) * 0.1
     with pytest.raises(_lib.CasaposeHipError):
         ops.conv2d_fused([dev(x, device)], w2.astype(np.float32), pad=2, dilation=2, tile_hint=SPLIT3)   # dilated
