@@ -241,3 +241,43 @@ def test_casapose_alias_package_serves_the_reference_import_surface():
     with pytest.raises(ModuleNotFoundError, match="casapose_amd.utils.draw_utils"):
         importlib.import_module("casapose.utils.draw_utils")
     assert casapose.__path__ == [] and casapose_amd.__name__ == "casapose_amd"
+
+
+def test_split_kernel_host_packers(hip_lib):
+    """cp_conv_pack_weights_split_host / cp_conv_pack_head_split_host (pure host code): the fp32 image of the bf16-pipe kernel's fragment
+    stream -- [pass][step][cout block][64 lanes][8 k] with 9 steps per 16-channel slice and 3 tap-major steps for the 4-channel image
+    source; passes of 64 output channels above 64."""
+    import ctypes as C
+
+    rng = np.random.default_rng(0)
+    # 32 + image -> 32 (decoder block 5 / 10)
+    w = rng.standard_normal((3, 3, 35, 32)).astype(np.float32)
+    ch, re = (C.c_int * 2)(32, 4), (C.c_int * 2)(32, 3)
+    n = hip_lib.cp_conv_split_weight_floats(32, 2, ch)
+    assert n == (2 * 9 + 3) * 1 * 512 and hip_lib.cp_conv_split_weight_bytes(32, 2, ch, 3) == (2 * 9 + 3) * 3 * 1024
+    dst = np.full(n, np.nan, np.float32)
+    assert hip_lib.cp_conv_pack_weights_split_host(w.ctypes.data, 0, 32, 2, ch, re, dst.ctypes.data) == 0
+    f = dst.reshape(21, 64, 8)
+    for c, t, l, e in ((0, 0, 0, 0), (1, 4, 37, 5), (1, 8, 63, 7)):      # slice c, tap t: W[co = l & 31][channel 16c + 8(l >> 5) + e]
+        assert f[c * 9 + t, l, e] == w[t // 3, t % 3, 16 * c + 8 * (l >> 5) + e, l & 31]
+    for s3, l, e in ((0, 3, 0), (1, 40, 6), (2, 5, 2)):                   # image step s3: tap 4 s3 + 2 (l >> 5) + (e >> 2), channel e & 3
+        t, cch = 4 * s3 + 2 * (l >> 5) + (e >> 2), e & 3
+        want = w[t // 3, t % 3, 32 + cch, l & 31] if (t < 9 and cch < 3) else 0.0
+        assert f[18 + s3, l, e] == want
+    assert f[20, 40, 0] == 0.0 and not np.isnan(dst).any()               # tap 10 does not exist
+    # 32 -> 160 in the partial-convolution layout [Cin,3,3,Cout]: three passes of 64 output channels, zero rows beyond 160
+    w2 = rng.standard_normal((32, 3, 3, 160)).astype(np.float32)
+    ch1, re1 = (C.c_int * 2)(32, 0), (C.c_int * 2)(32, 0)
+    n2 = hip_lib.cp_conv_split_weight_floats(160, 1, ch1)
+    assert n2 == 3 * 18 * 2 * 512
+    d2 = np.empty(n2, np.float32)
+    assert hip_lib.cp_conv_pack_weights_split_host(w2.ctypes.data, 1, 160, 1, ch1, re1, d2.ctypes.data) == 0
+    g = d2.reshape(3, 18, 2, 64, 8)
+    assert g[1, 9 + 5, 1, 33, 2] == w2[16 + 8 + 2, 5 // 3, 5 % 3, 64 + 32 + 1]
+    assert g[2, 0, 0, 7, 0] == w2[0, 0, 0, 128 + 7] and (g[2, :, 1] == 0).all()
+    # fused head: step m, lane (q, kh), element e <- Wh[8 (2m + (e >> 2)) + 4 kh + (e & 3)][q]
+    wh = rng.standard_normal((32, 9)).astype(np.float32)
+    dh = np.empty(1024, np.float32)
+    assert hip_lib.cp_conv_pack_head_split_host(wh.ctypes.data, 9, dh.ctypes.data) == 0
+    hh = dh.reshape(2, 64, 8)
+    assert hh[1, 32 + 4, 6] == wh[8 * (2 + 1) + 4 + 2, 4] and hh[0, 20, 3] == 0.0      # q = 20 >= 9: zero
