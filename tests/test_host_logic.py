@@ -23,8 +23,10 @@ def test_registry_names_match_reference_and_unknown_name_raises():
         Classifiers.get("does_not_exist")
     with pytest.raises(NotImplementedError):   # registered by the reference, not built here: the bare backbones
         Classifiers.get("resnet34")(input_shape=(64, 64, 3))
-    with pytest.raises(NotImplementedError):   # pvnet with separated vector fields: 9 + 18*8 output channels
-        Classifiers.get("pvnet")(ver_dim=144, seg_dim=9)
+    from casapose_amd._lib import CasaposeHipError
+
+    with pytest.raises(CasaposeHipError):      # pvnet with separated vector fields (9 + 18*8 output channels) constructs -- on a GPU (no CPU fallback)
+        Classifiers.get("pvnet")(ver_dim=144, seg_dim=9, device="cpu")
 
 
 def test_no_cpu_fallback():
