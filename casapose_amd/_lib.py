@@ -131,6 +131,8 @@ SYMBOLS = [
     ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     # ---- training path ----
     ("cp_conv2d_wgrad_f32", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
+    ("cp_conv_wgrad_split_applicable", _i, [C.POINTER(ConvDesc)]),
+    ("cp_conv2d_wgrad_split", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _i, _vp]),
     ("cp_bn_stats_f32", _i, [_vp, _ll, _i, _i, _vp, _vp]),
     ("cp_bn_finalize_f32", _i, [_vp, C.c_double, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cp_bn_param_grads_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -48,4 +48,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return start + idx;
 }
 
+// conv_wgrad.hip: the fp32 weight-gradient kernel over the packed K chunks [first_chunk, ktot / 32) only, accumulating
+int wgrad_f32_chunks(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int first_chunk, hipStream_t st);
+
 }  // namespace cp

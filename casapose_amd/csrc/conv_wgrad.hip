@@ -44,6 +44,7 @@ struct WgK {
     int Hin, Win, Ho, Wo, Cout, KW, ntaps, stride, dil, pad;
     int M;
     int tiles_co, tiles_k, nsplit, steps_per_split;
+    int q_begin; // first K chunk computed (cp::wgrad_f32_chunks: only the trailing chunks of the packed rows)
     int groups;  // grouped GEMM (Winograd planes): pixels [g*M, (g+1)*M) accumulate into dw + g*Cout*ktot; M = rows per group
 };
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgK p) {
     const int t2 = logical - split * ntiles;
     const int tile_k = t2 / p.tiles_co, tile_co = t2 - tile_k * p.tiles_co;
     const int co0 = tile_co * (WCO * 32);
-    const int q0 = tile_k * WK;  // first K chunk of this tile
+    const int q0 = p.q_begin + tile_k * WK;  // first K chunk of this tile
     const int step0 = split * p.steps_per_split;
     const int total_steps = (p.M + 31) >> 5;
     const int nsteps = min(p.steps_per_split, total_steps - step0);
@@ -227,7 +228,7 @@ template <int WCO, bool PARTIAL>
 int launch_wgrad(WgK k, hipStream_t st) {
     constexpr int WK = 4 / WCO;
     k.tiles_co = (k.Cout + WCO * 32 - 1) / (WCO * 32);
-    k.tiles_k = (k.nchunks + WK - 1) / WK;
+    k.tiles_k = (k.nchunks - k.q_begin + WK - 1) / WK;
     const int total_steps = (k.M + 31) / 32;
     const int tiles = k.tiles_co * k.tiles_k;
     // enough blocks to fill 256 CUs x 2 several times over, but >= 8 steps per block so the pipeline fill amortises
@@ -243,7 +244,7 @@ int launch_wgrad(WgK k, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int cp_conv2d_wgrad_f32(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, void* stream) {
+static int wgrad_f32_impl(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, int first_chunk, void* stream) {
     CP_REQUIRE(d && dy && dw_packed, "cp_conv2d_wgrad_f32: null pointer");
     CP_REQUIRE(d->num_sources == 1 || d->num_sources == 2, "cp_conv2d_wgrad_f32: num_sources must be 1 or 2");
     CP_REQUIRE(d->kh * d->kw <= MAX_TAPS && d->kh > 0 && d->kw > 0, "cp_conv2d_wgrad_f32: unsupported kernel %dx%d", d->kh, d->kw);
@@ -282,6 +283,8 @@ extern "C" int cp_conv2d_wgrad_f32(const cp_conv_desc* d, const float* dy, int d
     k.Hin = d->in_h; k.Win = d->in_w; k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->cout; k.KW = d->kw; k.ntaps = d->kh * d->kw;
     k.stride = d->stride; k.dil = d->dilation; k.pad = d->pad; k.M = (int)M;
     k.groups = 1;
+    k.q_begin = first_chunk;
+    CP_REQUIRE(first_chunk >= 0 && first_chunk < k.nchunks && (first_chunk == 0 || !d->group_rows), "cp_conv2d_wgrad_f32: bad first chunk");
     if (d->group_rows) {  // the 36 Winograd planes in one launch: a 1x1 problem per group of rows, dw_packed is [groups][cout][ktot]
         CP_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->num_sources == 1 && !d->tap_label && d->batch * d->in_h == 1,
                    "cp_conv2d_wgrad_f32: grouped mode is a plain 1x1 problem laid out as one row of pixels (batch = in_h = 1)");
@@ -295,4 +298,13 @@ extern "C" int cp_conv2d_wgrad_f32(const cp_conv_desc* d, const float* dy, int d
         if (hipMemsetAsync(dw_packed, 0, sizeof(float) * (size_t)k.groups * d->cout * k.ktot, st) != hipSuccess) return cp::check_launch("cp_conv2d_wgrad_f32 memset");
     if (d->cout <= 32) return d->tap_label ? launch_wgrad<1, true>(k, st) : launch_wgrad<1, false>(k, st);
     return d->tap_label ? launch_wgrad<2, true>(k, st) : launch_wgrad<2, false>(k, st);
+}
+
+extern "C" int cp_conv2d_wgrad_f32(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, void* stream) {
+    return wgrad_f32_impl(d, dy, dy_ld, dw_packed, accumulate, 0, stream);
+}
+
+// the packed columns [first_chunk * 32, ktot) only, accumulated into dw_packed (conv_wgrad_split.hip: the 4-channel image source)
+int cp::wgrad_f32_chunks(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int first_chunk, hipStream_t st) {
+    return wgrad_f32_impl(d, dy, dy_ld, dw_packed, 1, first_chunk, (void*)st);
 }

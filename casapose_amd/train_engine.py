@@ -534,7 +534,13 @@ class ConvOp:
                 out[pipe] += mult * direct
             else:
                 out["f32"] += direct
-            out["f32"] += direct                 # weight gradient (conv_wgrad_kernel, fp32 MFMA)
+            wp = self.wgrad_planes()             # weight gradient: conv_wgrad_split.hip (32-multiple sources; the image source stays fp32) or fp32 MFMA
+            if wp:
+                big = sum(s[1] for s in L.sources if s[0] != 4)
+                out["bf16"] += (6.0 if wp == 3 else 1.0) * direct * big / cin
+                out["f32"] += direct * (cin - big) / cin
+            else:
+                out["f32"] += direct
         c0 = 0
         for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
             if ent is None:
@@ -551,6 +557,14 @@ class ConvOp:
                 else:
                     out["f32"] += d
         return out
+
+    def wgrad_planes(self) -> int:
+        """3 / 1 when this op's weight gradient runs on the bf16 matrix pipe (CASAPOSE_CONV_MODE split / bf16 and a descriptor that
+        cp_conv2d_wgrad_split covers: 3x3 / stride 1 / pad 1, 32-multiple sources + optional image, cout % 32 == 0), else 0 = fp32 MFMA."""
+        planes = conv_split_planes()
+        if not planes or getattr(self, "wino_fwd", None) is not None:
+            return 0
+        return planes if _lib.load().cp_conv_wgrad_split_applicable(C.byref(self.layer.desc)) else 0
 
     def _dy(self):
         if self.dy_ptr_ld is not None:
@@ -579,7 +593,11 @@ class ConvOp:
                 c0 += cr
                 k0 += cp_
         else:
-            check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
+            planes = self.wgrad_planes()
+            if planes:   # bf16 matrix pipe (csrc/conv_wgrad_split.hip): same packed result
+                check(lib.cp_conv2d_wgrad_split(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, planes, stream), "cp_conv2d_wgrad_split(%s)" % L.name)
+            else:
+                check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
             check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 1 if self.accumulate_master else 0,
                                      stream), "cp_scatter_f32")
         for s, ent in enumerate(L.dgrad):

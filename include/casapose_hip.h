@@ -335,6 +335,13 @@ int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int
  * of cp_conv_pack_weights_host.  Sources must be CP_SRC_DIRECT without pre-affine.  Split over pixels
  * with fp32 atomics: the summation order is not fixed (results reproducible to fp32 rounding only). */
 int cp_conv2d_wgrad_f32(const cp_conv_desc* desc, const float* dy, int dy_ld, float* dw_packed, int accumulate, void* stream);
+/* The same product on the bf16 matrix pipe (csrc/conv_wgrad_split.hip), the backward partner of cp_conv2d_fwd_split: 3x3 / stride 1 / pad 1,
+ * direct sources whose channel counts are multiples of 32 plus an optional trailing 4-channel source (the image: its columns are computed by
+ * the fp32 kernel), cout a multiple of 32, tap_label as above.  planes = 3: both operands split exactly into three bf16 terms, six products per
+ * fp32 product, fp32 accumulation (fp32-equivalent); planes = 1: operands rounded to bf16 (BASELINE.json configs[2]).  Same dw_packed layout,
+ * same accumulate flag, same unfixed summation order as cp_conv2d_wgrad_f32. */
+int cp_conv_wgrad_split_applicable(const cp_conv_desc* desc);
+int cp_conv2d_wgrad_split(const cp_conv_desc* desc, const float* dy, int dy_ld, float* dw_packed, int accumulate, int planes, void* stream);
 
 /* The DATA gradient needs no entry point of its own: it is cp_conv2d_fwd_f32 over dy with the kernel
  * flipped and transposed (host-side repack), pad' = dilation*(k-1) - pad, the same dilation, and, for a
