@@ -38,6 +38,39 @@ def test_ccl_filter_matches_oracle_including_quirks(device):
     assert (got[0] == 1).sum() == 144 and (got[0] == 2).sum() == 49 and (got[0] == 3).sum() == 9
 
 
+def test_ccl_components_across_tile_borders(device):
+    """Blobs, rings and salt-and-pepper over several 64x16 tiles of the kernel, including blobs that cover the corner where four tiles
+    meet: every (image, object) map against the oracle's filter (voting_layers_2d.py:43-79)."""
+    from casapose_amd import _lib
+
+    lib = _lib.load()
+    b, h, w, objs = 3, 70, 200, 5
+    rng = np.random.default_rng(11)
+    lab = np.zeros((b, h, w), np.uint8)
+    lab[0, 10:40, 50:140] = 1      # spans 3x3 tiles incl. the corners at (16, 64), (32, 128)
+    lab[0, 14:18, 62:66] = 0       # a hole right on a corner
+    lab[0, 50:66, 0:200] = 2       # full-width band over the last (ragged) tile row
+    lab[0, 55:60, 60:70] = 3       # island inside the band, across x = 64
+    lab[0, 0:8, 190:200] = 1       # second, smaller component of object 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    ring = (np.hypot(yy - 35, xx - 100) < 30) & (np.hypot(yy - 35, xx - 100) > 22)
+    lab[1][ring] = 4               # a ring through many tiles
+    lab[1, 30:40, 95:105] = 4      # its (separate) centre blob
+    lab[1, 15:17, 0:200:2] = 5     # isolated pixels along a tile border row
+    lab[2] = (rng.random((h, w)) < 0.6) * rng.integers(1, objs + 1, (h, w))
+    lab[2, 20:50, 40:160] = 2
+    t = torch.from_numpy(lab).to(device)
+    ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objs), dtype=torch.uint8, device=device)
+    out = torch.empty_like(t)
+    for _ in range(2):   # twice with the same workspace: nothing may depend on its previous content
+        _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    for bi in range(b):
+        for o in range(1, objs + 1):
+            keep = O.largest_component_filter((lab[bi] == o).astype(np.float32))
+            assert np.array_equal(got[bi] == o, keep > 0), (bi, o)
+
+
 def test_ccl_object_larger_than_rest_of_image_is_dropped(device):
     from casapose_amd import _lib
 
