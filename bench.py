@@ -160,18 +160,19 @@ def measured_traffic(tile):
 def _dtype_note_train():
     """the training plan's defaults put two kernel groups on the bf16 matrix pipe with fp32-EQUIVALENT arithmetic (exact three-way splits, six
     products, fp32 accumulate): the Winograd GEMMs (CASAPOSE_WINO_GEMM) and the forward / data-gradient of the shallow 3x3 layers
-    (CASAPOSE_CONV_MODE); CASAPOSE_CONV_MODE=bf16 rounds the latter's operands to bf16 (BASELINE configs[2])."""
+    and the forward / data gradient / weight gradient of the plain 3x3 layers that are not on the Winograd path (CASAPOSE_CONV_MODE);
+    CASAPOSE_CONV_MODE=bf16 rounds the latter's operands to bf16 (BASELINE configs[2])."""
     parts = []
     if os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split":
         parts.append("Winograd GEMMs")
     conv = os.environ.get("CASAPOSE_CONV_MODE", "split")
     if conv == "split":
-        parts.append("forward / data gradient of the shallow 3x3 layers")
+        parts.append("forward / data gradient / weight gradient of the 3x3 layers off the Winograd path")
     note = "f32"
     if parts:
         note += " (%s as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)" % " and ".join(parts)
     if conv == "bf16":
-        note = "bf16 operands / f32 accumulate in the forward / data gradient of the shallow 3x3 layers; " + note + " elsewhere"
+        note = "bf16 operands / f32 accumulate in the forward / data gradient / weight gradient of the 3x3 layers off the Winograd path; " + note + " elsewhere"
     return note
 
 
@@ -268,7 +269,7 @@ def bench_train(args):
                      "frac": round((ex["f32"] / PEAK_F32_MFMA_TFLOPS + ex["bf16"] / PEAK_BF16_MFMA_TFLOPS) / 1e12 / (dt / args.steps), 4),
                      "frac_definition": "(f32 FLOPs / 157.3 TF + bf16 FLOPs / 2500 TF) / step time",
                      "direct_equivalent_tflops": round(3.0 * fwd_flops * args.steps / dt / 1e12, 3), "traffic": None,
-                     "kernel": "all convolution launches of the step (forward, data gradient, weight gradient; conv_f32 / conv_halo / conv_hsplit / wino_gemm(_split) / conv_wgrad)"},
+                     "kernel": "all convolution launches of the step (forward, data gradient, weight gradient; conv_f32 / conv_halo / conv_hsplit / wino_gemm(_split) / conv_wgrad(_split))"},
         "losses": {"mask": float(sums[0]), "vertex": float(sums[1]), "proxy": float(sums[2]), "keypoint": float(kpl)},
     }
     if rank == 0:
