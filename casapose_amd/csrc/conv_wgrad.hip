@@ -16,6 +16,9 @@
 // dY and im2col rows for the step after next while the current 32-pixel step is multiplied.
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -222,6 +225,147 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgK p) {
     }
 }
 
+// Grouped 1x1 problem of the Winograd weight gradient (dU[g][co][k] = sum over the group's rows of M[g][row][co] * V[g][row][k], 36 groups):
+// the same MFMA scheme with a 128 co x 128 k tile per block -- each consumer wave holds 2 x 2 accumulators, so an LDS operand value feeds
+// two MFMAs and a block reads half the bytes per FLOP of the 64 x 64 tile above (these layers were L2-bandwidth-bound there: 7.4 GB per
+// stage-4 layer at 5 TB/s).  Rows in steps of 32, two LDS stages, 4 producer waves (8 x 16-byte loads per thread and step).
+struct GemmT {
+    const float* a;   // [groups][rows][K]   (V)
+    const float* d;   // [groups][rows][Cout] (M)
+    float* dw;        // [groups][Cout][K]
+    int K, Cout, lda, ldd;
+    unsigned a_bytes, d_bytes;
+    int rows, groups, tiles_co, tiles_k, spt;   // spt = 32-row steps per tile
+    long long total;                            // groups * tiles * spt: the step stream the persistent blocks share out evenly
+};
+
+__global__ __launch_bounds__(512, 2) void wgrad_gemm128_kernel(const GemmT p) {
+    constexpr int TS = 128 + 4;   // LDS row stride (floats)
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Dt = smem;                  // [2][32][TS]
+    float* At = smem + 2 * 32 * TS;    // [2][32][TS]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x & 255, lane = tid & 63;
+    // a block takes a contiguous range of the (tile, step) stream: every block the same number of steps (+-1), at most two tiles
+    // touched partially -> at most two more flushes than tiles, and no tail of half-empty rounds (576 tiles on 512 block slots)
+    const long long s0 = p.total * blockIdx.x / gridDim.x, s1 = p.total * (blockIdx.x + 1) / gridDim.x;
+    const int nsteps = (int)(s1 - s0);
+    if (nsteps <= 0) return;
+    const int ntiles = p.tiles_co * p.tiles_k;
+    int tile0 = (int)(s0 / p.spt), st0 = (int)(s0 - (long long)tile0 * p.spt);
+#define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (wave >= 4) {
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.d, 0, p.d_bytes, 0x00020000);
+        const int col4 = tid & 31, prow = tid >> 5;   // 32 float4 columns x 8 rows per pass, 4 passes
+        float4 areg[4], dreg[4];
+        int tile = tile0, st = st0;
+        auto issue = [&]() {
+            const int grp = tile / ntiles, t2 = tile - grp * ntiles;
+            const int tile_k = t2 / p.tiles_co, tile_co = t2 - tile_k * p.tiles_co;
+            const int kc = tile_k * 128 + col4 * 4, cc = tile_co * 128 + col4 * 4;
+            const unsigned acol = (unsigned)kc * 4u | (kc < p.K ? 0u : OOB), dcol = (unsigned)cc * 4u | (cc < p.Cout ? 0u : OOB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = st * 32 + prow + i * 8;
+                const unsigned oob = r < p.rows ? 0u : OOB;
+                const unsigned gr = (unsigned)(grp * p.rows + r);
+                areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsa, (int)((gr * (unsigned)p.lda * 4u + acol) | oob), 0, 0));
+                dreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)((gr * (unsigned)p.ldd * 4u + dcol) | oob), 0, 0));
+            }
+            if (++st == p.spt) { st = 0; ++tile; }
+        };
+        auto store = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float4*>(At + buf * 32 * TS + (prow + i * 8) * TS + col4 * 4) = areg[i];
+                *reinterpret_cast<float4*>(Dt + buf * 32 * TS + (prow + i * 8) * TS + col4 * 4) = dreg[i];
+            }
+        };
+        issue();
+        store(0);
+        if (nsteps > 1) issue();
+        CP_BARRIER();
+        for (int q = 0; q < nsteps; ++q) {
+            if (q + 1 < nsteps) {
+                store((q + 1) & 1);
+                if (q + 2 < nsteps) issue();
+            }
+            CP_BARRIER();
+        }
+        return;
+    }
+    const int wco = wave & 1, wk = wave >> 1;
+    const int lrow = lane & 31, half = lane >> 5;
+    f32x16 acc[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    auto flush = [&](int tile) {
+        const int grp = tile / ntiles, t2 = tile - grp * ntiles;
+        const int tile_k = t2 / p.tiles_co, tile_co = t2 - tile_k * p.tiles_co;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = tile_k * 128 + wk * 64 + j * 32 + lrow;
+                if (k >= p.K) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = tile_co * 128 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Cout) atomicAdd(p.dw + ((size_t)grp * p.Cout + co) * p.K + k, acc[i][j][r]);
+                }
+            }
+        zero();
+    };
+    zero();
+    int tile = tile0, st = st0;
+    CP_BARRIER();
+    for (int q = 0; q < nsteps; ++q) {
+        const float* d = Dt + (q & 1) * 32 * TS + half * TS + wco * 64 + lrow;
+        const float* a = At + (q & 1) * 32 * TS + half * TS + wk * 64 + lrow;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float fd0 = d[2 * s * TS], fd1 = d[2 * s * TS + 32];
+            const float fa0 = a[2 * s * TS], fa1 = a[2 * s * TS + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd0, fa0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd0, fa1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd1, fa0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd1, fa1, acc[1][1], 0, 0, 0);
+        }
+        CP_BARRIER();
+        if (++st == p.spt) {
+            flush(tile);
+            st = 0;
+            ++tile;
+        }
+    }
+#undef CP_BARRIER
+    if (st != 0) flush(tile);
+}
+
+int launch_gemm128(GemmT k, hipStream_t st) {
+    k.tiles_co = (k.Cout + 127) / 128;
+    k.tiles_k = (k.K + 127) / 128;
+    k.spt = (k.rows + 31) / 32;
+    k.total = (long long)k.groups * k.tiles_co * k.tiles_k * k.spt;
+    const long long grid = std::min<long long>(512, (k.total + 7) / 8);   // two blocks per CU; >= 8 steps per block
+    const size_t lds = (size_t)4 * 32 * (128 + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    CP_LAUNCH(wgrad_gemm128_kernel, dim3((unsigned)std::max<long long>(grid, 1)), dim3(512), lds, st, k);
+    return cp::check_launch("cp_conv2d_wgrad_f32 (grouped)");
+}
+
 int chunks_for(int taps, int C) { return (C == 4) ? (taps + 7) / 8 : taps * (C / 32); }
 
 template <int WCO, bool PARTIAL>
@@ -296,6 +440,14 @@ static int wgrad_f32_impl(const cp_conv_desc* d, const float* dy, int dy_ld, flo
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate)
         if (hipMemsetAsync(dw_packed, 0, sizeof(float) * (size_t)k.groups * d->cout * k.ktot, st) != hipSuccess) return cp::check_launch("cp_conv2d_wgrad_f32 memset");
+    if (d->group_rows && k.ktot % 128 == 0 && d->cout % 64 == 0 && d->cout >= 128 && !getenv("CP_WGRAD_GEMM64")) {
+        GemmT g{};
+        g.a = d->src[0].data; g.d = dy; g.dw = dw_packed;
+        g.K = k.ktot; g.Cout = d->cout; g.lda = d->src[0].ld; g.ldd = dy_ld;
+        g.a_bytes = k.s[0].bytes; g.d_bytes = k.dy_bytes;
+        g.rows = k.M; g.groups = k.groups;
+        return launch_gemm128(g, st);
+    }
     if (d->cout <= 32) return d->tap_label ? launch_wgrad<1, true>(k, st) : launch_wgrad<1, false>(k, st);
     return d->tap_label ? launch_wgrad<2, true>(k, st) : launch_wgrad<2, false>(k, st);
 }
