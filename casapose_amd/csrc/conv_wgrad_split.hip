@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -53,6 +54,9 @@ struct WSplitK {
     unsigned lab_bytes;
     float* dw;
     int ktot;
+    const float* img;       // optional trailing 4-channel source (the image), IMG instantiations: [B][H][W][img_ld]
+    int img_ld, img_kbase;
+    unsigned img_bytes;
     int B, H, W, Cout;
     int cblocks;            // 32-channel blocks of the sources handled here
     int tiles_m, tiles_n;   // (ci, co) tiles
@@ -112,6 +116,33 @@ __device__ __forceinline__ uint4 round8(const float4 v0, const float4 v1) {
     return make_uint4(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]), pack_hi16(r[4], r[5]), pack_hi16(r[6], r[7]));
 }
 
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float r1 = x[e] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+        m[e] = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, m[e] & 0xffff0000u);
+        l[e] = __builtin_bit_cast(unsigned, r2);
+    }
+    hi = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    mid = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    lo = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+}
+
+__device__ __forceinline__ uint2 round4(const float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[e]);
+        r[e] = u + 0x7fffu + ((u >> 16) & 1u);
+    }
+    return make_uint2(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]));
+}
+
 template <int NP>
 __device__ __forceinline__ void store_planes(unsigned char* dst, int plane_stride, const float4 v0, const float4 v1) {
     if constexpr (NP == 3) {
@@ -142,8 +173,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NP, int MB, int NB, bool PARTIAL>
+// IMG (MB = NB = 1 only): the trailing 4-channel image source is a 36-column block of its own -- columns (tap, channel), taps 0..7 in one
+// 32x32 accumulator and tap 8 in the first four columns of a second -- fed by transpose reads of an [pixel][4 bf16] image ring in which
+// the SUPPLYING lane picks its tap's row and column offset: 12 more MFMAs per 16 pixels instead of a second pass over dY by the fp32 kernel.
+template <int NP, int MB, int NB, bool PARTIAL, bool IMG>
 __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
+    static_assert(!IMG || (MB == 1 && NB == 1), "the image block needs the one-tile configuration");
+    constexpr int IPLANE = XC * 8, ISLOT = NP * IPLANE;   // image ring: [slot][plane][66 pixels][4 bf16]
     constexpr unsigned OOB = 0x80000000u;
     constexpr int XPLANE = MB * XROWB, XSLOT = NP * XPLANE;
     constexpr int DPLANE = NB * DROWB, DSLOT = NP * DPLANE;
@@ -158,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
     unsigned char* Xs = smem;
     unsigned char* Ds = smem + NXS * XSLOT;
     unsigned short* Ms = reinterpret_cast<unsigned short*>(Ds + NDS * DSLOT);   // [NDS][9 taps][SW] AND-masks 0xffff / 0 (PARTIAL)
+    unsigned char* Is = reinterpret_cast<unsigned char*>(Ms) + (PARTIAL ? NDS * 9 * SW * 2 : 0);   // [NXS][ISLOT] (IMG)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -182,7 +219,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
         const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(PARTIAL ? (const void*)p.label : (const void*)p.dy), 0,
                                                                               PARTIAL ? p.lab_bytes : 0u, 0x00020000);
-        float4 xr[D][XR][2], dr[D][DR][2];
+        float4 xr[D][XR][2], dr[D][DR][2], ir[D];
+        const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(IMG ? (const void*)p.img : (const void*)p.dy), 0, IMG ? p.img_bytes : 0u, 0x00020000);
+        const int i_px = lw * 17 + lane;   // IMG: 17 pixels of the 66-pixel image row per loader wave
         int lb[D][9];   // PARTIAL, loader wave 0: the 3x3 label neighbourhood of output column `lane`
         unsigned lbok[D];
 
@@ -228,6 +267,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
                 dr[d][r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)off, 0, 0));
                 dr[d][r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)(off + 16u), 0, 0));
             }
+            if constexpr (IMG) {
+                const int xx = un.x0 - 1 + i_px;
+                const bool ok = live && lane < 17 && i_px < XC && (unsigned)(y + 1) < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                ir[d] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)((unsigned)((rowpix + xx) * p.img_ld * 4) | (ok ? 0u : OOB)), 0, 0));
+            }
             if constexpr (PARTIAL) {
                 // lane = output column (loader wave 0 only; the others issue the same nine loads out of bounds); the comparison happens in
                 // write(): nothing here may wait for a load.  Bit t of lbok = neighbour t is inside the image.
@@ -266,6 +310,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
             unsigned char* db = Ds + (T & 1) * DSLOT + d_nb * DROWB + oct * 16;
 #pragma unroll
             for (int r = 0; r < DR; ++r) store_planes<NP>(db + (d_px0 + r * DPR) * 64, DPLANE, dr[d][r][0], dr[d][r][1]);
+            if constexpr (IMG) {
+                if (lane < 17 && i_px < XC) {
+                    unsigned char* ib = Is + (T & 3) * ISLOT + i_px * 8;
+                    if constexpr (NP == 3) {
+                        uint2 h, m, l;
+                        split4(ir[d], h, m, l);
+                        *reinterpret_cast<uint2*>(ib) = h;
+                        *reinterpret_cast<uint2*>(ib + IPLANE) = m;
+                        *reinterpret_cast<uint2*>(ib + 2 * IPLANE) = l;
+                    } else {
+                        *reinterpret_cast<uint2*>(ib) = round4(ir[d]);
+                    }
+                }
+            }
             if constexpr (PARTIAL) {
                 if (lw == 0) {
 #pragma unroll
@@ -300,6 +358,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x16 acci[IMG ? 2 : 1];   // IMG: columns (tap, channel) of the image source: taps 0..7 | tap 8
+#pragma unroll
+    for (int b = 0; b < (IMG ? 2 : 1); ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acci[b][r] = 0.f;
 
     auto flush = [&](const Unit& un) {
         const int cbi = un.tm * MB + mb;
@@ -325,6 +388,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        if constexpr (IMG) {
+            const int co0 = un.tn * 32 + 4 * (lane >> 5), n = lane & 31;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (r & 3) + 8 * (r >> 2);
+                    if (co < p.Cout && (b == 0 || n < 4)) atomicAdd(p.dw + (size_t)co * p.ktot + p.img_kbase + b * 32 + n, acci[b][r]);
+                    acci[b][r] = 0.f;
+                }
+        }
     };
 
     int T = 0;
@@ -410,13 +484,50 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
                 }
 #endif
             });
+            if constexpr (IMG) {   // KSW = 1: this wave's 16 pixels are step `ph`; a[0] still holds their dY fragments
+                const int kgp = 16 * ph + 8 * kg + (li >> 2);   // this lane's SUPPLIED pixel (transpose read: row li >> 2 of the group's 4)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int tap_s = b == 0 ? 4 * half + (li & 3) : 8;    // the tap whose 4 channels this lane supplies
+                    const int tap_r = b == 0 ? 4 * half + (li >> 2) : 8;   // the tap of the column this lane receives
+                    const unsigned char* ib = Is + ((T + 2 + tap_s / 3) & 3) * ISLOT + (kgp + tap_s % 3) * 8;
+                    bf16x8 bi[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ib + pl * IPLANE));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ib + pl * IPLANE + 4 * 8));
+                        bi[pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    if constexpr (PARTIAL) {
+                        const uint4 m = *reinterpret_cast<const uint4*>(mbase + tap_r * (SW * 2));
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) {
+                            uint4 bv = __builtin_bit_cast(uint4, bi[pl]);
+                            bv.x &= m.x; bv.y &= m.y; bv.z &= m.z; bv.w &= m.w;
+                            bi[pl] = __builtin_bit_cast(bf16x8, bv);
+                        }
+                    }
+                    f32x16& c = acci[b];
+                    if constexpr (NP == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], bi[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bi[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bi[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bi[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bi[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bi[0], c, 0, 0, 0);
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bi[0], c, 0, 0, 0);
+                    }
+                }
+            }
         }
     }
     for (; T < NTP; ++T) WS_BARRIER();
     flush(un);
 }
 
-template <int NP, int MB, int NB, bool PARTIAL>
+template <int NP, int MB, int NB, bool PARTIAL, bool IMG = false>
 int launch(WSplitK k, hipStream_t st) {
     k.tiles_m = (k.cblocks + MB - 1) / MB;
     k.tiles_n = (k.Cout / 32 + NB - 1) / NB;
@@ -444,13 +555,13 @@ int launch(WSplitK k, hipStream_t st) {
     }
     k.U = (int)U;
     const int G = (int)std::min<long long>(256, U);
-    const size_t lds = (size_t)NXS * NP * MB * XROWB + (size_t)NDS * NP * NB * DROWB + (PARTIAL ? NDS * 9 * SW * 2 : 0);
+    const size_t lds = (size_t)NXS * NP * MB * XROWB + (size_t)NDS * NP * NB * DROWB + (PARTIAL ? NDS * 9 * SW * 2 : 0) + (IMG ? NXS * NP * XC * 8 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<NP, MB, NB, PARTIAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<NP, MB, NB, PARTIAL, IMG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    CP_LAUNCH((wgrad_split_kernel<NP, MB, NB, PARTIAL>), dim3((unsigned)G), dim3(512), lds, st, k);
+    CP_LAUNCH((wgrad_split_kernel<NP, MB, NB, PARTIAL, IMG>), dim3((unsigned)G), dim3(512), lds, st, k);
     return cp::check_launch("cp_conv2d_wgrad_split");
 }
 
@@ -458,7 +569,8 @@ template <int NP, bool PARTIAL>
 int launch_shape(const WSplitK& k, hipStream_t st) {
     const int nbk = k.Cout / 32;
     if (k.cblocks >= 2) return nbk >= 2 ? launch<NP, 2, 2, PARTIAL>(k, st) : launch<NP, 2, 1, PARTIAL>(k, st);
-    return nbk >= 2 ? launch<NP, 1, 2, PARTIAL>(k, st) : launch<NP, 1, 1, PARTIAL>(k, st);
+    if (nbk >= 2) return launch<NP, 1, 2, PARTIAL>(k, st);
+    return k.img ? launch<NP, 1, 1, PARTIAL, true>(k, st) : launch<NP, 1, 1, PARTIAL>(k, st);
 }
 
 bool applicable(const cp_conv_desc* d) {
@@ -517,11 +629,20 @@ extern "C" int cp_conv2d_wgrad_split(const cp_conv_desc* d, const float* dy, int
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate)
         if (hipMemsetAsync(dw_packed, 0, sizeof(float) * (size_t)d->cout * k.ktot, st) != hipSuccess) return cp::check_launch("cp_conv2d_wgrad_split memset");
+    // the 4-channel image source (K = 36 of a few hundred): inside the kernel as a column block of its own when the rest is one 32 x 32 tile
+    // (decoder blocks 5 / 10), otherwise its columns of dWp come from the fp32 kernel restricted to those chunks
+    const cp_conv_source& last = d->src[d->num_sources - 1];
+    const bool img_inside = first_small_chunk >= 0 && k.cblocks == 1 && d->cout == 32 && last.ld % 4 == 0 && ((uintptr_t)last.data & 15) == 0 &&
+                            (long long)d->batch * d->in_h * d->in_w * last.ld * 4 < (1LL << 31) && !getenv("CP_WGRAD_IMG_F32");
+    if (img_inside) {
+        const cp_conv_source& in = last;
+        k.img = in.data; k.img_ld = in.ld; k.img_kbase = first_small_chunk * 32;
+        k.img_bytes = (unsigned)((long long)d->batch * d->in_h * d->in_w * in.ld * 4);
+    }
     int rc;
     if (planes == 3) rc = d->tap_label ? launch_shape<3, true>(k, st) : launch_shape<3, false>(k, st);
     else rc = d->tap_label ? launch_shape<1, true>(k, st) : launch_shape<1, false>(k, st);
     if (rc != CP_OK) return rc;
-    // the 4-channel image source (K = 36 of a few hundred): its columns of dWp come from the fp32 kernel restricted to those chunks
-    if (first_small_chunk >= 0) return cp::wgrad_f32_chunks(d, dy, dy_ld, dw_packed, first_small_chunk, st);
+    if (first_small_chunk >= 0 && !img_inside) return cp::wgrad_f32_chunks(d, dy, dy_ld, dw_packed, first_small_chunk, st);
     return CP_OK;
 }

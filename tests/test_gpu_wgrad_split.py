@@ -31,6 +31,8 @@ CASES = [
     ("64_64_two_strips", [(64, 64)], 64, False, (2, 20, 70)),
     ("two_sources_cout32_three_strips", [(64, 64), (32, 32)], 32, False, (1, 9, 130)),
     ("image_skip_partial", [(32, 32), (4, 3)], 32, True, (2, 18, 66)),
+    ("image_skip_wide_rows", [(32, 32), (4, 3)], 32, False, (1, 11, 150)),
+    ("image_skip_two_tiles", [(64, 64), (4, 3)], 64, False, (1, 9, 40)),   # image columns through the fp32 kernel (more than one 32x32 tile)
     ("128_128_four_tiles_row_chunks", [(128, 128)], 128, False, (1, 40, 33)),
     ("32_to_64", [(32, 32)], 64, False, (2, 7, 64)),
     ("96_odd_blocks_partial", [(96, 96)], 64, True, (2, 12, 40)),
