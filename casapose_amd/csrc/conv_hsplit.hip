@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -126,6 +127,14 @@ __global__ void hsplit_weights_kernel(const float* __restrict__ src, long long n
             const uint2 a = round4(v0), b = round4(v1);
             *reinterpret_cast<uint4*>(d) = make_uint4(a.x, a.y, b.x, b.y);
         }
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void hs_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        hs_static_for<I + 1, N>(f);
     }
 }
 
@@ -650,17 +659,34 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 const unsigned char* wg = wst + (gg & 1) * GROUP_B;
                 read_a(g3 * GT, 0);
                 ldw(wg, 0, 0);
-#pragma unroll
-                for (int st = 0; st < GT; ++st) {
+                hs_static_for<0, GT>([&](auto stc) {
+                    constexpr int st = decltype(stc)::value;
                     if (FAS == 2 && st + 1 < GT) read_a(g3 * GT + st + 1, (st + 1) & 1);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int sub = st * TN + j;
+                    hs_static_for<0, TN>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sub = st * TN + j;
                         if (sub + 1 < GSUB) ldw(wg, sub + 1, (sub + 1) & 1);
                         mfma_sub(st & (FAS - 1), sub & 1, j);
-                    }
+#ifndef HS_NO_SCHED
+                        if constexpr (NP == 3) {
+                            // order inside the sub-step (2 x 6 MFMAs): the LDS reads of the NEXT sub-step / tap go out between the first MFMAs,
+                            // so they have landed when it starts; left alone the scheduler sinks them behind the last use of the registers
+                            // they overwrite, i.e. to the end, and every sub-step begins with an LDS-latency stall
+                            constexpr int NR = (sub + 1 < GSUB ? NP : 0) + ((FAS == 2 && j == 0 && st + 1 < GT) ? 2 * NP : 0);
+                            constexpr int R0 = (NR + 2) / 3, R1 = (NR - R0 + 1) / 2, R2 = NR - R0 - R1;
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if constexpr (R0 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R0, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if constexpr (R1 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if constexpr (R2 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#endif
+                    });
                     if (FAS == 1 && st + 1 < GT) read_a(g3 * GT + st + 1, 0);
-                }
+                });
 #ifdef HS_NOEPI
                 if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) epilogue(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
 #else

@@ -178,7 +178,11 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
     // B fragments of flattened chunk `cc` (tile cc / nchunks of this block, chunk cc % nchunks) into register set `par`
     int f_it = -1, f_q = p.nchunks;
     unsigned f_base[2] = {0u, 0u};
-    auto fetch_b = [&](int par) {
+    // `valid` = false issues the same twelve loads out of bounds (they fetch nothing): with a branch around the loads the compiler's
+    // wait-count pass must assume they may not have been issued and then waits for the NEWEST outstanding loads before the first MFMA of
+    // every chunk -- an L2 round trip per 48 MFMAs
+    auto fetch_b = [&](int par, bool valid) {
+        const unsigned oob = valid ? 0u : 0x80000000u;
         if (++f_q >= p.nchunks) {
             f_q = 0;
             ++f_it;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     fb[par][ks][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        rbw, (int)(f_base[j] + ((unsigned)(f_q * 2 + ks) * 3u + (unsigned)s) * 1024u), 0, 0));
+                        rbw, (int)((f_base[j] + ((unsigned)(f_q * 2 + ks) * 3u + (unsigned)s) * 1024u) | oob), 0, 0));
     };
     auto mfma_step = [&](int slot, int par, int ks) {
         // smallest terms first; consecutive MFMAs hit different accumulators
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
     int it = 0, q = 0;
     auto chunk = [&](int c, int par) {
         const int buf = c & 1;
-        if (c + 1 < total_chunks) fetch_b(par ^ 1);   // next chunk's weights: in flight during this chunk's 48 MFMAs
+        fetch_b(par ^ 1, c + 1 < total_chunks);   // next chunk's weights: in flight during this chunk's 48 MFMAs
         read_a(buf, 1, 1);
         mfma_step(0, par, 0);
         mfma_step(1, par, 1);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             ++it;
         }
     };
-    fetch_b(0);
+    fetch_b(0, true);
     CP_BARRIER();  // stage 0 ready
     read_a(0, 0, 0);
     int c = 0;
