@@ -505,6 +505,11 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                     }
                 }
                 mfma4(u & 1, u % RING, u >> 2, u >> 2);
+#ifndef HX_NO_STEP_FENCE
+                // keep the step's weight prefetch IN the step: left alone the scheduler sinks the loads of step u + RD to just before their
+                // use (two live fragments instead of RING), which turns the ring into a one-step prefetch and exposes the L2 latency
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (!last) CP_BARRIER();  // halo stage consumed; the other stage is ready (the tile's last barrier follows below)
         }
