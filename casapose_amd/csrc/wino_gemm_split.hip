@@ -28,7 +28,7 @@ constexpr int ROWB = 80;        // bytes per staged row of one split: 32 bf16 (6
 constexpr int SPLIT_BYTES = BM * ROWB;          // one split plane of a 128-row tile
 constexpr int TILE_BYTES = 3 * SPLIT_BYTES;     // hi, mid, lo
 constexpr int STAGE_BYTES = TILE_BYTES;         // only A is staged; B fragments come pre-split straight from L2
-constexpr int NSTAGE = 2;
+constexpr int NSTAGE = 3;
 
 // exact three-way split of four floats into packed bf16 pairs: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of
 // x - hi - mid (that last remainder has at most 8 significant bits, so taking its top half is exact).  v_perm_b32 packs the high halves.
@@ -140,15 +140,23 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
             }
         };
+        // three LDS stages: chunk c + 2 is stored while the consumers multiply chunk c, so chunk c + 1 is complete one barrier early and its
+        // first fragments can be read during chunk c instead of behind the barrier
         issue();
         store(0);
-        if (total_chunks > 1) issue();
+        if (total_chunks > 1) {
+            issue();
+            store(1);
+        }
+        if (total_chunks > 2) issue();
         CP_BARRIER();
+        int st = 2;   // stage of chunk c + 2
         for (int c = 0; c < total_chunks; ++c) {
-            if (c + 1 < total_chunks) {
-                store((c + 1) & 1);
-                if (c + 2 < total_chunks) issue();
+            if (c + 2 < total_chunks) {
+                store(st);
+                if (c + 3 < total_chunks) issue();
             }
+            st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
         }
         return;
@@ -215,14 +223,20 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         }
     };
     int it = 0, q = 0;
+    int buf = 0;   // LDS stage of the current chunk (c % 3)
     auto chunk = [&](int c, int par) {
-        const int buf = c & 1;
+        const int nbuf = (buf == 2) ? 0 : buf + 1;
         fetch_b(par ^ 1, c + 1 < total_chunks);   // next chunk's weights: in flight during this chunk's 48 MFMAs
         read_a(buf, 1, 1);
         mfma_step(0, par, 0);
+        if (c + 1 < total_chunks) read_a(nbuf, 0, 0);   // the next chunk's first fragments: its stage has been complete since the last barrier
         mfma_step(1, par, 1);
+        // the six reads above go out behind the first MFMAs of the second step, not in front of the barrier
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
         CP_BARRIER();
-        if (c + 1 < total_chunks) read_a(buf ^ 1, 0, 0);
+        buf = nbuf;
         if (++q == p.nchunks) {
             const int tile = start + bidx + it * nb;
             const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
