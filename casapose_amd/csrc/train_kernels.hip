@@ -116,8 +116,14 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
                 atomicAdd(&sred[nred + c * 2 + 1], a[e][3]);
             }
         };
-        for (long long r0 = (long long)blockIdx.x * rows_per_pass; r0 < pixels; r0 += (long long)gridDim.x * rows_per_pass) {
-            const long long r = r0 + rl;
+        // a block takes runs of SUB consecutive passes (a thread's successive pixels inside a run are rows_per_pass apart, i.e. neighbours in
+        // the label map), the runs grid-strided: with a plain grid-strided walk a thread's next pixel lay ~32 k pixels away and nearly every
+        // step of a CLADE layer changed the label -> 16 LDS fp64 atomics per step (block 10: 1.37 ms against 0.79 ms without labels)
+        constexpr int SUB = 8;
+        const long long run = (long long)SUB * rows_per_pass;
+        for (long long rr = (long long)blockIdx.x * run; rr < pixels; rr += (long long)gridDim.x * run)
+        for (int k = 0; k < SUB; ++k) {
+            const long long r = rr + (long long)k * rows_per_pass + rl;
             if (r >= pixels) continue;
             const int l = labels ? labels[r] : 0;
             if (l != cur) {
