@@ -605,7 +605,7 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     seen = {}
 
     def host_loss(c, av):
-        lv, g, _ = T.bpnp_reprojection_loss_host(c, gt_xy, aff, av, p3d, cam, cap, kp_w)
+        lv, g, _ = T.bpnp_reprojection_loss_host(c, gt_xy, aff, av, p3d, cam, cap, kp_w, rng=np.random.default_rng(5))   # same RANSAC draws on both sides
         seen["coords"], seen["avail"], seen["loss"], seen["g"] = T._host(c).copy(), T._host(av).copy(), lv, g
         return lv, g
 
@@ -615,7 +615,7 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     assert avail.sum() >= 6, "the scene must show enough objects for the test to mean something"
     big = avail[0] > 0
     assert np.abs(seen["coords"][0][big] - coords_ref.detach().numpy()[0][big]).max() < 0.05 + 1e-3 * np.abs(coords_ref.detach().numpy()[0][big]).max()
-    lv_ref, g_ref, _ = T.bpnp_reprojection_loss_host(coords_ref.detach().numpy(), gt_xy_np, aff_np, avail, p3d, cam, cap, kp_w)
+    lv_ref, g_ref, _ = T.bpnp_reprojection_loss_host(coords_ref.detach().numpy(), gt_xy_np, aff_np, avail, p3d, cam, cap, kp_w, rng=np.random.default_rng(5))
     # confidence regulariser |mean_fg softplus(conf) - 0.7| (loss_functions.py:325-342) in torch
     fg = (labt > 0).double()
     cl = (F.softplus(ref[..., k + 2 * kp:]) * fg[..., None]).sum((1, 2)) / fg.sum((1, 2))[:, None]
