@@ -8,10 +8,11 @@
 //
 // Sizing (why this is not wino_gemm.hip with another instruction): at this MFMA rate a 32x32 per-wave tile would need ~3x the LDS
 // bandwidth of a CU for its fragment reads, so a block is 128 x 128 with four consumer waves of 64 x 64.  The activations (A) stay fp32 in
-// HBM and are split by the four producer waves while they stage them (two LDS stages of 30 KB); the weights (B) are pre-split once into
+// HBM and are split by the four producer waves while they stage them (three LDS stages of 30 KB: chunk c + 2 is stored while chunk c is multiplied, so the first
+// fragments of chunk c + 1 are read before the barrier); the weights (B) are pre-split once into
 // fragment-major bf16 planes (split_weights_kernel) and every consumer wave fetches its 12 fragments of a chunk straight from L2 one
-// chunk ahead.  One persistent block per CU.  Measured 176-185 TFLOP/s-equivalent against 115-120 for the fp32 MFMA kernel = ~1.1 PFLOP/s
-// of bf16 MFMA work.  Variants measured within 3 %: all six planes staged in LDS (182); fp32 in LDS, split in the consumers (149).
+// chunk ahead (issued unconditionally: a branch around the loads makes the compiler's wait counts conservative).  One persistent block per
+// CU.  Measured 178-195 TFLOP/s-equivalent against 115-120 for the fp32 MFMA kernel = ~1.1 PFLOP/s of bf16 MFMA work.  Variants measured within 3 %: all six planes staged in LDS (182); fp32 in LDS, split in the consumers (149).
 #include "common.h"
 
 #include <algorithm>
@@ -86,7 +87,7 @@ __global__ void split_weights_kernel(const float* __restrict__ U, int groups, in
 }
 
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][A | B][3 splits][128 rows][80 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE stages][3 splits][128 rows][80 B]
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool producer = wave >= 4;
