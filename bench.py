@@ -157,6 +157,31 @@ def measured_traffic(tile):
     return round(tot / n) if n else None
 
 
+def _sustained_mfma(dev):
+    """What the matrix pipes SUSTAIN on this box under the power limit: a bare MFMA stream on every SIMD (csrc/capi.hip: cp_mfma_probe), timed
+    with HIP events -- reported beside the datasheet peaks the roofline fractions are priced against, never instead of them."""
+    import ctypes as C
+
+    import torch
+
+    from casapose_amd import _lib
+    lib = _lib.load()
+    ws = torch.empty(lib.cp_mfma_probe_workspace_bytes(), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for which, name, iters in ((0, "f32_mfma_tflops", 4000), (1, "bf16_mfma_tflops", 8000)):
+        fl = C.c_double(0.0)
+        _lib.check(lib.cp_mfma_probe(which, iters // 10, ws.data_ptr(), C.byref(fl), stream), "cp_mfma_probe")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            _lib.check(lib.cp_mfma_probe(which, iters, ws.data_ptr(), C.byref(fl), stream), "cp_mfma_probe")
+        e1.record()
+        e1.synchronize()
+        out[name] = round(3.0 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    return out
+
+
 def _dtype_note_train():
     """the training plan's defaults put two kernel groups on the bf16 matrix pipe with fp32-EQUIVALENT arithmetic (exact three-way splits, six
     products, fp32 accumulate): the Winograd GEMMs (CASAPOSE_WINO_GEMM) and the forward / data-gradient of the shallow 3x3 layers
@@ -591,6 +616,13 @@ def main():
             "winograd": {"layers": wino["layers"], "ms_per_step": round(wino["ms"], 3), "gemm_ms": round(wino["gemm_ms"], 3),
                          "transform_ms": round(wino["ms"] - wino["gemm_ms"], 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
         }
+        try:
+            sus = _sustained_mfma(dev)
+            result["roofline"]["sustained_on_this_box"] = dict(sus, what="bare MFMA stream on every SIMD (cp_mfma_probe), HIP-event timed in this run; the "
+                                                               "datasheet peak above stays the denominator of `frac`",
+                                                               frac_of_sustained_f32=round(ach_all / sus["f32_mfma_tflops"], 4))
+        except Exception as exc:  # the probe is an annotation: never fail the bench line over it
+            result["roofline"]["sustained_on_this_box"] = {"error": str(exc)}
     _log("roofline section done")
     if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode == "f32" and os.environ.get("CASAPOSE_WINO_GEMM", "") != "split":
         # the same workload with the two fp32-EQUIVALENT opt-ins switched on (exact three-way bf16 splits on the bf16 matrix pipe: the shallow

@@ -87,6 +87,8 @@ SYMBOLS = [
     ("cp_last_error", C.c_char_p, []),
     ("cp_version", _i, []),
     ("cp_device_count", _i, []),
+    ("cp_mfma_probe_workspace_bytes", C.c_size_t, []),
+    ("cp_mfma_probe", _i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("cp_conv_ktot", _i, [_i, _i, _i, C.POINTER(_i)]),
     ("cp_conv_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     ("cp_conv_halo_weight_floats", _i, [_i, _i, C.POINTER(_i)]),

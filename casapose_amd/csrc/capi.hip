@@ -28,3 +28,52 @@ extern "C" int cp_device_count(void) {
     }
     return n;
 }
+
+// ---- matrix-pipe probe -------------------------------------------------------------------------------------------------------------
+// A bare stream of MFMAs on every SIMD (one wave per SIMD, nine accumulators in rotation, no memory traffic): what the part SUSTAINS under
+// its power limit, as opposed to the datasheet peak the roofline entries are priced against.  bench.py times it with HIP events and prints
+// the result beside the roofline fraction.  which = 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16.
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters) {
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const float x = 1.0f + (float)(threadIdx.x & 7) * 0.125f, y = 0.5f + (float)(threadIdx.x & 3) * 0.25f;   // non-trivial operands: zeros would raise the clock
+    bf16x8 bx, by;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bx[e] = (__bf16)(x + 0.0625f * e); by[e] = (__bf16)(y - 0.03125f * e); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+                if constexpr (WHICH == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+                else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx, by, acc[a], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" size_t cp_mfma_probe_workspace_bytes(void) { return (size_t)256 * 256 * sizeof(float); }
+
+// launches the probe once; returns the FLOPs it executes in *flops (2*M*N*K per MFMA x 36 per iteration x 1024 waves)
+extern "C" int cp_mfma_probe(int which, int iters, void* ws, double* flops, void* stream) {
+    CP_REQUIRE(ws && flops && iters > 0 && (which == 0 || which == 1), "cp_mfma_probe: bad arguments");
+    float* out = reinterpret_cast<float*>(ws);
+    if (which == 0) CP_LAUNCH(mfma_probe_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, out, iters);
+    else CP_LAUNCH(mfma_probe_kernel<1>, dim3(256), dim3(256), 0, (hipStream_t)stream, out, iters);
+    *flops = (double)iters * 36.0 * 1024.0 * (which == 0 ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16);
+    return cp::check_launch("cp_mfma_probe");
+}

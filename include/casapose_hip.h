@@ -37,6 +37,11 @@ const char* cp_last_error(void);
 int cp_version(void);
 /* number of visible gfx950 devices (0 on a CPU-only host); never initialises a context */
 int cp_device_count(void);
+/* Matrix-pipe probe (measurement aid, bench.py): one launch of a bare MFMA stream on every SIMD -- which = 0: v_mfma_f32_32x32x2_f32,
+ * 1: v_mfma_f32_32x32x16_bf16 -- so that the rate the part SUSTAINS under its power limit can be printed beside the datasheet peak the
+ * roofline entries use.  ws: cp_mfma_probe_workspace_bytes() of device memory; *flops receives the FLOPs of the launch (host memory). */
+size_t cp_mfma_probe_workspace_bytes(void);
+int cp_mfma_probe(int which, int iters, void* ws, double* flops, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused implicit-GEMM convolution, forward, fp32 on v_mfma_f32_32x32x2_f32.
