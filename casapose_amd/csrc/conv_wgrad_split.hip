@@ -333,6 +333,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
             }
         };
 
+#ifdef WS_CONSUMER_ONLY   // timing ablation: the loaders fill the rings once with pseudo-random bits and leave; the consumers run alone
+        if (p.ktot >= 0) {
+            unsigned* w = reinterpret_cast<unsigned*>(smem);
+            const int nw = (NXS * XSLOT + NDS * DSLOT) / 4;
+            for (int i = threadIdx.x - 256; i < nw; i += 256) w[i] = (0x3f803f80u ^ ((unsigned)i * 2654435761u)) & 0x3fff3fffu;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
+        }
+#endif
 #pragma unroll
         for (int d = 0; d < D; ++d) issue(d);
         for (int T = 0; T < NTP; T += D) {   // NTP = NT rounded up to a multiple of D: the padding steps move nothing and the consumers only meet their barriers
