@@ -108,6 +108,7 @@ SYMBOLS = [
     ("cp_maxpool3x3s2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     ("cp_upsample_bilinear_x2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     ("cp_guided_upsample_x2_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cp_mask_to_labels_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_argmax_labels", _i, [_vp, _i, _i, _ll, _vp, _vp]),
     ("cp_label_pyramid", _i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     ("cp_ls_vote_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -196,6 +196,29 @@ __global__ void guided_sel_kernel(const uint8_t* __restrict__ hi, const uint8_t*
     }
 }
 
+// ransac_voting_layer_all_masks front end (ransac_voting.py:276-301): object masks [b,h,w,oc] (float, > 0.5 = inside) -> uint8 label map
+// (the highest such object index + 1, 0 = none) and the per-(image, object) pixel counts the sub-sampling rule needs, in one pass
+__global__ __launch_bounds__(256) void mask_to_labels_kernel(const float* __restrict__ mask, int hw, int oc, uint8_t* __restrict__ labels,
+                                                             int* __restrict__ counts) {
+    __shared__ int cnt[256];
+    const int n = blockIdx.y;
+    if (threadIdx.x < oc) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const float* m = mask + (size_t)n * hw * oc;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+        int lab = 0;
+        for (int k = 0; k < oc; ++k) {
+            const bool in = m[(size_t)p * oc + k] > 0.5f;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
+            if (in) lab = k + 1;
+            if (b && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(b)) atomicAdd(&cnt[k], (int)__popcll(b));
+        }
+        labels[(size_t)n * hw + p] = (uint8_t)lab;
+    }
+    __syncthreads();
+    if (threadIdx.x < oc && cnt[threadIdx.x]) atomicAdd(&counts[n * oc + threadIdx.x], cnt[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" int cp_pad_channels_3to4(const float* src, float* dst, long long pixels, void* stream) {
@@ -229,6 +252,18 @@ extern "C" int cp_guided_upsample_x2_f32(const float* src, const uint8_t* sel, i
     long long total = (long long)batch * 4 * h * w * (channels / 4);
     CP_LAUNCH(guided_x2_kernel, dim3(grid_for(total)), dim3(THREADS), 0, (hipStream_t)stream, src, sel, batch, h, w, channels, dst);
     return cp::check_launch("cp_guided_upsample_x2_f32");
+}
+
+extern "C" int cp_mask_to_labels_f32(const float* mask, int batch, int h, int w, int objects, uint8_t* labels, int32_t* counts, void* stream) {
+    CP_REQUIRE(mask && labels && counts && batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_mask_to_labels_f32: bad arguments");
+    CP_REQUIRE((long long)h * w < (1LL << 31), "cp_mask_to_labels_f32: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)batch * objects, st) != hipSuccess) return cp::check_launch("cp_mask_to_labels_f32 memset");
+    const int hw = h * w;
+    int gx = (hw + 255) / 256;
+    if (gx > 512) gx = 512;
+    CP_LAUNCH(mask_to_labels_kernel, dim3(gx, batch), dim3(256), 0, st, mask, hw, objects, labels, counts);
+    return cp::check_launch("cp_mask_to_labels_f32");
 }
 
 extern "C" int cp_argmax_labels(const float* logits, int ld, int classes, long long pixels, uint8_t* labels, void* stream) {

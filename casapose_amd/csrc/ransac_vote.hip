@@ -20,10 +20,12 @@
 // generates them with torch); a draw d selects pixel d % tn.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int KP = 9;
-constexpr int HB = 16;  // hypotheses per voting block
+constexpr int HB = 16;  // granularity of the hypotheses per round (a voting block takes 16 or, when the count allows, 64 of them)
 
 struct ObjState {        // one per (image, object)
     int tn;              // pixels (after min_num gate: 0 if skipped)
@@ -54,16 +56,25 @@ __global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, i
 }
 
 __global__ void rowscan_kernel(int* __restrict__ rowcnt, int H, int n_obj_total, int min_num, ObjState* __restrict__ st) {
-    // one thread per (image, object): exclusive scan over rows, in place
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one WAVE per (image, object): exclusive scan over rows, in place, 64 rows per step (a thread per object walked the rows one by one: 64 us)
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n_obj_total) return;
     int* r = rowcnt + (size_t)i * H;
     int run = 0;
-    for (int y = 0; y < H; ++y) {
-        int c = r[y];
-        r[y] = run;
-        run += c;
+    for (int y0 = 0; y0 < H; y0 += 64) {
+        const int y = y0 + lane;
+        const int c = y < H ? r[y] : 0;
+        int x = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off);
+            if (lane >= off) x += t;
+        }
+        if (y < H) r[y] = run + x - c;
+        run += __shfl(x, 63);
     }
+    if (lane != 0) return;
     ObjState s;
     s.tn = (run < min_num) ? 0 : run;  // ransac_voting.py:290-292
     s.done = s.tn == 0;
@@ -112,7 +123,7 @@ __device__ __forceinline__ void pixel_record(const float* __restrict__ vertex, i
 
 __global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects, const int* __restrict__ pixlist,
                               int list_stride, const int32_t* __restrict__ draws, int hyp, const ObjState* __restrict__ st,
-                              float* __restrict__ hyp_pts, int n_obj_total) {
+                              float* __restrict__ hyp_pts, int n_obj_total, int* __restrict__ counts) {
     // one thread per (image*object, h, v)
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long per = (long long)hyp * KP;
@@ -121,6 +132,7 @@ __global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_
     const int hv = (int)(i % per);
     const ObjState& s = st[io];
     if (s.done) return;
+    counts[i] = 0;   // this round's inlier counter of (object, hypothesis, keypoint): same index space (a separate zeroing launch before)
     const int img = io / objects;
     const int v = hv % KP;
     const int32_t* d = draws + ((size_t)io * per + hv) * 2;
@@ -154,6 +166,7 @@ __device__ __forceinline__ bool inlier_test(float dx, float dy, float nd, float 
 // more than the rounding of either form) the reference's own expression is evaluated, so the decision is the reference's in every case.
 // Per pixel (dx, dy, |d|, t^2|d|^2) are prepared once for all hypotheses (|d| <= 1e-6: d = 0 and t^2|d|^2 = 1, never an inlier); an invalid
 // hypothesis is stored as NaN (every comparison false).
+template <int HB>   // hypotheses per block: every pixel record a block gathers (18 uncoalesced loads per pixel) is used for HB x 9 tests
 __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects,
                                                    const int* __restrict__ pixlist, int list_stride, const float* __restrict__ hyp_pts,
                                                    int hyp, const ObjState* __restrict__ st, int* __restrict__ counts, float thresh,
@@ -168,13 +181,16 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ ver
     const int img = io / objects;
     const int h0 = blockIdx.x * HB;
     const int tid = threadIdx.x, lane = tid & 63;
+    int near = 0;   // some hypothesis point within 1e-5 of a pixel centre (x + 0.5, y + 0.5)?  Only then can |e| ~ 0 occur for a pixel
     for (int i = tid; i < HB * KP; i += blockDim.x) {
         float hx = hyp_pts[(((size_t)io * hyp + h0) * KP + i) * 2], hy = hyp_pts[(((size_t)io * hyp + h0) * KP + i) * 2 + 1];
         if (!(fabsf(hx + hy) > 1e-6f)) hx = hy = __builtin_nanf("");
         hp[i] = make_float2(hx, hy);
         cnt[i] = 0;
+        const float fx = hx - 0.5f - rintf(hx - 0.5f), fy = hy - 0.5f - rintf(hy - 0.5f);
+        near |= (fabsf(fx) < 1e-5f && fabsf(fy) < 1e-5f) ? 1 : 0;
     }
-    __syncthreads();
+    const bool check_e2 = __syncthreads_or(near) != 0;
     const int* pl = pixlist + (size_t)io * list_stride;
     const int per_chunk = (s.tn + px_chunks - 1) / px_chunks;
     const int t_begin = blockIdx.y * per_chunk, t_end = min(s.tn, t_begin + per_chunk);
@@ -202,25 +218,53 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ ver
                 if (nd > 1e-6f) { dxv[v] = dx; dyv[v] = dy; ndv[v] = nd; qv[v] = t2 * (nd * nd); }
             }
         }
+        auto vote_tile = [&](auto check_c) {
+            constexpr bool CHECK_E2 = decltype(check_c)::value;
 #pragma unroll 1
-        for (int hh = 0; hh < HB; ++hh) {
-            const bool mine = lane == hh;
+            for (int hh = 0; hh < HB; ++hh) {
+                // nine tests of hypothesis hh.  The wave's inlier counts stay in scalar registers (__builtin_amdgcn_ballot_w64 takes the comparison
+                // mask as it is; HIP's __ballot(int) goes through v_cndmask + v_cmp_ne), the borderline margin |d| - 1e-5 rhs is a running
+                // minimum that is checked ONCE per hypothesis (round 1 branched inside every test), and the counts land in lane hh with nine
+                // adds under one exec mask.  |e|^2 < 1.1e-12 needs a hypothesis within 1e-6 of this pixel's centre: tested only in blocks that
+                // hold such a hypothesis (CHECK_E2).
+                int c[KP];
+                float zmin = 1.f, e2min = 1.f;
 #pragma unroll
-            for (int v = 0; v < KP; ++v) {
-                const float2 h = hp[hh * KP + v];
-                const float ex = h.x - cx, ey = h.y - cy;
-                const float e2 = ex * ex + ey * ey;
-                const float sd = dxv[v] * ex + dyv[v] * ey;
-                const float lhs = sd * sd, rhs = qv[v] * e2;
-                bool in = sd > 0.f && lhs > rhs && e2 > 0.9e-12f;
-                if (exact_only || fabsf(lhs - rhs) <= 1e-5f * rhs || e2 < 1.1e-12f) {  // borderline: the reference's expression
-                    const float nh = sqrtf(e2);
-                    in = nh > 1e-6f && (sd / (ndv[v] * nh)) > thresh && (dxv[v] != 0.f || dyv[v] != 0.f);
+                for (int v = 0; v < KP; ++v) {
+                    const float2 h = hp[hh * KP + v];
+                    const float ex = h.x - cx, ey = h.y - cy;
+                    const float e2 = ex * ex + ey * ey;
+                    const float sd = dxv[v] * ex + dyv[v] * ey;
+                    const float rhs = qv[v] * e2;
+                    const float d = __builtin_fmaf(sd, __builtin_fabsf(sd), -rhs);   // > 0  <=>  s > 0 and s^2 > t^2 |d|^2 |e|^2
+                    c[v] = __popcll(__builtin_amdgcn_ballot_w64(d > 0.f && act));
+                    zmin = fminf(zmin, __builtin_fmaf(-1e-5f, rhs, __builtin_fabsf(d)));   // NaN (invalid hypothesis) leaves the minimum alone
+                    if constexpr (CHECK_E2) e2min = fminf(e2min, e2);
                 }
-                const int c = __popcll(__ballot(in && act));  // wave-uniform
-                cntv[v] += mine ? c : 0;
+                const bool suspect = (zmin <= 0.f || (CHECK_E2 && e2min < 1.1e-12f)) && act;
+                if (exact_only || __builtin_amdgcn_ballot_w64(suspect)) {   // rare: those lanes take the reference's own expression
+#pragma unroll
+                    for (int v = 0; v < KP; ++v) {
+                        const float2 h = hp[hh * KP + v];
+                        const float ex = h.x - cx, ey = h.y - cy;
+                        const float e2 = ex * ex + ey * ey;
+                        const float sd = dxv[v] * ex + dyv[v] * ey;
+                        const float rhs = qv[v] * e2;
+                        const float d = __builtin_fmaf(sd, __builtin_fabsf(sd), -rhs);
+                        const bool bl = (exact_only || __builtin_fabsf(d) <= 1e-5f * rhs || e2 < 1.1e-12f) && act;
+                        const float nh = sqrtf(e2);
+                        const bool in = nh > 1e-6f && (sd / (ndv[v] * nh)) > thresh && (dxv[v] != 0.f || dyv[v] != 0.f);
+                        c[v] += __popcll(__builtin_amdgcn_ballot_w64(bl && in)) - __popcll(__builtin_amdgcn_ballot_w64(bl && d > 0.f));
+                    }
+                }
+                if (lane == hh) {
+#pragma unroll
+                    for (int v = 0; v < KP; ++v) cntv[v] += c[v];
+                }
             }
-        }
+        };
+        if (check_e2) vote_tile(std::true_type{});
+        else vote_tile(std::false_type{});
     }
     if (lane < HB) {
 #pragma unroll
@@ -267,8 +311,15 @@ __global__ void update_kernel(const int* __restrict__ counts, const float* __res
     if (lane == 0) st[io] = s;
 }
 
-__global__ void zero_int_kernel(int* __restrict__ p, long long n) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+__global__ void count_active_kernel(const ObjState* __restrict__ st, int n, int* __restrict__ out) {
+    __shared__ int acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    int a = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += st[i].done ? 0 : 1;
+    if (a) atomicAdd(&acc, a);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = acc;
 }
 
 // ---- 5. refinement ------------------------------------------------------------------------------
@@ -366,6 +417,7 @@ struct Workspace {
     float* hyp_pts;
     int* counts;
     double* sums;
+    int* nactive;
     size_t bytes;
 };
 
@@ -385,6 +437,7 @@ Workspace carve(void* base, int batch, int h, int w, int objects, int hyp) {
     ws.hyp_pts = reinterpret_cast<float*>(take(no * hyp * KP * 2 * sizeof(float)));
     ws.counts = reinterpret_cast<int*>(take(no * hyp * KP * sizeof(int)));
     ws.sums = reinterpret_cast<double*>(take(no * KP * 5 * sizeof(double)));
+    ws.nactive = reinterpret_cast<int*>(take(sizeof(int)));
     ws.bytes = p - reinterpret_cast<uintptr_t>(base) + 256;
     return ws;
 }
@@ -413,18 +466,32 @@ extern "C" int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, in
     const int rows = batch * h;
     (void)hipMemsetAsync(ws.sums, 0, (size_t)no * KP * 5 * sizeof(double), st);
     CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt);
-    CP_LAUNCH(rowscan_kernel, dim3((no + 63) / 64), dim3(64), 0, st, ws.rowcnt, h, no, min_num, ws.st);
+    CP_LAUNCH(rowscan_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, min_num, ws.st);
     CP_LAUNCH(compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, ws.pixlist, list_stride);
     const int px_chunks = 8;
     const long long nhyp = (long long)no * hyp * KP;
     for (int r = 0; r < max_iter; ++r) {
         const int32_t* draws = idx + (size_t)r * nhyp * 2;
-        CP_LAUNCH(zero_int_kernel, dim3((int)((nhyp + 255) / 256 > 4096 ? 4096 : (nhyp + 255) / 256)), dim3(256), 0, st, ws.counts, nhyp);
         CP_LAUNCH(hypgen_kernel, dim3((unsigned)((nhyp + 255) / 256)), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist,
-                  list_stride, draws, hyp, ws.st, ws.hyp_pts, no);
-        CP_LAUNCH(vote_kernel, dim3(hyp / HB, px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
-                  ws.hyp_pts, hyp, ws.st, ws.counts, inlier_thresh, px_chunks);
+                  list_stride, draws, hyp, ws.st, ws.hyp_pts, no, ws.counts);
+        if (hyp % 64 == 0)
+            CP_LAUNCH(vote_kernel<64>, dim3(hyp / 64, px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
+                      ws.hyp_pts, hyp, ws.st, ws.counts, inlier_thresh, px_chunks);
+        else
+            CP_LAUNCH(vote_kernel<HB>, dim3(hyp / HB, px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
+                      ws.hyp_pts, hyp, ws.st, ws.counts, inlier_thresh, px_chunks);
         CP_LAUNCH(update_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.counts, ws.hyp_pts, hyp, ws.st, no, confidence, max_iter);
+        // The stopping rule lives on the device; the remaining rounds of finished objects are empty launches (4 per round, ~25 us).  After
+        // rounds 1, 2, 4, 8, 16 the host asks how many objects are still voting (one 4-byte copy + stream synchronisation, ~20 us) and stops
+        // launching when none is: the usual case ends after one or two rounds of the reference's max_iter = 20.
+        const int done_rounds = r + 1;
+        if (done_rounds < max_iter && (done_rounds & (done_rounds - 1)) == 0) {
+            CP_LAUNCH(count_active_kernel, dim3(1), dim3(256), 0, st, ws.st, no, ws.nactive);
+            int active = 1;
+            if (hipMemcpyAsync(&active, ws.nactive, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return cp::check_launch("cp_ransac_vote_f32 (round check)");
+            if (active == 0) break;
+        }
     }
     CP_LAUNCH(refine_accumulate_kernel, dim3(px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
               ws.st, ws.sums, inlier_thresh, px_chunks);

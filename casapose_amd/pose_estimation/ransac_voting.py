@@ -27,10 +27,12 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     b, h, w, oc = mask.shape
     vert = vertex.reshape(b, h, w, -1).to(torch.float32).contiguous()
     vn = vert.shape[3] // 2
-    fg = mask > 0.5
-    labels = (fg.to(torch.uint8) * torch.arange(1, oc + 1, device=mask.device, dtype=torch.uint8)).amax(dim=3).contiguous()
-    counts = fg.reshape(b, h * w, oc).sum(dim=1)  # [b,oc]
-    if bool((counts > max_num).any()):
+    stream = torch.cuda.current_stream(mask.device).cuda_stream
+    labels = torch.empty(b, h, w, dtype=torch.uint8, device=mask.device)
+    counts = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
+    check(lib.cp_mask_to_labels_f32(mask.to(torch.float32).contiguous().data_ptr(), b, h, w, oc, labels.data_ptr(), counts.data_ptr(), stream),
+          "cp_mask_to_labels_f32")   # one pass instead of five PyTorch reductions / elementwise kernels over [b,h,w,oc]
+    if int(counts.max()) > max_num:
         # random down-sampling of large masks (:295-301): keep a pixel with probability max_num / count
         keep_p = (max_num / counts.clamp(min=1).to(torch.float32)).clamp(max=1.0)  # [b,oc]
         u = torch.rand(b, h, w, device=mask.device, generator=generator)
@@ -45,7 +47,6 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     ws = torch.empty(lib.cp_ransac_workspace_bytes(b, h, w, oc, vn, round_hyp_num), dtype=torch.uint8, device=mask.device)
     out = torch.empty(b, oc, vn, 2, dtype=torch.float32, device=mask.device)
     rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
-    stream = torch.cuda.current_stream(mask.device).cuda_stream
     check(lib.cp_ransac_vote_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, draws.data_ptr(), round_hyp_num,
                                  float(inlier_thresh), float(confidence), int(max_iter), int(min_num), int(max_num), ws.data_ptr(),
                                  out.data_ptr(), rounds.data_ptr(), stream), "cp_ransac_vote_f32")

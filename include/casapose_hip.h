@@ -203,6 +203,10 @@ int cp_upsample_bilinear_x2_f32(const float* src, int batch, int h, int w, int c
 int cp_guided_upsample_x2_f32(const float* src, const uint8_t* sel, int batch, int h, int w, int channels,
                               float* dst, void* stream);
 
+/* Front end of ransac_voting_layer_all_masks (ransac_voting.py:276-301): object masks [b,h,w,objects] (float, > 0.5 = inside, no background
+ * channel) -> uint8 label map (highest such object index + 1; 0 = none) and counts[b][objects] = pixels inside each mask. */
+int cp_mask_to_labels_f32(const float* mask, int batch, int h, int w, int objects, uint8_t* labels, int32_t* counts, void* stream);
+
 /* arg-max over `classes` contiguous values per pixel (pixel stride ld) -> uint8 label.
  * Replaces softmax(1e6*x) as a hard one-hot (pose_models.py:547-554; voting_layers_2d.py:38-41).
  * First maximum wins (ties are undefined behaviour in the reference). */
@@ -260,7 +264,8 @@ size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects);
  * give zeros (:290-292).  The random sub-sampling of objects above max_num pixels
  * (:295-301) is the caller's job (apply it to `labels`); max_num is accepted for signature
  * parity only.  Rounds stop per object when 1-(1-r_min^2)^hyps > confidence or after
- * max_iter rounds (:340-347), decided on the device.  hyp must be a multiple of 16.
+ * max_iter rounds (:340-347), decided on the device; after rounds 1, 2, 4, 8, 16 the call synchronises `stream` once to learn whether any object
+ * is still voting and stops launching rounds when none is.  hyp must be a multiple of 16.
  * out: fp32 [n][objects][kp][2] in (x,y); rounds_out (optional) int32 [n][objects].
  * ws: workspace of cp_ransac_workspace_bytes. */
 int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h,
