@@ -615,7 +615,11 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     assert avail.sum() >= 6, "the scene must show enough objects for the test to mean something"
     big = avail[0] > 0
     assert np.abs(seen["coords"][0][big] - coords_ref.detach().numpy()[0][big]).max() < 0.05 + 1e-3 * np.abs(coords_ref.detach().numpy()[0][big]).max()
-    lv_ref, g_ref, _ = T.bpnp_reprojection_loss_host(coords_ref.detach().numpy(), gt_xy_np, aff_np, avail, p3d, cam, cap, kp_w, rng=np.random.default_rng(5))
+    # the host PnP (RANSAC inlier selection) is not continuous in its input: evaluated at the reference's keypoints it can pick another inlier
+    # set than at the GPU's (they agree to < 0.05 px, asserted above) and return a gradient that differs by several per cent -- seen with
+    # CASAPOSE_CONV_MODE=f32.  The host routine is therefore evaluated ONCE, at the keypoints the GPU voted; what this test checks is the
+    # chain behind it (voter and network backward); the routine's own gradient is checked against finite differences below.
+    lv_ref, g_ref, _ = T.bpnp_reprojection_loss_host(seen["coords"], gt_xy_np, aff_np, avail, p3d, cam, cap, kp_w, rng=np.random.default_rng(5))
     # confidence regulariser |mean_fg softplus(conf) - 0.7| (loss_functions.py:325-342) in torch
     fg = (labt > 0).double()
     cl = (F.softplus(ref[..., k + 2 * kp:]) * fg[..., None]).sum((1, 2)) / fg.sum((1, 2))[:, None]
