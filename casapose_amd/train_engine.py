@@ -370,6 +370,11 @@ class ConvOp:
         d.head_weights = d.head_out = None
         d.head_cout = d.head_out_ld = 0
         self.dy_ptr_ld = dy_ptr_ld
+        # the full-resolution 1x1 heads (32 -> K / ver_dim): streaming kernels on the Keras kernel itself (csrc/head1x1.hip) unless CASAPOSE_HEAD_CONV=generic
+        self.head_fast = (k == 1 and stride == 1 and pad == 0 and len(srcs) == 1 and layer.sources[0] == (32, 32) and layer.cout <= 32
+                          and tap_label is None and row_scale is None and residual is None and srcs[0][1] % 4 == 0
+                          and os.environ.get("CASAPOSE_HEAD_CONV", "stream") != "generic")
+        self._out_ptr_ld = out_ptr_ld
         # data-gradient descriptors
         for s, ent in enumerate(layer.dgrad):
             if ent is None:
@@ -497,6 +502,12 @@ class ConvOp:
                            self.residual.data.data_ptr() if self.residual is not None else None, d.out_raw, stream)
             return
         lib = _lib.load()
+        if self.head_fast:
+            t, ld = self.srcs[0]
+            st_, off, old_ = self._out_ptr_ld
+            check(lib.cp_head1x1_fwd_f32(t.data.data_ptr(), ld, self.batch * self.out_h * self.out_w, self.layer.master.data_ptr(), self.layer.cout,
+                                         st_.data_ptr() + 4 * off, old_, stream), "cp_head1x1_fwd_f32(%s)" % self.layer.name)
+            return
         sp = self.layer.split
         if sp is not None:
             if getattr(self, "_split_fwd", None) is None:
@@ -578,6 +589,17 @@ class ConvOp:
         L = self.layer
         dy, dy_ld = self._dy()
         d = L.desc  # one op per layer: filled by this op's constructor
+        if self.head_fast:
+            t, ld = self.srcs[0]
+            px = self.batch * self.out_h * self.out_w
+            readable = (self.dy_ptr_ld[2] - self.dy_ptr_ld[1] % self.dy_ptr_ld[2]) if self.dy_ptr_ld is not None else self.out.c
+            check(lib.cp_head1x1_wgrad_f32(t.data.data_ptr(), ld, dy, dy_ld, px, L.cout, L.master_grad.data_ptr(), 1 if self.accumulate_master else 0, stream),
+                  "cp_head1x1_wgrad_f32(%s)" % L.name)
+            if t.needs_grad:
+                check(lib.cp_head1x1_dgrad_f32(dy, dy_ld, min(32, readable), px, L.master.data_ptr(), L.cout, t.grad.data_ptr(), t.c, 1 if t.has_grad else 0, stream),
+                      "cp_head1x1_dgrad_f32(%s)" % L.name)
+                t.has_grad = True
+            return
         if getattr(self, "wino_fwd", None) is not None:
             # weight gradient through the Winograd planes: a quarter of the MFMA work of the direct kernel (V kept from the forward)
             w = self.wino_fwd

@@ -353,6 +353,15 @@ int cp_conv2d_wgrad_f32(const cp_conv_desc* desc, const float* dy, int dy_ld, fl
 int cp_conv_wgrad_split_applicable(const cp_conv_desc* desc);
 int cp_conv2d_wgrad_split(const cp_conv_desc* desc, const float* dy, int dy_ld, float* dw_packed, int accumulate, int planes, void* stream);
 
+/* The two full-resolution 1x1 heads of the training step (pv_final_conv_segmentation / pv_final_conv_vertex, pose_models.py:546,616: 32 input
+ * channels, cout <= 32) as streaming kernels (csrc/head1x1.hip; exact fp32 MFMA like cp_conv2d_fwd_f32 / cp_conv2d_wgrad_f32): w and dw are the
+ * Keras kernel [32][cout] itself (no packing).  x rows: 32 channels, 16-byte aligned, ld_x % 4 == 0.  dy_row_floats = floats that may be READ in
+ * each dy row starting at dy (>= cout; >= 32 enables 16-byte loads, columns >= cout are ignored).  accumulate: add to dx / dw. */
+int cp_head1x1_fwd_f32(const float* x, int ld_x, long long pixels, const float* w, int cout, float* out, int ld_out, void* stream);
+int cp_head1x1_dgrad_f32(const float* dy, int ld_dy, int dy_row_floats, long long pixels, const float* w, int cout, float* dx, int ld_dx,
+                         int accumulate, void* stream);
+int cp_head1x1_wgrad_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int cout, float* dw, int accumulate, void* stream);
+
 /* The DATA gradient needs no entry point of its own: it is cp_conv2d_fwd_f32 over dy with the kernel
  * flipped and transposed (host-side repack), pad' = dilation*(k-1) - pad, the same dilation, and, for a
  * stride-2 forward, source mode CP_SRC_ZERO_INSERT_X2.  A partial convolution keeps its tap_label (the mask
