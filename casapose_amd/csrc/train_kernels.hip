@@ -199,49 +199,83 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ x, int ld_x, c
 // max-pool 3x3/s2 zero-pad-1: dx(iy,ix) = sum over the <=4 windows containing it where x(iy,ix) is the
 // window's FIRST maximum in raster order (the tie rule of the forward arg-max; post-ReLU inputs: the zero
 // padding can tie with zeros, in which case the padded tap wins only if it comes first)
+// A thread owns the 2x2 input block (2oy + {0,1}, 2ox + {0,1}) of four channels: the four windows that can contain those inputs,
+// (oy + {0,1}, ox + {0,1}), cover a 5x5 input patch, which is loaded ONCE (25 x 16 bytes; the first version re-derived the arg-max of up to
+// four windows per input element, 36 loads each: 0.74 ms at bs 32 against ~0.1 ms of traffic).
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
                                    float* __restrict__ dx, int accumulate) {
     const int c4n = C >> 2;
-    const long long total = (long long)B * H * W * c4n;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;   // 2x2 input blocks
+    const long long total = (long long)B * Hb * Wb * c4n;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
-        long long pix = i / c4n;
-        const int ix = (int)(pix % W);
-        long long t = pix / W;
-        const int iy = (int)(t % H);
-        const int n = (int)(t / H);
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)pix * C + c4 * 4);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        float o[4] = {0, 0, 0, 0};
-        for (int oy = (iy + 1) / 2 - 1; oy <= (iy + 1) / 2; ++oy) {
-            if (oy < 0 || oy >= Ho || iy < 2 * oy - 1 || iy > 2 * oy + 1) continue;
-            for (int ox = (ix + 1) / 2 - 1; ox <= (ix + 1) / 2; ++ox) {
-                if (ox < 0 || ox >= Wo || ix < 2 * ox - 1 || ix > 2 * ox + 1) continue;
-                // arg-max of window (oy,ox) per channel
+        long long t = i / c4n;
+        const int bx = (int)(t % Wb);
+        t /= Wb;
+        const int by = (int)(t % Hb);
+        const int n = (int)(t / Hb);
+        // patch rows 2by-1 .. 2by+3, columns 2bx-1 .. 2bx+3 (zero outside the image: the forward pads with zeros)
+        float4 pt[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int yy = 2 * by - 1 + r, xx = 2 * bx - 1 + q;
+                pt[r][q] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                               ? *reinterpret_cast<const float4*>(x + (((size_t)n * H + yy) * W + xx) * C + c4 * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float o[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[a][b][e] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = by + wy, ox = bx + wx;
+                if (oy >= Ho || ox >= Wo) continue;
+                // first maximum of the window in raster order, per channel (its taps are patch rows 2wy.., columns 2wx..)
                 float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 int bidx[4] = {-1, -1, -1, -1};
+#pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int yy = 2 * oy - 1 + ky, xx = 2 * ox - 1 + kx;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                            v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + yy) * W + xx) * C + c4 * 4);
+                        const float4 v = pt[2 * wy + ky][2 * wx + kx];
                         const float vs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (vs[e] > best[e]) { best[e] = vs[e]; bidx[e] = ky * 3 + kx; }
                     }
-                const int mine = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
                 const float4 g = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4);
                 const float gs[4] = {g.x, g.y, g.z, g.w};
+                // the block's inputs inside this window: input (a, b) sits at patch (1 + a, 1 + b) = window tap (1 + a - 2wy, 1 + b - 2wx)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (bidx[e] == mine && xs[e] == best[e]) o[e] += gs[e];
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int ky = 1 + a - 2 * wy, kx = 1 + b - 2 * wx;
+                        if (ky < 0 || ky > 2 || kx < 0 || kx > 2) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (bidx[e] == ky * 3 + kx) o[a][b][e] += gs[e];
+                    }
             }
-        }
-        float4* dst = reinterpret_cast<float4*>(dx + (size_t)pix * C + c4 * 4);
-        if (accumulate) { const float4 old = *dst; o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
-        *dst = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int iy = 2 * by + a, ix = 2 * bx + b;
+                if (iy >= H || ix >= W) continue;
+                float4* dst = reinterpret_cast<float4*>(dx + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
+                float4 r = make_float4(o[a][b][0], o[a][b][1], o[a][b][2], o[a][b][3]);
+                if (accumulate) { const float4 old = *dst; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                *dst = r;
+            }
     }
 }
 
@@ -470,8 +504,8 @@ extern "C" int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy
 extern "C" int cp_maxpool3x3s2_bwd_f32(const float* x, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate, void* stream) {
     CP_REQUIRE(x && dy && dx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0, "cp_maxpool3x3s2_bwd_f32: bad arguments");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    CP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long long)batch * h * w * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, dy, batch, h, w,
-              channels, ho, wo, dx, accumulate);
+    CP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long long)batch * ((h + 1) / 2) * ((w + 1) / 2) * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, dy,
+              batch, h, w, channels, ho, wo, dx, accumulate);
     return cp::check_launch("cp_maxpool3x3s2_bwd_f32");
 }
 
