@@ -564,7 +564,7 @@ def main():
                 gemm_ms = timed(lambda: conv.run_gemm(stream))
                 whole_ms = timed(lambda: conv.run(stream))
                 t["ms"] += gemm_ms
-                t["flops"] += conv.gemm_flops * (6.0 if pipe == 3 else 1.0)
+                t["flops"] += conv.gemm_flops * ((3.0 if getattr(conv, "planes", 3) == 2 else 6.0) if pipe == 3 else 1.0)
                 t["launches"] += 1
                 t["bytes"] += 4.0 * (36.0 * conv.Tp * (conv.ktot + conv.cout) + conv.U.numel())
                 wino["layers"] += 1

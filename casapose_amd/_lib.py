@@ -124,6 +124,7 @@ SYMBOLS = [
     ("cp_wino_tiles", _i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("cp_wino_gemm_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     ("cp_wino_gemm_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    ("cp_wino_gemm_split_planes_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_split_weights_bytes", C.c_size_t, [_i, _i, _i]),
     ("cp_wino_split_weights_f32", _i, [_vp, _i, _i, _i, _vp, _vp]),
     ("cp_wino_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

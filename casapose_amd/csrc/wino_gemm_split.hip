@@ -86,6 +86,9 @@ __global__ void split_weights_kernel(const float* __restrict__ U, int groups, in
     }
 }
 
+// NPL = 3: the exact three-way split (six products, fp32-equivalent).  NPL = 2: hi + mid planes only (16 significand bits per operand, products
+// hi*hi, hi*mid, mid*hi): half the MFMAs, for the bf16 conv modes whose gates are 3e-2 -- NOT fp32-equivalent.
+template <int NPL>
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE stages][3 splits][128 rows][80 B]
 
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                 split4(areg[i], h, m, l);
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB) = h;
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + SPLIT_BYTES) = m;
-                *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
+                if constexpr (NPL == 3) *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
             }
         };
         // three LDS stages: chunk c + 2 is stored while the consumers multiply chunk c, so chunk c + 1 is complete one barrier early and its
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[2][2][3];        // [slot][row block][split]: A fragments from LDS
-    bf16x8 fb[2][2][2][3];     // [chunk parity][k16 step][column block][split]: B fragments of a whole chunk, fetched one chunk ahead from L2
+    bf16x8 fa[2][2][NPL];      // [slot][row block][split]: A fragments from LDS
+    bf16x8 fb[2][2][2][NPL];   // [chunk parity][k16 step][column block][split]: B fragments of a whole chunk, fetched one chunk ahead from L2
     const __amdgpu_buffer_rsrc_t rbw = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
     const unsigned ks_total = (unsigned)(p.K / 16);
     auto read_a = [&](int buf, int ks, int slot) {
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) fa[slot][i][s] = *reinterpret_cast<const bf16x8*>(a + i * 32 * ROWB + s * SPLIT_BYTES);
+            for (int s = 0; s < NPL; ++s) fa[slot][i][s] = *reinterpret_cast<const bf16x8*>(a + i * 32 * ROWB + s * SPLIT_BYTES);
     };
     // B fragments of flattened chunk `cc` (tile cc / nchunks of this block, chunk cc % nchunks) into register set `par`
     int f_it = -1, f_q = p.nchunks;
@@ -206,14 +209,16 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NPL; ++s)
                     fb[par][ks][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                         rbw, (int)((f_base[j] + ((unsigned)(f_q * 2 + ks) * 3u + (unsigned)s) * 1024u) | oob), 0, 0));
     };
     auto mfma_step = [&](int slot, int par, int ks) {
         // smallest terms first; consecutive MFMAs hit different accumulators
+        constexpr int NPR = (NPL == 3) ? 6 : 3;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+        for (int t0 = 0; t0 < NPR; ++t0) {
+            const int t = (NPL == 3) ? t0 : t0 + 3;   // two planes: the last three products (mid*hi, hi*mid, hi*hi)
             const int sa = (t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0;   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             const int sb = (t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0;
 #pragma unroll
@@ -234,8 +239,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         mfma_step(1, par, 1);
         // the six reads above go out behind the first MFMAs of the second step, not in front of the barrier
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * ((NPL == 3) ? 6 : 3) - 4, 0);
         CP_BARRIER();
         buf = nbuf;
         if (++q == p.nchunks) {
@@ -288,7 +293,8 @@ extern "C" int cp_wino_split_weights_f32(const float* U, int groups, int n, int 
     return cp::check_launch("cp_wino_split_weights_f32");
 }
 
-extern "C" int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream) {
+extern "C" int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream) {
+    CP_REQUIRE(planes == 3 || planes == 2, "cp_wino_gemm_split_planes_f32: planes must be 3 (exact split) or 2 (hi + mid)");
     CP_REQUIRE(V && Usplit && M, "cp_wino_gemm_split_f32: null pointer");
     CP_REQUIRE(rows > 0 && group_rows > 0 && rows % group_rows == 0 && group_rows % 128 == 0, "cp_wino_gemm_split_f32: rows must be whole groups of a multiple of 128 rows");
     CP_REQUIRE(k > 0 && k % 32 == 0 && n > 0, "cp_wino_gemm_split_f32: K must be a multiple of 32");
@@ -305,9 +311,15 @@ extern "C" int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float*
     const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    CP_LAUNCH(wino_gemm_split_kernel, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
+    if (planes == 3) CP_LAUNCH(wino_gemm_split_kernel<3>, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
+    else CP_LAUNCH(wino_gemm_split_kernel<2>, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
     return cp::check_launch("cp_wino_gemm_split_f32");
+}
+
+extern "C" int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream) {
+    return cp_wino_gemm_split_planes_f32(V, Usplit, M, rows, group_rows, k, n, 3, stream);
 }

@@ -275,7 +275,8 @@ class WinoConv:
     """A deep 3x3 / stride-1 convolution executed as Winograd F(4x4,3x3): input transform(s), ONE grouped 1x1 launch over
     the 36 planes, output transform with the fused epilogue (csrc/wino.hip).  Same interface as FusedConv.run()."""
 
-    def __init__(self, name: str, kernel_hwio: np.ndarray, cout: int, sources: Sequence[Tuple[int, int]], device: torch.device):
+    def __init__(self, name: str, kernel_hwio: np.ndarray, cout: int, sources: Sequence[Tuple[int, int]], device: torch.device,
+                 split_planes: Optional[int] = None):
         lib = _lib.load()
         self.name, self.cout, self.sources = name, cout, list(sources)
         self.kh = self.kw = 3
@@ -293,7 +294,9 @@ class WinoConv:
             c0 += creal
             k0 += cpad
         self.U = torch.from_numpy(U).to(device)
-        self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if WINO_GEMM_SPLIT else None   # pre-split bf16 planes of the opt-in GEMM
+        # pre-split bf16 planes of the opt-in GEMM; split_planes = 2 (the bf16 conv mode): hi + mid planes only, three products, NOT fp32-equivalent
+        self.planes = split_planes or 3
+        self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if (WINO_GEMM_SPLIT or split_planes) else None
         self.desc = ConvDesc()  # the grouped GEMM
         self._keep: List = []
 
@@ -362,8 +365,8 @@ class WinoConv:
             check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
         else:
             if self.Us is not None:
-                check(lib.cp_wino_gemm_split_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
-                      "cp_wino_gemm_split_f32(%s)" % self.name)
+                check(lib.cp_wino_gemm_split_planes_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, self.planes,
+                                                        stream), "cp_wino_gemm_split_planes_f32(%s)" % self.name)
             else:
                 check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
                       "cp_wino_gemm_f32(%s)" % self.name)
@@ -769,7 +772,8 @@ class CasaposeNet:
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev, want_split=bool(self.conv_planes))
             pad = dil * (k // 2) if pad is None else pad
             if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout):
-                Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev)
+                Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev,
+                                    split_planes=2 if self.conv_mode == "bf16" else None)
 
         add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])
         cin = 64

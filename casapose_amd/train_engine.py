@@ -487,8 +487,9 @@ class ConvOp:
                   "cp_wino_input_transform_f32(%s)" % self.layer.name)
             off += ch
         if w.get("Us") is not None:
-            check(lib.cp_wino_gemm_split_f32(V.data_ptr(), w["Us"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
-                  "cp_wino_gemm_split_f32(%s)" % self.layer.name)
+            # CASAPOSE_CONV_MODE=bf16: hi + mid planes only (three products, not fp32-equivalent: that mode's gates are 3e-2); else the exact split
+            check(lib.cp_wino_gemm_split_planes_f32(V.data_ptr(), w["Us"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"],
+                                                    2 if conv_split_planes() == 1 else 3, stream), "cp_wino_gemm_split_planes_f32(%s)" % self.layer.name)
         else:
             check(lib.cp_wino_gemm_f32(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
                   "cp_wino_gemm_f32(%s)" % self.layer.name)
@@ -529,7 +530,7 @@ class ConvOp:
         m_out = float(self.batch * self.out_h * self.out_w)
         cin = sum(s[1] for s in L.sources)
         direct = 2.0 * m_out * L.k * L.k * cin * L.cout
-        wino_pipe, wino_mult = ("bf16", 6.0) if TRAIN_WINO_GEMM_SPLIT else ("f32", 1.0)
+        wino_pipe, wino_mult = ("bf16", 3.0 if conv_split_planes() == 1 else 6.0) if TRAIN_WINO_GEMM_SPLIT else ("f32", 1.0)
 
         def split_pipe(sp):
             return ("bf16", 6.0 if sp["np"] == 3 else 1.0)

@@ -309,6 +309,9 @@ int cp_wino_gemm_f32(const float* V, const float* U, float* M, int rows, int gro
 size_t cp_wino_split_weights_bytes(int groups, int n, int k);
 int cp_wino_split_weights_f32(const float* U, int groups, int n, int k, void* out, void* stream);
 int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream);
+/* planes = 3: the above.  planes = 2: hi + mid planes only (16 significand bits per operand; products hi*hi, hi*mid, mid*hi): half the MFMAs, NOT
+ * fp32-equivalent -- for the bf16 conv modes (BASELINE.json configs[2]; gates 3e-2).  Same pre-split weights. */
+int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream);
 int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
                               int k_off, float* dst);
 /* device version of the weight transform (training: after every optimizer step): g(ky,kx,c,o) is read at

@@ -340,4 +340,9 @@ def test_split_bf16_gemm_is_fp32_equivalent(device):
         e1 = float(((M1.cpu().double() - ref).abs() / bound).max())
         e2 = float(((M2.cpu().double() - ref).abs() / bound).max())
         assert e2 < 2e-6 and e2 < 2.0 * e1 + 1e-7, (rows, n, k, e1, e2)
+        # two planes (hi + mid, three products; the bf16 conv modes): 16 significand bits per operand -> 2^-15 of sum |v||u|, far from fp32
+        M3 = torch.empty(rows, n, device=device)
+        check(lib.cp_wino_gemm_split_planes_f32(Vd.data_ptr(), Us.data_ptr(), M3.data_ptr(), rows, group, k, n, 2, st), "split, two planes")
+        e3 = float(((M3.cpu().double() - ref).abs() / bound).max())
+        assert 1e-7 < e3 < 4e-5, (rows, n, k, e3)
         del scale

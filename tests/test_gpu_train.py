@@ -385,6 +385,44 @@ def test_train_forward_backward_matches_autograd(device, variant):
     assert rel(mm, exp) < 1e-4
 
 
+def test_train_forward_backward_bf16_conv_mode_within_its_gates(device, monkeypatch):
+    """CASAPOSE_CONV_MODE=bf16 (BASELINE.json configs[2] "bf16 convs"): the 3x3 layers off the Winograd path with bf16 operands in forward,
+    data gradient and weight gradient, the Winograd GEMMs with hi + mid planes.  SURVEY 8d gate for the bf16 path: outputs <= 3e-2 of the
+    fp64 reference's range.  The GRADIENTS of this loss are not smooth in the outputs (smooth-L1 / proxy-voting kinks, arg-max conditioning):
+    an output error of 1-2 % of range turns into ~20 % relative L2 on every variable (measured identically with the Winograd GEMMs in fp32,
+    `tools/debug/bf16_grad_probe.py`), so they are held to a sanity gate only -- right direction, right size -- while each bf16 kernel has its
+    own 2e-2 / 3e-2 parity test (tests/test_gpu_hsplit.py, tests/test_gpu_wgrad_split.py, tests/test_gpu_conv.py)."""
+    monkeypatch.setenv("CASAPOSE_CONV_MODE", "bf16")
+    b, h, w, k = 2, 64, 96, 4
+    part, guid = O.VARIANTS["casapose_c_gcu5"]
+    params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, partial=part, guided=guid, bilinear=(False,) * 5, sharing={})
+    assert any(getattr(op, "wgrad_planes", lambda: 0)() == 1 for op in plan.ops), "the bf16 weight-gradient kernel is not on the path"
+    stream = torch.cuda.current_stream(device).cuda_stream
+    plan.refresh_weights(stream)
+    labd = torch.from_numpy(lab).to(device)
+    out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd)
+    p64 = R.to_torch(params)
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), {}, partial=part, guided=guid,
+                          bilinear=(False,) * 5)
+    got = out.cpu().numpy()
+    e_seg, e_vec = rel(got[..., :k], ref.detach().numpy()[..., :k]), rel(got[..., k:], ref.detach().numpy()[..., k:])
+    assert e_seg < 3e-2 and e_vec < 3e-2, (e_seg, e_vec)
+    assert max(e_seg, e_vec) > 1e-5, "these are bf16 operands: an fp32-like error means the mode did not take effect"
+    wts = (1.0, 0.5, 0.015)
+    plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(device), *wts, filter_with_segmentation=False)
+    ml, vl, pl = R.losses(ref, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, 9, False)
+    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
+    plan.backward()
+    torch.cuda.synchronize()
+    worst = {name: rel_l2(store.grad_view(name).cpu().numpy(), p64[name].grad.numpy()) for name in store.offsets}
+    bad = {n: e for n, e in worst.items() if e > 0.5}
+    assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
+    assert np.median(list(worst.values())) < 0.3, np.median(list(worst.values()))
+    for name in ("conv0.kernel", "stage4_unit2_conv2.kernel", "pv_block_10_prepare_conv2d.weights"):
+        g, gr = store.grad_view(name).cpu().numpy().ravel().astype(np.float64), p64[name].grad.numpy().ravel()
+        assert g @ gr / (np.linalg.norm(g) * np.linalg.norm(gr)) > 0.9, name
+
+
 def test_train_steps_reduce_the_loss(device):
     b, h, w, k = 2, 32, 32, 3
     params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, seed=99)
