@@ -72,6 +72,8 @@ class ConvDesc(C.Structure):
         ("head_out_ld", C.c_int),
         ("group_rows", C.c_int),
         ("group_weight_stride", C.c_int),
+        ("head_label_out", C.c_void_p),
+        ("head_label_classes", C.c_int),
     ]
 
 

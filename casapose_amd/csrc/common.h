@@ -48,6 +48,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return start + idx;
 }
 
+// Arg-max over the first `classes` head channels of this lane's pixel from the fused head's accumulator (conv_halo.hip / conv_hsplit.hip):
+// register g4 * 4 + e of lane half `half` holds channel q = 8 g4 + 4 half + e, so a pixel's 32 channels sit in lanes l and l ^ 32.
+// First maximum wins (cp_argmax_labels); all lanes of the wave must call it.
+template <typename V>
+__device__ __forceinline__ int head_argmax(const V& a2, int half, int classes) {
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = g4 * 8 + half * 4 + e;
+            const float v = a2[g4 * 4 + e];
+            if (q < classes && v > best) { best = v; bi = q; }
+        }
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (ob > best || (ob == best && oi < bi)) bi = oi;
+    return bi == 0x7fffffff ? 0 : bi;
+}
+
 // conv_wgrad.hip: the fp32 weight-gradient kernel over the packed K chunks [first_chunk, ktot / 32) only, accumulating
 int wgrad_f32_chunks(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int first_chunk, hipStream_t st);
 

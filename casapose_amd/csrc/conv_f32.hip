@@ -585,6 +585,9 @@ extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
         CP_REQUIRE(d->head_weights && d->head_cout >= 1 && d->head_cout <= 32 && d->head_out_ld >= d->head_cout && d->cout == 32,
                    "cp_conv2d_fwd_f32: fused head needs head_weights, 1 <= head_cout <= 32 <= ... and cout == 32");
         CP_REQUIRE(cp::halo_applicable(d) && (d->tile_hint == 0 || d->tile_hint == CP_TILE_HALO), "cp_conv2d_fwd_f32: the fused head is implemented by the halo-tile kernel only (3x3/s1/p1, weights_halo)");
+        CP_REQUIRE(!d->head_label_out || (d->head_label_classes >= 1 && d->head_label_classes <= d->head_cout), "cp_conv2d_fwd_f32: head_label_classes must be in [1, head_cout]");
+    } else {
+        CP_REQUIRE(!d->head_label_out, "cp_conv2d_fwd_f32: head_label_out needs a fused head");
     }
     CP_REQUIRE(!d->tap_label || d->stride == 1, "cp_conv2d_fwd_f32: tap_label needs stride 1");
     CP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "cp_conv2d_fwd_f32: scale and shift come together");

@@ -60,6 +60,8 @@ struct HaloK {
     const float* head_w;   // fused 1x1 head [4][2][32][4] (cout == 32 only)
     float* head_out;
     int head_cout, head_ld;
+    uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
+    int head_lab_classes;
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -439,6 +441,10 @@ __global__ __launch_bounds__(512, (TMW * TN <= 2) ? 4 : 2) void conv_halo_kernel
                     else if (nq == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v0, v1}, r_head, (int)o, 0, 0);
                     else if (nq == 1) __builtin_amdgcn_raw_buffer_store_b32(v0, r_head, (int)o, 0, 0);
                 }
+                if (p.head_lab) {   // the hard label map straight from the head's registers (no second pass over the strided records)
+                    const int lab = cp::head_argmax(a2, half, p.head_lab_classes);
+                    if (half == 0 && pok) p.head_lab[pix] = (uint8_t)lab;
+                }
             }
         }
     };
@@ -686,6 +692,7 @@ int launch_halo_conv(const cp_conv_desc* d, hipStream_t st) {
     k.norm = d->row_scale != nullptr;  // tap mask without row_scale = un-normalised (the data gradient of a partial convolution)
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
     k.head_w = d->head_out ? d->head_weights : nullptr; k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
+    k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
     const bool partial = d->tap_label != nullptr;
     const bool bil = d->src[0].mode == CP_SRC_BILINEAR_X2, sel = d->src[0].mode == CP_SRC_NEAREST_SEL;
     const int tn = d->cout <= 32 ? 1 : 2;

@@ -72,6 +72,8 @@ struct HSplitK {
     const unsigned char* head_w;   // fused 1x1 head (cout == 32): [2 steps][plane][64 lanes][8 bf16], cp_conv_pack_head_split_host
     float* head_out;
     int head_cout, head_ld;
+    uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
+    int head_lab_classes;
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -607,6 +609,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         else if (nq == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v0, v1}, r_head, (int)o, 0, 0);
                         else if (nq == 1) __builtin_amdgcn_raw_buffer_store_b32(v0, r_head, (int)o, 0, 0);
                     }
+                    if (p.head_lab) {   // the hard label map straight from the head's registers
+                        const int lab = cp::head_argmax(a2, kh, p.head_lab_classes);
+                        if (kh == 0 && pok) p.head_lab[pix] = (uint8_t)lab;
+                    }
                 }
             }
         }
@@ -931,6 +937,7 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;
     k.head_w = d->head_out ? reinterpret_cast<const unsigned char*>(head_weights_split) : nullptr;
     k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
+    k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
     const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0);
     const int tn = split_tn(d->cout);
     hipStream_t st = (hipStream_t)stream;

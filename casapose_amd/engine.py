@@ -180,7 +180,7 @@ class FusedConv:
 
     def bind(self, *, batch, in_h, in_w, stride=1, dilation=1, pad=0, srcs, tap_label=None, row_scale=None,
              residual=None, scale=None, shift=None, epi_label=None, act=0, out_raw=None, out_raw_ld=None,
-             out_act=None, out_act_ld=None, tile_hint=0, head_out=None, head_out_ld=0):
+             out_act=None, out_act_ld=None, tile_hint=0, head_out=None, head_out_ld=0, head_label_out=None, head_label_classes=0):
         """srcs: list of dicts(data=tensor, ld=int, mode=int, sel=tensor|None, pre=(scale,shift)|None)."""
         d = self.desc
         eh = (self.kh - 1) * dilation + 1
@@ -228,7 +228,9 @@ class FusedConv:
         d.head_out = _ptr(head_out)
         d.head_cout = self.head_cout if head_out is not None else 0
         d.head_out_ld = head_out_ld
-        keep += [tap_label, row_scale, residual, scale, shift, epi_label, out_raw, out_act]
+        d.head_label_out = _ptr(head_label_out) if head_out is not None else None
+        d.head_label_classes = head_label_classes if head_label_out is not None else 0
+        keep += [head_label_out, tap_label, row_scale, residual, scale, shift, epi_label, out_raw, out_act]
         self._keep = [k for k in keep if k is not None]
         return d.out_h, d.out_w
 
@@ -327,6 +329,7 @@ class WinoConv:
         d.out_raw, d.out_raw_ld, d.out_act, d.out_act_ld = M.data_ptr(), self.cout, None, self.cout
         d.tile_hint = 0
         d.head_weights = d.head_out = None
+        d.head_label_out, d.head_label_classes = None, 0
         d.head_cout = d.head_out_ld = 0
         d.group_rows, d.group_weight_stride = self.Tp, self.cout * self.ktot
         self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
@@ -417,6 +420,7 @@ class ForwardPlan:
         # ---- buffers that are (re)bound per call ------------------------------------------
         self.img4 = new(B, h, w, 4)
         self.labels = [torch.empty(B, hs[l], ws[l], **u8) for l in range(4)]
+        self.labels_from_head = False   # True: block 5's fused segmentation head writes labels[0] in its epilogue
         self.pnorm = [new(B, hs[l], ws[l]) for l in range(4)]
         self.sel = [torch.empty(B, hs[l], ws[l], **u8) for l in range(3)]
         self.sel_zero = [torch.zeros(B, hs[l], ws[l], **u8) for l in range(3)]  # plain nearest x2 = "guided" with neighbour 0 everywhere
@@ -536,9 +540,11 @@ class ForwardPlan:
             fused = self.fuse_heads and i == 4
             if fused:  # blocks 5 + pv_final_conv_segmentation in one launch; the 32-channel tensor is never stored
                 L[name].attach_head(net.params["pv_final_conv_segmentation.kernel"])
+                # ... and the hard label map (arg-max of the K logits) straight from the head's registers: no pass over the strided records
                 conv(L[name], in_h=hs[l], in_w=ws[l], pad=1, srcs=srcs, scale=bn[0], shift=bn[1], act=_lib.ACT_LEAKY01,
-                     head_out=self.img4, head_out_ld=self.out_ld)
+                     head_out=self.img4, head_out_ld=self.out_ld, head_label_out=self.labels[0], head_label_classes=K)
                 self._out_bound.append((L[name], 0, "head_out"))
+                self.labels_from_head = True
             else:
                 extra = {}
                 if i == 0 and net.reuse_first:
@@ -569,7 +575,8 @@ class ForwardPlan:
                 src, ld = self.seg_input_ptr, K
             else:
                 src, ld = self.out.data_ptr(), self.out_ld
-            check(lib.cp_argmax_labels(src, ld, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
+            if self.seg_input_ptr is not None or not self.labels_from_head:   # else block 5's fused head has written labels[0] already
+                check(lib.cp_argmax_labels(src, ld, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
             lab = (C.c_void_p * 4)(*[t.data_ptr() for t in self.labels])
             pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
             sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])

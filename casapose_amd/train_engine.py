@@ -369,6 +369,7 @@ class ConvOp:
         d.tile_hint = 0
         d.head_weights = d.head_out = None
         d.head_cout = d.head_out_ld = 0
+        d.head_label_out, d.head_label_classes = None, 0
         self.dy_ptr_ld = dy_ptr_ld
         # the full-resolution 1x1 heads (32 -> K / ver_dim): streaming kernels on the Keras kernel itself (csrc/head1x1.hip) unless CASAPOSE_HEAD_CONV=generic
         self.head_fast = (k == 1 and stride == 1 and pad == 0 and len(srcs) == 1 and layer.sources[0] == (32, 32) and layer.cout <= 32
@@ -402,6 +403,7 @@ class ConvOp:
             g.tile_hint = 0
             g.head_weights = g.head_out = None
             g.head_cout = g.head_out_ld = 0
+            g.head_label_out, g.head_label_classes = None, 0
 
     # ---- Winograd F(4x4,3x3) for the deep layers (csrc/wino.hip): forward and data gradient ------------------------
     def setup_winograd(self):

@@ -126,6 +126,10 @@ typedef struct cp_conv_desc {
     /* optional grouped GEMM (the 36 Winograd planes in one launch): output pixels [g*group_rows, (g+1)*group_rows) use the
      * packed weights at weights + g*group_weight_stride floats.  group_rows must be a multiple of 128; 0 = ungrouped. */
     int group_rows, group_weight_stride;
+    /* optional, with a fused head: head_label_out[n,y,x] = arg-max over the first head_label_classes head channels of the pixel (uint8; first
+     * maximum wins, as cp_argmax_labels) -- the hard label map of pose_models.py:547-554 straight from the head's registers */
+    uint8_t* head_label_out;
+    int head_label_classes;
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,
