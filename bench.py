@@ -554,7 +554,10 @@ def main():
             pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe (opt-in conv mode), csrc/conv_hsplit.hip
             if hasattr(conv, "gemm_flops") and getattr(conv, "Us", None) is not None:
                 pipe = 3                                # Winograd GEMM as exact three-way splits (opt-in CASAPOSE_WINO_GEMM=split)
-            tile = (103 if pipe else 100) if hasattr(conv, "gemm_flops") else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
+            gemm1x1 = getattr(conv, "_gemm", None)   # 1x1 / stride-1 layer on the bf16-pipe GEMM (opt-in conv modes)
+            if gemm1x1 is not None:
+                pipe = 3
+            tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
             d_ = conv.desc
             t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS if pipe else PEAK_F32_MFMA_TFLOPS})
             direct_flops += conv.flops
@@ -571,6 +574,11 @@ def main():
                 wino["ms"] += whole_ms
                 wino["gemm_ms"] += gemm_ms
                 wino["replaced_flops"] += conv.flops
+                continue
+            if gemm1x1 is not None:
+                t["ms"] += timed(lambda: conv.run(stream))
+                t["flops"] += conv.flops * (6.0 if gemm1x1["planes"] == 3 else 3.0)
+                t["launches"] += 1
                 continue
             t["ms"] += timed(lambda: conv.run(stream))
             t["flops"] += conv.flops * (6.0 if pipe == 3 else 1.0)   # the exact split executes six bf16 products per fp32 product

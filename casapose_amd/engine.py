@@ -234,8 +234,31 @@ class FusedConv:
         self._keep = [k for k in keep if k is not None]
         return d.out_h, d.out_w
 
+    def enable_gemm_split(self, kernel_hwio: np.ndarray, planes: int) -> bool:
+        """1x1 / stride 1 / one source / plain output: the layer is a GEMM rows x cin x cout, which the bf16-pipe GEMM of the Winograd path
+        (csrc/wino_gemm_split.hip) computes as it is -- 3 planes exact split (fp32-equivalent), 2 planes hi + mid (the bf16 conv mode).
+        Called by the forward plan in the opt-in conv modes after bind(); False when the descriptor is outside that shape."""
+        d = self.desc
+        rows = d.batch * d.out_h * d.out_w
+        cin = self.sources[0][0]
+        ok = (self.kh == 1 and self.kw == 1 and d.stride == 1 and d.pad == 0 and d.num_sources == 1 and d.src[0].mode == _lib.SRC_DIRECT
+              and not d.src[0].pre_scale and d.src[0].ld == cin and self.sources[0][1] == cin and cin % 32 == 0 and rows % 128 == 0
+              and d.out_raw and d.out_raw_ld == self.cout and not d.out_act and not d.scale and not d.residual and not d.row_scale
+              and not d.tap_label and not d.head_out and d.act == 0)
+        if not ok:
+            return False
+        U = torch.from_numpy(np.ascontiguousarray(kernel_hwio.reshape(cin, self.cout).T[None])).to(torch.float32).to(self.wp.device if self.wp is not None else "cuda")
+        self._gemm = dict(Us=split_wino_weights(U, 1, self.cout, cin), rows=rows, k=cin, planes=planes)
+        return True
+
     def run(self, stream: int):
         lib = _lib.load()
+        g = getattr(self, "_gemm", None)
+        if g is not None:
+            d = self.desc
+            check(lib.cp_wino_gemm_split_planes_f32(d.src[0].data, g["Us"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["k"], self.cout, g["planes"], stream),
+                  "cp_wino_gemm_split_planes_f32(%s)" % self.name)
+            return
         if self.split_mode:
             if not lib.cp_conv_split_applicable(C.byref(self.desc)):
                 raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
@@ -452,6 +475,8 @@ class ForwardPlan:
             # 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside its range keep the fp32-MFMA kernels
             if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
                 layer.split_mode = net.conv_planes
+            elif net.conv_planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
+                layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), 3 if net.conv_planes == 3 else 2)
             self.convs.append(layer)
             self.steps.append(layer.run)
 
