@@ -37,7 +37,15 @@ class ConvSource(C.Structure):
 
 
 class ConvDesc(C.Structure):
+    """cp_conv_desc of include/casapose_hip.h, field for field (tests/test_capi_symbols.py parses the header and compares).  `struct_size` is
+    filled by the constructor; load() refuses a library whose sizeof(cp_conv_desc) differs from this declaration."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(ConvDesc)
+
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("batch", C.c_int),
         ("in_h", C.c_int),
         ("in_w", C.c_int),
@@ -77,6 +85,8 @@ class ConvDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 300  # CP_ABI_VERSION of include/casapose_hip.h
+
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO, TILE_STEM = range(9)
@@ -88,6 +98,8 @@ _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SYMBOLS = [
     ("cp_last_error", C.c_char_p, []),
     ("cp_version", _i, []),
+    ("cp_conv_desc_size", C.c_size_t, []),
+    ("cp_conv_source_size", C.c_size_t, []),
     ("cp_device_count", _i, []),
     ("cp_mfma_probe_workspace_bytes", C.c_size_t, []),
     ("cp_mfma_probe", _i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
@@ -146,8 +158,8 @@ SYMBOLS = [
     ("cp_bn_finalize_f32", _i, [_vp, C.c_double, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cp_bn_param_grads_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_affine_act_f32", _i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
-    ("cp_bn_act_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    ("cp_bn_act_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, _vp, _vp, _i, _i, _vp]),
+    ("cp_bn_act_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("cp_bn_act_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.c_double, _vp, _vp, _i, _i, _vp]),
     ("cp_maxpool3x3s2_bwd_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     ("cp_upsample_bilinear_x2_bwd_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_guided_upsample_x2_bwd_f32", _i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -180,6 +192,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    # ABI check: the descriptor grew between rounds; a library built from another revision of the header must not be handed this struct
+    if lib.cp_version() != ABI_VERSION or lib.cp_conv_desc_size() != C.sizeof(ConvDesc) or lib.cp_conv_source_size() != C.sizeof(ConvSource):
+        raise CasaposeHipError("%s has ABI %d with sizeof(cp_conv_desc) = %d, sizeof(cp_conv_source) = %d; this binding is ABI %d with %d / %d -- "
+                               "rebuild the library (python __graft_entry__.py)" % (LIB_PATH, lib.cp_version(), lib.cp_conv_desc_size(),
+                                                                                  lib.cp_conv_source_size(), ABI_VERSION, C.sizeof(ConvDesc), C.sizeof(ConvSource)))
     _lib = lib
     return lib
 

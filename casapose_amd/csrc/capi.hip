@@ -19,7 +19,9 @@ void set_error(const char* fmt, ...) {
 }  // namespace cp
 
 extern "C" const char* cp_last_error(void) { return g_last_error.c_str(); }
-extern "C" int cp_version(void) { return 100; }
+extern "C" int cp_version(void) { return CP_ABI_VERSION; }
+extern "C" size_t cp_conv_desc_size(void) { return sizeof(cp_conv_desc); }
+extern "C" size_t cp_conv_source_size(void) { return sizeof(cp_conv_source); }
 extern "C" int cp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

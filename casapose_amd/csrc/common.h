@@ -37,6 +37,13 @@ inline int check_launch(const char* what) {
         }                                \
     } while (0)
 
+// a descriptor built against another revision of the header (cp_conv_desc grew at its tail between rounds): refuse it by size
+#define CP_REQUIRE_DESC(d, fn)                                                                                                        \
+    CP_REQUIRE((d) && (d)->struct_size == (uint32_t)sizeof(cp_conv_desc),                                                             \
+               fn ": descriptor is null or its struct_size (%u) is not this library's sizeof(cp_conv_desc) = %u (ABI %d); rebuild the " \
+                  "caller against include/casapose_hip.h",                                                                           \
+               (d) ? (unsigned)(d)->struct_size : 0u, (unsigned)sizeof(cp_conv_desc), CP_ABI_VERSION)
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b, b+8, b+16, ... land on the same
 // XCD (observed dispatch, MI355X_MICROARCH.md), so give each XCD one contiguous run of
 // logical tiles to keep operand panels in that XCD's L2.  Speed only, never correctness.

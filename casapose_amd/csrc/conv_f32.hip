@@ -536,7 +536,7 @@ extern "C" int cp_conv_pack_weights_host(const float* w, int layout, int kh, int
 }
 
 extern "C" int cp_conv_selected_tile(const cp_conv_desc* d) {
-    if (!d) return CP_ERR_INVALID;
+    CP_REQUIRE_DESC(d, "cp_conv_selected_tile");
     if (d->tile_hint) return d->tile_hint;
     if (cp::stem_applicable(d)) return CP_TILE_STEM;
     if (cp::halo_applicable(d)) return CP_TILE_HALO;
@@ -570,7 +570,7 @@ extern "C" int cp_conv_pack_weights_halo_host(const float* w, int layout, int co
 }
 
 extern "C" int cp_conv2d_fwd_f32(const cp_conv_desc* d, void* stream) {
-    CP_REQUIRE(d, "cp_conv2d_fwd_f32: null descriptor");
+    CP_REQUIRE_DESC(d, "cp_conv2d_fwd_f32");
     CP_REQUIRE(d->num_sources == 1 || d->num_sources == 2, "cp_conv2d_fwd_f32: num_sources must be 1 or 2");
     CP_REQUIRE(d->kh * d->kw <= MAX_TAPS && d->kh > 0 && d->kw > 0, "cp_conv2d_fwd_f32: unsupported kernel %dx%d", d->kh, d->kw);
     CP_REQUIRE(d->stride >= 1 && d->dilation >= 1 && d->pad >= 0, "cp_conv2d_fwd_f32: bad stride/dilation/pad");

@@ -785,7 +785,7 @@ int split_fragments(int cout, int num_sources, const int* channels) {
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------------------
 extern "C" int cp_conv_split_applicable(const cp_conv_desc* d) {
-    if (!d) return 0;
+    if (!d || d->struct_size != (uint32_t)sizeof(cp_conv_desc)) return 0;   // another revision of the header: not ours to read
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return 0;
     if (d->cout > 512 || d->cout % 4 != 0 || d->group_rows) return 0;
     if (d->head_out && (d->cout != 32 || !d->head_weights || d->head_cout < 1 || d->head_cout > 32)) return 0;
@@ -894,8 +894,9 @@ extern "C" int cp_conv_pack_head_split_host(const float* w, int head_cout, float
 }
 
 extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_split, const void* head_weights_split, int planes, void* stream) {
-    CP_REQUIRE(d && weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_split: bad arguments");
-    CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 64, sources "
+    CP_REQUIRE_DESC(d, "cp_conv2d_fwd_split");
+    CP_REQUIRE(weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_split: bad arguments");
+    CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 512 and a multiple of 4, sources "
                                             "of 16-multiple channels + optional trailing 4-channel source; source 0 direct, bilinear x2 or guided x2)");
     CP_REQUIRE(d->out_raw || d->out_act || d->head_out, "cp_conv2d_fwd_split: no output");
     CP_REQUIRE(!d->head_out || head_weights_split, "cp_conv2d_fwd_split: a fused head needs its split weights");

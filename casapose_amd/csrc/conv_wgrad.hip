@@ -389,7 +389,8 @@ int launch_wgrad(WgK k, hipStream_t st) {
 }  // namespace
 
 static int wgrad_f32_impl(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, int first_chunk, void* stream) {
-    CP_REQUIRE(d && dy && dw_packed, "cp_conv2d_wgrad_f32: null pointer");
+    CP_REQUIRE_DESC(d, "cp_conv2d_wgrad_f32");
+    CP_REQUIRE(dy && dw_packed, "cp_conv2d_wgrad_f32: null pointer");
     CP_REQUIRE(d->num_sources == 1 || d->num_sources == 2, "cp_conv2d_wgrad_f32: num_sources must be 1 or 2");
     CP_REQUIRE(d->kh * d->kw <= MAX_TAPS && d->kh > 0 && d->kw > 0, "cp_conv2d_wgrad_f32: unsupported kernel %dx%d", d->kh, d->kw);
     CP_REQUIRE(d->stride >= 1 && d->dilation >= 1 && d->pad >= 0, "cp_conv2d_wgrad_f32: bad stride/dilation/pad");

@@ -583,7 +583,8 @@ int launch_shape(const WSplitK& k, hipStream_t st) {
 }
 
 bool applicable(const cp_conv_desc* d) {
-    if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return false;
+    if (!d || d->struct_size != (uint32_t)sizeof(cp_conv_desc)) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1 || d->pad != 1) return false;
     if (d->num_sources < 1 || d->num_sources > 2 || d->group_rows) return false;
     if (d->cout <= 0 || d->cout % 32) return false;
     if (d->out_h != d->in_h || d->out_w != d->in_w) return false;
@@ -607,7 +608,8 @@ bool applicable(const cp_conv_desc* d) {
 extern "C" int cp_conv_wgrad_split_applicable(const cp_conv_desc* d) { return applicable(d) ? 1 : 0; }
 
 extern "C" int cp_conv2d_wgrad_split(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, int planes, void* stream) {
-    CP_REQUIRE(d && dy && dw_packed, "cp_conv2d_wgrad_split: null pointer");
+    CP_REQUIRE_DESC(d, "cp_conv2d_wgrad_split");
+    CP_REQUIRE(dy && dw_packed, "cp_conv2d_wgrad_split: null pointer");
     CP_REQUIRE(planes == 1 || planes == 3, "cp_conv2d_wgrad_split: planes must be 3 (exact split) or 1 (bf16)");
     CP_REQUIRE(applicable(d), "cp_conv2d_wgrad_split: descriptor not covered (3x3 / stride 1 / pad 1, direct sources with 32-multiple channels + "
                               "an optional trailing 4-channel source, cout a multiple of 32); see cp_conv_wgrad_split_applicable");

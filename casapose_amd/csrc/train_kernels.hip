@@ -78,8 +78,9 @@ __global__ void affine_act_kernel(const float* __restrict__ x, long long pixels,
         const float4 s = *reinterpret_cast<const float4*>(scale + (size_t)l * C + c4 * 4);
         const float4 b = *reinterpret_cast<const float4*>(shift + (size_t)l * C + c4 * 4);
         float4 o;
-        o.x = act_fwd(v.x * s.x + b.x, act); o.y = act_fwd(v.y * s.y + b.y, act);
-        o.z = act_fwd(v.z * s.z + b.z, act); o.w = act_fwd(v.w * s.w + b.w, act);
+        // one explicit fused multiply-add per element: the backward kernels repeat exactly this expression to decide the activation's branch
+        o.x = act_fwd(__builtin_fmaf(v.x, s.x, b.x), act); o.y = act_fwd(__builtin_fmaf(v.y, s.y, b.y), act);
+        o.z = act_fwd(__builtin_fmaf(v.z, s.z, b.z), act); o.w = act_fwd(__builtin_fmaf(v.w, s.w, b.w), act);
         *reinterpret_cast<float4*>(y + r * ld_y + c4 * 4) = o;
     }
 }
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
                                                                     long long pixels, int C, int classes, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const uint8_t* __restrict__ labels,
-                                                                    int act, double* __restrict__ red, double* __restrict__ chan) {
+                                                                    int act, const float* __restrict__ fscale, const float* __restrict__ fshift,
+                                                                    double* __restrict__ red, double* __restrict__ chan) {
     extern __shared__ double sred[];  // [classes*C*2] + [C*2]
     const int nred = classes * C * 2, nch = C * 2;
     for (int i = threadIdx.x; i < nred + nch; i += THREADS) sred[i] = 0.0;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
         int cur = -1;
         double a[4][4];  // per channel: g, g*xhat, g*gamma, g*gamma*xhat for the current label
         float4 gm = make_float4(1, 1, 1, 1), bt = make_float4(0, 0, 0, 0);
+        float4 fs = make_float4(0, 0, 0, 0), fb = make_float4(0, 0, 0, 0);   // the forward's folded table row (branch decision)
         auto flush = [&]() {
             if (cur < 0) return;
 #pragma unroll
@@ -133,16 +136,23 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
                 for (int e = 0; e < 4; ++e) a[e][0] = a[e][1] = a[e][2] = a[e][3] = 0.0;
                 gm = gamma ? *reinterpret_cast<const float4*>(gamma + (size_t)l * C + c4 * 4) : make_float4(1, 1, 1, 1);
                 bt = beta ? *reinterpret_cast<const float4*>(beta + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+                if (fscale) {
+                    fs = *reinterpret_cast<const float4*>(fscale + (size_t)l * C + c4 * 4);
+                    fb = *reinterpret_cast<const float4*>(fshift + (size_t)l * C + c4 * 4);
+                }
             }
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
             const float4 dv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c4 * 4);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
             const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
             const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+            const float fss[4] = {fs.x, fs.y, fs.z, fs.w}, fbs[4] = {fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (xs[e] - mus[e]) * rss[e];
-                const float g = ds[e] * act_grad(gms[e] * xh + bts[e], act);
+                // the branch the FORWARD took (affine_act_kernel's own expression) when its tables are given, else recomputed from gamma / beta
+                const float t = fscale ? __builtin_fmaf(xs[e], fss[e], fbs[e]) : gms[e] * xh + bts[e];
+                const float g = ds[e] * act_grad(t, act);
                 a[e][0] += g;
                 a[e][1] += (double)g * xh;
                 a[e][2] += (double)g * gms[e];
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
 __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy, long long pixels, int C,
                                         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, const uint8_t* __restrict__ labels, int act,
+                                        const float* __restrict__ fscale, const float* __restrict__ fshift,
                                         const double* __restrict__ chan, double inv_n, const float* __restrict__ row_scale,
                                         float* __restrict__ dx, int ld_dx, int accumulate) {
     const int c4n = C >> 2;
@@ -179,12 +190,16 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ x, int ld_x, c
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
         const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
         const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+        const float4 fs = fscale ? *reinterpret_cast<const float4*>(fscale + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float4 fb = fscale ? *reinterpret_cast<const float4*>(fshift + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float fss[4] = {fs.x, fs.y, fs.z, fs.w}, fbs[4] = {fb.x, fb.y, fb.z, fb.w};
         float o[4];
         const float rsc = row_scale ? row_scale[r] : 1.f;  // partial convolution: the normalised tensor was rowscale * conv
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (xs[e] - mus[e]) * rss[e];
-            const float g = ds[e] * act_grad(gms[e] * xh + bts[e], act) * gms[e];
+            const float t = fscale ? __builtin_fmaf(xs[e], fss[e], fbs[e]) : gms[e] * xh + bts[e];   // same branch as the forward and the reduce pass
+            const float g = ds[e] * act_grad(t, act) * gms[e];
             const float m1 = (float)(chan[(c4 * 4 + e) * 2 + 0] * inv_n), m2 = (float)(chan[(c4 * 4 + e) * 2 + 1] * inv_n);
             o[e] = rss[e] * (g - m1 - xh * m2) * rsc;
         }
@@ -468,8 +483,9 @@ extern "C" int cp_affine_act_f32(const float* x, long long pixels, int channels,
 
 extern "C" int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, int classes,
                                         const float* mean, const float* rstd, const float* gamma, const float* beta, const uint8_t* labels,
-                                        int act, double* red, double* chan, void* stream) {
+                                        int act, const float* fwd_scale, const float* fwd_shift, double* red, double* chan, void* stream) {
     CP_REQUIRE(x && dy && mean && rstd && red && chan && pixels > 0, "cp_bn_act_bwd_reduce_f32: null pointer");
+    CP_REQUIRE((fwd_scale == nullptr) == (fwd_shift == nullptr), "cp_bn_act_bwd_reduce_f32: fwd_scale and fwd_shift come together");
     CP_REQUIRE(channels % 4 == 0 && channels <= 1024 && classes >= 1 && classes <= 64, "cp_bn_act_bwd_reduce_f32: channels %% 4, classes <= 64");
     CP_REQUIRE(classes == 1 || labels, "cp_bn_act_bwd_reduce_f32: class-adaptive form needs labels");
     hipStream_t st = (hipStream_t)stream;
@@ -488,16 +504,18 @@ extern "C" int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* d
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     CP_LAUNCH(bn_act_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, x, ld_x, dy, ld_dy, pixels, channels, classes, mean, rstd,
-              gamma, beta, labels, act, red, chan);
+              gamma, beta, labels, act, fwd_scale, fwd_shift, red, chan);
     return cp::check_launch("cp_bn_act_bwd_reduce_f32");
 }
 
 extern "C" int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, const float* mean,
                                        const float* rstd, const float* gamma, const float* beta, const uint8_t* labels, int act,
+                                       const float* fwd_scale, const float* fwd_shift,
                                        const double* chan, double global_pixels, const float* row_scale, float* dx, int ld_dx, int accumulate, void* stream) {
     CP_REQUIRE(x && dy && mean && rstd && chan && dx && pixels > 0 && channels % 4 == 0 && global_pixels > 0, "cp_bn_act_bwd_apply_f32: bad arguments");
+    CP_REQUIRE((fwd_scale == nullptr) == (fwd_shift == nullptr), "cp_bn_act_bwd_apply_f32: fwd_scale and fwd_shift come together");
     CP_LAUNCH(bn_act_bwd_apply_kernel, dim3(grid_for(pixels * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, ld_x, dy, ld_dy, pixels,
-              channels, mean, rstd, gamma, beta, labels, act, chan, 1.0 / global_pixels, row_scale, dx, ld_dx, accumulate);
+              channels, mean, rstd, gamma, beta, labels, act, fwd_scale, fwd_shift, chan, 1.0 / global_pixels, row_scale, dx, ld_dx, accumulate);
     return cp::check_launch("cp_bn_act_bwd_apply_f32");
 }
 

@@ -143,6 +143,7 @@ class FusedConv:
         self._keep: List[torch.Tensor] = []
         self.head_w: Optional[torch.Tensor] = None
         self.head_cout = 0
+        self._gemm: Optional[dict] = None   # set by enable_gemm_split() for the CURRENT binding only
 
     def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
         """bf16 planes of the weights for cp_conv2d_fwd_split (made once per mode; refresh=True after the fp32 image changed)."""
@@ -183,6 +184,7 @@ class FusedConv:
              out_act=None, out_act_ld=None, tile_hint=0, head_out=None, head_out_ld=0, head_label_out=None, head_label_classes=0):
         """srcs: list of dicts(data=tensor, ld=int, mode=int, sel=tensor|None, pre=(scale,shift)|None)."""
         d = self.desc
+        self._gemm = None   # a GEMM route decided for an earlier shape must not survive a re-bind (rows would be stale: out-of-bounds launch)
         eh = (self.kh - 1) * dilation + 1
         ew = (self.kw - 1) * dilation + 1
         d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -245,6 +247,7 @@ class FusedConv:
               and not d.src[0].pre_scale and d.src[0].ld == cin and self.sources[0][1] == cin and cin % 32 == 0 and rows % 128 == 0
               and d.out_raw and d.out_raw_ld == self.cout and not d.out_act and not d.scale and not d.residual and not d.row_scale
               and not d.tap_label and not d.head_out and d.act == 0)
+        self._gemm = None
         if not ok:
             return False
         U = torch.from_numpy(np.ascontiguousarray(kernel_hwio.reshape(cin, self.cout).T[None])).to(torch.float32).to(self.wp.device if self.wp is not None else "cuda")
@@ -253,9 +256,10 @@ class FusedConv:
 
     def run(self, stream: int):
         lib = _lib.load()
-        g = getattr(self, "_gemm", None)
+        g = self._gemm
         if g is not None:
             d = self.desc
+            assert g["rows"] == d.batch * d.out_h * d.out_w, "%s: GEMM route bound for another shape" % self.name
             check(lib.cp_wino_gemm_split_planes_f32(d.src[0].data, g["Us"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["k"], self.cout, g["planes"], stream),
                   "cp_wino_gemm_split_planes_f32(%s)" % self.name)
             return
@@ -362,7 +366,8 @@ class WinoConv:
         """[(first image, images, padded tiles)]: the batch is processed in groups of WINO_CHUNK images so that the two scratch tensors
         of a group (V: 36*Tp*K, M: 36*Tp*Cout floats -- 2.25x the layer's input and output) stay resident in the 256 MiB Infinity Cache
         between the input transform, the GEMM and the output transform instead of making two round trips to HBM each."""
-        n = WINO_CHUNK if 0 < WINO_CHUNK < self.batch else self.batch
+        # the grouped mode of the general kernel reads desc.group_rows = the whole batch's Tp: chunking does not apply to it
+        n = WINO_CHUNK if 0 < WINO_CHUNK < self.batch and not WINO_GROUPED_CONV else self.batch
         return [(b0, min(n, self.batch - b0), self.tiles(min(n, self.batch - b0), self.h, self.w, self.dil)[1]) for b0 in range(0, self.batch, n)]
 
     def run(self, stream: int):
@@ -471,7 +476,7 @@ class ForwardPlan:
                 self.steps.append(wl.run)
                 return
             layer.bind(batch=B, **kw)
-            # opt-in (CASAPOSE_CONV_MODE / CasaposeNet(conv_mode=...)): the shallow 3x3 layers on the bf16 matrix pipe (csrc/conv_hsplit.hip),
+            # opt-in (CASAPOSE_INFER_CONV_MODE / CasaposeNet(conv_mode=...)): the shallow 3x3 layers on the bf16 matrix pipe (csrc/conv_hsplit.hip),
             # 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside its range keep the fp32-MFMA kernels
             if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
                 layer.split_mode = net.conv_planes

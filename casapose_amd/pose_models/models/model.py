@@ -225,7 +225,7 @@ class CasaposeModel:
     def save_weights(self, path: str):
         """`net.save_weights(frozen_path + "/result_w.h5")` (train_casapose.py:903): a path ending in .h5 / .hdf5 / .keras gets a
         real HDF5 file with Keras' group tree, dataset names and `layer_names` / `weight_names` attributes
-        (utils/h5_weights.write_keras_h5), readable by Keras' load_weights(by_name=True) and by load_weights() below; any other
+        (utils/h5_weights.write_keras_h5), laid out for Keras' load_weights(by_name=True) (variable order of the nested backbone as derived in h5_weights.keras_backbone_layer_order; not verifiable without Keras here) and read by load_weights() below; any other
         extension stores the '<layer>.<field>' -> array mapping as .npz."""
         self._sync_from_store()
         if str(path).lower().endswith((".h5", ".hdf5", ".keras")):

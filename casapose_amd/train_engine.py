@@ -710,12 +710,13 @@ class BnActOp:
         assert y.has_grad, "gradient of %s output not produced" % self.name
         gam, bet = self.gamma_full.data_ptr(), self.beta_full.data_ptr()
         check(lib.cp_bn_act_bwd_reduce_f32(x.data.data_ptr(), C_, y.grad.data_ptr(), C_, x.pixels, C_, self.classes, self.mean.data_ptr(),
-                                           self.rstd.data_ptr(), gam, bet, _ptr(self.labels), self.act, self.red.data_ptr(), self.chan.data_ptr(),
-                                           stream), "cp_bn_act_bwd_reduce_f32(%s)" % self.name)
+                                           self.rstd.data_ptr(), gam, bet, _ptr(self.labels), self.act, self.scale.data_ptr(), self.shift.data_ptr(),
+                                           self.red.data_ptr(), self.chan.data_ptr(), stream), "cp_bn_act_bwd_reduce_f32(%s)" % self.name)
         n = p.all_reduce_stats(self.chan, x.pixels)
         if x.needs_grad:
             check(lib.cp_bn_act_bwd_apply_f32(x.data.data_ptr(), C_, y.grad.data_ptr(), C_, x.pixels, C_, self.mean.data_ptr(), self.rstd.data_ptr(),
-                                              gam, bet, _ptr(self.labels), self.act, self.chan.data_ptr(), float(n), _ptr(self.row_scale),
+                                              gam, bet, _ptr(self.labels), self.act, self.scale.data_ptr(), self.shift.data_ptr(), self.chan.data_ptr(),
+                                              float(n), _ptr(self.row_scale),
                                               x.grad.data_ptr(), C_, 1 if x.has_grad else 0, stream), "cp_bn_act_bwd_apply_f32(%s)" % self.name)
             x.has_grad = True
         if self.dgamma_p is not None or self.dbeta_p is not None:
@@ -1028,6 +1029,13 @@ class TrainPlan:
         for t in self.taps.values():
             seen[id(t)] = t
         return list(seen.values())
+
+    def activation_pattern(self) -> Dict[str, torch.Tensor]:
+        """{normalisation layer name: bool tensor} -- the branch every ReLU / leaky pair took in the last forward (the sign of its output).
+        The backward differentiates exactly this piecewise-linear function (cp_bn_act_bwd_* decide the branch with the forward's own
+        expression); the gradient tests hand the pattern to the fp64 oracle so that elements sitting within rounding of a kink do not
+        count as gradient error."""
+        return {op.name: (op.y.data > 0).cpu() for op in self.ops if isinstance(op, BnActOp) and op.act != _lib.ACT_NONE}
 
     # ---- distributed hooks ---------------------------------------------------------------------------
     def all_reduce_stats(self, table: torch.Tensor, local_pixels: int) -> int:

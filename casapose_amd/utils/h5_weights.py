@@ -393,16 +393,40 @@ def is_backbone_layer(layer: str) -> bool:
     return layer == "conv0" or layer.startswith(("bn_data", "bn0", "bn1", "stage"))
 
 
+def keras_backbone_layer_order() -> List[str]:
+    """The weighted layers of the nested ResNet-18 model in the order of Keras' `model.layers` -- which is what orders `model.weights` and
+    therefore the nested group's `weight_names`.  A functional model sorts its layers by DEPTH (longest path to an output, deepest first)
+    and breaks ties by the order in which a walk from the outputs first meets them (keras/engine/functional.py, `_map_graph_network` /
+    `_build_map_helper`).  Along the residual chain (resnet.py:78-110) that gives bn1, conv1, bn2, conv2 per unit; the 1x1 shortcut of a
+    `cut="post"` unit sits at the same depth as conv2 (both feed the Add) and is met after it, because Add lists `[x, shortcut]`
+    (resnet.py:110).  Not verifiable here (no Keras): tools/make_tf_goldens.py stores what Keras reads back from a file written with
+    this order."""
+    order = ["bn_data", "conv0", "bn0"]
+    for s in range(1, 5):
+        for u in range(1, 3):
+            base = "stage%d_unit%d_" % (s, u)
+            order += [base + "bn1", base + "conv1", base + "bn2", base + "conv2"] + ([base + "sc"] if u == 1 else [])
+    return order + ["bn1"]
+
+
 def keras_layout(params: Dict[str, np.ndarray], backbone_group: str = BACKBONE_GROUP):
     """(datasets, attrs) of the file Keras' `save_weights` writes for a model holding `params` ('<layer>.<field>' keys):
     top-level layers are groups `<layer>` whose datasets are named by the variable (`<layer>/<field>:0`, custom layers prefixing
     the field with the layer name), the nested backbone model is ONE top-level layer whose variables keep their own layer scope
-    (`model/conv0/kernel:0`), the CLADE layer's moving statistics live in its inner `sync_batch_normalization_<n>` scope."""
+    (`model/conv0/kernel:0`), the CLADE layer's moving statistics live in its inner `sync_batch_normalization[_<n>]` scope (Keras'
+    automatic names: the first unnamed layer of a class carries no suffix, the n-th `_<n-1>`).
+    ORDER of `weight_names` inside a group: Keras' HDF5 saver lists `layer.trainable_weights + layer.non_trainable_weights` and
+    `load_weights(by_name=True)` zips that list POSITIONALLY with the layer's variables.  For an ordinary layer this is its creation
+    order; for the nested backbone model it means ALL trainable variables in layer order (kernels, gamma, beta) and then all moving
+    statistics -- interleaving them per layer would load statistics into the wrong variables, or be skipped on a shape mismatch."""
     layers: Dict[str, List[str]] = {}
     for k in params:
         layers.setdefault(k.split(".")[0], []).append(k)
+    rank = {n: i for i, n in enumerate(keras_backbone_layer_order())}
+    layers = dict(sorted(layers.items(), key=lambda kv: rank.get(kv[0], len(rank))))   # stable: the other layers keep their order
     datasets: Dict[str, np.ndarray] = {}
     weight_names: Dict[str, List[bytes]] = {}
+    non_trainable: Dict[str, List[bytes]] = {}
     top_order: List[str] = []
     inner_bn = 0
     for layer, keys in layers.items():
@@ -419,13 +443,16 @@ def keras_layout(params: Dict[str, np.ndarray], backbone_group: str = BACKBONE_G
             if clade and field in ("gamma", "beta"):
                 var = "%s/%s_%s:0" % (layer, layer, field)
             elif clade:
-                var = "%s/sync_batch_normalization_%d/%s:0" % (layer, inner_bn, field)
+                var = "%s/sync_batch_normalization%s/%s:0" % (layer, "" if inner_bn == 1 else "_%d" % (inner_bn - 1), field)
             elif field == "weights":
                 var = "%s/%s_weights:0" % (layer, layer)
             else:
                 var = "%s/%s:0" % (layer, field)
-            weight_names.setdefault(top, []).append(var.encode())
+            moving = field in ("moving_mean", "moving_variance")
+            (non_trainable if moving else weight_names).setdefault(top, []).append(var.encode())
             datasets["%s/%s" % (top, var)] = params[k]
+    for top in top_order:   # trainable variables first, then the non-trainable ones (see ORDER above)
+        weight_names[top] = weight_names.get(top, []) + non_trainable.get(top, [])
     attrs: Dict[str, Dict[str, object]] = {"": {"layer_names": [t.encode() for t in top_order], "backend": b"tensorflow",
                                                 "keras_version": b"2.9.0"}}
     for top, names in weight_names.items():

@@ -56,37 +56,66 @@ class ExponentialDecayLateStart:
 
 
 class LossWeightHandler:
-    """Loss weights with a multiplicative per-epoch update clamped to [lo, hi] borders."""
+    """The four loss weights of compute_loss (mask, vertex, proxy, kp) with a per-epoch multiplicative schedule: update() multiplies
+    each weight by its factor and clips it into its [low, high] border pair.  Interface of the reference's object
+    (learning_rate_schedules.py:62-115: positional order and keyword names of the constructor, the attributes `<term>_loss_weight`,
+    `<term>_loss_factor`, `<term>_loss_borders`, the two filter flags read by compute_loss, update(), clamp(), print()); the state lives in
+    one table keyed by term instead of fourteen hand-written attributes."""
 
-    def __init__(self, mask_loss_weight=1.0, vertex_loss_weight=1.0, proxy_loss_weight=0.01, kp_loss_weight=1.0,
-                 mask_loss_factor=1.0, vertex_loss_factor=1.0, proxy_loss_factor=1.0, kp_loss_factor=1.0,
-                 mask_loss_borders=(0.0, 2.5), vertex_loss_borders=(0.000, 10.0), proxy_loss_borders=(0.000, 0.025),
-                 kp_loss_borders=(0.0, 2.5), filter_vertex_with_segmentation=False, filter_high_proxy_errors=False):
-        self.mask_loss_weight = mask_loss_weight
-        self.vertex_loss_weight = vertex_loss_weight
-        self.proxy_loss_weight = proxy_loss_weight
-        self.kp_loss_weight = kp_loss_weight
-        self.mask_loss_factor = mask_loss_factor
-        self.vertex_loss_factor = vertex_loss_factor
-        self.proxy_loss_factor = proxy_loss_factor
-        self.kp_loss_factor = kp_loss_factor
-        self.mask_loss_borders = mask_loss_borders
-        self.vertex_loss_borders = vertex_loss_borders
-        self.proxy_loss_borders = proxy_loss_borders
-        self.kp_loss_borders = kp_loss_borders
-        self.filter_vertex_with_segmentation = filter_vertex_with_segmentation
-        self.filter_high_proxy_errors = filter_high_proxy_errors
+    TERMS = ("mask", "vertex", "proxy", "kp")
+    _DEFAULT_WEIGHT = {"mask": 1.0, "vertex": 1.0, "proxy": 0.01, "kp": 1.0}
+    _DEFAULT_BORDERS = {"mask": (0.0, 2.5), "vertex": (0.0, 10.0), "proxy": (0.0, 0.025), "kp": (0.0, 2.5)}
+    _FIELDS = ("weight", "factor", "borders")
+
+    def __init__(self, *args, filter_vertex_with_segmentation=False, filter_high_proxy_errors=False, **kw):
+        # positional order of the reference: 4 weights, 4 factors, 4 border pairs, then the two flags
+        names = ["%s_loss_%s" % (t, f) for f in self._FIELDS for t in self.TERMS] + ["filter_vertex_with_segmentation", "filter_high_proxy_errors"]
+        if len(args) > len(names):
+            raise TypeError("LossWeightHandler takes at most %d positional arguments (%d given)" % (len(names), len(args)))
+        for n, v in zip(names, args):
+            if n in kw:
+                raise TypeError("LossWeightHandler got multiple values for argument %r" % n)
+            kw[n] = v
+        self.filter_vertex_with_segmentation = kw.pop("filter_vertex_with_segmentation", filter_vertex_with_segmentation)
+        self.filter_high_proxy_errors = kw.pop("filter_high_proxy_errors", filter_high_proxy_errors)
+        self._state = {}
+        for t in self.TERMS:
+            self._state[t] = {"weight": kw.pop(t + "_loss_weight", self._DEFAULT_WEIGHT[t]), "factor": kw.pop(t + "_loss_factor", 1.0),
+                              "borders": kw.pop(t + "_loss_borders", self._DEFAULT_BORDERS[t])}
+        if kw:
+            raise TypeError("LossWeightHandler got an unexpected keyword argument %r" % sorted(kw)[0])
+
+    # `<term>_loss_<field>` attributes resolve into the table (read and write)
+    @classmethod
+    def _split(cls, name):
+        for t in cls.TERMS:
+            for f in cls._FIELDS:
+                if name == "%s_loss_%s" % (t, f):
+                    return t, f
+        return None
+
+    def __getattr__(self, name):
+        key = None if name.startswith("_") else self._split(name)
+        if key is None:
+            raise AttributeError(name)
+        return self._state[key[0]][key[1]]
+
+    def __setattr__(self, name, value):
+        key = None if name.startswith("_") else self._split(name)
+        if key is None:
+            object.__setattr__(self, name, value)
+        else:
+            self._state[key[0]][key[1]] = value
 
     @staticmethod
     def clamp(n, min_max):
-        return max(min_max[0], min(n, min_max[1]))
+        lo, hi = min_max
+        return max(lo, min(n, hi))
 
     def update(self):
-        self.mask_loss_weight = self.clamp(self.mask_loss_weight * self.mask_loss_factor, self.mask_loss_borders)
-        self.vertex_loss_weight = self.clamp(self.vertex_loss_weight * self.vertex_loss_factor, self.vertex_loss_borders)
-        self.proxy_loss_weight = self.clamp(self.proxy_loss_weight * self.proxy_loss_factor, self.proxy_loss_borders)
-        self.kp_loss_weight = self.clamp(self.kp_loss_weight * self.kp_loss_factor, self.kp_loss_borders)
+        for st in self._state.values():
+            st["weight"] = self.clamp(st["weight"] * st["factor"], st["borders"])
 
     def print(self, print_fn=print):
-        print_fn("==Mask loss weight: {} , vertex loss weight: {} , proxy loss weight: {} , keypoint loss weight: {}==".format(
-            self.mask_loss_weight, self.vertex_loss_weight, self.proxy_loss_weight, self.kp_loss_weight))
+        w = [self._state[t]["weight"] for t in self.TERMS]
+        print_fn("==Mask loss weight: {} , vertex loss weight: {} , proxy loss weight: {} , keypoint loss weight: {}==".format(*w))

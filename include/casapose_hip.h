@@ -34,7 +34,14 @@ typedef enum cp_status {
 } cp_status;
 
 const char* cp_last_error(void);
+/* ABI version of the library: CP_ABI_VERSION of the header it was built from.  300 (round 3): cp_conv_desc starts with `struct_size`
+ * and every entry point that takes a descriptor refuses one whose struct_size differs from the library's sizeof(cp_conv_desc)
+ * (CP_ERR_INVALID, message in cp_last_error()) instead of reading fields a shorter or longer caller-side struct does not have. */
+#define CP_ABI_VERSION 300
 int cp_version(void);
+/* sizeof(cp_conv_desc) / sizeof(cp_conv_source) as this library was compiled: a binder checks them against its own declaration at load time */
+size_t cp_conv_desc_size(void);
+size_t cp_conv_source_size(void);
 /* number of visible gfx950 devices (0 on a CPU-only host); never initialises a context */
 int cp_device_count(void);
 /* Matrix-pipe probe (measurement aid, bench.py): one launch of a bare MFMA stream on every SIMD -- which = 0: v_mfma_f32_32x32x2_f32,
@@ -94,6 +101,7 @@ typedef struct cp_conv_source {
 } cp_conv_source;
 
 typedef struct cp_conv_desc {
+    uint32_t struct_size;       /* = sizeof(cp_conv_desc) of the header the CALLER was built against; checked by every entry point */
     int batch, in_h, in_w;      /* conv-input grid (after any fused x2 upsampling)           */
     int out_h, out_w, cout;
     int kh, kw, stride, dilation, pad;
@@ -160,7 +168,7 @@ int cp_conv_selected_tile(const cp_conv_desc* desc);
 
 /* ------------------------------------------------------------------------------------
  * The same convolution on the bf16 matrix pipe (csrc/conv_hsplit.hip), for the shallow high-resolution layers: 3x3 / stride 1 /
- * pad 1, cout <= 64, sources with 16-multiple channels plus an optional trailing 4-channel source (the image); source 0 may be
+ * pad 1, cout <= 512 (a multiple of 4; channels beyond 64 in passes of 64), sources with 16-multiple channels plus an optional trailing 4-channel source (the image); source 0 may be
  * CP_SRC_BILINEAR_X2 or (with tap_label) CP_SRC_NEAREST_SEL, the fused upsamplings of the decoders; a fused 1x1 head as in cp_conv2d_fwd_f32.
  * Replaces the same reference call sites as cp_conv2d_fwd_f32 for those layers (models/casapose.py:61-82, resnet.py:97-103 stage 1).
  *   planes = 3: fp32-EQUIVALENT -- every fp32 operand is split exactly into three bf16 terms and six bf16 products are accumulated in fp32
@@ -401,16 +409,20 @@ int cp_affine_act_f32(const float* x, long long pixels, int channels, int ld_x, 
  *   red[(l*C+c)*2 + {0,1}] = sum_p {g, g*xhat}           (g = dy*act')  -> d beta[l][c], d gamma[l][c]
  *   chan[c*2 + {0,1}]      = sum_p {g*gamma, g*gamma*xhat}                -> the two batch means of pass 2
  * (fp64, zeroed by the call; gamma/beta may be null = 1/0; classes = 1 without labels).  The caller
- * all-reduces `chan` across replicas for SyncBN. */
+ * all-reduces `chan` across replicas for SyncBN.
+ * fwd_scale / fwd_shift (optional, [classes][channels], both or neither): the folded tables the forward's cp_affine_act_f32 was called
+ * with.  When given, act' is evaluated at the forward's own pre-activation fma(x, scale, shift) -- the branch of every ReLU / leaky pair is
+ * then bit-for-bit the one the forward took, so the result is the exact gradient of the piecewise-linear function the forward evaluated
+ * (recomputing gamma*xhat + beta rounds differently and flips elements that sit within an ulp of zero). */
 int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, int classes,
                              const float* mean, const float* rstd, const float* gamma, const float* beta, const uint8_t* labels,
-                             int act, double* red, double* chan, void* stream);
+                             int act, const float* fwd_scale, const float* fwd_shift, double* red, double* chan, void* stream);
 /* pass 2: dx = rstd*(g*gamma - chan[c][0]/N - xhat*chan[c][1]/N) * (row_scale ? row_scale[p] : 1),
  * N = global_pixels (all replicas); accumulate != 0 adds to dx (a tensor with several consumers). */
 int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int channels, const float* mean,
                             const float* rstd, const float* gamma, const float* beta, const uint8_t* labels, int act,
-                            const double* chan, double global_pixels, const float* row_scale, float* dx, int ld_dx, int accumulate,
-                            void* stream);
+                            const float* fwd_scale, const float* fwd_shift, const double* chan, double global_pixels, const float* row_scale,
+                            float* dx, int ld_dx, int accumulate, void* stream);
 
 /* Adjoints of MaxPooling2D(3, strides 2) after ZeroPadding2D(1) (resnet.py:252-253), UpSampling2D(bilinear)
  * (casapose.py:135-140) and the GuidedUpsampling gather (_normalization_layers.py:554-558).  Gather form

@@ -153,13 +153,28 @@ def batchnorm_inference(x, gamma, beta, mean, var):
 
 def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optional[torch.Tensor], stats_out: Optional[dict] = None,
                   partial=(True,) * 5, guided=(False, True, True, True, False), bilinear=(False,) * 5, pvnet: bool = False,
-                  shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True, training: bool = True):
+                  shared=(False,) * 5, reuse_first: bool = False, skips2: bool = True, training: bool = True,
+                  act_pattern: Optional[dict] = None, preact_out: Optional[dict] = None):
     """casapose_c_gcu5 (or a sibling: per decoder-2 block `partial` convolution / `guided` upsampling flags, else an ordinary
     convolution / plain nearest upsampling; pose_models.py:14-635) with training=True and decoder 2 conditioned on the given
     hard label map (the `data_segmentation` input of config_8.ini:71; pose_models.py:550-554).  Returns [B,H,W,K+ver_dim].
     training=False normalises with the moving statistics (the inference graph); labels=None conditions decoder 2 on the arg-max of
     the network's own logits (the estimated mask of pose_models.py:548-549, README.md:74-80).  That combination, in fp32 on all
-    host cores, is the CPU baseline `bench.py` times beside the GPU."""
+    host cores, is the CPU baseline `bench.py` times beside the GPU.
+
+    Kink analysis of the gradient tests: `preact_out` (dict) receives the input of every ReLU / leaky pair under the normalisation
+    layer's name; `act_pattern` {layer name: bool tensor} REPLACES the branch decision z > 0 of those activations by a given pattern
+    (relu(z) -> z*m, leaky(z) -> z*(m + 0.1(1-m))).  A device forward in fp32 takes the other branch at the few elements whose
+    pre-activation is within rounding of zero; the gradient it must then produce is the fp64 gradient of the network WITH ITS pattern,
+    and the forward value changes by at most 1.1|z| at those elements."""
+
+    def act(name, z, leaky):
+        if preact_out is not None:
+            preact_out[name] = z.detach()
+        if act_pattern is not None and name in act_pattern:
+            m = act_pattern[name].to(z.dtype)
+            return z * (m + 0.1 * (1.0 - m)) if leaky else z * m
+        return leaky_pair(z) if leaky else F.relu(z)
 
     def bn(name, x):
         if not training:
@@ -168,7 +183,7 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optiona
 
     x = bn("bn_data", img)
     x = conv_nhwc(x, p["conv0.kernel"], stride=2, pad=3)
-    x2s = F.relu(bn("bn0", x))
+    x2s = act("bn0", bn("bn0", x), False)
     x = maxpool_zero_pad(x2s)
     taps = []
     for s in range(4):
@@ -176,15 +191,15 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optiona
         for u in range(2):
             base = "stage%d_unit%d_" % (s + 1, u + 1)
             stride = STAGE_STRIDE[s] if u == 0 else 1
-            a = F.relu(bn(base + "bn1", x))
+            a = act(base + "bn1", bn(base + "bn1", x), False)
             shortcut = conv_nhwc(a, p[base + "sc.kernel"], stride=stride) if u == 0 else x
             y = conv_nhwc(a, p[base + "conv1.kernel"], stride=stride, dilation=d, pad=d)
-            y = F.relu(bn(base + "bn2", y))
+            y = act(base + "bn2", bn(base + "bn2", y), False)
             y = conv_nhwc(y, p[base + "conv2.kernel"], dilation=d, pad=d)
             x = y + shortcut
             if u == 0 and s > 0:
                 taps.append(a)
-    x32s = F.relu(bn("bn1", x))
+    x32s = act("bn1", bn("bn1", x), False)
     x4s, x8s, _x16s = taps
     skips = [None, x8s, x4s, x2s, img]
     d1 = None
@@ -197,8 +212,7 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optiona
             y = conv_nhwc(inp, p[n + "_conv2d.kernel"], pad=1)
         if i == 0:
             y_raw = y
-        y = bn(n + "_bn", y)
-        y = F.relu(y) if i == 0 else leaky_pair(y)
+        y = act(n + "_bn", bn(n + "_bn", y), i != 0)
         if 0 < i < 4:
             y = bilinear_x2(y)
         d1 = y
@@ -228,7 +242,7 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optiona
         else:
             y = batchnorm_inference(y, None, None, p[n + "_clade.moving_mean"], p[n + "_clade.moving_variance"])
             y = p[n + "_clade.gamma"][lab.to(torch.int64)] * y + p[n + "_clade.beta"][lab.to(torch.int64)]
-        y = F.relu(y) if i == 0 else leaky_pair(y)
+        y = act(n + "_clade", y, i != 0)
         if 0 < i < 4:
             if guided[i] and bilinear[i]:
                 y = guided_bilinear_upsample(y, lab, labs[lvl[i] - 1])
@@ -239,6 +253,21 @@ def forward_train(p: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optiona
         d2 = y
     vertex = conv_nhwc(d2, p["pv_final_conv_vertex.kernel"])
     return torch.cat([logits, vertex], dim=3)
+
+
+def kink_report(pattern: Dict[str, torch.Tensor], preact: Dict[str, torch.Tensor]):
+    """(elements whose branch in `pattern` differs from the sign of the fp64 pre-activation, elements in all, largest |pre-activation| among the
+    differing ones).  A device forward in fp32 may only take another branch where the fp64 pre-activation is within its rounding error of
+    zero; the gradient tests assert that margin and then compare gradients against forward_train(act_pattern=pattern)."""
+    flips, total, margin = 0, 0, 0.0
+    for name, m in pattern.items():
+        z = preact[name]
+        d = (z > 0) != m.to(torch.bool)
+        flips += int(d.sum())
+        total += m.numel()
+        if d.any():
+            margin = max(margin, float(z[d].abs().max()))
+    return flips, total, margin
 
 
 # --------------------------------------------------------------------------------------

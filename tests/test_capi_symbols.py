@@ -40,8 +40,93 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert bound <= set(names), "bound symbols missing from the header: %s" % (bound - set(names))
 
 
+def header_struct_fields(name):
+    """[(field, kind)] of `typedef struct <name> { ... } <name>;` in the header, in declaration order; kind = "ptr", "int", "u32" or
+    "<struct> * n"."""
+    text = open(os.path.join(ROOT, "include", "casapose_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const )?(\w+)\s*(.*)", decl)
+        base, rest = m.group(2), m.group(3)
+        for item in rest.split(","):
+            item = item.strip()
+            arr = re.match(r"(\w+)\[(\d+)\]", item)
+            if arr:
+                out.append((arr.group(1), "%s * %s" % (base, arr.group(2))))
+            elif item.startswith("*") or base.endswith("*"):
+                out.append((item.lstrip("* "), "ptr"))
+            else:
+                out.append((item, {"int": "int", "uint32_t": "u32"}[base]))
+    return out
+
+
+def ctypes_struct_fields(cls):
+    kinds = {C.c_void_p: "ptr", C.c_int: "int", C.c_uint32: "u32"}
+    out = []
+    for n, t in cls._fields_:
+        if isinstance(t, type) and issubclass(t, C.Array):
+            out.append((n, "%s * %d" % ({"ConvSource": "cp_conv_source"}[t._type_.__name__], t._length_)))
+        else:
+            out.append((n, kinds[t]))
+    return out
+
+
+def test_descriptor_structs_match_the_header_field_for_field(lib):
+    """The round-2 defect: cp_conv_desc grew at its tail while a documented binding kept the shorter struct.  The ctypes declarations must
+    list the header's fields in the header's order with the header's kinds, and the library must report the same sizes."""
+    from casapose_amd import _lib
+
+    assert ctypes_struct_fields(_lib.ConvSource) == header_struct_fields("cp_conv_source")
+    assert ctypes_struct_fields(_lib.ConvDesc) == header_struct_fields("cp_conv_desc")
+    assert _lib.ConvDesc._fields_[0][0] == "struct_size"
+    assert lib.cp_conv_desc_size() == C.sizeof(_lib.ConvDesc) and lib.cp_conv_source_size() == C.sizeof(_lib.ConvSource)
+    assert _lib.ConvDesc().struct_size == C.sizeof(_lib.ConvDesc)
+
+
+def test_descriptor_of_another_abi_revision_is_refused(lib):
+    """A caller built against a header with a shorter (or longer) cp_conv_desc is refused by size in every entry point that takes one."""
+    from casapose_amd._lib import ConvDesc
+
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.cout = 1, 8, 8, 8, 8, 32
+    d.kh = d.kw = 3
+    d.stride = d.dilation = d.pad = 1
+    d.num_sources = 1
+    d.src[0].channels = d.src[0].ld = 32
+    d.src[0].data = d.weights = d.out_raw = 16
+    d.out_raw_ld = 32
+    for size in (0, C.sizeof(ConvDesc) - 16, C.sizeof(ConvDesc) + 8):
+        d.struct_size = size
+        assert lib.cp_conv2d_fwd_f32(C.byref(d), None) == -1 and b"struct_size" in lib.cp_last_error()
+        assert lib.cp_conv2d_fwd_split(C.byref(d), 16, None, 3, None) == -1 and b"struct_size" in lib.cp_last_error()
+        assert lib.cp_conv2d_wgrad_f32(C.byref(d), 16, 32, 16, 0, None) == -1 and b"struct_size" in lib.cp_last_error()
+        assert lib.cp_conv2d_wgrad_split(C.byref(d), 16, 32, 16, 0, 3, None) == -1 and b"struct_size" in lib.cp_last_error()
+        assert lib.cp_conv_selected_tile(C.byref(d)) == -1
+        assert lib.cp_conv_split_applicable(C.byref(d)) == 0 and lib.cp_conv_wgrad_split_applicable(C.byref(d)) == 0
+    d.struct_size = C.sizeof(ConvDesc)
+    assert lib.cp_conv_split_applicable(C.byref(d)) == 1 and lib.cp_conv_wgrad_split_applicable(C.byref(d)) == 1
+
+
+def test_integration_doc_binding_is_current():
+    """INTEGRATION.md section 3 shows the binding a maintainer would write; it is generated from casapose_amd/_lib.py."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_binding.py"), "--check"])
+    assert r.returncode == 0, "INTEGRATION.md's ctypes block is stale: run python tools/gen_integration_binding.py"
+
+
 def test_version_and_device_probe(lib):
-    assert lib.cp_version() >= 100
+    from casapose_amd import _lib
+
+    assert lib.cp_version() == _lib.ABI_VERSION == 300
+    text = open(os.path.join(ROOT, "include", "casapose_hip.h")).read()
+    assert int(re.search(r"#define CP_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION
     assert lib.cp_device_count() >= 0  # 0 on the CPU-only build container; never raises
 
 
@@ -80,7 +165,7 @@ def test_argument_validation_reports_errors_without_a_gpu(lib):
     from casapose_amd._lib import ConvDesc
 
     assert lib.cp_conv2d_fwd_f32(None, None) == -1
-    assert b"null descriptor" in lib.cp_last_error()
+    assert b"descriptor is null" in lib.cp_last_error()
     d = ConvDesc()
     d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.cout = 1, 8, 8, 8, 8, 4
     d.kh = d.kw = 3

@@ -183,7 +183,8 @@ def test_bn_act_forward_backward(device, hip_lib, classes, act, c):
     scale = (gamma * rstd[None]).astype(np.float32)
     shift = (beta - gamma * (meanv * rstd)[None]).astype(np.float32)
     y = torch.empty(n, c, device=device)
-    check(lib.cp_affine_act_f32(xd.data_ptr(), n, c, c, d(scale).data_ptr(), d(shift).data_ptr(), labd.data_ptr() if classes > 1 else None, act,
+    scd, shd = d(scale), d(shift)
+    check(lib.cp_affine_act_f32(xd.data_ptr(), n, c, c, scd.data_ptr(), shd.data_ptr(), labd.data_ptr() if classes > 1 else None, act,
                                 y.data_ptr(), c, st))
     assert rel(y.cpu().numpy(), yr.detach().numpy()) < 2e-5
     # device backward
@@ -191,19 +192,33 @@ def test_bn_act_forward_backward(device, hip_lib, classes, act, c):
     chan = torch.zeros(c * 2, dtype=torch.float64, device=device)
     md, rd, gd, bd = d(meanv.astype(np.float32)), d(rstd.astype(np.float32)), d(gamma), d(beta)
     lp = labd.data_ptr() if classes > 1 else None
-    check(lib.cp_bn_act_bwd_reduce_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, classes, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
-                                       red.data_ptr(), chan.data_ptr(), st))
-    dx = torch.full((n, c), 7.0, device=device)
-    check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
-                                      chan.data_ptr(), float(n), None, dx.data_ptr(), c, 0, st))
-    r = red.cpu().numpy().reshape(classes, c, 2)
-    assert rel(r[..., 0], bt.grad.numpy()) < 2e-5, "d beta"
-    assert rel(r[..., 1], gt.grad.numpy()) < 2e-5, "d gamma"
-    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 5e-5, "dx"
-    # row scale + accumulate
-    check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
-                                      chan.data_ptr(), float(n), d(rs).data_ptr(), dx.data_ptr(), c, 1, st))
-    assert rel(dx.cpu().numpy(), xt.grad.numpy() * (1 + rs[:, None])) < 5e-5
+    # both forms of the branch decision: recomputed from gamma / beta (tables None), and the forward's own fma(x, scale, shift) (the training plan)
+    for fs, fb in ((None, None), (scd.data_ptr(), shd.data_ptr())):
+        check(lib.cp_bn_act_bwd_reduce_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, classes, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                           fs, fb, red.data_ptr(), chan.data_ptr(), st))
+        dx = torch.full((n, c), 7.0, device=device)
+        check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                          fs, fb, chan.data_ptr(), float(n), None, dx.data_ptr(), c, 0, st))
+        r = red.cpu().numpy().reshape(classes, c, 2)
+        assert rel(r[..., 0], bt.grad.numpy()) < 2e-5, "d beta"
+        assert rel(r[..., 1], gt.grad.numpy()) < 2e-5, "d gamma"
+        assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 5e-5, "dx"
+        # row scale + accumulate
+        check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, dyd.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                          fs, fb, chan.data_ptr(), float(n), d(rs).data_ptr(), dx.data_ptr(), c, 1, st))
+        assert rel(dx.cpu().numpy(), xt.grad.numpy() * (1 + rs[:, None])) < 5e-5
+    if act:
+        # with the forward's tables the branch is the forward's, bit for bit: at an element whose pre-activation is a rounding error away
+        # from zero the gradient follows the sign of the forward's OUTPUT.  Build such elements: x chosen so that fma(x, scale, shift) is
+        # the smallest positive / negative float the forward can produce at that element, dy = 1.
+        y0 = y.cpu().numpy()
+        one = torch.ones(n, c, device=device)
+        check(lib.cp_bn_act_bwd_reduce_f32(xd.data_ptr(), c, one.data_ptr(), c, n, c, classes, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                           scd.data_ptr(), shd.data_ptr(), red.data_ptr(), chan.data_ptr(), st))
+        slope = np.where(y0 > 0, 1.0, float(np.float32(0.1)) if act == 2 else 0.0) * (y0 != 0 if act == 2 else 1)
+        want = np.zeros((classes, c))
+        np.add.at(want, lab.astype(np.int64), slope)
+        assert np.allclose(red.cpu().numpy().reshape(classes, c, 2)[..., 0], want, rtol=0, atol=1e-9), "d beta with dy = 1 counts the forward's own branches"
 
 
 def test_resampling_adjoints(device, hip_lib):
@@ -358,9 +373,9 @@ def test_train_forward_backward_matches_autograd(device, variant):
     labd = torch.from_numpy(lab).to(device)
     out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd)
     p64 = R.to_torch(params)
-    stats = {}
+    stats, pre = {}, {}
     ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), stats, partial=part, guided=guid, bilinear=bil,
-                          **sharing)
+                          preact_out=pre, **sharing)
     got = out.cpu().numpy()
     assert rel(got[..., :k], ref.detach().numpy()[..., :k]) < 1e-3
     assert rel(got[..., k:], ref.detach().numpy()[..., k:]) < 1e-3
@@ -369,15 +384,25 @@ def test_train_forward_backward_matches_autograd(device, variant):
     ml, vl, pl = R.losses(ref, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, 9, False)
     s = sums.cpu().numpy()
     assert abs(s[0] - ml.item()) < 1e-3 * abs(ml.item()) and abs(s[1] - vl.item()) < 1e-3 * abs(vl.item()) and abs(s[2] - pl.item()) < 1e-3 * abs(pl.item())
-    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
     plan.backward()
     torch.cuda.synchronize()
-    worst = {}
-    for name in store.offsets:
-        g = store.grad_view(name).cpu().numpy()
-        gr = p64[name].grad.numpy()
-        worst[name] = rel_l2(g, gr)
-    bad = {n: e for n, e in worst.items() if e > 2e-2}
+    # ReLU / leaky kinks: the fp32 forward takes the other branch at the few elements whose fp64 pre-activation is a rounding error away
+    # from zero (one such element moves a [classes, C] table reduced over 32 pixels by ~1e-2).  The device differentiates the function it
+    # evaluated, so the reference is the fp64 gradient ON THE DEVICE'S BRANCHES; that those branches differ from the oracle's own only at
+    # |pre-activation| < 1e-4 is asserted, and with it every variable is gated at 1e-3 relative L2 (round 2: 2e-2, no kink handling).
+    pattern = plan.activation_pattern()
+    flips, total, margin = R.kink_report(pattern, pre)
+    assert margin < 1e-4 and flips < 1e-4 * total, (flips, total, margin)
+    if flips:
+        p64 = R.to_torch(params)
+        ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), None, partial=part, guided=guid,
+                              bilinear=bil, act_pattern=pattern, **sharing)
+        ml, vl, pl = R.losses(ref, torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64)), k, 9, False)
+    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
+    worst = {name: rel_l2(store.grad_view(name).cpu().numpy(), p64[name].grad.numpy()) for name in store.offsets}
+    top = sorted(worst.items(), key=lambda t: -t[1])
+    print("%s: %d kink flips (margin %.1e); worst gradient %s %.2e, median %.2e" % (variant, flips, margin, top[0][0], top[0][1], np.median(list(worst.values()))))
+    bad = {n: e for n, e in worst.items() if e > 1e-3}
     assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
     # moving statistics were updated with the batch statistics
     mm = store.state["bn0.moving_mean"].cpu().numpy()
@@ -605,7 +630,8 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     the whole backward.  Reference: oracle/torch_train_ref.py in fp64 -- autograd through the network and the differentiable LS
     voter, with d loss / d keypoints of the BPnP term supplied by the same host routine evaluated on the REFERENCE's voted
     keypoints (that routine's implicit gradient is itself checked against finite differences below, at this configuration).
-    Gates: outputs <= 1e-3 of range, loss values <= 1e-3 relative, every trainable variable's gradient <= 2e-2 relative L2."""
+    Gates: outputs <= 1e-3 of range, loss values <= 1e-3 relative, every trainable variable's gradient <= 1e-3 relative L2 against the oracle on
+    the device's activation branches (which may differ from the oracle's own only at |pre-activation| < 1e-4)."""
     from casapose_amd import training as T
     from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
     from casapose_amd.train_engine import ParamStore, TrainPlan, crop_to_image_affine, project_keypoints
@@ -625,7 +651,8 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     # ---- reference forward ----
     p64 = R.to_torch(params)
     labt = torch.from_numpy(lab.astype(np.int64))
-    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), labt)
+    pre = {}
+    ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), labt, preact_out=pre)
     assert rel(out[..., :k], ref.detach().numpy()[..., :k]) < 1e-3 and rel(out[..., k:], ref.detach().numpy()[..., k:]) < 1e-3
     # ---- losses: mask + vertex + proxy on both sides ----
     wts, kp_w, cap = (1.0, 0.5, 0.015), 0.007, 12.5
@@ -663,12 +690,25 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     cl = (F.softplus(ref[..., k + 2 * kp:]) * fg[..., None]).sum((1, 2)) / fg.sum((1, 2))[:, None]
     reg = (cl - 0.7).abs().mean()
     assert abs(val.item() - (lv_ref + reg.item())) < 2e-3 * abs(lv_ref + reg.item())
-    total = wts[0] * ml + wts[1] * vl + wts[2] * pl + kp_w * reg + (coords_ref * torch.from_numpy(g_ref.astype(np.float64))).sum()
-    total.backward()
     plan.backward()
     torch.cuda.synchronize()
+    # gradients against the oracle evaluated on the DEVICE's activation branches (see test_train_forward_backward_matches_autograd)
+    pattern = plan.activation_pattern()
+    flips, total_el, margin = R.kink_report(pattern, pre)
+    assert margin < 1e-4 and flips < 1e-4 * total_el, (flips, total_el, margin)
+    if flips:
+        p64 = R.to_torch(params)
+        ref = R.forward_train(p64, torch.from_numpy(img.astype(np.float64)), labt, act_pattern=pattern)
+        ml, vl, pl = R.losses(ref, labt, torch.from_numpy(kpts.astype(np.float64)), k, kp, True)
+        coords_ref = R.ls_voting(labt, ref[..., k:k + 2 * kp], ref[..., k + 2 * kp:], k - 1)
+        cl = (F.softplus(ref[..., k + 2 * kp:]) * fg[..., None]).sum((1, 2)) / fg.sum((1, 2))[:, None]
+        reg = (cl - 0.7).abs().mean()
+    total = wts[0] * ml + wts[1] * vl + wts[2] * pl + kp_w * reg + (coords_ref * torch.from_numpy(g_ref.astype(np.float64))).sum()
+    total.backward()
     worst = {name: rel_l2(store.grad_view(name).cpu().numpy(), p64[name].grad.numpy()) for name in store.offsets}
-    bad = {n: e for n, e in worst.items() if e > 2e-2}
+    top = sorted(worst.items(), key=lambda t: -t[1])
+    print("config 13 @448: %d kink flips (margin %.1e); worst gradient %s %.2e, median %.2e" % (flips, margin, top[0][0], top[0][1], np.median(list(worst.values()))))
+    bad = {n: e for n, e in worst.items() if e > 1e-3}
     assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
     # ---- the host BPnP gradient itself, by central differences on two visible objects of THIS scene ----
     c0 = coords_ref.detach().numpy().copy()

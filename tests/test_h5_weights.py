@@ -87,11 +87,16 @@ def test_keras_save_layout_round_trip(tmp_path):
         wn = attrs["/" + layer.decode()]["weight_names"]
         assert wn and all("/%s/%s" % (layer.decode(), w.decode()) in paths for w in wn)
     m = [w.decode() for w in attrs["/model"]["weight_names"]]
-    i = m.index("bn0/gamma:0")
-    assert m[i:i + 4] == ["bn0/gamma:0", "bn0/beta:0", "bn0/moving_mean:0", "bn0/moving_variance:0"]
+    # the nested model's list is trainable_weights + non_trainable_weights (Keras' _legacy_weights): every kernel / gamma / beta in layer
+    # order first, every moving statistic after them -- load_weights(by_name=True) zips this list positionally
+    assert m[:5] == ["bn_data/beta:0", "conv0/kernel:0", "bn0/gamma:0", "bn0/beta:0", "stage1_unit1_bn1/gamma:0"] and "stage4_unit2_conv2/kernel:0" in m
+    first_moving = min(i for i, n in enumerate(m) if "moving_" in n)
+    assert all("moving_" in n for n in m[first_moving:]) and not any("moving_" in n for n in m[:first_moving])
+    assert m[first_moving:first_moving + 4] == ["bn_data/moving_mean:0", "bn_data/moving_variance:0", "bn0/moving_mean:0", "bn0/moving_variance:0"]
     c = [w.decode() for w in attrs["/pv_block_6_clade"]["weight_names"]]
     assert c[:2] == ["pv_block_6_clade/pv_block_6_clade_beta:0", "pv_block_6_clade/pv_block_6_clade_gamma:0"]   # add_weight order
-    assert c[2].startswith("pv_block_6_clade/sync_batch_normalization_") and c[2].endswith("/moving_mean:0")
+    assert c[2] == "pv_block_6_clade/sync_batch_normalization/moving_mean:0"     # Keras' first automatic name has no suffix
+    assert [w.decode() for w in attrs["/pv_block_7_clade"]["weight_names"]][3] == "pv_block_7_clade/sync_batch_normalization_1/moving_variance:0"
     assert [w.decode() for w in attrs["/pv_block_6_prepare_conv2d"]["weight_names"]] == ["pv_block_6_prepare_conv2d/pv_block_6_prepare_conv2d_weights:0"]
 
 

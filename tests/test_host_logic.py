@@ -182,6 +182,24 @@ def test_learning_rate_schedules_and_loss_weights():
                           kp_loss_factor=0.5)
     h.update()
     assert (h.mask_loss_weight, h.vertex_loss_weight, h.proxy_loss_weight, h.kp_loss_weight) == (1.0, 0.5, 0.025, 0.0035)
+    # the reference's positional order (weights, factors, borders, flags: learning_rate_schedules.py:63-79), attribute surface, clamping
+    p = LossWeightHandler(1.0, 0.5, 0.015, 0.007, 3.0, 1.0, 1.0, 0.1, (0.0, 2.5), (0.0, 10.0), (0.0, 0.025), (0.005, 2.5), True)
+    assert p.filter_vertex_with_segmentation is True and p.filter_high_proxy_errors is False and p.kp_loss_borders == (0.005, 2.5)
+    p.update()
+    assert (p.mask_loss_weight, p.kp_loss_weight) == (2.5, 0.005)          # clamped at the upper / lower border
+    p.vertex_loss_weight = 4.0
+    p.vertex_loss_factor = 3.0
+    p.update()
+    assert p.vertex_loss_weight == 10.0 and p.clamp(7, (0, 5)) == 5
+    lines = []
+    p.print(lines.append)
+    assert lines == ["==Mask loss weight: 2.5 , vertex loss weight: 10.0 , proxy loss weight: 0.015 , keypoint loss weight: 0.005=="]
+    d = LossWeightHandler()
+    assert (d.mask_loss_weight, d.vertex_loss_weight, d.proxy_loss_weight, d.kp_loss_weight, d.proxy_loss_borders) == (1.0, 1.0, 0.01, 1.0, (0.0, 0.025))
+    with pytest.raises(TypeError):
+        LossWeightHandler(colour_loss_weight=1.0)
+    with pytest.raises(AttributeError):
+        d.colour_loss_weight
 
 
 def test_crop_affine_and_projection_match_oracle():
