@@ -235,7 +235,7 @@ def bench_train(args):
     seg_dim, ver_dim, kp = 9, 27, 9
     net = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), input_segmentation_shape=(H, W, seg_dim),
                                              weights=None, base_model="resnet18", device=dev, seed=1237)
-    group = dist.group.WORLD if world > 1 else None
+    group = dist.group.WORLD if dist.is_initialized() else None   # world 1 only with CASAPOSE_DIST_FORCE=1 (the RCCL path on one GPU)
     plan, _ = net.training_plan(B, H, W, group, world)
     rng = np.random.default_rng(1237 + rank)
     gen = torch.Generator(device="cpu").manual_seed(1237 + rank)
@@ -299,7 +299,7 @@ def bench_train(args):
     }
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -394,7 +394,7 @@ def bench_vote(args):
     }
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or parallel.force_collectives():
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -672,7 +672,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -12,6 +12,13 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives() -> bool:
+    """CASAPOSE_DIST_FORCE=1: create the process group and run every collective of the data-parallel protocol even with ONE rank, so that
+    the RCCL code path (group creation, barrier with device ids, fp64 statistic all-reduces, asynchronous gradient buckets on RCCL's
+    stream) executes on a single-GPU box.  A SUM over one rank is the identity: results must equal the plain single-process run."""
+    return os.environ.get("CASAPOSE_DIST_FORCE", "0") == "1"
+
+
 def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE (torchrun contract); returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -19,7 +26,7 @@ def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # CASAPOSE_DIST_BACKEND=gloo lets several ranks share ONE GPU in tests (RCCL refuses duplicate devices)
     backend = os.environ.get("CASAPOSE_DIST_BACKEND", backend)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -66,7 +73,7 @@ def all_reduce_sum_(t: torch.Tensor, group=None, world_size: int = 1) -> torch.T
     """In-place SUM all-reduce (RCCL on GPU tensors, gloo on CPU tensors); no-op for a single replica.  The training
     step uses it for (a) the fp64 SyncBN statistic tables -- forward sums and the two backward means -- and (b) the
     flat fp32 gradient before Adam (MirroredStrategy's SUM reduction, train_casapose.py:641-643)."""
-    if world_size > 1:
+    if world_size > 1 or (force_collectives() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 

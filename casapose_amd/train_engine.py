@@ -1166,7 +1166,7 @@ class TrainPlan:
         for t in self.tensors:
             t.has_grad = False
         self._pending = []
-        multi = self.group is not None and self.world_size > 1
+        multi = self.group is not None and (self.world_size > 1 or parallel.force_collectives())
         if multi and self._buckets is None:
             self._buckets = self._gradient_buckets()
         for i in range(len(self.ops) - 1, -1, -1):

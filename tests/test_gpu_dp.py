@@ -138,3 +138,82 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["gpus_requested"] == 2 and d["value"] > 0
     bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+# --------------------------------------------------------------------------------------------------
+# the RCCL code path itself, on ONE GPU: backend "nccl" at world size 1 with every collective forced (CASAPOSE_DIST_FORCE=1)
+# --------------------------------------------------------------------------------------------------
+def _rccl_worker(port, outdir):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CASAPOSE_DIST_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.environ.pop("CASAPOSE_DIST_BACKEND", None)
+    import torch.distributed as dist
+
+    from casapose_amd import parallel
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    rank, local, world = parallel.init_from_env("nccl")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and (rank, local, world) == (0, 0, 1)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    parallel.barrier_sync(dev)                                           # dist.barrier(device_ids=[0]) over RCCL
+    assert parallel.max_over_ranks(1.25, dev) == 1.25 and parallel.sum_over_ranks(2.5, dev) == 2.5
+    params, img, lab, kpts = _data()
+    plan = TrainPlan(ParamStore(params, dev), K, 27, B, H, W, group=dist.group.WORLD, world_size=1)
+    plan.refresh_weights(torch.cuda.current_stream(dev).cuda_stream)
+    out, sums, grad = _run(plan, dev, img, lab, kpts)                    # SyncBN fp64 tables, four asynchronous gradient buckets, all over RCCL
+    assert plan._buckets is not None and len(plan._buckets) == 4 and not plan._pending
+    losses, st = parallel.reduce_step_log([1.0, 2.0, 3.0, 4.0, 5.0], [np.arange(3.0) + j for j in range(8)], 1, dev)
+    assert losses == [1.0, 2.0, 3.0, 4.0, 5.0] and st.shape == (6, 3)
+    np.savez(os.path.join(outdir, "rccl.npz"), out=out, sums=sums, grad=grad)
+    parallel.barrier_sync(dev)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_at_world_size_one(device, tmp_path):
+    """Process-group creation on backend "nccl" (= RCCL), the barrier with device ids, the scalar reductions of bench.py, and one whole
+    training step whose 58 SyncBN table all-reduces and four bucketed asynchronous gradient all-reduces really go through RCCL -- on the
+    one GPU a test box has.  SUM over one rank is the identity, so everything must equal the plain single-process step to rounding
+    (a real difference would mean the collective path drops or double-counts something)."""
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(port, str(tmp_path)))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    params, img, lab, kpts = _data()
+    plan = TrainPlan(ParamStore(params, device), K, 27, B, H, W)
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    out, sums, grad = _run(plan, device, img, lab, kpts)
+    r = np.load(tmp_path / "rccl.npz")
+    # statistics and weight gradients are accumulated with atomics (summation order not fixed): equal to rounding, not bit for bit
+    assert np.abs(r["out"] - out).max() <= 1e-6 * np.abs(out).max() and np.allclose(r["sums"], sums, rtol=1e-6)
+    assert np.linalg.norm(r["grad"] - grad) <= 1e-5 * np.linalg.norm(grad)
+
+
+def test_bench_train_over_rccl_world_one():
+    """`bench.py --mode train` under the torchrun contract with WORLD_SIZE=1 and the RCCL branch forced: the line the driver will parse on
+    a multi-GPU node, produced through the same group / barrier / max-over-ranks / bucketed all-reduce code."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", CASAPOSE_DIST_FORCE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("CASAPOSE_DIST_BACKEND", None)
+    for extra in (["--mode", "train", "--batch", "4", "--height", "64", "--width", "96"], ["--batch", "2", "--height", "64", "--width", "96"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 2
