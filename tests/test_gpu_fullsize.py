@@ -139,11 +139,16 @@ def test_full_size_ransac_voting_recovers_exact_keypoints(device):
     assert np.abs(got[..., ::-1] - kpts).max() < 5e-2  # the RANSAC voter returns (x, y)
 
 
-def test_full_size_training_gradient_is_the_directional_derivative(device):
+@pytest.mark.parametrize("mode,tol", [("split", 0.02), ("bf16", 0.02)])
+def test_full_size_training_gradient_is_the_directional_derivative(device, monkeypatch, mode, tol):
     """BASELINE.json configs[2] size (bs = 32, 448x448, K = 9): the analytic gradient of the whole step (forward with batch statistics,
     CE + vertex + proxy losses, backward through 28 convolutions incl. the Winograd layers) must predict the change of the loss along
-    its own direction: (L(theta + e d) - L(theta - e d)) / 2e = g . d, with d = g / |g|."""
+    its own direction: (L(theta + e d) - L(theta - e d)) / 2e = g . d, with d = g / |g|.  In the training plan's default mode (exact
+    bf16 splits, fp32-equivalent) and in CASAPOSE_CONV_MODE=bf16 -- configs[2]'s "bf16 convs" -- where the loss itself is the bf16-rounded
+    network's (measured ratios 0.9998 and 1.0006)."""
     from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    monkeypatch.setenv("CASAPOSE_CONV_MODE", mode)
 
     b, h, w = 32, 448, 448
     rng = np.random.default_rng(21)
@@ -187,4 +192,5 @@ def test_full_size_training_gradient_is_the_directional_derivative(device):
     lm = loss()
     store.theta.copy_(theta0)
     fd = (lp - lm) / (2 * eps)
-    assert abs(fd - gn) < 0.05 * gn, "directional derivative %.6g vs |g| %.6g (loss %.6g)" % (fd, gn, l0)
+    print("%s mode: directional derivative %.6g vs |g| %.6g (ratio %.4f), loss %.6g" % (mode, fd, gn, fd / gn, l0))
+    assert abs(fd - gn) < tol * gn, "directional derivative %.6g vs |g| %.6g (loss %.6g)" % (fd, gn, l0)
