@@ -111,6 +111,11 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
     probe = 2.0 * torch.rand(1, h, w, 3, generator=gen) - 1.0
     timing = {}
     for n in sorted({min(cores, 32), cores}):  # the safe count first; then ONE forward with every core, kept only if it is faster
+        if timing and min(timing.values()) < 2.0:
+            # a 256-thread host took 74 s for ONE image in the all-cores probe (thread-pool overhead on the small layers) against 0.86 s
+            # with 32 threads: when the capped count already runs an image in under 2 s the all-cores probe is skipped
+            _log("cpu baseline: %d-thread probe skipped (%.2f s per image with %d threads)" % (n, min(timing.values()), min(timing, key=timing.get)))
+            break
         torch.set_num_threads(n)
         if not timing:
             forward(probe)
@@ -143,18 +148,56 @@ TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1
                    203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel"}
 
 
+def binary_stamp():
+    """What identifies the code a measurement was taken on: sha256 over the kernel sources + C ABI header + the host files that choose
+    launches (stable across rebuilds and machines, unlike the .so's bytes) and the sha256 of the loaded libcasapose_hip.so itself.  Every
+    GPU-side profiling script stores it beside its output (`python3 bench.py --stamp`); tools/make_summary.py refuses to mix stamps, and the
+    bench line only quotes PMC traffic from a committed profile whose source stamp equals the running tree's."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "casapose_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "casapose_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "casapose_amd", "csrc", "Makefile")]
+                   + [os.path.join(ROOT, "casapose_amd", n) for n in ("engine.py", "train_engine.py", "_lib.py", "ops.py")] + [os.path.join(ROOT, "bench.py")])
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0" + open(f, "rb").read() + b"\0")
+    so = os.path.join(ROOT, "casapose_amd", "libcasapose_hip.so")
+    so_sha = hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None
+    return {"src_sha256": h.hexdigest()[:16], "so_sha256": so_sha[:16] if so_sha else None, "files": len(files)}
+
+
+def _committed_profile(name):
+    """newest profiles/r0N_<name> (by round number) and the stamp recorded for it in profiles/r0N_STAMP.json (None if unstamped)"""
+    import glob
+    import re
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)), key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)))
+    if not cands:
+        return None, None
+    path = cands[-1]
+    tag = os.path.basename(path).split("_")[0]
+    sp = os.path.join(ROOT, "profiles", tag + "_STAMP.json")
+    stamp = json.load(open(sp)).get("stamp") if os.path.exists(sp) else None
+    return path, stamp
+
+
 def measured_traffic(tile):
-    """Average HBM bytes per launch of the instantiation family `tile`, from the committed PMC passes (None if absent)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    """(average HBM bytes per launch of the instantiation family `tile` from the newest committed PMC passes, note).  The figure is only
+    quoted when that profile was taken on THIS source tree (stamp match); otherwise None and the note says which profile was refused."""
+    path, stamp = _committed_profile("pmc_traffic.json")
     if path is None or tile not in TILE_PMC_PREFIX:
-        return None
+        return None, "no committed PMC profile"
+    rel = os.path.relpath(path, ROOT)
+    if stamp is None or stamp.get("src_sha256") != binary_stamp()["src_sha256"]:
+        return None, "%s was measured on another source tree (stamp %s, this tree %s): not quoted" % (rel, (stamp or {}).get("src_sha256"), binary_stamp()["src_sha256"])
     tab = json.load(open(path))
     tot = n = 0.0
     for name, v in tab.items():
         if TILE_PMC_PREFIX[tile] in name:
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
-    return round(tot / n) if n else None
+    return (round(tot / n) if n else None), "%s (same source stamp %s as this run)" % (rel, stamp["src_sha256"])
 
 
 def _sustained_mfma(dev):
@@ -220,18 +263,37 @@ def bench_train(args):
     """Secondary workload (BASELINE.json configs[2]/[3]): one data-parallel TRAINING step of casapose_c_gcu5 --
     forward with batch statistics (SyncBN all-reduced across ranks), mask/vertex/proxy/keypoint losses, hand-written
     backward, SUM all-reduce of the flat gradient over RCCL, Adam, weight re-pack -- at 448x448, K=9, fp32."""
+    import torch
+    import torch.distributed as dist
+
+    from casapose_amd import parallel
+
+    rank, local, world = parallel.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    result = train_leg(args.batch, args.height, args.width, args.steps, args.warmup, dev, rank, world)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def train_leg(B, H, W, steps, warmup, dev, rank, world):
+    """`steps` timed training steps (after `warmup`) on this rank's synthetic batch; returns the result dict of `--mode train`.  Also run by
+    the DEFAULT bench line (3 steps at bs 32, 448x448, key `training_leg`) so that the driver's clock covers the training path too."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from casapose_amd import parallel
     from casapose_amd.pose_models.tfkeras import Classifiers
-    from casapose_amd.train_engine import crop_to_image_affine, project_keypoints
+    from casapose_amd.train_engine import crop_to_image_affine
 
-    rank, local, world = parallel.init_from_env("nccl")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    B, H, W = args.batch, args.height, args.width
+    class _A:
+        pass
+
+    args = _A()
+    args.steps, args.warmup = steps, warmup
     seg_dim, ver_dim, kp = 9, 27, 9
     net = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), input_segmentation_shape=(H, W, seg_dim),
                                              weights=None, base_model="resnet18", device=dev, seed=1237)
@@ -297,10 +359,7 @@ def bench_train(args):
                      "kernel": "all convolution launches of the step (forward, data gradient, weight gradient; conv_f32 / conv_halo / conv_hsplit / wino_gemm(_split) / conv_wgrad(_split))"},
         "losses": {"mask": float(sums[0]), "vertex": float(sums[1]), "proxy": float(sums[2]), "keypoint": float(kpl)},
     }
-    if rank == 0:
-        print(json.dumps(result))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    return result
 
 
 def bench_vote(args):
@@ -446,7 +505,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra fp32-equivalent opt-in line (exact bf16 splits) reported beside the headline")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the 3-step training leg (BASELINE configs[2]) the default line reports under `training_leg`")
+    ap.add_argument("--stamp", action="store_true", help="print the source / binary stamp (JSON) and exit; no GPU is touched")
     args = ap.parse_args()
+    if args.stamp:
+        print(json.dumps(binary_stamp()))
+        return
     launched = launch_ranks(args)
     if launched is not None:
         sys.exit(launched)
@@ -612,7 +676,8 @@ def main():
             "ms_per_step": round(f32_ms, 3), "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
             "all_conv_ms_per_step": round(conv_ms, 3), "time_weighted_frac_of_each_family_s_own_peak": round(weighted, 4),
             "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
-            "traffic": measured_traffic(dom),
+            "traffic": measured_traffic(dom)[0],
+            "traffic_source": measured_traffic(dom)[1],
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
                             "(separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.sh), not measured by this run",
             "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / d["peak"], 4), "peak": d["peak"],
@@ -638,7 +703,7 @@ def main():
         from casapose_amd import engine as _engine
 
         ref_logits = net([img], training=False)[..., :seg_dim].clone()
-        del net
+        net = None
         torch.cuda.empty_cache()
         _engine.WINO_GEMM_SPLIT = True
         try:
@@ -668,6 +733,17 @@ def main():
             _log("opt-in line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
         finally:
             _engine.WINO_GEMM_SPLIT = False
+    if rank == 0 and world == 1 and not args.no_train_leg:
+        # BASELINE configs[2] beside the headline, under the driver's clock: 3 training steps (1 warm-up) at the --mode train defaults
+        net = net2 = plan = None   # noqa: F841  (drop the inference plans' buffers before the training plan allocates its own)
+        torch.cuda.empty_cache()
+        try:
+            leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
+            result["training_leg"] = {k: leg[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "losses")}
+            _log("training leg done: %.2f ms/step" % leg["ms_per_step"])
+        except Exception as exc:  # an annotation of the headline line: report, never fail it
+            result["training_leg"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    result["binary"] = binary_stamp()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)
     if rank == 0:
