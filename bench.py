@@ -245,18 +245,22 @@ def _dtype_note_train():
 
 
 def _dtype_note():
-    """the arithmetic type of the MFMA kernels: exact fp32 MFMA by default; the opt-ins (CASAPOSE_WINO_GEMM=split: Winograd GEMMs,
-    CASAPOSE_INFER_CONV_MODE=split: shallow 3x3 layers, as exact three-way bf16 splits on the bf16 matrix pipe -- fp32-equivalent results,
-    DESIGN.md 8; CASAPOSE_INFER_CONV_MODE=bf16: those layers with bf16 operands) are named in the line when set."""
-    notes = []
-    if os.environ.get("CASAPOSE_WINO_GEMM", "") == "split":
-        notes.append("Winograd GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six products, fp32 accumulate")
-    mode = os.environ.get("CASAPOSE_INFER_CONV_MODE", "f32")
+    """The arithmetic the convolutions compute in.  Default since round 3 (conv mode "split"): fp32 values, every product formed EXACTLY on the
+    bf16 matrix pipe -- each fp32 operand is split into three bf16 terms (8+8+8 significand bits), six bf16 x bf16 products (each exact in fp32)
+    are accumulated in fp32; the three dropped terms are <= 2^-24 of the product, the rounding an fp32 multiply makes itself, and the measured
+    error against fp64 is at or below the fp32 MFMA's (tests/test_gpu_hsplit.py, test_gpu_conv.py).  Tensors stay fp32 in HBM.  Layers the split
+    kernels do not cover (stem, strided / dilated 3x3, a few 1x1) run on v_mfma_f32_32x32x2_f32.  CASAPOSE_INFER_CONV_MODE=f32 puts every layer
+    there; =bf16 rounds operands to bf16 (not fp32-equivalent)."""
+    from casapose_amd import engine
+
+    mode = os.environ.get("CASAPOSE_INFER_CONV_MODE", engine.DEFAULT_INFER_CONV_MODE)
+    wino = os.environ.get("CASAPOSE_WINO_GEMM", "")
+    if mode == "bf16":
+        return "bf16 operands / f32 accumulate in the 3x3 layers off the Winograd path, Winograd GEMMs on hi + mid bf16 planes, f32 elsewhere (NOT fp32-equivalent)"
     if mode == "split":
-        notes.append("shallow 3x3 layers (stage 1, decoder blocks 3-5 / 8-10) as exact 3-way bf16 splits, fp32-equivalent")
-    elif mode == "bf16":
-        return "bf16 operands / f32 accumulate in the shallow 3x3 layers (stage 1, decoder blocks 3-5 / 8-10), f32 elsewhere (OPT-IN)"
-    return "f32" + (" (OPT-IN: %s)" % "; ".join(notes) if notes else "")
+        return ("f32 (fp32-equivalent: exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six exact products per fp32 product, fp32 accumulate, for the 3x3 / "
+                "stride-1 layers%s; stem / strided / dilated layers on v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))
+    return "f32 (v_mfma_f32_32x32x2_f32 in every convolution%s)" % ("; Winograd GEMMs as exact 3-way bf16 splits" if wino == "split" else "")
 
 
 def bench_train(args):
@@ -504,7 +508,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-optin", action="store_true", help="skip the extra fp32-equivalent opt-in line (exact bf16 splits) reported beside the headline")
+    ap.add_argument("--no-optin", action="store_true", help="skip the extra line on the fp32 MFMA (conv_mode f32) reported beside the headline")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the 3-step training leg (BASELINE configs[2]) the default line reports under `training_leg`")
     ap.add_argument("--stamp", action="store_true", help="print the source / binary stamp (JSON) and exit; no GPU is touched")
     args = ap.parse_args()
@@ -590,17 +594,20 @@ def main():
         "dtype": _dtype_note(),
         "data": "synthetic (seed 1237: uniform [-1,1) images, he_uniform weights, randomised BN/CLADE statistics)",
         "config": {"workload": "config_8.ini inference: casapose_c_gcu5, K=9 classes, ver_dim=27, bs=%d per GPU, %dx%d, fp32, estimated-mask conditioning, connected-component filter + LS voting" % (B, H, W),
+                   "conv_mode": net._net.conv_mode,
                    "images_per_gpu_per_step": B, "parallelism": "replicas x%d (no collective)" % world},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # ---- per-launch durations of the convolution kernels, HIP events on the launch stream ----
-        plan = net._net.plan(B, H, W)
+    def conv_roofline(net_):
+        """Per-launch durations of the convolution kernels of net_'s plan (HIP events on the launch stream), grouped by kernel family and
+        priced per MATRIX PIPE: a family on the bf16 pipe (exact three-way splits: six executed bf16 FLOPs per fp32 FLOP; the hi + mid
+        Winograd GEMM: three) against the dense bf16 peak, a family on the fp32 MFMA against the fp32 peak.  `frac` = the time-weighted
+        mean of (family rate / its pipe's peak) over ALL convolution time incl. the Winograd transform passes (which execute no FLOPs)."""
+        plan = net_._net.plan(B, H, W)
         lib = _lib.load()
         stream = torch.cuda.current_stream(dev).cuda_stream
         reps = max(3, min(args.steps, 10))
         per_tile = {}
-        import ctypes as C_
 
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -615,10 +622,10 @@ def main():
         wino = {"layers": 0, "ms": 0.0, "gemm_ms": 0.0, "replaced_flops": 0.0}
         direct_flops = 0.0
         for conv in plan.convs:
-            pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe (opt-in conv mode), csrc/conv_hsplit.hip
+            pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe, csrc/conv_hsplit.hip
             if hasattr(conv, "gemm_flops") and getattr(conv, "Us", None) is not None:
-                pipe = 3                                # Winograd GEMM as exact three-way splits (opt-in CASAPOSE_WINO_GEMM=split)
-            gemm1x1 = getattr(conv, "_gemm", None)   # 1x1 / stride-1 layer on the bf16-pipe GEMM (opt-in conv modes)
+                pipe = 3                                # Winograd GEMM on the bf16 pipe (exact three-way split, or hi + mid planes in the bf16 mode)
+            gemm1x1 = getattr(conv, "_gemm", None)   # 1x1 / stride-1 layer on the bf16-pipe GEMM
             if gemm1x1 is not None:
                 pipe = 3
             tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
@@ -657,27 +664,32 @@ def main():
             t["bytes"] += byt
         dom = max(per_tile, key=lambda k: per_tile[k]["ms"])
         d = per_tile[dom]
-        conv_ms = sum(t["ms"] for t in per_tile.values()) + (wino["ms"] - wino["gemm_ms"])   # MFMA launches + Winograd transform passes
-        conv_fl = sum(t["flops"] for t in per_tile.values())
-        f32_ms = sum(t["ms"] for t in per_tile.values() if t["peak"] == PEAK_F32_MFMA_TFLOPS) + (wino["ms"] - wino["gemm_ms"])
-        conv_fl = sum(t["flops"] for t in per_tile.values() if t["peak"] == PEAK_F32_MFMA_TFLOPS)   # headline: the fp32-MFMA launches (all of them by default)
-        ach_all = conv_fl / (f32_ms * 1e-3) / 1e12
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        # with an opt-in conv mode some layers run on the bf16 pipe: each family is priced against ITS pipe's peak, and the time-weighted
-        # mean of those fractions over all convolution time is reported beside the fp32 figure
+        transform_ms = wino["ms"] - wino["gemm_ms"]
+        conv_ms = sum(t["ms"] for t in per_tile.values()) + transform_ms   # MFMA launches + Winograd transform passes
+        pipes = {}
+        for name, peak in (("f32", PEAK_F32_MFMA_TFLOPS), ("bf16", PEAK_BF16_MFMA_TFLOPS)):
+            fam = [t for t in per_tile.values() if t["peak"] == peak]
+            ms, fl = sum(t["ms"] for t in fam), sum(t["flops"] for t in fam)
+            if ms > 0:
+                pipes[name] = {"ms_per_step": round(ms, 3), "executed_gflop_per_step": round(fl / 1e9, 1), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                               "peak": peak, "frac_of_its_peak": round(fl / (ms * 1e-3) / 1e12 / peak, 4)}
+        # time-weighted mean of each family's fraction of ITS pipe's peak over all convolution time (transform passes count as zero)
         weighted = sum(t["ms"] * (t["flops"] / (t["ms"] * 1e-3) / 1e12 / t["peak"]) for t in per_tile.values()) / conv_ms
-        # headline = EXECUTED FLOPs of every convolution launch of the forward (Winograd layers count the grouped GEMM they run, not the
-        # direct convolution they replace) over the summed HIP-event durations of those launches incl. the Winograd transform passes;
-        # the north-star target (>= 0.70 of the fp32-MFMA peak) is quoted on the whole encoder-decoder forward, so that is `frac`
-        result["roofline"] = {
-            "bound": "mfma", "achieved": round(ach_all, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_all / PEAK_F32_MFMA_TFLOPS, 4),
-            "kernel": "all convolution launches of the forward (conv_halo / wino_gemm / conv_f32 / conv_stem kernels + Winograd transform passes)",
-            "ms_per_step": round(f32_ms, 3), "gflop_per_step": round(conv_fl / 1e9, 2), "launches_per_step": len(plan.convs),
-            "all_conv_ms_per_step": round(conv_ms, 3), "time_weighted_frac_of_each_family_s_own_peak": round(weighted, 4),
-            "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2),
-            "traffic": measured_traffic(dom)[0],
-            "traffic_source": measured_traffic(dom)[1],
+        main_pipe = max(pipes, key=lambda k: pipes[k]["ms_per_step"])
+        peak = pipes[main_pipe]["peak"]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(dom)
+        return {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": round(weighted * peak, 3), "frac": round(weighted, 4),
+            "frac_definition": "time-weighted mean over all convolution time (incl. the Winograd transform passes, which execute no FLOPs) of each kernel "
+                               "family's EXECUTED FLOP rate / the dense peak of the matrix pipe it runs on (fp32 MFMA %.1f, bf16 MFMA %.0f TFLOP/s; an exact "
+                               "three-way split executes six bf16 FLOPs per fp32 FLOP); `achieved` = frac x `peak` of the pipe that holds most of the time (%s)"
+                               % (PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS, main_pipe),
+            "kernel": "all convolution launches of the forward (conv_hsplit / wino_gemm_split / conv_halo / wino_gemm / conv_f32 / conv_stem kernels + Winograd transform passes)",
+            "per_pipe": pipes, "winograd_transform_ms_per_step": round(transform_ms, 3),
+            "all_conv_ms_per_step": round(conv_ms, 3), "launches_per_step": len(plan.convs),
+            "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2), "direct_equivalent_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 2),
+            "traffic": traffic, "traffic_source": traffic_src,
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
                             "(separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.sh), not measured by this run",
             "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / d["peak"], 4), "peak": d["peak"],
@@ -687,52 +699,48 @@ def main():
                                                                                                   "peak": t["peak"]}
                          for k, t in sorted(per_tile.items())},
             "winograd": {"layers": wino["layers"], "ms_per_step": round(wino["ms"], 3), "gemm_ms": round(wino["gemm_ms"], 3),
-                         "transform_ms": round(wino["ms"] - wino["gemm_ms"], 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
+                         "transform_ms": round(transform_ms, 3), "replaced_direct_gflop": round(wino["replaced_flops"] / 1e9, 2)},
         }
+
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = conv_roofline(net)
         try:
             sus = _sustained_mfma(dev)
             result["roofline"]["sustained_on_this_box"] = dict(sus, what="bare MFMA stream on every SIMD (cp_mfma_probe), HIP-event timed in this run; the "
-                                                               "datasheet peak above stays the denominator of `frac`",
-                                                               frac_of_sustained_f32=round(ach_all / sus["f32_mfma_tflops"], 4))
+                                                               "datasheet peaks above stay the denominators of `frac`")
         except Exception as exc:  # the probe is an annotation: never fail the bench line over it
             result["roofline"]["sustained_on_this_box"] = {"error": str(exc)}
     _log("roofline section done")
-    if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode == "f32" and os.environ.get("CASAPOSE_WINO_GEMM", "") != "split":
-        # the same workload with the two fp32-EQUIVALENT opt-ins switched on (exact three-way bf16 splits on the bf16 matrix pipe: the shallow
-        # 3x3 layers, csrc/conv_hsplit.hip, and the Winograd GEMMs, csrc/wino_gemm_split.hip) -- reported BESIDE the headline, never as it
-        from casapose_amd import engine as _engine
-
+    if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode == "split":
+        # the same workload on the fp32 MFMA everywhere (conv_mode="f32": v_mfma_f32_32x32x2_f32 in every convolution, the round-1/2 headline) --
+        # measured in the same run and reported BESIDE the headline with its own roofline, so that the two arithmetic routes can be compared
         ref_logits = net([img], training=False)[..., :seg_dim].clone()
         net = None
         torch.cuda.empty_cache()
-        _engine.WINO_GEMM_SPLIT = True
-        try:
-            net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None, base_model="resnet18", device=dev,
-                                                      seed=1237, conv_mode="split")
-            net2.set_parameters(params)
+        net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None, base_model="resnet18", device=dev,
+                                                  seed=1237, conv_mode="f32")
+        net2.set_parameters(params)
 
-            def step2():
-                out = net2([img], training=False)
-                s_, d_, c_ = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
-                return voter([s_, d_, c_])
+        def step2():
+            out = net2([img], training=False)
+            s_, d_, c_ = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
+            return voter([s_, d_, c_])
 
-            for _ in range(args.warmup):
-                step2()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step2()
-            torch.cuda.synchronize(dev)
-            dt2 = time.perf_counter() - t1
-            result["optin_fp32_equivalent"] = {
-                "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
-                # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)
-                "max_logit_difference_vs_headline_rel": float("%.3g" % float((net2([img], training=False)[..., :seg_dim] - ref_logits).abs().max() / ref_logits.abs().max())),
-                "what": "CASAPOSE_INFER_CONV_MODE=split + CASAPOSE_WINO_GEMM=split: shallow 3x3 layers and Winograd GEMMs as exact 3-way bf16 splits "
-                        "(six bf16 products per fp32 product, fp32 accumulate; error <= the fp32 MFMA's, tests/test_gpu_hsplit.py, test_gpu_conv.py); NOT the headline"}
-            _log("opt-in line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
-        finally:
-            _engine.WINO_GEMM_SPLIT = False
+        for _ in range(args.warmup):
+            step2()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t1
+        result["exact_fp32_mfma"] = {
+            "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
+            # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)
+            "max_logit_difference_vs_headline_rel": float("%.3g" % float((net2([img], training=False)[..., :seg_dim] - ref_logits).abs().max() / ref_logits.abs().max())),
+            "what": "CASAPOSE_INFER_CONV_MODE=f32: every convolution on v_mfma_f32_32x32x2_f32 (the headline of rounds 1 and 2); NOT this round's headline",
+            "roofline": conv_roofline(net2) if not args.no_roofline else None}
+        _log("fp32-MFMA line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
     if rank == 0 and world == 1 and not args.no_train_leg:
         # BASELINE configs[2] beside the headline, under the driver's clock: 3 training steps (1 warm-up) at the --mode train defaults
         net = net2 = plan = None   # noqa: F841  (drop the inference plans' buffers before the training plan allocates its own)

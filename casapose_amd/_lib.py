@@ -171,6 +171,11 @@ SYMBOLS = [
     ("cp_ls_vote_bwd_f32", _i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     ("cp_kp_stats_f32", _i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_kp_reproj_loss_f32", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    ("cp_pose_loss_sep_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
+    ("cp_pose_loss_sep_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
+    ("cp_vector_field_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    ("cp_smooth_l1_f32", _i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _ll, _vp, _vp, _vp]),
+    ("cp_proxy_voting_f32", _i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cp_pose_loss_f32", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 ]
 

@@ -281,11 +281,16 @@ class FusedConv:
 
 
 WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
-# opt-in: the Winograd GEMM as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent; csrc/wino_gemm_split.hip)
+# The Winograd GEMM as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-EQUIVALENT: every product exact, fp32 accumulation, measured
+# error <= the fp32 MFMA's; csrc/wino_gemm_split.hip).  Round 3: the DEFAULT of both plans -- the training plan since round 2, the
+# inference plan whenever its conv mode is "split" (its default, see CasaposeNet); CASAPOSE_WINO_GEMM=f32 restores the fp32 MFMA in both,
+# CASAPOSE_WINO_GEMM=split forces the split GEMM even with conv_mode="f32".
 WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
-# The TRAINING plan uses it by default (BASELINE configs[2] asks for bf16 convolutions; this is the fp32-equivalent way to use that pipe);
-# CASAPOSE_WINO_GEMM=f32 restores the fp32 MFMA there.  Inference (the headline metric, fp32) stays on the fp32 MFMA unless asked.
+WINO_GEMM_F32 = os.environ.get("CASAPOSE_WINO_GEMM", "") == "f32"
 TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
+# default arithmetic of the inference plan's convolutions (CasaposeNet(conv_mode=None)): "split" = exact three-way bf16 splits on the bf16 matrix
+# pipe for every layer the split kernels cover (fp32-equivalent), "f32" = the fp32 MFMA everywhere, "bf16" = bf16 operands (3e-2 gates)
+DEFAULT_INFER_CONV_MODE = "split"
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 
@@ -414,10 +419,17 @@ class WinoConv:
         return sum(2.0 * 36 * tp * self.ktot * self.cout for _, _, tp in self.chunks())
 
 
-def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int) -> bool:
-    """Measured on MI355X (profiles/): the 4x MFMA saving beats the two transform passes once the GEMM is deep and wide enough."""
+WINO_MIN_K = int(os.environ.get("CASAPOSE_WINO_MIN_K", "0"))      # 0 = the measured defaults below
+WINO_MIN_COUT = int(os.environ.get("CASAPOSE_WINO_MIN_COUT", "128"))
+
+
+def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int, split_gemm: bool = False) -> bool:
+    """Measured on MI355X (profiles/): the 4x MFMA saving beats the two transform passes once the GEMM is deep and wide enough -- K >= 256 with
+    the fp32-MFMA GEMM; K >= 128 when the GEMM runs on the bf16 pipe (split_gemm: the dilated 128 -> 256 layer stage3_unit1_conv1, which no
+    split kernel covers directly, 0.43 -> 0.17 ms at bs 16; the three 128 -> 128 stage-2 layers 0.37 -> 0.36 ms)."""
     k = sum(s[0] for s in sources)
-    return kh == 3 and stride == 1 and pad == dilation and k >= 256 and k % 32 == 0 and cout >= 128 and cout % 4 == 0
+    min_k = WINO_MIN_K or (128 if split_gemm else 256)
+    return kh == 3 and stride == 1 and pad == dilation and k >= min_k and k % 32 == 0 and cout >= WINO_MIN_COUT and cout % 4 == 0
 
 
 class ForwardPlan:
@@ -476,8 +488,9 @@ class ForwardPlan:
                 self.steps.append(wl.run)
                 return
             layer.bind(batch=B, **kw)
-            # opt-in (CASAPOSE_INFER_CONV_MODE / CasaposeNet(conv_mode=...)): the shallow 3x3 layers on the bf16 matrix pipe (csrc/conv_hsplit.hip),
-            # 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside its range keep the fp32-MFMA kernels
+            # conv mode (CASAPOSE_INFER_CONV_MODE / CasaposeNet(conv_mode=...), default "split"): the 3x3 / stride-1 layers off the Winograd path on the
+            # bf16 matrix pipe (csrc/conv_hsplit.hip), 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside
+            # its range (stem, strided and dilated layers, ...) keep the fp32-MFMA kernels
             if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
                 layer.split_mode = net.conv_planes
             elif net.conv_planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
@@ -771,7 +784,7 @@ class CasaposeNet:
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
-        mode = conv_mode if conv_mode is not None else os.environ.get("CASAPOSE_INFER_CONV_MODE", "f32")
+        mode = conv_mode if conv_mode is not None else os.environ.get("CASAPOSE_INFER_CONV_MODE", DEFAULT_INFER_CONV_MODE)
         if mode not in ("f32", "split", "bf16"):
             raise ValueError("conv_mode must be f32, split or bf16 (got %r)" % mode)
         self.conv_mode = mode
@@ -808,9 +821,9 @@ class CasaposeNet:
         def add(name, key, layout, k, cout, sources, stride=1, dil=1, pad=None, partial=False):
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev, want_split=bool(self.conv_planes))
             pad = dil * (k // 2) if pad is None else pad
-            if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout):
-                Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev,
-                                    split_planes=2 if self.conv_mode == "bf16" else None)
+            planes = 2 if self.conv_mode == "bf16" else (3 if self.conv_mode == "split" and not WINO_GEMM_F32 else None)
+            if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout, split_gemm=bool(planes) or WINO_GEMM_SPLIT):
+                Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev, split_planes=planes)
 
         add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])
         cin = 64

@@ -466,6 +466,41 @@ int cp_pose_loss_f32(const float* out, int ld, int seg_dim, int kp, const uint8_
                      int filter_high_proxy_errors, float mask_w, float vertex_w, float proxy_w, void* ws, float* dout, int dld,
                      int vert_off, double* loss_sums, float* object_loss_values, void* stream);
 
+/* compute_loss for the `pvnet` model with SEPARATED vector fields (train_casapose.py:57,97-125): the output holds seg_dim logits followed by
+ * objects*2*kp direction channels, object o in [seg_dim + o*2kp, seg_dim + (o+1)*2kp).  vertex = sum over objects of smooth_l1_loss(slice,
+ * target slice, one-hot of the object), proxy = sum over objects of proxy_voting_loss_v2(slice, the object's keypoints, one-hot of the object):
+ * a pixel contributes to the slice of its own object only, normalised by 2kp * (pixels of that object in the image) + 1e-3, mean over the
+ * batch.  Everything else as cp_pose_loss_f32 (labels, filter_with_segmentation, the gradient row: logits in [0,seg_dim), the directions of
+ * object o in [vert_off + o*2kp, ...)).  ws: cp_pose_loss_sep_workspace_bytes. */
+size_t cp_pose_loss_sep_workspace_bytes(int batch, int h, int w, int seg_dim);
+int cp_pose_loss_sep_f32(const float* out, int ld, int seg_dim, int kp, const uint8_t* labels_ce, const uint8_t* labels_fg,
+                         const float* keypoints_yx, int objects, int batch, int h, int w, int filter_with_segmentation, float mask_w,
+                         float vertex_w, float proxy_w, void* ws, float* dout, int dld, int vert_off, double* loss_sums, void* stream);
+
+/* The reference's loss / target functions as stand-alone passes (values only; the training step differentiates the fused kernels above).
+ * They back the importable casapose.utils.loss_functions / casapose.utils.image_utils modules.
+ *
+ * cp_vector_field_f32 -- compute_vertex_hcoords_batch_v3 (utils/image_utils.py:17-63) and, with separated != 0, the per-object concatenation of
+ * get_all_vectorfields (:66-79): out[p][slot*2kp + 2j..] = (keypoint_j - pixel centre) of the pixel's object (label l in 1..objects, slot =
+ * separated ? l-1 : 0), l2-normalised when normalize != 0 (tf.math.l2_normalize, epsilon 1e-12), zero elsewhere.  keypoints_yx:
+ * [batch][objects][instances][kp][2]; with several instances the one whose first keypoint (the centre) is nearest to the pixel is used. */
+int cp_vector_field_f32(const uint8_t* labels, const float* keypoints_yx, int batch, int h, int w, int objects, int instances, int kp,
+                        int separated, int normalize, float* out, int ld, void* stream);
+/* smooth_l1_loss (utils/loss_functions.py:14-44) up to its final normalisation: sums[2b] = sum over the image's pixels and channels of
+ * smoothL1(|w (pred - target)|), sums[2b+1] = sum of w; w = weights[p*wld] (wmode 0), |1 - weights[p*wld]| (wmode 1, `invert_weights`) or 1
+ * (wmode 2, `ignore_weights`).  elem (optional, [batch*pixels][channels]) receives the per-element values (`normalize=False, reduce=False`). */
+int cp_smooth_l1_f32(const float* pred, int pld, const float* target, int tld, const float* weights, int wld, int wmode, int channels,
+                     int batch, long long pixels_per_image, double* sums, float* elem, void* stream);
+/* proxy_voting_dist / proxy_voting_loss_v2 (utils/loss_functions.py:47-203) up to their final normalisations: per pixel and keypoint the
+ * perpendicular distance between the keypoint of the pixel's object (labels: 0 = no object -> object 0, as the arg-max of an all-zero one-hot
+ * row; l -> object l-1; minimum over the object's instances) and the line through the pixel centre along the predicted direction, times the
+ * pixel weight (as cp_smooth_l1_f32).  img_sums[2b], [2b+1] = sum of smoothL1(dist), sum of weights; obj_sums / obj_counts (optional,
+ * [batch][objects]) = the same sum per object (unsorted_segment_sum) and the object's pixel count; dist_out / elem (optional, [pixels][kp]) =
+ * the distances / their smooth-L1 values. */
+int cp_proxy_voting_f32(const float* pred, int pld, int kp, const uint8_t* labels, const float* weights, int wld, int wmode,
+                        const float* keypoints_yx, int objects, int instances, int batch, int h, int w, double* img_sums, double* obj_sums,
+                        int32_t* obj_counts, float* dist_out, float* elem, void* stream);
+
 /* Backward of cp_ls_vote_f32 (the reference differentiates CoordLSVotingWeighted with tf.GradientTape,
  * train_casapose.py:555-579): dkeypoints = d loss / d keypoints [batch][objects][kp][2] (y,x px); sums_ws = the workspace
  * the forward left behind; pu_ws: float [batch*objects*kp*4] scratch.  Writes (accumulate: adds) d loss / d directions

@@ -303,12 +303,13 @@ def test_load_weights_from_keras_h5(device, tmp_path):
     assert np.array_equal(got["conv0.kernel"], other["conv0.kernel"]) and np.array_equal(got["pv_block_6_clade.gamma"], params["pv_block_6_clade.gamma"])
 
 
-@pytest.mark.parametrize("mode,tol", [("split", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("split", 1e-3), ("bf16", 3e-2)])
 @pytest.mark.parametrize("fuse", [True, False])
-def test_forward_on_the_bf16_matrix_pipe(device, mode, tol, fuse):
-    """conv_mode="split": the shallow 3x3 layers run as exact three-way bf16 splits (csrc/conv_hsplit.hip) -- the SAME 1e-3 gate as the
-    fp32-MFMA forward; conv_mode="bf16": their operands are rounded to bf16 -- the 3e-2 gate of SURVEY 8(d).  fuse=True exercises the kernel's
-    fused x2 bilinear / guided sources and 1x1 heads, fuse=False its direct sources."""
+def test_forward_in_every_conv_mode(device, mode, tol, fuse):
+    """conv_mode="split" (the inference default since round 3): the 3x3 layers off the Winograd path run as exact three-way bf16 splits
+    (csrc/conv_hsplit.hip) and the Winograd GEMMs likewise -- the SAME 1e-3 gate as conv_mode="f32", the fp32 MFMA everywhere, which this test
+    keeps covered whatever the default is; conv_mode="bf16": operands rounded to bf16 -- the 3e-2 gate of SURVEY 8(d).  fuse=True exercises
+    the kernels' fused x2 bilinear / guided sources and 1x1 heads, fuse=False their direct sources."""
     from casapose_amd import _lib
 
     b, h, w, k, v = 2, 64, 96, 5, 27
@@ -324,6 +325,19 @@ def test_forward_on_the_bf16_matrix_pipe(device, mode, tol, fuse):
     ref = O.casapose_c_gcu5(p64, img.astype(np.float64), seg_input=seg.astype(np.float64))
     got = net([img, seg], training=False).cpu().numpy().astype(np.float64)
     assert rel_err(got[..., :k], ref[..., :k]) < tol and rel_err(got[..., k:], ref[..., k:]) < tol
-    on_pipe = [c.name for c in net._net.plan(b, h, w).convs if getattr(c, "split_mode", 0)]
+    convs = net._net.plan(b, h, w).convs
+    on_pipe = [c.name for c in convs if getattr(c, "split_mode", 0)]
+    wino_split = [c.name for c in convs if hasattr(c, "gemm_flops") and getattr(c, "Us", None) is not None]
+    if mode == "f32":
+        assert not on_pipe and not wino_split and net._net.conv_mode == "f32"
+        return
     assert len(on_pipe) >= 10, on_pipe     # stage 1 (4 layers) and decoder blocks 3-5 / 8-10, with fused upsampling / heads or without
-    assert all(getattr(c, "split_mode", 0) in (0, 3 if mode == "split" else 1) for c in net._net.plan(b, h, w).convs)
+    assert all(getattr(c, "split_mode", 0) in (0, 3 if mode == "split" else 1) for c in convs)
+    assert len(wino_split) >= 9, wino_split   # the deep layers' Winograd GEMMs on the bf16 pipe too (3 planes / hi + mid)
+
+
+def test_default_inference_mode_is_the_fp32_equivalent_split(device):
+    from casapose_amd import engine
+
+    net, _ = build(device, 5, 27, 64, 96)
+    assert engine.DEFAULT_INFER_CONV_MODE == "split" and net._net.conv_mode == "split" and net._net.conv_planes == 3
