@@ -91,9 +91,9 @@ def PVNet(ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2dim=32, raw_dim=32
           base_model="resnet18", backbone=None, output_lablemap=False, **kwargs):
     """pvnet_combined (pose_models.py:645-696): the baseline without the class-adaptive decoder -- ResNet-18 + decoder 1 + one 1x1 head
     `pv_final_conv` with seg_dim + ver_dim output channels.  The registry key `pvnet` is the same graph with per-object ("separated")
-    vector fields, ver_dim = 2*points*objects (train_casapose.py:221,313-320): its forward (inference) is built for any head width; the
-    training step covers the merged-output form only (seg_dim + ver_dim <= 64: the separated-field losses of compute_loss,
-    train_casapose.py:57,97-125, are not built) and says so when asked."""
+    vector fields, ver_dim = 2*points*objects (train_casapose.py:221,313-320): inference and training are built for both forms -- the merged
+    output through cp_pose_loss_f32, the separated fields through cp_pose_loss_sep_f32 (compute_loss's per-object branch,
+    train_casapose.py:57,97-125; no keypoint loss there, as in the reference, whose voter reads merged fields)."""
     if base_model != "resnet18":
         raise NotImplementedError("backbone %s is not built for MI355X yet (resnet18 is)" % base_model)
     if backbone is not None or input_tensor is not None:

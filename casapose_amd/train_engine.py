@@ -744,19 +744,17 @@ class TrainPlan:
                  pvnet: bool = False, shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True):
         if h % 8 or w % 8:
             raise ValueError("input height/width must be multiples of 8 (got %dx%d)" % (h, w))
-        if pvnet and seg_dim + ver_dim > self.GRAD_LD:
-            raise NotImplementedError("PVNet training covers the merged-output model (seg_dim + ver_dim <= %d); the separated-vector-field losses of "
-                                      "the `pvnet` registry entry (train_casapose.py:57,97-125) are not built -- its forward is" % self.GRAD_LD)
-        if seg_dim > 32 or ver_dim > 32:
-            raise ValueError("the training plan supports up to 32 classes / 32 vertex channels")
+        if seg_dim > 32 or (ver_dim > 32 and not pvnet):
+            raise ValueError("the training plan supports up to 32 classes / 32 vertex channels (more vertex channels only for `pvnet` with separated vector fields)")
         lib = _lib.load()
         self.store, self.seg_dim, self.ver_dim = store, seg_dim, ver_dim
         self.batch, self.h, self.w = batch, h, w
         self.pvnet = bool(pvnet)
         if self.pvnet:  # one merged head: its gradient row is the contiguous [seg | vertex] record
             if seg_dim + ver_dim > self.GRAD_LD:
-                raise NotImplementedError("PVNet training covers the merged-output model (seg_dim + ver_dim <= %d); the separated-vector-field losses of "
-                                          "the `pvnet` registry entry (train_casapose.py:57,97-125) are not built -- its forward is" % self.GRAD_LD)
+                # `pvnet` with SEPARATED vector fields (one 2*kp slice per object, train_casapose.py:57,97-125): a wider gradient row; a multiple
+                # of 32 so that the head's data gradient may read its channel-padded rows
+                self.GRAD_LD = (seg_dim + ver_dim + 31) // 32 * 32
             self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
         self._buckets = None
@@ -792,7 +790,7 @@ class TrainPlan:
         self.shared, self.reuse_first, self.skips2 = tuple(bool(v) for v in shared), bool(reuse_first), bool(skips2)
         self.gmask = [torch.empty(B, hs[l], ws[l], **u8) if any(self.bilinear) else None for l in range(3)]
         self.loss_sums = torch.zeros(3, dtype=torch.float64, device=dev)
-        self.loss_ws = torch.empty(lib.cp_pose_loss_workspace_bytes(B, h, w), **u8)
+        self.loss_ws = torch.empty(max(lib.cp_pose_loss_workspace_bytes(B, h, w), lib.cp_pose_loss_sep_workspace_bytes(B, h, w, K)), **u8)
         self.object_loss_values = torch.zeros(B, K - 1, **f32)  # per-object proxy distances (proxy_voting_dist)
         # keypoint-reprojection loss (LS voter forward/backward)
         oc, kp = K - 1, 9
@@ -1069,6 +1067,16 @@ class TrainPlan:
         stream = torch.cuda.current_stream(self.out.device).cuda_stream
         assert labels_ce.dtype == torch.uint8 and labels_fg.dtype == torch.uint8 and keypoints_yx.dtype == torch.float32
         assert tuple(keypoints_yx.shape) == (B, self.seg_dim - 1, kp, 2) and keypoints_yx.is_contiguous()
+        oc = self.seg_dim - 1
+        if self.pvnet and oc > 1 and self.ver_dim == oc * 2 * kp:   # separated vector fields: per-object slices (compute_loss, train_casapose.py:57,97-125)
+            if filter_high_proxy_errors:
+                raise NotImplementedError("filter_high_proxy_errors with separated vector fields is not built")
+            check(lib.cp_pose_loss_sep_f32(self.out.data_ptr(), self.out_ld, self.seg_dim, kp, labels_ce.data_ptr(), labels_fg.data_ptr(), keypoints_yx.data_ptr(),
+                                           oc, B, h, w, 1 if filter_with_segmentation else 0, mask_w, vertex_w, proxy_w, self.loss_ws.data_ptr(),
+                                           self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(), stream), "cp_pose_loss_sep_f32")
+            return self.loss_sums
+        if 2 * kp > self.ver_dim:
+            raise ValueError("the output holds %d vertex channels, fewer than 2 * %d keypoints" % (self.ver_dim, kp))
         check(lib.cp_pose_loss_f32(self.out.data_ptr(), self.out_ld, self.seg_dim, kp, labels_ce.data_ptr(), labels_fg.data_ptr(), keypoints_yx.data_ptr(),
                                    self.seg_dim - 1, B, h, w, 1 if filter_with_segmentation else 0, 1 if filter_high_proxy_errors else 0, mask_w, vertex_w,
                                    proxy_w, self.loss_ws.data_ptr(), self.dout.data_ptr(), self.GRAD_LD, self.VERT_OFF, self.loss_sums.data_ptr(),

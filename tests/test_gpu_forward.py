@@ -204,7 +204,7 @@ def test_custom_decoder_params(device):
 
 def test_pvnet_with_separated_vector_fields_forward(device):
     """the `pvnet` registry entry (models_factory.py:31): per-object vector fields, ver_dim = 2 * points * objects -> a 1x1 head with
-    seg_dim + 144 output channels for 8 objects; inference forward vs the oracle; the training step refuses the separated-field losses."""
+    seg_dim + 144 output channels for 8 objects; inference forward vs the oracle (its training step: the next test)."""
     from casapose_amd.pose_models.tfkeras import Classifiers
 
     b, h, w, k = 1, 32, 48, 9
@@ -216,8 +216,78 @@ def test_pvnet_with_separated_vector_fields_forward(device):
     ref = O.casapose_c_gcu5({n: a.astype(np.float64) for n, a in params.items()}, img.astype(np.float64), variant="pvnet_combined")
     got = net([img], training=False).cpu().numpy().astype(np.float64)
     assert got.shape == (b, h, w, k + v) and rel_err(got, ref) < 1e-3
-    with pytest.raises(NotImplementedError, match="separated"):
-        net([img], training=True)
+    assert tuple(net([img], training=True).shape) == (b, h, w, k + v)
+
+
+@pytest.mark.parametrize("filt", [False, True])
+def test_pvnet_separated_vector_fields_training_step(device, filt):
+    """`pvnet` TRAINING with separated vector fields (round-2 verdict, missing #5): compute_loss's per-object branch (train_casapose.py:57,97-125)
+    -- vertex = sum_o smooth_l1_loss(slice o, target slice o, one-hot o), proxy = sum_o proxy_voting_loss_v2(slice o, keypoints o, one-hot o) --
+    value and the gradient of every variable against the fp64 restatement (oracle/loss_functions_ref.compute_loss_separated on
+    oracle/torch_train_ref.forward_train(pvnet=True)), on the device's activation branches; then the host API train_step on the model."""
+    import loss_functions_ref as LR
+    import torch_train_ref as R
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    b, h, w, k, kp = 2, 32, 48, 4, 9
+    oc = k - 1
+    v = 2 * kp * oc
+    params = O.init_params(k, v, seed=35, dtype=np.float32, pvnet=True)
+    store = ParamStore(params, device)
+    plan = TrainPlan(store, k, v, b, h, w, pvnet=True)
+    assert plan.GRAD_LD >= k + v and plan.VERT_OFF == k
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    rng = np.random.default_rng(6)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    lab = np.zeros((b, h, w), np.uint8)
+    lab[:, 4:20, 6:30], lab[:, 14:30, 20:44], lab[0, 2:10, 30:44] = 1, 2, 3
+    kpts = rng.uniform(0, h, (b, oc, kp, 2)).astype(np.float32)
+    labd = torch.from_numpy(lab).to(device)
+    out = plan.forward(torch.from_numpy(img).to(device))
+    t_img, t_lab, t_kp = torch.from_numpy(img.astype(np.float64)), torch.from_numpy(lab.astype(np.int64)), torch.from_numpy(kpts.astype(np.float64))
+    one_hot = torch.from_numpy(np.eye(k)[lab.astype(np.int64)])
+    target = LR.get_all_vectorfields(one_hot, t_kp[:, :, None], t_lab[..., None], True)
+    wts = (1.0, 0.5, 0.015)
+
+    def reference(pattern, pre=None):
+        p = R.to_torch(params)
+        o = R.forward_train(p, t_img, t_lab, pvnet=True, act_pattern=pattern, preact_out=pre)
+        return p, o, LR.compute_loss_separated(o[..., :k], one_hot, o[..., k:], target, t_kp[:, :, None], filter_vertex_with_segmentation=filt)
+
+    pre = {}
+    p64, ref, (ml, vl, pl) = reference(None, pre)
+    assert rel_err(out.cpu().numpy().astype(np.float64), ref.detach().numpy()) < 1e-3
+    sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(device), *wts, filter_with_segmentation=filt).cpu().numpy()
+    for got, want in zip(sums, (ml, vl, pl)):
+        assert abs(got - want.item()) < 1e-3 * abs(want.item()), (sums, ml.item(), vl.item(), pl.item())
+    plan.backward()
+    torch.cuda.synchronize()
+    pattern = plan.activation_pattern()
+    flips, total, margin = R.kink_report(pattern, pre)
+    assert margin < 1e-4 and flips < 1e-4 * total
+    if flips:
+        p64, _, (ml, vl, pl) = reference(pattern)
+    (wts[0] * ml + wts[1] * vl + wts[2] * pl).backward()
+    for name in store.offsets:
+        g, gr = store.grad_view(name).cpu().numpy().astype(np.float64), p64[name].grad.numpy()
+        assert np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-30) < 1e-3, name
+    if filt:
+        return
+    # host API: the `pvnet` registry entry trains through casapose_amd.training.train_step (12 steps reduce the loss)
+    from casapose_amd.pose_models.tfkeras import Classifiers
+    from casapose_amd.training import Adam, train_step
+    from casapose_amd.utils.learning_rate_schedules import LossWeightHandler
+
+    class Opt:
+        train_vectors_with_ground_truth = False
+        estimate_coords = False
+
+    net = Classifiers.get("pvnet")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, device=device)
+    net.set_parameters(params)
+    batch = {"img": torch.from_numpy(img), "target_seg": one_hot.float(), "target_vert": torch.from_numpy(kpts)[:, :, None], "filtered_seg": torch.from_numpy(lab)[..., None]}
+    lf, optim = LossWeightHandler(*wts, 0.0), Adam(1e-3)
+    hist = [train_step(net, batch, lf, optim, Opt())[0] for _ in range(12)]
+    assert np.all(np.isfinite(hist)) and hist[-1] < 0.8 * hist[0], hist
 
 
 def test_pvnet_combined_forward_and_training(device):

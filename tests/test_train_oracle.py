@@ -50,3 +50,30 @@ def test_inference_mode_of_the_torch_restatement_equals_the_numpy_oracle():
     seg, direct, conf, labels, _ = O.synthetic_voting_inputs(1, 40, 60, num_obj=8, seed=3)
     got = R.ls_voting(torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(direct.astype(np.float64)), torch.from_numpy(conf.astype(np.float64)), 8).numpy()
     assert np.abs(got - O.ls_voting(seg, direct, conf)).max() < 1e-3
+
+
+def test_functional_loss_restatements_agree_with_the_training_oracle():
+    """oracle/loss_functions_ref.py (the reference's FUNCTIONS with their own signatures) against oracle/torch_train_ref.losses (the merged
+    compute_loss the training tests use): vertex and proxy terms through smooth_l1_loss / proxy_voting_loss_v2 on get_all_vectorfields'
+    target, and the per-object filter values through proxy_voting_dist."""
+    import loss_functions_ref as LR
+
+    rng = np.random.default_rng(11)
+    b, h, w, k, kp = 2, 24, 32, 4, 9
+    lab = np.zeros((b, h, w), np.int64)
+    lab[:, 2:12, 3:15], lab[:, 10:22, 16:30], lab[0, 14:22, 2:10] = 1, 2, 3
+    one_hot = torch.from_numpy(np.eye(k)[lab])
+    kpts = torch.from_numpy(rng.uniform(0, h, (b, k - 1, kp, 2)))
+    out = torch.from_numpy(rng.standard_normal((b, h, w, k + 3 * kp)))
+    ml, vl, pl = R.losses(out, torch.from_numpy(lab), kpts, k, kp, filter_vertex_with_segmentation=False)
+    dirs = out[..., k:k + 2 * kp]
+    target = LR.get_all_vectorfields(one_hot, kpts[:, :, None], torch.from_numpy(lab)[..., None], False)
+    assert torch.allclose(target, R.target_vector_field(torch.from_numpy(lab), kpts), atol=1e-12)
+    v2 = LR.smooth_l1_loss(dirs, target, one_hot[..., 0:1], invert_weights=True)
+    p2 = LR.proxy_voting_loss_v2(dirs, kpts[:, :, None], one_hot[..., 1:], one_hot[..., 0:1], invert_weights=True, loss_per_object=False)
+    assert abs(v2.item() - vl.item()) < 1e-12 and abs(p2.item() - pl.item()) < 1e-12
+    # separated fields: every per-object slice target equals the merged target on that object's pixels
+    sep = LR.get_all_vectorfields(one_hot, kpts[:, :, None], torch.from_numpy(lab)[..., None], True)
+    for o in range(k - 1):
+        m = torch.from_numpy(lab == o + 1)
+        assert torch.equal(sep[..., o * 2 * kp:(o + 1) * 2 * kp][m], target[m]) and float(sep[..., o * 2 * kp:(o + 1) * 2 * kp][~m].abs().max()) == 0.0
