@@ -181,7 +181,14 @@ def estimate_and_evaluate_poses(output_seg, target_seg, output_vertex, poses_gt,
         lab = torch.argmax(output_seg, dim=3)
         onehot = torch.nn.functional.one_hot(lab, output_seg.shape[3])[..., 1:].to(torch.float32)
         kw = {} if draws is None else {"draws": draws}
-        vert = output_vertex.reshape(b, h, w, -1, 2)
+        vc = _np(object_points_3d).shape[3]
+        if oc > 1 and output_vertex.shape[-1] == vc * oc * 2:
+            # `pvnet` with separated vector fields (pose_evaluation.py:38-45): every pixel votes with the slice of its own (arg-max) object,
+            # background pixels with zeros -- an indexing step
+            sl = output_vertex.reshape(b, h, w, oc, vc * 2)
+            idx = torch.clamp(lab - 1, min=0)[..., None, None].expand(b, h, w, 1, vc * 2)
+            output_vertex = torch.where((lab == 0)[..., None], torch.zeros((), dtype=sl.dtype, device=sl.device), torch.gather(sl, 3, idx)[:, :, :, 0])
+        vert = output_vertex.reshape(b, h, w, -1, 2).contiguous()
         points_estimated = ransac_voting_layer_all_masks(onehot, vert, 512, inlier_thresh=0.99, max_iter=20, min_num=min_num, max_num=30000, **kw)
     else:
         points_estimated = _np(points_estimated) * np.array([[[[h, w]]]], np.float64)

@@ -239,7 +239,10 @@ def test_step(net, batch, opt, loss_factors, evaluation_points=None, object_poin
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     out = net([img, seg] if with_gt else [img], training=False)
-    o_seg, o_dirs, conf = torch.split(out, [K, 2 * kp, out.shape[3] - K - 2 * kp], dim=3)
+    if K > 2 and out.shape[3] - K == 2 * kp * (K - 1):    # `pvnet`, separated vector fields: no confidences, RANSAC voting on per-object slices
+        o_seg, o_dirs, conf = out[..., :K], out[..., K:], None
+    else:
+        o_seg, o_dirs, conf = torch.split(out, [K, 2 * kp, out.shape[3] - K - 2 * kp], dim=3)
     coords = None
     if getattr(opt, "estimate_coords", False):
         voter = CoordLSVotingWeighted(name="coords_ls_voting", num_classes=K, num_points=kp,

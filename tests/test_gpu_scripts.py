@@ -135,3 +135,44 @@ def test_ransac_voting_pose_chain_on_ground_truth_fields(device):
     pts = np.asarray(pts.cpu() if hasattr(pts, "cpu") else pts)
     big = batch["pixel_gt_count"].numpy()[0, :, 0, 0] > 200
     assert np.abs(pts[0][big] - kp2[0][big][..., ::-1]).max() < 0.5          # RANSAC keypoints are (x,y)
+
+
+def test_pvnet_separated_fields_drivers_and_evaluation_chain(device, tmp_path):
+    """modelname pvnet (separated vector fields, train_casapose.py:221,313-320 / test_casapose.py:143): both drivers run end to end with
+    estimate_confidence = estimate_coords = 0, and the evaluation chain for that output layout -- per-pixel selection of the arg-max object's
+    slice (pose_evaluation.py:38-45), RANSAC voting, PnP, ADD -- recovers every visible object from ground-truth fields."""
+    import test_casapose
+    import train_casapose
+    from casapose_amd.data_handler.synthetic_scene import SyntheticSceneDataset
+    from casapose_amd.pose_estimation.pose_evaluation import estimate_and_evaluate_poses
+
+    out = str(tmp_path / "run")
+    names = "obj_000001,obj_000005,obj_000006"
+    common = ["-c", CFG, "--outf", out, "--manualseed", "5", "--workers", "0", "--modelname", "pvnet", "--object", names, "--estimate_confidence", "0",
+              "--estimate_coords", "0", "--confidence_regularization", "0", "--train_vectors_with_ground_truth", "0"]
+    train_casapose.main(common + ["--data", "synthetic:4", "--datatest", "synthetic:2", "--epochs", "1", "--batchsize", "2", "--imagesize", "128", "160",
+                                  "--saveinterval", "1", "--loginterval", "1", "--validationinterval", "1"])
+    rows = list(csv.reader(open(out + "/loss_train.csv")))
+    vals = np.array([[float(v) for v in r[2:7]] for r in rows[1:]])
+    assert len(rows) == 3 and np.all(np.isfinite(vals)) and np.all(vals[:, 4] == 0)          # no keypoint loss with separated fields
+    res = test_casapose.main(common + ["--datatest", "synthetic:2", "--load_h5_weights", "1", "--imagesize_test", "128", "160"])
+    assert res["valid_3d"].shape == (3,) and np.all(np.isfinite(res["loss"]))
+    # ground-truth separated fields -> 100 % recall
+    oc, h, w, kp = 3, 448, 448, 9
+    ds = SyntheticSceneDataset(oc, (h, w), length=1, seed=8)
+    batch = ds.batch(0, 1)
+    lab = batch["filtered_seg"][..., 0].numpy()
+    kp2 = batch["target_vert"][:, :, 0].numpy()
+    yy, xx = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+    dirs = np.random.default_rng(0).standard_normal((1, h, w, oc, kp, 2)).astype(np.float32)  # foreign slices hold noise: they must not be read
+    for o in range(oc):
+        m = lab[0] == o + 1
+        d = kp2[0, o][None, None] - np.stack([yy, xx], -1)[:, :, None, :]
+        d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+        dirs[0, :, :, o][m] = d[m]
+    seg = (10.0 * batch["target_seg"]).to(device)
+    stats, poses, _ = estimate_and_evaluate_poses(seg, batch["target_seg"], torch.from_numpy(dirs.reshape(1, h, w, oc * kp * 2)).to(device), batch["poses_gt"],
+                                                  batch["keypoints3d"], batch["cam_mat"], batch["diameters"], batch["offsets"],
+                                                  evaluation_points=ds.mesh_vertex_array, object_points_3d_count=ds.mesh_vertex_count, min_num=200)
+    valid_2d, valid_3d, count_gt = stats[0], stats[1], stats[2]
+    assert count_gt.sum() >= 2 and np.all(valid_3d == count_gt) and np.all(valid_2d == count_gt)

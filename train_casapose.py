@@ -118,7 +118,10 @@ def main(argv=None):
 
     height, width = opt.imagesize
     input_segmentation_shape = (height, width, 1 + no_objects) if opt.train_vectors_with_ground_truth else None
-    ver_dim = opt.no_points * 2 + (opt.no_points if opt.estimate_confidence else 0)
+    separated_vectorfields = opt.modelname == "pvnet"      # train_casapose.py:221,313-320: one 2*points slice per object, no confidence / keypoint loss
+    if separated_vectorfields and (opt.estimate_confidence or opt.estimate_coords) and no_objects > 1:
+        raise SystemExit("modelname pvnet (separated vector fields) is not compatible with estimate_confidence / estimate_coords")
+    ver_dim = opt.no_points * 2 * (no_objects if separated_vectorfields else 1) + (opt.no_points if opt.estimate_confidence else 0)
     net = Classifiers.get(opt.modelname)(ver_dim=ver_dim, seg_dim=1 + no_objects, input_shape=(height, width, 3),
                                          input_segmentation_shape=input_segmentation_shape, weights="imagenet" if opt.pretrained else None,
                                          base_model=opt.backbonename, device=device, seed=opt.manualseed)
