@@ -549,6 +549,7 @@ class ForwardPlan:
                 if u == 1:
                     taps[tap_names[s]] = a
         self.taps = taps
+        self.encoder_steps = len(self.steps)   # run_encoder() stops here: the bare ResNet-18 backbone (resnet.py:319: the model's five outputs)
         x32s, x8s, x4s = taps["x32s"], taps["x8s"], taps["x4s"]
         skips = [None, (x8s, 128), (x4s, 64), (x2s, 64), (self.img4, 4)]
         dims = net.decoder_dims
@@ -726,6 +727,19 @@ class ForwardPlan:
 
     def conv_flops(self) -> float:
         return sum(c.flops for c in self.convs)
+
+    def run_encoder(self, img: torch.Tensor) -> List[torch.Tensor]:
+        """The encoder alone: the five taps of the reference's backbone model in its output order (resnet.py:251-252,291,303-305,319) --
+        relu0 [B,H/2,W/2,64], stage2_unit1_relu1 [B,H/4,W/4,64], stage3_unit1_relu1 [B,H/8,W/8,128], stage4_unit1_relu1 [B,H/8,W/8,256],
+        relu1 [B,H/8,W/8,512].  The tensors are the plan's own buffers (valid until the next run)."""
+        B, h, w = self.batch, self.h, self.w
+        if tuple(img.shape) != (B, h, w, 3) or img.dtype != torch.float32 or not img.is_contiguous():
+            raise ValueError("image must be a contiguous float32 [%d,%d,%d,3] tensor" % (B, h, w))
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        check(_lib.load().cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
+        for step in self.steps[:self.encoder_steps]:
+            step(stream)
+        return [self.taps[n] for n in ("x2s", "x4s", "x8s", "x16s", "x32s")]
 
     def run(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         lib = _lib.load()

@@ -13,27 +13,17 @@ import functools
 
 from .models import casapose as _cp
 from .models import pose_models as _pm
-
-
-def _not_built(name):
-    def ctor(*args, **kwargs):
-        raise NotImplementedError(
-            "model `%s` is registered by the reference but its graph has not been built for MI355X yet; "
-            "every casapose_* / pvnet* entry is" % name
-        )
-
-    ctor.__name__ = name
-    return ctor
+from .models import resnet as _rn
 
 
 class ModelsFactory:
     _models = {
         # reference registry keys (models_factory.py:9-32)
-        "resnet18": _not_built("resnet18"),
-        "resnet34": _not_built("resnet34"),
-        "resnet50": _not_built("resnet50"),
-        "resnet101": _not_built("resnet101"),
-        "resnet152": _not_built("resnet152"),
+        "resnet18": _rn.ResNet18,      # the OS-8 encoder with its five taps (include_top=False); deeper variants raise by name
+        "resnet34": _rn.ResNet34,
+        "resnet50": _rn.ResNet50,
+        "resnet101": _rn.ResNet101,
+        "resnet152": _rn.ResNet152,
         "casapose_c": _pm.CASAPoseConditional1,
         "casapose_c_gu": _pm.CASAPoseConditional2,
         "casapose_c_gcu3": _pm.CASAPoseConditional3,
@@ -46,7 +36,7 @@ class ModelsFactory:
         "casapose_c_gcu5_sw1": _pm.CASAPoseConditional8,
         "casapose_c_gcu4_bilat": _pm.CASAPoseConditional9,
         "casapose_c_gcu4_sw2": _pm.CASAPoseConditional10,
-        "pvnet": _pm.PVNet,  # same graph; raises for the separated-vector-field sizes (> 64 output channels)
+        "pvnet": _pm.PVNet,  # same graph with per-object (separated) vector fields: ver_dim = 2 * points * objects
     }
 
     @property

@@ -433,7 +433,7 @@ def keras_layout(params: Dict[str, np.ndarray], backbone_group: str = BACKBONE_G
         clade = layer.endswith("_clade")
         order = dict(KERAS_FIELD_ORDER, **({"beta": 1, "gamma": 2} if clade else {}))
         keys = sorted(keys, key=lambda k: order[k.split(".")[1]])
-        top = backbone_group if is_backbone_layer(layer) else layer
+        top = backbone_group if (backbone_group and is_backbone_layer(layer)) else layer
         if top not in top_order:
             top_order.append(top)
         if clade:

@@ -411,3 +411,35 @@ def test_default_inference_mode_is_the_fp32_equivalent_split(device):
 
     net, _ = build(device, 5, 27, 64, 96)
     assert engine.DEFAULT_INFER_CONV_MODE == "split" and net._net.conv_mode == "split" and net._net.conv_planes == 3
+
+
+def test_bare_resnet18_backbone_taps(device, tmp_path):
+    """`Classifiers.get("resnet18")(include_top=False)` -- the registry's bare backbone (models_factory.py:9, resnet.py:374-383; round-2 verdict:
+    NotImplementedError): five taps in the reference's output order against the oracle's encoder, the Keras-like surface restricted to the
+    encoder's layers, weights through a stand-alone (un-nested) Keras file."""
+    from casapose_amd.pose_models.models.resnet import get_backbone
+    from casapose_amd.pose_models.tfkeras import Classifiers
+    from casapose_amd.utils import h5_weights
+
+    b, h, w = 2, 64, 96
+    params = O.init_params(5, 27, seed=51, dtype=np.float32)
+    enc = {k: v for k, v in params.items() if h5_weights.is_backbone_layer(k.split(".")[0])}
+    net = Classifiers.get("resnet18")(input_shape=(h, w, 3), weights=None, include_top=False, device=device)
+    assert set(net.get_parameters()) == set(enc) and {l.name for l in net.layers} == {k.split(".")[0] for k in enc}
+    net.set_parameters(enc)
+    img = np.random.default_rng(1).uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    taps = net([img], training=False)
+    ref = O.resnet18_os8({n: a.astype(np.float64) for n, a in params.items()}, img.astype(np.float64))
+    assert [tuple(t.shape) for t in taps] == [(b, 32, 48, 64), (b, 16, 24, 64), (b, 8, 12, 128), (b, 8, 12, 256), (b, 8, 12, 512)]
+    for t, r in zip(taps, ref):
+        assert rel_err(t.cpu().numpy().astype(np.float64), r) < 1e-3
+    # weights round trip through a top-level (not nested) Keras layout; get_backbone() builds the same thing
+    path = str(tmp_path / "backbone.h5")
+    net.save_weights(path)
+    attrs = h5_weights.read_attrs(path)
+    assert b"conv0" in attrs["/"]["layer_names"] and b"model" not in attrs["/"]["layer_names"]
+    other = get_backbone("resnet18", input_shape=(h, w, 3), weights=path, device=device)
+    got = other.get_parameters()
+    assert all(np.array_equal(got[k], enc[k]) for k in enc)
+    for t, t2 in zip(taps, other(img)):
+        assert torch.equal(t, t2)

@@ -21,8 +21,14 @@ def test_registry_names_match_reference_and_unknown_name_raises():
     assert len(names) == 18  # models_factory.py:9-32
     with pytest.raises(ValueError, match="No such model"):
         Classifiers.get("does_not_exist")
-    with pytest.raises(NotImplementedError):   # registered by the reference, not built here: the bare backbones
+    with pytest.raises(NotImplementedError, match="resnet34"):   # registered by the reference; no model of the path uses the deeper backbones
         Classifiers.get("resnet34")(input_shape=(64, 64, 3))
+    with pytest.raises(NotImplementedError, match="include_top"):  # resnet18 itself is built (GPU tests) -- without the ImageNet classifier top
+        Classifiers.get("resnet18")(input_shape=(224, 224, 3))
+    from casapose_amd.pose_models.models.resnet import get_backbone
+
+    with pytest.raises(TypeError, match="Undefined base model type"):   # resnet.py:368-369
+        get_backbone("vgg16")
     from casapose_amd._lib import CasaposeHipError
 
     with pytest.raises(CasaposeHipError):      # pvnet with separated vector fields (9 + 18*8 output channels) constructs -- on a GPU (no CPU fallback)
