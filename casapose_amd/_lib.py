@@ -128,7 +128,7 @@ SYMBOLS = [
     ("cp_ls_vote_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ls_vote_w_f32", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ls_vote_workspace_bytes", C.c_size_t, [_i, _i, _i]),
-    ("cp_ccl_filter_labels", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_ccl_filter_labels", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
     ("cp_ransac_vote_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("cp_ransac_workspace_bytes", C.c_size_t, [_i, _i, _i, _i, _i, _i]),

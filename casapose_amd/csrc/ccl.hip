@@ -166,22 +166,23 @@ __device__ __forceinline__ unsigned long long comp_key(int cnt, int min_size, un
     return ((unsigned long long)c << 32) | tie;
 }
 
-// Pass 4 (one block per image, over the root list): per object the foreground size, then the best and the second-best histogram entry
+// Pass 4 (one block per image, over the root list): per object the foreground size, then the best, the second-best and (rank 2:
+// output_second_largest_component, voting_layers_2d.py:58-74, top_k with three bins) the third-best histogram entry
 __global__ __launch_bounds__(256) void ccl_select(const uint8_t* __restrict__ lab, const int* __restrict__ count, const int* __restrict__ nroots,
                                                   const int* __restrict__ roots, unsigned long long* __restrict__ stats, int objects, long long hw,
-                                                  int min_size) {
+                                                  int min_size, int rank) {
     __shared__ unsigned fg[256];
-    __shared__ unsigned long long best[256], second[256];
+    __shared__ unsigned long long best[256], second[256], third[256];
     const int n = blockIdx.x, nr = nroots[n];
     const int* list = roots + (long long)n * hw;
-    for (int o = threadIdx.x; o < objects; o += 256) { fg[o] = 0u; best[o] = 0ull; second[o] = 0ull; }
+    for (int o = threadIdx.x; o < objects; o += 256) { fg[o] = 0u; best[o] = 0ull; second[o] = 0ull; third[o] = 0ull; }
     __syncthreads();
     for (int k = threadIdx.x; k < nr; k += 256) {
         const int i = list[k];
         atomicAdd(&fg[lab[i] - 1], (unsigned)count[i]);
     }
     __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass <= rank; ++pass) {
         for (int k = threadIdx.x; k < nr + objects; k += 256) {
             unsigned long long key;
             int o;
@@ -194,11 +195,13 @@ __global__ __launch_bounds__(256) void ccl_select(const uint8_t* __restrict__ la
                 key = comp_key((int)(hw - (long long)fg[o]), min_size, 0xFFFFFFFFu);
             }
             if (pass == 0) atomicMax(&best[o], key);
-            else if (key < best[o]) atomicMax(&second[o], key);
+            else if (pass == 1) { if (key < best[o]) atomicMax(&second[o], key); }
+            else if (key < second[o]) atomicMax(&third[o], key);
         }
         __syncthreads();
     }
-    for (int o = threadIdx.x; o < objects; o += 256) stats[((long long)n * objects + o) * 3 + 2] = second[o];
+    // the selected histogram entry: rank 1 = second in top_k order (rank 0 is assumed to be the background bin), rank 2 = third
+    for (int o = threadIdx.x; o < objects; o += 256) stats[((long long)n * objects + o) * 3 + 2] = rank == 2 ? third[o] : second[o];
 }
 
 __global__ void ccl_write(const uint8_t* __restrict__ lab, const int* __restrict__ parent, const unsigned long long* __restrict__ stats,
@@ -227,9 +230,10 @@ extern "C" size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects) {
     return px * sizeof(int) * 3 + ((size_t)batch * sizeof(int) + 63) / 64 * 64 + (size_t)batch * objects * 3 * sizeof(unsigned long long) + 128;
 }
 
-extern "C" int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size, void* ws,
+extern "C" int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size, int rank, void* ws,
                                     uint8_t* labels_out, void* stream) {
     CP_REQUIRE(labels_in && labels_out && ws, "cp_ccl_filter_labels: null pointer");
+    CP_REQUIRE(rank == 1 || rank == 2, "cp_ccl_filter_labels: rank 1 (largest component) or 2 (second largest, output_second_largest_component)");
     CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ccl_filter_labels: bad sizes");
     const long long hw = (long long)h * w, total = hw * batch;
     CP_REQUIRE(total < (1LL << 31) && hw < 0xFFFFFFF0LL, "cp_ccl_filter_labels: too many pixels for 32-bit component ids");
@@ -248,7 +252,7 @@ extern "C" int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, 
     const long long nb = (long long)batch * (tiles_y - 1) * w + (long long)batch * h * (tiles_x - 1);
     if (nb > 0) CP_LAUNCH(ccl_border, dim3(grid_for(nb)), dim3(THREADS), 0, st, labels_in, parent, batch, h, w, tiles_x, tiles_y);
     CP_LAUNCH(ccl_flatten_count, dim3(g), dim3(THREADS), 0, st, labels_in, parent, count, nroots, roots, hw, total);
-    CP_LAUNCH(ccl_select, dim3(batch), dim3(256), 0, st, labels_in, count, nroots, roots, stats, objects, hw, min_size);
+    CP_LAUNCH(ccl_select, dim3(batch), dim3(256), 0, st, labels_in, count, nroots, roots, stats, objects, hw, min_size, rank);
     CP_LAUNCH(ccl_write, dim3(g), dim3(THREADS), 0, st, labels_in, parent, stats, objects, hw, total, labels_out);
     return cp::check_launch("cp_ccl_filter_labels");
 }

@@ -38,9 +38,10 @@ def _as_record(seg: torch.Tensor, direct: torch.Tensor, conf: torch.Tensor):
 class CoordLSVotingWeighted:
     def __init__(self, name, num_classes, num_points=9, sigmoid_weights=False, filter_estimates=False,
                  output_second_largest_component=False):
-        if output_second_largest_component:
-            raise NotImplementedError("output_second_largest_component is a reference debugging switch and is not built")
         self.name = name
+        # voting_layers_2d.py:58-59,71-73 ("just for testing"): vote with the SECOND largest component of each object (three histogram bins,
+        # the third entry of top_k) instead of the largest; only read with filter_estimates
+        self.output_second_largest_component = bool(output_second_largest_component)
         self.num_classes = num_classes
         self.num_points = num_points
         self.filter_estimates = filter_estimates
@@ -66,7 +67,7 @@ class CoordLSVotingWeighted:
                 lab0 = ops.argmax_labels(rec, classes=objects + 1, offset=so)
             ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objects), dtype=torch.uint8, device=rec.device)
             labels = torch.empty_like(lab0)
-            check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, objects, self.min_component, ws.data_ptr(),
+            check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, objects, self.min_component, 2 if self.output_second_largest_component else 1, ws.data_ptr(),
                                            labels.data_ptr(), torch.cuda.current_stream(rec.device).cuda_stream),
                   "cp_ccl_filter_labels")
         return ops.ls_vote(rec, so, do, co, objects, self.num_points, labels=labels, sigmoid_weights=self.sigmoid_weights)

@@ -261,9 +261,10 @@ size_t cp_ls_vote_workspace_bytes(int batch, int objects, int kp);
 /* Largest-connected-component filter of voting_layers_2d.py:43-79 (tfa.image.connected_components,
  * 4-connectivity, keep the largest component of each object if it has >= min_size pixels):
  * labels_in uint8 [n,h,w] -> labels_out (pixels outside the kept component become 0).
- * ws: int32 workspace of cp_ccl_workspace_bytes. */
-int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size,
-                         void* ws, uint8_t* labels_out, void* stream);
+ * rank 1 = the reference's default: the histogram entry that ranks SECOND in top_k order (the first is assumed to be bin 0, "everything
+ * else"); rank 2 = output_second_largest_component (:58-59,71-73: three bins, the THIRD entry).  ws: int32 workspace of cp_ccl_workspace_bytes. */
+int cp_ccl_filter_labels(const uint8_t* labels_in, int batch, int h, int w, int objects, int min_size, int rank, void* ws,
+                         uint8_t* labels_out, void* stream);
 size_t cp_ccl_workspace_bytes(int batch, int h, int w, int objects);
 
 /* ransac_voting_layer_all_masks (casapose/pose_estimation/ransac_voting.py:276-368,447-484).

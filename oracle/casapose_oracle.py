@@ -577,7 +577,7 @@ def label_components_4(binary: np.ndarray) -> np.ndarray:
     return lab
 
 
-def largest_component_filter(hot: np.ndarray, min_size: int = 50) -> np.ndarray:
+def largest_component_filter(hot: np.ndarray, min_size: int = 50, rank: int = 1) -> np.ndarray:
     """voting_layers_2d.py:43-79 for one [h,w] 0/1 map: keep the component that ranks
     second in the size histogram (rank 0 is assumed to be id 0 = background) after zeroing
     bins with fewer than ``min_size`` pixels.  If that bin is empty the selected id is
@@ -585,15 +585,15 @@ def largest_component_filter(hot: np.ndarray, min_size: int = 50) -> np.ndarray:
     every foreground pixel unless that id is 0 (then background pixels would be selected,
     but they are multiplied by hot == 0 afterwards)."""
     comp = label_components_4(hot > 0)
-    counts = np.bincount(comp.ravel(), minlength=2)
+    counts = np.bincount(comp.ravel(), minlength=rank + 1)   # rank 2 = output_second_largest_component: three bins, third entry (:58-59,71-73)
     counts = np.where(counts < min_size, 0, counts)
     # tf.math.top_k: descending, ties -> lower index first
     order = np.lexsort((np.arange(counts.size), -counts))
-    keep_id = order[1]
+    keep_id = order[rank]
     return ((comp == keep_id) & (hot > 0)).astype(hot.dtype)
 
 
-def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_override=None, sigmoid_weights=False):
+def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_override=None, sigmoid_weights=False, second_largest=False):
     """CoordLSVotingWeighted.call/calc (voting_layers_2d.py:28-122).
     seg [B,H,W,K] logits, direct [B,H,W,2*kp] (dy,dx pairs), conf [B,H,W,kp].
     Returns [B,K-1,kp,2] keypoints in (y,x) pixels; accumulation in fp64."""
@@ -610,7 +610,7 @@ def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_overr
         keep = np.zeros_like(hot)
         for bi in range(b):
             for o in range(k - 1):
-                keep[bi, :, :, o] = largest_component_filter(hot_i[bi, :, :, o])
+                keep[bi, :, :, o] = largest_component_filter(hot_i[bi, :, :, o], rank=2 if second_largest else 1)
         hot = keep * hot
     n = direct.reshape(b, h, w, num_points, 2).astype(np.float32)
     nrm = np.sqrt((n * n).sum(-1, keepdims=True))

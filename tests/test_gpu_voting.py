@@ -29,13 +29,52 @@ def test_ccl_filter_matches_oracle_including_quirks(device):
     t = torch.from_numpy(lab).to(device)
     ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objs), dtype=torch.uint8, device=device)
     out = torch.empty_like(t)
-    _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, 1, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     got = out.cpu().numpy()
     for bi in range(b):
         for o in range(1, objs + 1):
             keep = O.largest_component_filter((lab[bi] == o).astype(np.float32))
             assert np.array_equal(got[bi] == o, keep > 0), (bi, o)
     assert (got[0] == 1).sum() == 144 and (got[0] == 2).sum() == 49 and (got[0] == 3).sum() == 9
+
+
+def test_second_largest_component_switch(device):
+    """output_second_largest_component (voting_layers_2d.py:58-59,71-73, "just for testing"): three histogram bins, the THIRD entry of top_k --
+    the second largest component of each object, with the same zero-bin quirks; the filter bit-exact against the oracle, the voter against
+    the oracle's vote on that component."""
+    from casapose_amd import _lib
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+
+    lib = _lib.load()
+    b, h, w, objs = 2, 48, 64, 4
+    lab = np.zeros((b, h, w), np.uint8)
+    lab[0, 2:14, 2:14] = 1       # 144 px (largest)
+    lab[0, 20:28, 30:40] = 1     # 80 px  (second largest: kept)
+    lab[0, 30:38, 2:10] = 1      # 64 px  (third)
+    lab[0, 2:12, 40:50] = 2      # one component only: the third bin is empty -> nothing kept
+    lab[0, 40:46, 20:30] = 3     # 60 px ...
+    lab[0, 30:33, 50:53] = 3     # ... and a 9-px speck (< 50 -> zeroed bin, still the lowest zero bin after the real ones: kept, a quirk)
+    lab[1] = np.random.default_rng(2).integers(0, objs + 1, (h, w)) * (np.random.default_rng(3).random((h, w)) < 0.5)
+    lab[1, 4:20, 4:30], lab[1, 28:44, 34:60] = 4, 4
+    t = torch.from_numpy(lab).to(device)
+    ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objs), dtype=torch.uint8, device=device)
+    out = torch.empty_like(t)
+    _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, 2, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    for bi in range(b):
+        for o in range(1, objs + 1):
+            keep = O.largest_component_filter((lab[bi] == o).astype(np.float32), rank=2)
+            assert np.array_equal(got[bi] == o, keep > 0), (bi, o)
+    assert (got[0] == 1).sum() == 80 and (got[0] == 2).sum() == 0 and (got[0] == 3).sum() == 9
+    assert lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, 3, ws.data_ptr(), out.data_ptr(), None) == -1
+    seg, direct, conf, _, _ = O.synthetic_voting_inputs(1, 60, 80, num_obj=4, seed=5)
+    seg[0, 0:9, 0:9, :] = 0.0
+    seg[0, 0:9, 0:9, 1] = 5.0     # a detached 81-px part of object 1: its second largest component
+    s, d, c = (torch.from_numpy(a).to(device) for a in (seg, direct, conf))
+    got = CoordLSVotingWeighted("v", 5, filter_estimates=True, output_second_largest_component=True)([s, d, c]).cpu().numpy()
+    want = O.ls_voting(seg, direct, conf, filter_estimates=True, second_largest=True)
+    m = np.isfinite(want).all(axis=(2, 3))
+    assert np.abs(got[m] - want[m]).max() < 0.05 and m[0, 0]
 
 
 def test_ccl_components_across_tile_borders(device):
@@ -63,7 +102,7 @@ def test_ccl_components_across_tile_borders(device):
     ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, objs), dtype=torch.uint8, device=device)
     out = torch.empty_like(t)
     for _ in range(2):   # twice with the same workspace: nothing may depend on its previous content
-        _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), b, h, w, objs, 50, 1, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     got = out.cpu().numpy()
     for bi in range(b):
         for o in range(1, objs + 1):
@@ -80,7 +119,7 @@ def test_ccl_object_larger_than_rest_of_image_is_dropped(device):
     t = torch.from_numpy(lab).to(device)
     ws = torch.empty(lib.cp_ccl_workspace_bytes(1, 16, 16, 1), dtype=torch.uint8, device=device)
     out = torch.empty_like(t)
-    _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), 1, 16, 16, 1, 50, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    _lib.check(lib.cp_ccl_filter_labels(t.data_ptr(), 1, 16, 16, 1, 50, 1, ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     assert out.sum().item() == 0
     assert O.largest_component_filter((lab[0] == 1).astype(np.float32)).sum() == 0
 

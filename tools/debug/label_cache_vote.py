@@ -22,7 +22,7 @@ lib = _lib.load()
 lab0 = torch.from_numpy(lab.astype(np.uint8)).to(dev)
 ws = torch.empty(lib.cp_ccl_workspace_bytes(b, h, w, k - 1), dtype=torch.uint8, device=dev)
 filt = torch.empty_like(lab0)
-_lib.check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, k - 1, 50, ws.data_ptr(), filt.data_ptr(), torch.cuda.current_stream().cuda_stream), "ccl")
+_lib.check(lib.cp_ccl_filter_labels(lab0.data_ptr(), b, h, w, k - 1, 50, 1, ws.data_ptr(), filt.data_ptr(), torch.cuda.current_stream().cuda_stream), "ccl")
 filt = filt.cpu().numpy()
 for o in range(1, k):
     hot = (lab[0] == o).astype(np.int32)
