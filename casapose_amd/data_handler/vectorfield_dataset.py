@@ -129,6 +129,21 @@ def _bbox_corners(v: np.ndarray) -> np.ndarray:
     return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float64)
 
 
+def _shared_random_seed() -> int:
+    """A fresh random seed that is the SAME on every replica: rank 0 draws it and broadcasts it when a process group exists."""
+    seed = int(np.random.SeedSequence().entropy % (1 << 31))
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
+    except Exception:  # no process group: a single process keeps its own draw
+        pass
+    return seed
+
+
 def load_split(path: str, ratio: float, rng: np.random.Generator) -> List[int]:
     """_split_settings.json (utils/dataset_utils.py:462-497): reuse a stored split with the same ratio, else draw and store one."""
     fp = os.path.join(path, "_split_settings.json")
@@ -160,8 +175,12 @@ class VectorfieldDataset:
         self.contrast, self.brightness = contrast, brightness
         self.use_train_split, self.use_validation_split, self.train_validation_split = use_train_split, use_validation_split, train_validation_split
         self.visibility_filter, self.wxyz_quaterion_input = visibility_filter, wxyz_quaterion_input
-        self.rng = np.random.default_rng(seed)
-        self.order_rng = np.random.default_rng([seed if seed is not None else 0, 1])  # epoch permutations only: identical on every replica
+        if seed is None:
+            seed = _shared_random_seed()   # the reference shuffles / augments differently on every run; all replicas must still agree on ONE stream
+        self.seed = int(seed)
+        self.rng = np.random.default_rng(self.seed)   # re-seeded per image in generate_dataset(): the augmentation of image i of epoch e does
+        #                                               not depend on the number of replicas or on which of them reads it
+        self.order_rng = np.random.default_rng([self.seed, 1])  # epoch permutations only: identical on every replica
         self.meshes = self.load_meshes(path_meshes)
         self.imgs: List[Tuple[str, str, str, str, str]] = []
         self.class_labels: Dict[str, Dict[str, int]] = {}
@@ -339,11 +358,15 @@ class VectorfieldDataset:
         oc = len(self.objectsofinterest)
         begin, end = shard_range(batchsize, shard[0], shard[1])
 
+        def sample(epoch, i):
+            self.rng = np.random.default_rng([self.seed, 2, epoch, int(i)])   # crop / rotation / colour draws of THIS image in THIS epoch
+            return self.apply_preprocessing(self.imgs[i], imagesize, cropratio)
+
         def it():
-            for _ in range(max(int(epochs), 1)):
+            for epoch in range(max(int(epochs), 1)):
                 order = self.order_rng.permutation(data_size) if shuffle else np.arange(data_size)
                 for b in range(epoch_batches):
-                    items = [self.apply_preprocessing(self.imgs[i], imagesize, cropratio) for i in order[b * batchsize + begin:b * batchsize + end]]
+                    items = [sample(epoch, i) for i in order[b * batchsize + begin:b * batchsize + end]]
                     lab = np.stack([x["label"] for x in items])
                     st = lambda k: torch.from_numpy(np.stack([x[k] for x in items]))  # noqa: E731
                     yield dict(img=st("img"), target_seg=torch.from_numpy(np.eye(oc + 1, dtype=np.float32)[lab]), target_vert=st("target_vert"),

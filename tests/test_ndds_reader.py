@@ -87,3 +87,26 @@ def test_centre_crop_and_augmented_geometry(exported):
     xy = a["target_vert"][:, :, 0].numpy()[..., ::-1].astype(np.float64)
     back = np.einsum("bij,bokj->boki", A[:, :, :2], xy) + A[:, None, None, :, 2]
     assert np.abs(back - gt).max() < 0.05, "crop keypoints mapped back with the offsets must hit the projected 3-D keypoints"
+
+
+def test_augmentation_does_not_depend_on_the_number_of_replicas(exported):
+    """Round-2 advisor finding: with source sharding every rank applied the SAME crop / colour sequence to its slice, and the stream depended
+    on the world size.  Now the draws of image i in epoch e come from a generator keyed by (seed, e, i): the global batch is the same
+    whether one process reads it or two ranks read half each; seed=None draws a fresh seed (different runs differ)."""
+    root, _ = exported
+    kw = dict(objectsofinterest=NAMES, color_input=True, noise=0.01, brightness=0.2, contrast=0.2, random_translation=(20, 20), random_rotation=10,
+              random_crop=True)
+
+    def batches(shard, seed=3):
+        ds = VectorfieldDataset(str(root / "data"), str(root / "models"), seed=seed, **kw)
+        it, nb = ds.generate_dataset(4, 2, 0, (224, 320), 0.8, 1, len(NAMES), shuffle=True, shard=shard)
+        return [next(it) for _ in range(2 * nb)]
+
+    whole, r0, r1 = batches((0, 1)), batches((0, 2)), batches((1, 2))
+    for a, b0, b1 in zip(whole, r0, r1):
+        for key in ("img", "offsets", "target_vert", "filtered_seg"):
+            assert torch.equal(a[key], torch.cat([b0[key], b1[key]])), key
+    assert not torch.equal(whole[0]["offsets"], whole[1]["offsets"])           # two epochs of the same images: different draws
+    assert not torch.equal(whole[0]["offsets"][0], whole[0]["offsets"][1])     # and different draws per image
+    a, b = batches((0, 1), seed=None), batches((0, 1), seed=None)
+    assert not torch.equal(a[0]["offsets"], b[0]["offsets"])
