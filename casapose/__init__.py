@@ -34,10 +34,18 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.machinery.ModuleSpec(fullname, self, is_package=spec.submodule_search_locations is not None)
 
     def create_module(self, spec):
-        return importlib.import_module(_REAL + spec.name[len(_PREFIX):])  # the SAME module object under a second name
+        module = importlib.import_module(_REAL + spec.name[len(_PREFIX):])  # the SAME module object under a second name
+        self._real_spec[id(module)] = module.__spec__
+        return module
 
     def exec_module(self, module):
-        pass
+        # importlib has just overwritten module.__spec__ with the ALIAS spec (it does so unconditionally): put the real one back, so that
+        # importlib.reload() re-executes the real source and relative imports inside the module see __package__ == __spec__.parent
+        real = self._real_spec.pop(id(module), None)
+        if real is not None:
+            module.__spec__ = real
+
+    _real_spec = {}
 
 
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):

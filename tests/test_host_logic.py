@@ -255,9 +255,15 @@ def test_casapose_alias_package_serves_the_reference_import_surface():
     import casapose_amd
 
     pairs = ["pose_models.tfkeras", "pose_models.models_factory", "pose_models.model_factory", "pose_estimation.voting_layers_2d", "pose_estimation.ransac_voting",
-             "pose_estimation.pose_evaluation", "utils.config_parser", "utils.io_utils", "utils.learning_rate_schedules", "data_handler.vectorfield_dataset"]
+             "pose_estimation.pose_evaluation", "utils.config_parser", "utils.io_utils", "utils.learning_rate_schedules", "data_handler.vectorfield_dataset",
+             "utils.loss_functions", "utils.image_utils", "pose_models.models.resnet"]
     for name in pairs:
-        assert importlib.import_module("casapose." + name) is importlib.import_module("casapose_amd." + name), name
+        mod = importlib.import_module("casapose." + name)
+        assert mod is importlib.import_module("casapose_amd." + name), name
+        # the alias import must leave the real module's spec in place (round-2 advisor finding: reload() was a no-op, relative imports warned)
+        assert mod.__spec__.name == "casapose_amd." + name and mod.__package__ == mod.__spec__.parent, (name, mod.__spec__)
+    lrs = importlib.import_module("casapose.utils.learning_rate_schedules")
+    assert importlib.reload(lrs) is lrs and hasattr(lrs, "LossWeightHandler")
     from casapose.pose_models.tfkeras import Classifiers
     from casapose_amd.pose_models.tfkeras import Classifiers as C2
 
