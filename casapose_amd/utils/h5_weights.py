@@ -1,4 +1,4 @@
-"""Minimal HDF5 reader and writer for Keras weight files -- h5py is not available in this environment.
+"""Minimal HDF5 reader and writer for Keras weight files -- the product's interpreter has no h5py.
 
 `model.load_weights("result_w_8.h5", by_name=True, skip_mismatch=True)` (test_casapose.py:225-228) needs the float32 datasets
 of a Keras `save_weights` file: every layer is a group, every weight a contiguous little-endian float dataset whose path ends in
@@ -14,9 +14,11 @@ length types) raises `H5FormatError` with the feature named -- never a silent pa
 read weights (they are addressed by their path); attribute messages are skipped by the dataset reader and parsed by
 `read_attrs()` when they hold fixed-length strings (`layer_names`, `weight_names`, `backend`, `keras_version`).
 `write_keras_h5()` is what `model.save_weights("*.h5")` calls (train_casapose.py:903): the group tree, dataset names and
-attributes of Keras' `save_weights_to_hdf5_group`.  Format reference: "HDF5 File Format Specification Version 2.0" (The HDF Group); parity
-with libhdf5 is untested here (no h5py, no Keras file on this machine): the reader is pinned against `write_h5()` below, which
-emits the same structures from the specification.
+attributes of Keras' `save_weights_to_hdf5_group`.  Format reference: "HDF5 File Format Specification Version 2.0" (The HDF Group).
+Pinned against libhdf5 since round 3: the image's conda environment has h5py 3.3.0 / libhdf5 1.10.6 (Keras' own I/O library; Keras itself is
+absent), tests/golden/make_h5py_golden.py writes a Keras-layout file WITH h5py that this reader parses (committed fixture
+tests/golden/h5py_keras_layout.h5), and reads a file written by `write_keras_h5()` back through h5py the way Keras' loader does
+(tests/test_h5_weights.py).
 """
 from __future__ import annotations
 
@@ -26,6 +28,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 SIGNATURE = b"\x89HDF\r\n\x1a\n"
+GROUP_INTERNAL_K = 16   # written into the superblock; fixes the on-disk size of every group B-tree node
 UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
@@ -183,6 +186,23 @@ class _File:
         return np.frombuffer(self.buf, dtype=dtype, count=count, offset=start).reshape(shape).astype(dtype.newbyteorder("="))
 
     # ---- attributes ---------------------------------------------------------------------------------------------
+    def global_heap_object(self, collection_addr: int, index: int) -> bytes:
+        """object `index` of the global heap collection at `collection_addr` (HDF5 spec III.E: "GCOL", version 1; objects are
+        {index u16, reference count u16, reserved u32, size u64, data padded to 8 bytes}, index 0 = free space)"""
+        a = self.addr(collection_addr)
+        if bytes(self.buf[a:a + 4]) != b"GCOL" or self.buf[a + 4] != 1:
+            raise H5FormatError("global heap collection expected at %#x" % collection_addr)
+        end = a + self.u64(a + 8)
+        p = a + 16
+        while p + 16 <= end:
+            idx, size = self.u16(p), self.u64(p + 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(self.buf[p + 16:p + 16 + size])
+            p += 16 + ((size + 7) & ~7)
+        raise H5FormatError("global heap object %d not found in the collection at %#x" % (index, collection_addr))
+
     def read_attributes(self, msgs) -> Dict[str, object]:
         """Fixed-length-string attributes of an object header ({name: bytes | [bytes]}); other types map to None."""
         out: Dict[str, object] = {}
@@ -202,6 +222,13 @@ class _File:
             cls, tsize = self.buf[t] & 0x0F, self.u32(t + 4)
             sver, rank = self.buf[sp], self.buf[sp + 1]
             dims = tuple(self.u64(sp + (8 if sver == 1 else 4) + 8 * i) for i in range(rank))
+            if cls == 9 and (self.buf[t + 1] & 0x0F) == 1:
+                # variable-length string (h5py stores a python bytes / str scalar this way: Keras' `backend`, `keras_version`): each element is
+                # {length u32, global-heap collection address u64, object index u32}
+                n = int(np.prod(dims)) if dims else 1
+                vals = [self.global_heap_object(self.u64(data + 16 * i + 4), self.u32(data + 16 * i + 12))[:self.u32(data + 16 * i)] for i in range(n)]
+                out[name] = vals if dims else vals[0]
+                continue
             if cls != 3:
                 out[name] = None
                 continue
@@ -357,7 +384,9 @@ def write_h5(path: str, datasets: Dict[str, np.ndarray], attrs: Dict[str, Dict[s
             while len(heap_data) % 8:
                 heap_data.append(0)
         data_addr = put(bytes(heap_data))
-        heap = put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, data_addr))
+        # offset of the free-list head: libhdf5 encodes "no free block" as 1 (H5HL_FREE_NULL), not as the undefined address the format
+        # document suggests -- with 0xFFFF... it refuses the heap ("bad heap free list"; found by reading this writer's files with h5py)
+        heap = put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, data_addr))
         snods = []
         for i in range(0, max(len(children), 1), 8):  # leaf nodes of up to 8 symbols
             part = list(zip(offs[i:i + 8], children[i:i + 8]))
@@ -369,6 +398,11 @@ def write_h5(path: str, datasets: Dict[str, np.ndarray], attrs: Dict[str, Dict[s
         node_b = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), UNDEF, UNDEF) + struct.pack("<Q", 0)
         for addr, last_key in snods:
             node_b += struct.pack("<QQ", addr, last_key)
+        # libhdf5 reads a group B-tree node at its FULL size, 24 + (2K+1) keys + 2K children with K = the superblock's internal node K (16):
+        # a shorter node at the end of the file fails its bounds check ("addr overflow"; found by reading this writer's files with h5py)
+        if len(snods) > 2 * GROUP_INTERNAL_K:
+            raise H5FormatError("group %r has %d entries: more than one B-tree node (%d symbols) is not written" % (path, len(children), 2 * GROUP_INTERNAL_K * 8))
+        node_b += b"\x00" * (24 + (2 * GROUP_INTERNAL_K + 1) * 8 + 2 * GROUP_INTERNAL_K * 8 - len(node_b))
         btree = put(node_b)
         hdr = object_header([message(0x0011, struct.pack("<QQ", btree, heap))] + [attribute(k, v) for k, v in attrs.get(path, {}).items()])
         return hdr, btree, heap

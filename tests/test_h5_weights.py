@@ -109,3 +109,68 @@ def test_attribute_messages_do_not_disturb_the_dataset_reader(tmp_path):
     assert all(np.array_equal(got["/" + k], v) for k, v in data.items())
     at = H.read_attrs(p)
     assert at["/"]["layer_names"] == [b"a"] and at["/"]["note"] == b"x" * 300 and at["/a"]["weight_names"] == [b"b/w:0", b"c:0"] and at["/a/b"]["k"] == b"v"
+
+
+# --------------------------------------------------------------------------------------------------
+# against the real HDF5 library (h5py 3.3.0 / libhdf5 1.10.6 of the image's conda environment -- what Keras itself reads and writes with)
+# --------------------------------------------------------------------------------------------------
+import importlib.util  # noqa: E402
+import os  # noqa: E402
+import subprocess  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONDA_PY = "/opt/conda/bin/python3.9"
+
+
+def _maker():
+    spec = importlib.util.spec_from_file_location("make_h5py_golden", os.path.join(GOLDEN, "make_h5py_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _have_h5py():
+    return os.path.exists(CONDA_PY) and subprocess.run([CONDA_PY, "-c", "import h5py"], capture_output=True).returncode == 0
+
+
+def test_reader_parses_a_file_written_by_h5py():
+    """tests/golden/h5py_keras_layout.h5 was written by h5py (make_h5py_golden.py write) in Keras' save_weights layout: nested backbone
+    group, CLADE layer with its inner normalisation scope, PartialConvolution, fixed-length `layer_names` / `weight_names` arrays and the
+    VARIABLE-length scalar strings h5py makes of `backend` / `keras_version`.  Every dataset must come back bit-equal under its
+    '<layer>.<field>' key -- the first bytes of libhdf5 this reader has met (rounds 1-2: reader and writer had only met each other)."""
+    mk = _maker()
+    want = mk.params(20)
+    path = os.path.join(GOLDEN, "h5py_keras_layout.h5")
+    assert H.is_hdf5(path)
+    found = H.keras_weights_from_h5(path, {k.split(".")[0] for k in want})
+    assert set(found) == set(want) and all(found[k].dtype == np.float32 and np.array_equal(found[k], want[k]) for k in want)
+    attrs = H.read_attrs(path)
+    assert attrs["/"]["backend"] == b"tensorflow" and attrs["/"]["keras_version"] == b"2.9.0"
+    assert attrs["/"]["layer_names"] == [b"model", b"pv_block_10_prepare_conv2d", b"pv_block_10_clade", b"pv_block_5_bn", b"pv_final_conv_vertex"]
+    assert attrs["/model"]["weight_names"][:3] == [b"bn_data/beta:0", b"conv0/kernel:0", b"bn0/gamma:0"]
+    assert attrs["/pv_block_10_clade"]["weight_names"][2] == b"pv_block_10_clade/sync_batch_normalization/moving_mean:0"
+
+
+@pytest.mark.skipif(not _have_h5py(), reason="needs the image's conda interpreter with h5py")
+def test_h5py_reads_files_written_by_our_writer(tmp_path):
+    """The other direction: libhdf5 (through h5py, read the way Keras' loader reads: f.attrs['layer_names'], g.attrs['weight_names'],
+    np.asarray(g[name])) must accept write_keras_h5's output -- the reduced layer set and the WHOLE 14.75 M-parameter network.  This
+    comparison found two writer bugs in round 3 (local-heap free-list sentinel, group B-tree nodes shorter than their fixed size)."""
+    import casapose_oracle as O
+
+    mk = _maker()
+    small = str(tmp_path / "small.h5")
+    H.write_keras_h5(small, mk.params(31))
+    r = subprocess.run([CONDA_PY, os.path.join(GOLDEN, "make_h5py_golden.py"), "verify", small, "31"], capture_output=True, text=True)
+    assert r.returncode == 0 and '"datasets": 29' in r.stdout, r.stderr[-2000:]
+    params = O.init_params(9, 27, seed=7, dtype=np.float32)
+    full, npz = str(tmp_path / "result_w.h5"), str(tmp_path / "params.npz")
+    H.write_keras_h5(full, params)
+    np.savez(npz, **params)
+    r = subprocess.run([CONDA_PY, os.path.join(GOLDEN, "make_h5py_golden.py"), "verify", full, npz], capture_output=True, text=True)
+    assert r.returncode == 0 and '"datasets": %d' % len(params) in r.stdout, r.stderr[-2000:]
+    # and h5py writing the fixture again gives what is committed (content, not bytes)
+    again = str(tmp_path / "again.h5")
+    assert subprocess.run([CONDA_PY, os.path.join(GOLDEN, "make_h5py_golden.py"), "write", again], capture_output=True).returncode == 0
+    a, b = H.read_h5(again), H.read_h5(os.path.join(GOLDEN, "h5py_keras_layout.h5"))
+    assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
