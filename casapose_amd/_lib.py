@@ -145,6 +145,8 @@ SYMBOLS = [
     ("cp_wino_transform_weights_f32", _i, [_vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_wino_dy_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_wino_weight_grad_f32", _i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _i, _vp]),
+    ("cp_wino_wgrad_split_applicable", _i, [_i, _i, _i, _i]),
+    ("cp_wino_wgrad_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     # ---- training path ----

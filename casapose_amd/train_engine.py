@@ -465,8 +465,8 @@ class ConvOp:
             for w in ([self.wino_fwd] if self.wino_fwd is not None else []) + list(self.wino_dgrad.values()):
                 w["Us"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us"), stream=stream)
 
-    def bind_winograd(self, V: torch.Tensor, M: torch.Tensor):
-        self._wV, self._wM = V, M
+    def bind_winograd(self, V: torch.Tensor, M: torch.Tensor, M2: Optional[torch.Tensor] = None):
+        self._wV, self._wM, self._wM2 = V, M, (M2 if M2 is not None else M)
         for w in ([self.wino_fwd] if self.wino_fwd is not None else []) + list(self.wino_dgrad.values()):
             d = w["desc"]
             d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 36, 1, w["tp"], 1, w["tp"]
@@ -547,7 +547,10 @@ class ConvOp:
             w = self.wino_fwd
             g = 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
             out[wino_pipe] += wino_mult * g      # forward GEMM
-            out["f32"] += g                      # weight gradient: grouped fp32 GEMM over the 36 planes
+            if self.wino_wgrad_split():          # weight gradient: grouped GEMM over the 36 planes, exact splits on the bf16 pipe or fp32 MFMA
+                out["bf16"] += (1.0 if conv_split_planes() == 1 else 6.0) * g
+            else:
+                out["f32"] += g
         else:
             if L.split is not None and lib.cp_conv_split_applicable(C.byref(L.desc)):
                 pipe, mult = split_pipe(L.split)
@@ -578,6 +581,16 @@ class ConvOp:
                     out["f32"] += d
         return out
 
+    def wino_wgrad_split(self) -> bool:
+        """True when this Winograd layer's weight-gradient GEMM runs on the bf16 matrix pipe: the default wherever the Winograd GEMMs do
+        (CASAPOSE_WINO_GEMM != f32) and the shape fits (cout, cin multiples of 128); CASAPOSE_WINO_WGRAD=f32 keeps the fp32 grouped GEMM."""
+        from .engine import TRAIN_WINO_GEMM_SPLIT
+
+        w = getattr(self, "wino_fwd", None)
+        if w is None or not TRAIN_WINO_GEMM_SPLIT or os.environ.get("CASAPOSE_WINO_WGRAD", "split") == "f32":
+            return False
+        return bool(_lib.load().cp_wino_wgrad_split_applicable(36, w["tp"], self.layer.cout, w["ktot"]))
+
     def wgrad_planes(self) -> int:
         """3 / 1 when this op's weight gradient runs on the bf16 matrix pipe (CASAPOSE_CONV_MODE split / bf16 and a descriptor that
         cp_conv2d_wgrad_split covers: 3x3 / stride 1 / pad 1, 32-multiple sources + optional image, cout % 32 == 0), else 0 = fp32 MFMA."""
@@ -593,7 +606,14 @@ class ConvOp:
         assert self.out.has_grad, "gradient of %s not produced" % self.layer.name
         return self.out.grad.data_ptr(), self.out.c
 
-    def backward(self, stream: int):
+    def backward(self, stream: int, wgrad_stream: Optional[int] = None):
+        """weight gradient, then the data gradient of every source.  wgrad_stream (TrainPlan.backward with a side stream): the weight-gradient
+        launches go there -- they are off the critical path of the backward (nothing but Adam reads them) and MFMA-bound, so they can run under
+        the HBM-bound normalisation / resampling passes of the layers before; the caller orders the two streams with events."""
+        self.backward_wgrad(stream if wgrad_stream is None else wgrad_stream, side=wgrad_stream is not None)
+        self.backward_dgrad(stream)
+
+    def backward_wgrad(self, stream: int, side: bool = False):
         lib = _lib.load()
         L = self.layer
         dy, dy_ld = self._dy()
@@ -601,21 +621,23 @@ class ConvOp:
         if self.head_fast:
             t, ld = self.srcs[0]
             px = self.batch * self.out_h * self.out_w
-            readable = (self.dy_ptr_ld[2] - self.dy_ptr_ld[1] % self.dy_ptr_ld[2]) if self.dy_ptr_ld is not None else self.out.c
             check(lib.cp_head1x1_wgrad_f32(t.data.data_ptr(), ld, dy, dy_ld, px, L.cout, L.master_grad.data_ptr(), 1 if self.accumulate_master else 0, stream),
                   "cp_head1x1_wgrad_f32(%s)" % L.name)
-            if t.needs_grad:
-                check(lib.cp_head1x1_dgrad_f32(dy, dy_ld, min(32, readable), px, L.master.data_ptr(), L.cout, t.grad.data_ptr(), t.c, 1 if t.has_grad else 0, stream),
-                      "cp_head1x1_dgrad_f32(%s)" % L.name)
-                t.has_grad = True
             return
         if getattr(self, "wino_fwd", None) is not None:
             # weight gradient through the Winograd planes: a quarter of the MFMA work of the direct kernel (V kept from the forward)
             w = self.wino_fwd
             cin, cout = self._cin, L.cout
-            check(lib.cp_wino_dy_transform_f32(dy, dy_ld, cout, self.batch, self.in_h, self.in_w, self.dil, self._wM.data_ptr(), stream),
+            wM = self._wM2 if side else self._wM   # the side stream transforms dY into a scratch of its own (the data gradients use _wM)
+            check(lib.cp_wino_dy_transform_f32(dy, dy_ld, cout, self.batch, self.in_h, self.in_w, self.dil, wM.data_ptr(), stream),
                   "cp_wino_dy_transform_f32(%s)" % L.name)
-            check(lib.cp_conv2d_wgrad_f32(C.byref(w["wdesc"]), self._wM.data_ptr(), cout, w["dU"].data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(wino %s)" % L.name)
+            if self.wino_wgrad_split():   # the grouped GEMM dU[p] = dM[p]^T V[p] on the bf16 matrix pipe (exact splits; csrc/wino_wgrad_split.hip)
+                # exact splits (fp32-equivalent) by default; CASAPOSE_CONV_MODE=bf16 rounds the operands of this GEMM to bf16 like the other weight gradients
+                check(lib.cp_wino_wgrad_split_f32(wM.data_ptr(), w["V"].data_ptr(), w["dU"].data_ptr(), 36, w["tp"], cout, w["ktot"],
+                                                  1 if conv_split_planes() == 1 else 3, stream),
+                      "cp_wino_wgrad_split_f32(%s)" % L.name)
+            else:
+                check(lib.cp_conv2d_wgrad_f32(C.byref(w["wdesc"]), wM.data_ptr(), cout, w["dU"].data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(wino %s)" % L.name)
             c0 = k0 = 0
             for cp_, cr in L.sources:
                 check(lib.cp_wino_weight_grad_f32(w["dU"].data_ptr(), cr, cout, w["ktot"], k0, 3 * cin * cout, cin * cout, cout, 1,
@@ -631,6 +653,20 @@ class ConvOp:
                 check(lib.cp_conv2d_wgrad_f32(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(%s)" % L.name)
             check(lib.cp_scatter_f32(L.dwp.data_ptr(), L.idx_fwd.data_ptr(), L.idx_fwd.numel(), L.master_grad.data_ptr(), 1 if self.accumulate_master else 0,
                                      stream), "cp_scatter_f32")
+
+    def backward_dgrad(self, stream: int):
+        lib = _lib.load()
+        L = self.layer
+        dy, dy_ld = self._dy()
+        if self.head_fast:
+            t, ld = self.srcs[0]
+            px = self.batch * self.out_h * self.out_w
+            readable = (self.dy_ptr_ld[2] - self.dy_ptr_ld[1] % self.dy_ptr_ld[2]) if self.dy_ptr_ld is not None else self.out.c
+            if t.needs_grad:
+                check(lib.cp_head1x1_dgrad_f32(dy, dy_ld, min(32, readable), px, L.master.data_ptr(), L.cout, t.grad.data_ptr(), t.c, 1 if t.has_grad else 0, stream),
+                      "cp_head1x1_dgrad_f32(%s)" % L.name)
+                t.has_grad = True
+            return
         for s, ent in enumerate(L.dgrad):
             if ent is None:
                 continue
@@ -1000,6 +1036,9 @@ class TrainPlan:
                 op.accumulate_master = op.layer.key in seen
                 seen.add(op.layer.key)
         self.tensors = [o for o in self._all_tensors()]
+        # weight gradients on a second stream (CASAPOSE_WGRAD_STREAM=1; see backward())
+        self.wgrad_on_side_stream = os.environ.get("CASAPOSE_WGRAD_STREAM", "0") == "1"
+        self._side = torch.cuda.Stream(device=dev) if self.wgrad_on_side_stream else None
         # Winograd for the deep 3x3 layers (forward and data gradient); shared scratch sized for the largest of them
         self.use_winograd = os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
         self.wino_V = self.wino_M = None
@@ -1010,9 +1049,10 @@ class TrainPlan:
             if nv:
                 self.wino_V = torch.empty(nv, **f32)
                 self.wino_M = torch.empty(nm, **f32)
+                self.wino_M2 = torch.empty(nm, **f32) if self.wgrad_on_side_stream else None   # dY planes of the side stream's weight gradients
                 for op, sz in sizes:
                     if sz[0]:
-                        op.bind_winograd(self.wino_V, self.wino_M)
+                        op.bind_winograd(self.wino_V, self.wino_M, self.wino_M2)
         # gather map of conv0's packed weight-gradient entries that belong to the padding channel (c = 3)
         ramp = np.zeros((7, 7, 3, 64), np.int64)  # unused values; only the layout matters
         k0 = np.full((64, c0.ktot), -1, np.int64)
@@ -1183,12 +1223,27 @@ class TrainPlan:
         multi = self.group is not None and (self.world_size > 1 or parallel.force_collectives())
         if multi and self._buckets is None:
             self._buckets = self._gradient_buckets()
+        side = self._side
+        main = torch.cuda.current_stream(self.out.device)
+        if side is not None:
+            side.wait_stream(main)   # the forward's activations and the loss gradient are ready
         for i in range(len(self.ops) - 1, -1, -1):
-            self.ops[i].backward(stream)
+            op = self.ops[i]
+            if side is not None and isinstance(op, ConvOp):
+                ev = torch.cuda.Event()
+                ev.record(main)                 # dY of this layer is complete on the main stream
+                side.wait_event(ev)
+                op.backward(stream, wgrad_stream=side.cuda_stream)
+            else:
+                op.backward(stream)
             if multi:
                 for first, a, e in self._buckets:
                     if first == i and not (a == 0):  # the bucket holding bn_data.beta is completed below
+                        if side is not None:
+                            main.wait_stream(side)   # the bucket's weight gradients come from the side stream
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
+        if side is not None:
+            main.wait_stream(side)
         # d beta of bn_data from the padding-channel entries of conv0's weight gradient (see __init__)
         G = self.conv0.dwp[self.g_idx.reshape(-1)].view(49, 64)            # [tap][cout]
         W0 = self.store.view("conv0.kernel").reshape(49, 3, 64)               # [tap][c][cout]

@@ -339,6 +339,14 @@ int cp_wino_transform_weights_f32(const float* w, long long stride_ky, long long
 int cp_wino_dy_transform_f32(const float* dy, int ld, int channels, int batch, int h, int w, int dilation, float* dM, void* stream);
 int cp_wino_weight_grad_f32(const float* dU, int channels, int cout, int ldk, int k_off, long long stride_ky, long long stride_kx,
                             long long stride_in, long long stride_out, float* dw, int accumulate, void* stream);
+/* The grouped weight-gradient GEMM of the Winograd layers on the bf16 matrix pipe (csrc/wino_wgrad_split.hip):
+ *   du[g][n][k] = sum_t dm[g][t][n] * v[g][t][k]      (g < groups = 36 planes, t < rows = padded tiles, n = cout, k = cin)
+ * what cp_conv2d_wgrad_f32 computes in its grouped mode with fp32 MFMAs, here as exact three-way bf16 splits (planes = 3, fp32-equivalent:
+ * six exact products per fp32 product, fp32 accumulation) or with operands rounded to bf16 (planes = 1).  dm = the output of
+ * cp_wino_dy_transform_f32, v = the forward's transformed input, du feeds cp_wino_weight_grad_f32.  n and k multiples of 128
+ * (cp_wino_wgrad_split_applicable); du is overwritten. */
+int cp_wino_wgrad_split_applicable(int groups, int rows, int n, int k);
+int cp_wino_wgrad_split_f32(const float* dm, const float* v, float* du, int groups, int rows, int n, int k, int planes, void* stream);
 int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
                                 int c_off, void* stream);
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,

@@ -131,3 +131,40 @@ def test_wgrad_split_refuses_what_it_does_not_cover(device):
     out = torch.zeros(32 * 288, device=device)
     rc = lib.cp_conv2d_wgrad_split(C.byref(d), x.data_ptr(), 32, out.data_ptr(), 0, 3, None)
     assert rc != 0 and b"not covered" in lib.cp_last_error()
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("groups,rows,n,k", [(36, 128, 128, 128), (36, 384, 256, 384), (5, 200, 128, 256), (2, 2176, 512, 512), (3, 33, 384, 128)])
+def test_wino_weight_gradient_gemm_on_the_bf16_pipe(device, planes, groups, rows, n, k):
+    """cp_wino_wgrad_split_f32: du[g] = dm[g]^T v[g] (the grouped GEMM of the Winograd layers' weight gradient) against fp64 -- exact split at
+    the fp32 gate and no worse than the fp32-MFMA grouped GEMM it replaces, bf16 operands at 2e-2; ragged row counts (the slab is 32 rows),
+    several tiles per plane, stale content of du overwritten."""
+    from casapose_amd import _lib
+    from casapose_amd._lib import ConvDesc, check
+
+    lib = _lib.load()
+    rng = np.random.default_rng(groups + rows + n + k)
+    dm = (rng.standard_normal((groups, rows, n)) * np.exp(rng.uniform(-3, 3, (1, 1, n)))).astype(np.float32)
+    v = rng.standard_normal((groups, rows, k)).astype(np.float32)
+    ref = np.einsum("gtn,gtk->gnk", dm.astype(np.float64), v.astype(np.float64))
+    dmt, vt = torch.from_numpy(dm).to(device), torch.from_numpy(v).to(device)
+    du = torch.full((groups, n, k), 3.0, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    assert lib.cp_wino_wgrad_split_applicable(groups, rows, n, k) == 1 and lib.cp_wino_wgrad_split_applicable(groups, rows, n + 32, k) == 0
+    check(lib.cp_wino_wgrad_split_f32(dmt.data_ptr(), vt.data_ptr(), du.data_ptr(), groups, rows, n, k, planes, stream), "cp_wino_wgrad_split_f32")
+    torch.cuda.synchronize()
+    got = du.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    err = (np.abs(got - ref) / scale).max()
+    assert err < (1e-5 if planes == 3 else 2e-2), err
+    if planes == 3 and rows % 128 == 0:   # the fp32 grouped GEMM needs group_rows % 128 == 0
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 1, 1, groups * rows, 1, groups * rows
+        d.cout, d.kh, d.kw, d.stride, d.dilation, d.pad = n, 1, 1, 1, 1, 0
+        d.num_sources = 1
+        d.src[0].data, d.src[0].channels, d.src[0].ld, d.src[0].mode = vt.data_ptr(), k, k, 0
+        d.group_rows = rows
+        f32 = torch.empty((groups, n, k), device=device)
+        check(lib.cp_conv2d_wgrad_f32(C.byref(d), dmt.data_ptr(), n, f32.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(grouped)")
+        e32 = (np.abs(f32.cpu().numpy().astype(np.float64) - ref) / scale).max()
+        assert err <= 2.0 * e32 + 1e-7, (err, e32)
