@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Copy the round's profile artefacts from gpurun_out/ (written by tools/profile_bench.sh, pmc_traffic.sh, layer_times.py,
-profile_train.sh, train_times.py on the GPU box) into profiles/ and regenerate profiles/<tag>_summary.md from them.
+"""Copy ONE run's profile artefacts from gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into profiles/<tag>_*, stamp them
+(profiles/<tag>_STAMP.json: the source / binary stamp of `python bench.py --stamp`, git HEAD, file list) and regenerate profiles/<tag>_summary.md.
+Refuses a set whose stamp changed during the run or differs from the working tree's (round-2 verdict: stale PMC files next to a newer binary).
 usage: python tools/make_summary.py [tag]"""
 import csv
 import json
@@ -23,6 +24,7 @@ TRAIN_HISTORY_R01 = ("257 images/s with direct kernels only; 308 with Winograd f
 def copy(src, dst):
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst))
+        COPIED.append(dst)
         return True
     print("missing", src)
     return False
@@ -38,19 +40,51 @@ def stats_table(path, rows=24, width=70):
     return "\n".join(out)
 
 
-copy("prof_%s/bench.json" % tag, "%s_bench.json" % tag)
-copy("prof_%s/bench_profiled.json" % tag, "%s_bench_profiled.json" % tag)
-copy("prof_%s/trace/bench_kernel_stats.csv" % tag, "%s_bench_kernel_stats.csv" % tag)
-copy("layer_times.txt", "%s_layer_times.txt" % tag)
-copy("pmc_traffic_%s/traffic.json" % tag, "%s_pmc_traffic.json" % tag)
-copy("pmc_traffic_%s/summary.txt" % tag, "%s_pmc_traffic.txt" % tag)
-copy("pmc_mfma_%s/summary.txt" % tag, "%s_pmc_mfma.txt" % tag)
-copy("prof_train_%s/bench_train.json" % tag, "%s_bench_train.json" % tag)
-copy("prof_train_%s/trace/train_kernel_stats.csv" % tag, "%s_train_kernel_stats.csv" % tag)
-copy("train_times.txt", "%s_train_times.txt" % tag)
-copy("prof_vote_%s/bench_vote.json" % tag, "%s_bench_vote.json" % tag)
-copy("prof_vote_%s/trace/vote_kernel_stats.csv" % tag, "%s_vote_kernel_stats.csv" % tag)
+# ---- one stamp for the whole set: every file of profiles/<tag>_* comes from ONE run of tools/profile_round.sh on ONE source tree ----------------
+COPIED = []
+T = "%s/" % tag
+stamp_path = os.path.join(G, tag, "stamp.json")
+if not os.path.exists(stamp_path):
+    sys.exit("no %s: run `gpurun -- bash tools/profile_round.sh %s` first" % (stamp_path, tag))
+stamp, stamp_end = json.load(open(stamp_path)), json.load(open(os.path.join(G, tag, "stamp_end.json")))
+if stamp != stamp_end:
+    sys.exit("the tree changed while the profile set was being produced (%s vs %s): refusing to summarise mixed stamps" % (stamp, stamp_end))
+import subprocess  # noqa: E402
 
+here = json.loads(subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--stamp"], capture_output=True, text=True, check=True).stdout)
+if here["src_sha256"] != stamp["src_sha256"]:
+    sys.exit("profiles in gpurun_out/%s were measured on source stamp %s, the working tree is %s: re-run tools/profile_round.sh on this tree "
+             "(the bench line would refuse their PMC traffic anyway)" % (tag, stamp["src_sha256"], here["src_sha256"]))
+for old in [f for f in os.listdir(P) if f.startswith(tag + "_")]:   # nothing of an earlier stamp survives under this tag
+    os.remove(os.path.join(P, old))
+copy(T + "bench.json", "%s_bench.json" % tag)
+copy(T + "bench_bs32.json", "%s_bench_bs32.json" % tag)
+copy(T + "bench_f32.json", "%s_bench_infer_f32.json" % tag)
+copy(T + "bench_bf16.json", "%s_bench_infer_bf16.json" % tag)
+copy(T + "bench_profiled.json", "%s_bench_profiled.json" % tag)
+copy(T + "trace/bench_kernel_stats.csv", "%s_bench_kernel_stats.csv" % tag)
+copy(T + "layer_times.txt", "%s_layer_times.txt" % tag)
+copy(T + "layer_times_f32.txt", "%s_layer_times_conv_mode_f32.txt" % tag)
+copy(T + "pmc_traffic/traffic.json", "%s_pmc_traffic.json" % tag)
+copy(T + "pmc_traffic/summary.txt", "%s_pmc_traffic.txt" % tag)
+copy(T + "pmc_mfma/summary.txt", "%s_pmc_mfma.txt" % tag)
+copy(T + "bench_train.json", "%s_bench_train.json" % tag)
+copy(T + "bench_train_f32.json", "%s_bench_train_conv_mode_f32.json" % tag)
+copy(T + "bench_train_bf16.json", "%s_bench_train_conv_mode_bf16.json" % tag)
+copy(T + "train_trace/train_kernel_stats.csv", "%s_train_kernel_stats.csv" % tag)
+copy(T + "train_times.txt", "%s_train_times.txt" % tag)
+copy(T + "bench_vote.json", "%s_bench_vote.json" % tag)
+copy(T + "vote_trace/vote_kernel_stats.csv", "%s_vote_kernel_stats.csv" % tag)
+for extra in sorted(os.listdir(os.path.join(G, tag))):   # GPU suite logs written next to the profile set (tools/profile_round.sh does not run them)
+    if extra.startswith("gputests_") and extra.endswith(".log"):
+        copy(T + extra, "%s_%s" % (tag, extra))
+git_head = subprocess.run(["git", "-C", R, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", R, "status", "--porcelain", "--", "casapose_amd", "include", "bench.py"], capture_output=True, text=True).stdout.strip())
+json.dump({"tag": tag, "stamp": stamp, "git_head_when_summarised": git_head, "tracked_sources_dirty": dirty,
+           "what": "every profiles/%s_* file listed here was produced by ONE run of tools/profile_round.sh on the source tree identified by "
+                   "stamp.src_sha256 (sha256 over casapose_amd/csrc, include/, the engine files and bench.py: `python bench.py --stamp`); bench.py "
+                   "quotes PMC traffic only from a profile whose stamp equals the running tree's" % tag,
+           "files": sorted(COPIED)}, open(os.path.join(P, "%s_STAMP.json" % tag), "w"), indent=1)
 
 
 def load(name):
@@ -71,37 +105,43 @@ def tests_line(name):
 b, t = load("bench.json"), load("bench_train.json")
 rf, dom, wg = b["roofline"], b["roofline"]["dominant_family"], b["roofline"]["winograd"]
 md = ["# Round %s profile summary (MI355X)\n" % tag[1:].lstrip("0")]
-md.append("Generated by `python tools/make_summary.py {0}` from the files the GPU-box scripts wrote (`profiles/{0}_*`): `bench.json` (default `python bench.py`, "
-          "un-profiled), `bench_profiled.json` + `bench_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 "
-          "--no-cpu-baseline`, `tools/profile_bench.sh {0}`), `bench_bs32.json`, `bench_infer_{{split,bf16,allsplit,allsplit_bs32,split_bs32}}.json` (opt-in conv modes), "
-          "`layer_times*.txt` (`tools/layer_times.py`), `pmc_traffic.{{json,txt}}` (`tools/pmc_traffic.sh`: FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes, "
-          "FETCH doubled as the microarchitecture guide prescribes for gfx950), `pmc_mfma.txt` (`tools/pmc_mfma.sh`, per-dispatch join), `bench_train*.json` + "
-          "`train_kernel_stats.csv` + `train_times.txt` (`tools/profile_train.sh`, `tools/train_times.py`), `bench_vote.json` + `vote_kernel_stats.csv`, "
-          "`hsplit_ablation_*.txt` / `hsplit_times.txt` (`tools/debug/hsplit_times.py`, the first on `HS_*` variant builds), `wgrad_split_times.txt` / "
-          "`wgrad_split_ablation.txt` (`tools/debug/wgrad_split_times.py`: fp32 weight-gradient kernel vs the bf16-pipe one per training shape; the second on "
-          "`WS_*` variant builds), `gputests_*.log` (the whole `-m gpu` suite per conv mode).\n".format(tag))
-md.append("## Inference (BASELINE configs[1]: bs 16, 480x640, K = 9, fp32)\n")
+md.append("Generated by `python tools/make_summary.py {0}` from ONE run of `tools/profile_round.sh {0}` on the GPU box (`gpurun_out/{0}/`); source stamp "
+          "`{1}` (`python bench.py --stamp`; `profiles/{0}_STAMP.json` lists the files) -- the generator refuses a set whose stamp differs from the working "
+          "tree's.  Files: `bench.json` (default `python bench.py --steps 20 --warmup 5`, un-profiled), `bench_bs32.json`, `bench_infer_f32.json` / "
+          "`bench_infer_bf16.json` (the other conv modes), `bench_profiled.json` + `bench_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats`), "
+          "`layer_times*.txt` (`tools/layer_times.py`), `pmc_traffic.{{json,txt}}` (FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes, FETCH doubled as the "
+          "microarchitecture guide prescribes for gfx950), `pmc_mfma.txt` (SQ MFMA-busy counters, per-dispatch join), `bench_train*.json` + "
+          "`train_kernel_stats.csv` + `train_times.txt`, `bench_vote.json` + `vote_kernel_stats.csv`, `gputests_*.log` (the `-m gpu` suite per conv mode).\n".format(tag, stamp["src_sha256"]))
+md.append("## Inference (BASELINE configs[1]: bs 16, 480x640, K = 9)\n")
 bs32 = load("bench_bs32.json")
+pp = rf["per_pipe"]
 fam = "; ".join("%s %.2f ms at %.1f TFLOP/s" % (k, v["ms"], v["tflops"]) for k, v in sorted(rf["families"].items()))
-md.append("Headline (exact fp32 MFMA): **%.1f images/s**, %.2f ms/step%s.  `roofline`: executed FLOPs of all convolution launches / their summed HIP-event time "
-          "incl. the Winograd transform passes = **%.1f TFLOP/s = %.3f of %.1f**%s; dominant family `%s`: %.1f TFLOP/s = %.3f, %d launches/step, %.0f us average, "
-          "measured traffic %.0f MB vs %.0f MB algorithmic per launch (committed PMC passes).  Families: %s.  Winograd layers: %.2f ms/step = %.2f GEMM + %.2f "
-          "transforms.\n" % (b["value"], b["ms_per_step"], ("; bs 32: %.0f images/s" % bs32["value"]) if bs32 else "", rf["achieved"], rf["frac"], rf["peak"],
-                             (" (bs 32: %.1f = %.3f)" % (bs32["roofline"]["achieved"], bs32["roofline"]["frac"])) if bs32 else "", dom["kernel"], dom["achieved"],
-                             dom["frac"], dom["launches_per_step"], dom["avg_launch_us"], (rf["traffic"] or 0) / 1e6, dom["algorithmic_bytes_per_launch"] / 1e6,
-                             fam, wg["ms_per_step"], wg["gemm_ms"], wg["transform_ms"]))
-o = b.get("optin_fp32_equivalent")
+pipes = "; ".join("%s pipe: %.2f ms, %.1f TFLOP/s executed = %.3f of %.0f" % (k, v["ms_per_step"], v["tflops"], v["frac_of_its_peak"], v["peak"]) for k, v in sorted(pp.items()))
+md.append("Headline (conv mode `%s`: %s): **%.1f images/s**, %.2f ms/step%s.  `roofline.frac` = time-weighted mean, over all convolution time incl. the "
+          "Winograd transform passes, of each kernel family's executed FLOP rate / the dense peak of ITS matrix pipe = **%.3f** (%s; transforms %.2f ms with no "
+          "FLOPs); direct-convolution-equivalent rate of the whole forward %.0f TFLOP/s.  Dominant family `%s`: %.1f TFLOP/s = %.3f of its peak, %d launches/step, "
+          "%.0f us average, measured traffic %s MB vs %.0f MB algorithmic per launch (%s).  Families: %s.  Winograd layers: %.2f ms/step = %.2f GEMM + %.2f transforms.\n"
+          % (b["config"].get("conv_mode"), b["dtype"][:60] + "...", b["value"], b["ms_per_step"], ("; bs 32: %.0f images/s, frac %.3f" % (bs32["value"], bs32["roofline"]["frac"])) if bs32 else "",
+             rf["frac"], pipes, rf["winograd_transform_ms_per_step"], rf["direct_equivalent_tflops"], dom["kernel"], dom["achieved"], dom["frac"], dom["launches_per_step"],
+             dom["avg_launch_us"], ("%.0f" % (rf["traffic"] / 1e6)) if rf.get("traffic") else "n/a", dom["algorithmic_bytes_per_launch"] / 1e6, rf.get("traffic_source"), fam,
+             wg["ms_per_step"], wg["gemm_ms"], wg["transform_ms"]))
+o = b.get("exact_fp32_mfma")
+if o:
+    orf = o.get("roofline") or {}
+    md.append("Same run on the fp32 MFMA everywhere (`exact_fp32_mfma`, conv mode `f32`, the headline of rounds 1-2): **%.1f images/s**, %.2f ms/step, roofline "
+              "frac %.3f of %.1f (MFMA families alone %.3f); largest logit difference between the two forwards %.1e (relative).\n"
+              % (o["value"], o["ms_per_step"], orf.get("frac", float("nan")), orf.get("peak", float("nan")),
+                 (orf.get("per_pipe", {}).get("f32", {}) or {}).get("frac_of_its_peak", float("nan")), o.get("max_logit_difference_vs_headline_rel", float("nan"))))
 alone = []
-for name, label in (("bench_infer_allsplit.json", "both opt-ins via the environment"), ("bench_infer_allsplit_bs32.json", "both, bs 32"),
-                    ("bench_infer_split.json", "`CASAPOSE_INFER_CONV_MODE=split` alone"), ("bench_infer_split_bs32.json", "split alone, bs 32"),
-                    ("bench_infer_bf16.json", "`CASAPOSE_INFER_CONV_MODE=bf16` (operands rounded to bf16, NOT fp32-equivalent)")):
+for name, label in (("bench_infer_f32.json", "`CASAPOSE_INFER_CONV_MODE=f32` as its own run"), ("bench_infer_bf16.json", "`=bf16` (operands rounded to bf16, NOT fp32-equivalent)")):
     x = load(name)
     if x:
-        alone.append("%s %.0f images/s (%.2f ms)" % (label, x["value"], x["ms_per_step"]))
-if o:
-    md.append("Same run, fp32-EQUIVALENT opt-ins on (exact three-way bf16 splits for every plain 3x3 layer up to 512 channels that is not on the Winograd path and "
-              "for the Winograd GEMMs; `optin_fp32_equivalent`): **%.1f images/s**, %.2f ms/step, largest logit difference against the headline's forward "
-              "%.1e (relative).  Separate runs: %s.\n" % (o["value"], o["ms_per_step"], o.get("max_logit_difference_vs_headline_rel", float("nan")), "; ".join(alone)))
+        alone.append("%s %.0f images/s (%.2f ms, frac %.3f)" % (label, x["value"], x["ms_per_step"], x["roofline"]["frac"]))
+if alone:
+    md.append("Separate runs: %s.\n" % "; ".join(alone))
+tl = b.get("training_leg")
+if tl and "value" in tl:
+    md.append("Training leg inside the default line (3 steps at bs 32, 448x448): %.1f images/s, %.1f ms/step.\n" % (tl["value"], tl["ms_per_step"]))
 c = b.get("cpu_baseline")
 if c:
     md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s (`%s`; host has %s threads, thread probe s/image: %s).\n"
@@ -110,29 +150,28 @@ md.append(stats_table(os.path.join(P, "%s_bench_kernel_stats.csv" % tag), rows=1
 mf = os.path.join(P, "%s_pmc_mfma.txt" % tag)
 if os.path.exists(mf):
     md.append("\nrocprof MFMA utilisation per kernel (`%s_pmc_mfma.txt`):\n\n```\n%s```\n" % (tag, open(mf).read()))
-for name, label in (("layer_times.txt", "default"), ("layer_times_conv_mode_split.txt", "`CASAPOSE_INFER_CONV_MODE=split`"),
-                    ("layer_times_conv_mode_bf16.txt", "`=bf16`")):
-    p = os.path.join(P, "%s_%s" % (tag, name))
-    if os.path.exists(p):
+tf = os.path.join(P, "%s_pmc_traffic.txt" % tag)
+if os.path.exists(tf):
+    md.append("HBM traffic per launch (`%s_pmc_traffic.txt`, first rows):\n\n```\n%s\n```\n" % (tag, "\n".join(open(tf).read().splitlines()[:16])))
+for name, label in (("layer_times.txt", "default (split)"), ("layer_times_conv_mode_f32.txt", "`CASAPOSE_INFER_CONV_MODE=f32`")):
+    p_ = os.path.join(P, "%s_%s" % (tag, name))
+    if os.path.exists(p_):
         md.append("Per-layer times, %s: `%s_%s`." % (label, tag, name))
 md.append("\nGPU test suite (`python -m pytest tests -m gpu -q`) per mode:\n")
-for name, label in (("gputests_default.log", "default (fp32 MFMA)"), ("gputests_infer_conv_mode_split.log", "`CASAPOSE_INFER_CONV_MODE=split`"),
-                    ("gputests_infer_conv_mode_split_and_wino_split.log", "`CASAPOSE_INFER_CONV_MODE=split CASAPOSE_WINO_GEMM=split`"),
-                    ("gputests_train_conv_mode_f32.log", "training tests with `CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32` (fp32 MFMA everywhere)"),
-                    ("gputests_infer_conv_mode_bf16.log", "`CASAPOSE_INFER_CONV_MODE=bf16` (NOT fp32-equivalent: the failures are the fp32-tolerance "
-                     "comparisons of the whole forward against the fp64 oracle, expected in this mode; the bf16 pipe has its own 3e-2 gate in the default suite)")):
-    l = tests_line(name)
+for name in sorted(f for f in os.listdir(P) if f.startswith(tag + "_gputests_")):
+    l = tests_line(name[len(tag) + 1:])
     if l:
-        md.append("* %s: %s" % (label, l))
+        md.append("* `%s`: %s" % (name, l))
 md.append("\n## Training step (BASELINE configs[2]: bs 32, 448x448, K = 9; `python bench.py --mode train`)\n")
 tr = t["roofline"]
 extra = []
-for name, label in (("bench_train_conv_mode_f32.json", "`CASAPOSE_CONV_MODE=f32`"), ("bench_train_conv_mode_bf16.json", "`=bf16` (operands of those layers rounded to bf16)")):
+for name, label in (("bench_train_conv_mode_f32.json", "`CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32` (fp32 MFMA everywhere)"),
+                    ("bench_train_conv_mode_bf16.json", "`CASAPOSE_CONV_MODE=bf16` (operands rounded to bf16)")):
     x = load(name)
     if x:
         extra.append("%s: %.0f images/s (%.1f ms)" % (label, x["value"], x["ms_per_step"]))
-md.append("Default of the training plan (%s): **%.1f images/s**, %.1f ms/step (round 1: 400); %s.  `roofline`: executed %.0f GFLOP fp32-MFMA + %.0f GFLOP bf16-MFMA "
-          "per step; %s = %.3f.  Per op: `%s_train_times.txt`.\n" % (t["dtype"], t["value"], t["ms_per_step"], "; ".join(extra), tr["executed_f32_gflop_per_step"],
+md.append("Default of the training plan (%s): **%.1f images/s**, %.1f ms/step; %s.  `roofline`: executed %.0f GFLOP fp32-MFMA + %.0f GFLOP bf16-MFMA "
+          "per step; %s = %.3f.  Per op: `%s_train_times.txt`.\n" % (t["dtype"][:120] + "...", t["value"], t["ms_per_step"], "; ".join(extra), tr["executed_f32_gflop_per_step"],
                                                                     tr["executed_bf16_gflop_per_step"], tr["frac_definition"], tr["frac"], tag))
 md.append(stats_table(os.path.join(P, "%s_train_kernel_stats.csv" % tag), rows=26))
 v = load("bench_vote.json")
@@ -144,4 +183,4 @@ if v:
                                                                                   rs["ms_per_call"], rs["cosine_tests_per_s"]))
     md.append(stats_table(os.path.join(P, "%s_vote_kernel_stats.csv" % tag), rows=12))
 open(os.path.join(P, "%s_summary.md" % tag), "w").write("\n".join(md) + "\n")
-print("wrote profiles/%s_summary.md" % tag)
+print("wrote profiles/%s_summary.md and profiles/%s_STAMP.json (%d files)" % (tag, tag, len(COPIED)))
