@@ -483,3 +483,25 @@ def test_bare_resnet18_backbone_taps(device, tmp_path):
     assert all(np.array_equal(got[k], enc[k]) for k in enc)
     for t, t2 in zip(taps, other(img)):
         assert torch.equal(t, t2)
+
+
+def test_gemm_route_does_not_survive_a_shape_change(device):
+    """Round-2 advisor finding: in the split / bf16 conv modes the 1x1 stride-1 shortcuts run as a bf16-pipe GEMM when rows % 128 == 0; the route
+    was remembered across plan rebuilds, so a second shape with rows % 128 != 0 launched the GEMM with the FIRST shape's row count (out of bounds).
+    Shape A (applicable) then shape B (not) on one network object, against a conv_mode="f32" network with the same weights."""
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    k, v = 5, 27
+    params = O.init_params(k, v, seed=61, dtype=np.float32)
+    nets = {}
+    for mode in ("split", "f32"):
+        nets[mode] = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=None, weights=None, device=device, conv_mode=mode)
+        nets[mode].set_parameters(params)
+    rng = np.random.default_rng(8)
+    for b, h, w in ((2, 64, 128), (1, 64, 96), (2, 64, 128)):
+        img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+        outs = {m: n([img], training=False).cpu().numpy().astype(np.float64) for m, n in nets.items()}
+        routed = [c.name for c in nets["split"]._net.plan(b, h, w).convs if getattr(c, "_gemm", None) is not None]
+        rows = b * (h // 8) * (w // 8)
+        assert bool(routed) == (rows % 128 == 0), (routed, rows)
+        assert rel_err(outs["split"][..., :k], outs["f32"][..., :k]) < 1e-4, (b, h, w)
