@@ -110,3 +110,47 @@ def test_augmentation_does_not_depend_on_the_number_of_replicas(exported):
     assert not torch.equal(whole[0]["offsets"][0], whole[0]["offsets"][1])     # and different draws per image
     a, b = batches((0, 1), seed=None), batches((0, 1), seed=None)
     assert not torch.equal(a[0]["offsets"], b[0]["offsets"])
+
+
+def test_reader_on_the_reference_s_own_model_files(tmp_path):
+    """SURVEY 8(f) rank 2 / round-2 verdict row f2: the reader had only met files of its own writer.  The reference ships the LM keypoint files
+    and models_info.json (data/datasets/lm/models_eval); committed unchanged under tests/golden/ref_data, they go through `read_vertices`
+    (ASCII PLY with a `comment` line and trailing blanks) and through `load_meshes` in the folder layout the reference loads
+    (vectorfield_dataset.py:657-679: <meshes>/<obj>/<obj>.ply + <obj>_keypoints.ply, diameters from <meshes>/models_info.json)."""
+    import json
+    import os
+    import shutil
+
+    def write_ply(path, v):   # a stand-in mesh file (ASCII PLY)
+        with open(path, "w") as f:
+            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(v))
+            f.write("\n".join("%r %r %r" % tuple(float(c) for c in r) for r in v) + "\n")
+
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data", "lm_models_eval")
+    info = json.load(open(os.path.join(src, "models_info.json")))
+    names = ["obj_%06d" % i for i in (1, 5, 6, 8, 9, 10, 11, 12)]           # the LMO objects of config_8.ini
+    assert all(n in info for n in names) and abs(info["obj_000001"]["diameter"] - 102.099) < 1e-9
+    meshes_dir = tmp_path / "models"
+    rng = np.random.default_rng(0)
+    for n in names:
+        kp_file = os.path.join(src, n + "_keypoints.ply")
+        kp = read_vertices(kp_file)
+        # independent parse: the numeric lines after end_header
+        lines = open(kp_file).read().split("end_header")[1].strip().splitlines()
+        want = np.array([[float(v) for v in l.split()] for l in lines])
+        assert kp.shape == (9, 3) and np.allclose(kp, want, rtol=0, atol=1e-6)
+        b = info[n]
+        lo = np.array([b["min_x"], b["min_y"], b["min_z"]])
+        hi = lo + np.array([b["size_x"], b["size_y"], b["size_z"]])
+        assert np.all(kp[1:] >= lo - 1e-3) and np.all(kp[1:] <= hi + 1e-3)     # surface keypoints lie inside the model's bounding box
+        assert np.linalg.norm(kp[0]) < 0.05 * b["diameter"]                      # keypoint 0 is the object centre (the reference's convention)
+        os.makedirs(meshes_dir / n)
+        shutil.copy(kp_file, meshes_dir / n / (n + "_keypoints.ply"))
+        write_ply(str(meshes_dir / n / (n + ".ply")), rng.uniform(lo, hi, (50, 3)).astype(np.float32))   # a stand-in mesh inside the real bounding box
+    shutil.copy(os.path.join(src, "models_info.json"), meshes_dir / "models_info.json")
+    ds = VectorfieldDataset.__new__(VectorfieldDataset)
+    meshes = ds.load_meshes(str(meshes_dir))
+    assert sorted(meshes) == names
+    for n in names:
+        assert meshes[n]["diameter"] == info[n]["diameter"] and meshes[n]["keypoints"].shape == (9, 3)
+        assert np.allclose(meshes[n]["keypoints"], read_vertices(os.path.join(src, n + "_keypoints.ply")))
