@@ -449,6 +449,10 @@ def test_forward_in_every_conv_mode(device, mode, tol, fuse):
 def test_default_inference_mode_is_the_fp32_equivalent_split(device):
     from casapose_amd import engine
 
+    import os
+
+    if os.environ.get("CASAPOSE_INFER_CONV_MODE"):
+        pytest.skip("the environment overrides the default conv mode for this run")
     net, _ = build(device, 5, 27, 64, 96)
     assert engine.DEFAULT_INFER_CONV_MODE == "split" and net._net.conv_mode == "split" and net._net.conv_planes == 3
 
@@ -501,7 +505,11 @@ def test_gemm_route_does_not_survive_a_shape_change(device):
     for b, h, w in ((2, 64, 128), (1, 64, 96), (2, 64, 128)):
         img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
         outs = {m: n([img], training=False).cpu().numpy().astype(np.float64) for m, n in nets.items()}
-        routed = [c.name for c in nets["split"]._net.plan(b, h, w).convs if getattr(c, "_gemm", None) is not None]
-        rows = b * (h // 8) * (w // 8)
-        assert bool(routed) == (rows % 128 == 0), (routed, rows)
+        convs = nets["split"]._net.plan(b, h, w).convs
+        routed = {c.name: c._gemm["rows"] for c in convs if getattr(c, "_gemm", None) is not None}
+        for c in convs:   # a route exists exactly where the CURRENT binding's row count allows it, and carries that row count
+            if c.name in routed:
+                assert routed[c.name] == c.desc.batch * c.desc.out_h * c.desc.out_w and routed[c.name] % 128 == 0, (c.name, routed[c.name])
+        rows8 = b * (h // 8) * (w // 8)   # the stage-3 / stage-4 shortcuts run at 1/8 resolution
+        assert ("stage4_unit1_sc" in routed) == (rows8 % 128 == 0) and ("stage3_unit1_sc" in routed) == (rows8 % 128 == 0), (routed, rows8)
         assert rel_err(outs["split"][..., :k], outs["f32"][..., :k]) < 1e-4, (b, h, w)

@@ -2,6 +2,8 @@
 against the fp64 PyTorch-autograd restatement in oracle/torch_train_ref.py, through the C ABI."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -756,7 +758,13 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     worst = {name: rel_l2(store.grad_view(name).cpu().numpy(), p64[name].grad.numpy()) for name in store.offsets}
     top = sorted(worst.items(), key=lambda t: -t[1])
     print("config 13 @448: %d kink flips (margin %.1e); worst gradient %s %.2e, median %.2e" % (flips, margin, top[0][0], top[0][1], np.median(list(worst.values()))))
-    bad = {n: e for n, e in worst.items() if e > 1e-3}
+    # 1e-3 in the plan's default arithmetic (exact splits: measured median 6e-5).  With CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32 every product is
+    # rounded by the fp32 MFMA and this configuration lands at median 3e-3 / worst 4.4e-3 WITHOUT any kernel being wrong: the proxy-voting
+    # term divides by |v|^2 of a random-initialised direction field, so a few pixels with |v| ~ 1e-3 dominate the gradient and turn the
+    # forward's 1e-5 into per cents (tools/debug/grad_per_variable.py at 224x224: 8e-3 worst with fp32 MFMA and direct kernels only, 3.6e-3
+    # with the exact splits) -- that mode is gated at 1e-2 here and at 1e-3 on the better-conditioned shapes of the tests above.
+    gate = 1e-3 if os.environ.get("CASAPOSE_CONV_MODE", "split") == "split" else 1e-2
+    bad = {n: e for n, e in worst.items() if e > gate}
     assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
     # ---- the host BPnP gradient itself, by central differences on two visible objects of THIS scene ----
     c0 = coords_ref.detach().numpy().copy()
