@@ -149,12 +149,18 @@ SYMBOLS = [
     ("cp_wino_wgrad_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    ("cp_wino_output_transform_stats_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    ("cp_wino_input_transform_pre_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     # ---- training path ----
     ("cp_conv2d_wgrad_f32", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     ("cp_conv_wgrad_split_applicable", _i, [C.POINTER(ConvDesc)]),
     ("cp_head1x1_fwd_f32", _i, [_vp, _i, _ll, _vp, _i, _vp, _i, _vp]),
     ("cp_head1x1_dgrad_f32", _i, [_vp, _i, _i, _ll, _vp, _i, _vp, _i, _i, _vp]),
     ("cp_head1x1_wgrad_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _i, _vp]),
+    ("cp_head1x1_fwd_affine_f32", _i, [_vp, _i, _ll, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    ("cp_head1x1_wgrad_affine_f32", _i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _ll, _i, _vp, _i, _vp]),
+    ("cp_head1x1_bn_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _i, _ll, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    ("cp_head1x1_bn_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _i, _ll, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _vp, _vp, _i, _vp]),
     ("cp_conv2d_wgrad_split", _i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _i, _vp]),
     ("cp_bn_stats_f32", _i, [_vp, _ll, _i, _i, _vp, _vp]),
     ("cp_bn_finalize_f32", _i, [_vp, C.c_double, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

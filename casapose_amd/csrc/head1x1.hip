@@ -147,6 +147,312 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fused normalisation of decoder blocks 5 / 10 (casapose.py:76-105 is ONE Keras block: convolution, (class-adaptive) normalisation,
+// activation; the heads follow, pose_models.py:546,616).  With batch statistics the raw convolution output x [pixels][32] has to be in
+// memory once (the statistics are a global reduction), but the ACTIVATED tensor y = act(x * scale[l] + shift[l]) and its gradient need
+// not: the head's forward and weight gradient recompute y from x (table rows from LDS), and the two passes of the normalisation backward
+// recompute the head's data gradient g_y = dOut W^T on the matrix pipe instead of reading a stored one.  Per block that removes one
+// write + two reads of y and one write + two reads of g_y (822 MB each at bs 32 / 448 x 448).
+// tables: scale / shift / gamma [classes][32]; labels = nullptr means class 0 everywhere.
+constexpr int MAX_CLASSES = 64;
+
+__device__ __forceinline__ float head_act(float t, int act) {
+    if (act == CP_ACT_RELU) return fmaxf(t, 0.f);
+    if (act == CP_ACT_LEAKY01) return fmaxf(t, 0.f) - fmaxf(-0.1f * t, 0.f);
+    return t;
+}
+__device__ __forceinline__ float head_act_grad(float t, int act) {
+    if (act == CP_ACT_RELU) return t > 0.f ? 1.f : 0.f;
+    if (act == CP_ACT_LEAKY01) return t > 0.f ? 1.f : (t < 0.f ? 0.1f : 0.f);
+    return 1.f;
+}
+
+// out[p][q] = sum_c act(fma(x[p][c], scale[l_p][c], shift[l_p][c])) W[c][q]
+__global__ __launch_bounds__(256) void head_fwd_affine_kernel(const float* __restrict__ x, int ld_x, long long pixels, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const uint8_t* __restrict__ labels, int classes, int act,
+                                                              const float* __restrict__ w, int cout, float* __restrict__ out, int ld_out) {
+    extern __shared__ float4 ftab[];   // [2][classes * 8]
+    float4* tab[2] = {ftab, ftab + classes * 8};
+    for (int i = threadIdx.x; i < classes * 8; i += 256) {
+        tab[0][i] = reinterpret_cast<const float4*>(scale)[i];
+        tab[1][i] = reinterpret_cast<const float4*>(shift)[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    float wb[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wb[m] = row < cout ? w[(16 * h + m) * cout + row] : 0.f;
+    const long long groups = (pixels + 31) >> 5;
+    const long long gstep = (long long)gridDim.x * 4;
+    auto load = [&](long long g, float4 (&a)[4], int& l) {
+        const long long p = g * 32 + row;
+        l = 0;
+        if (g < groups && p < pixels) {
+            const float4* src = reinterpret_cast<const float4*>(x + p * ld_x + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = src[i];
+            if (labels) l = labels[p];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 a[4], an[4];
+    int l, ln;
+    long long g = (long long)blockIdx.x * 4 + wave;
+    load(g, a, l);
+    for (; g < groups; g += gstep) {
+        load(g + gstep, an, ln);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bool live = g * 32 + row < pixels;   // rows past the end stay zero (act(shift) would not be)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 s = tab[0][l * 8 + 4 * h + i], b = tab[1][l * 8 + 4 * h + i];
+            float4 y;
+            y.x = live ? head_act(__builtin_fmaf(a[i].x, s.x, b.x), act) : 0.f;
+            y.y = live ? head_act(__builtin_fmaf(a[i].y, s.y, b.y), act) : 0.f;
+            y.z = live ? head_act(__builtin_fmaf(a[i].z, s.z, b.z), act) : 0.f;
+            y.w = live ? head_act(__builtin_fmaf(a[i].w, s.w, b.w), act) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, wb[4 * i + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, wb[4 * i + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, wb[4 * i + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, wb[4 * i + 3], acc, 0, 0, 0);
+        }
+        if (row < cout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long pp = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (pp < pixels) out[pp * ld_out + row] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = an[i];
+        l = ln;
+    }
+}
+
+// dW[c][q] (+)= sum_p act(fma(x[p][c], scale[l_p][c], shift[l_p][c])) dy[p][q]
+// LABELS = false: one class, the lane's two table entries live in registers.  LABELS = true: the 32 labels of a pixel group arrive as two 16-byte
+// loads (the same address for every lane), the table rows come from LDS ([classes][32] floats: consecutive lanes, consecutive banks).
+template <bool LABELS>
+__global__ __launch_bounds__(256) void head_wgrad_affine_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const uint8_t* __restrict__ labels, int classes, int act,
+                                                                const float* __restrict__ dy, int ld_dy, long long pixels, int cout, float* __restrict__ dw) {
+    extern __shared__ float wsm[];   // [4][16][64] block reduction, then [2][classes * 32] tables
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(wsm);
+    float* tab0 = wsm + 4 * 16 * 64;
+    float* tab1 = tab0 + classes * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    if constexpr (LABELS) {
+        for (int i = threadIdx.x; i < classes * 32; i += 256) {
+            tab0[i] = scale[i];
+            tab1[i] = shift[i];
+        }
+        __syncthreads();
+    }
+    const float s0 = scale[row], b0 = shift[row];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const long long groups = pixels >> 5;   // pixels % 32 == 0
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        float av[16], bv[16];
+        uint32_t lw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (LABELS) {
+            const uint4 l0 = *reinterpret_cast<const uint4*>(labels + g * 32), l1 = *reinterpret_cast<const uint4*>(labels + g * 32 + 16);
+            lw[0] = l0.x; lw[1] = l0.y; lw[2] = l0.z; lw[3] = l0.w; lw[4] = l1.x; lw[5] = l1.y; lw[6] = l1.z; lw[7] = l1.w;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const long long p = g * 32 + 2 * m + h;
+            av[m] = x[p * ld_x + row];
+            bv[m] = row < cout ? dy[p * ld_dy + row] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float s = s0, b = b0;
+            if constexpr (LABELS) {
+                const int l = (int)((lw[m >> 1] >> (16 * (m & 1) + 8 * h)) & 255u);   // pixel 2m + h of the group
+                s = tab0[l * 32 + row];
+                b = tab1[l * 32 + row];
+            }
+            av[m] = head_act(__builtin_fmaf(av[m], s, b), act);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[m], acc, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int r = i >> 6, l = i & 63;
+        const float s = red[0][r][l] + red[1][r][l] + red[2][r][l] + red[3][r][l];
+        const int c = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), q = l & 31;
+        if (q < cout && s != 0.f) atomicAdd(&dw[c * cout + q], s);
+    }
+}
+
+struct HeadBn {
+    const float* x;        // raw convolution output [pixels][ld_x], 32 channels
+    int ld_x;
+    const float* dout;     // gradient of the head's output, rows of ld_dout floats, >= 32 readable floats per row from here on (16-byte aligned)
+    int ld_dout;
+    long long pixels;      // multiple of 32
+    const float* w;        // head weights [32][cout] (Keras)
+    int cout;
+    const float* mean;     // [32]
+    const float* rstd;     // [32]
+    const float* gamma;    // [classes][32]
+    const float* fscale;   // [classes][32] the forward's folded tables: the activation branch is decided by fma(x, fscale, fshift)
+    const float* fshift;
+    const uint8_t* labels; // or nullptr
+    int classes, act;
+};
+
+// g_y tile of pixel group g: acc[r] = (dOut W^T)[pixel g*32 + (r & 3) + 8 (r >> 2) + 4 h][channel row]
+__device__ __forceinline__ f32x16 head_gy_tile(const HeadBn& k, long long g, int row, int h, const float (&wb)[16]) {
+    const long long p = g * 32 + row;
+    float av[16];
+    const float4* src = reinterpret_cast<const float4*>(k.dout + p * k.ld_dout + 16 * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = src[i];
+        av[4 * i + 0] = v.x; av[4 * i + 1] = v.y; av[4 * i + 2] = v.z; av[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (16 * h + m >= k.cout) av[m] = 0.f;   // another head's gradient / padding lives there
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wb[m], acc, 0, 0, 0);
+    return acc;
+}
+
+// reduce pass of the normalisation backward with g_y recomputed: red[(l*32 + c)*2 + {0,1}] += {g, g*xhat}, chan[c*2 + {0,1}] += gamma[l][c] * {g, g*xhat}
+__global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(HeadBn k, double* __restrict__ red, double* __restrict__ chan) {
+    extern __shared__ double sred[];   // [classes*32*2] + [32*2], then three float tables [classes*32]
+    const int nred = k.classes * 64;
+    float* tab = reinterpret_cast<float*>(sred + nred + 64);
+    float* t_fs = tab;
+    float* t_fb = tab + k.classes * 32;
+    float* t_gm = tab + 2 * k.classes * 32;
+    for (int i = threadIdx.x; i < nred + 64; i += 256) sred[i] = 0.0;
+    for (int i = threadIdx.x; i < k.classes * 32; i += 256) {
+        t_fs[i] = k.fscale[i];
+        t_fb[i] = k.fshift[i];
+        t_gm[i] = k.gamma ? k.gamma[i] : 1.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    float wb[16];   // B[k = q = 16h + m][j = c = row] = W[c][q]
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wb[m] = (16 * h + m) < k.cout ? k.w[row * k.cout + 16 * h + m] : 0.f;
+    const float mu = k.mean[row], rs = k.rstd[row];
+    int cur = -1;
+    double a0 = 0.0, a1 = 0.0;
+    float fs = 0.f, fb = 0.f;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        const double gm = (double)t_gm[cur * 32 + row];
+        atomicAdd(&sred[(cur * 32 + row) * 2 + 0], a0);
+        atomicAdd(&sred[(cur * 32 + row) * 2 + 1], a1);
+        atomicAdd(&sred[nred + row * 2 + 0], a0 * gm);
+        atomicAdd(&sred[nred + row * 2 + 1], a1 * gm);
+    };
+    const long long groups = k.pixels >> 5;
+    // a wave takes runs of 8 consecutive groups (256 consecutive pixels of a row: long label runs), the runs grid-strided
+    const long long nrun = (groups + 7) >> 3;
+    for (long long run = (long long)blockIdx.x * 4 + wave; run < nrun; run += (long long)gridDim.x * 4)
+        for (long long g = run * 8; g < run * 8 + 8 && g < groups; ++g) {
+            const f32x16 gy = head_gy_tile(k, g, row, h, wb);
+            uint32_t lw[4] = {0, 0, 0, 0};
+            if (k.labels) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lw[j] = *reinterpret_cast<const uint32_t*>(k.labels + g * 32 + 8 * j + 4 * h);
+            }
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = k.x[(g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * k.ld_x + row];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = (int)((lw[r >> 2] >> (8 * (r & 3))) & 255u);
+                if (l != cur) {
+                    flush();
+                    cur = l;
+                    a0 = a1 = 0.0;
+                    fs = t_fs[l * 32 + row];
+                    fb = t_fb[l * 32 + row];
+                }
+                const float t = __builtin_fmaf(xv[r], fs, fb);
+                const float gg = gy[r] * head_act_grad(t, k.act);
+                const float xh = (xv[r] - mu) * rs;
+                a0 += gg;
+                a1 += (double)gg * xh;
+            }
+        }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < nred; i += 256)
+        if (sred[i] != 0.0) atomicAdd(&red[i], sred[i]);
+    for (int i = threadIdx.x; i < 64; i += 256)
+        if (sred[nred + i] != 0.0) atomicAdd(&chan[i], sred[nred + i]);
+}
+
+// apply pass: dx[p][c] = rstd[c] * (g*gamma[l][c] - m1[c] - xhat*m2[c]) * row_scale[p], g = g_y * act'(t) recomputed as in the reduce pass
+__global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(HeadBn k, const double* __restrict__ chan, double inv_n, const float* __restrict__ row_scale,
+                                                                float* __restrict__ dx, int ld_dx) {
+    extern __shared__ float atab[];   // three float tables [classes*32]
+    float* t_fs = atab;
+    float* t_fb = atab + k.classes * 32;
+    float* t_gm = atab + 2 * k.classes * 32;
+    for (int i = threadIdx.x; i < k.classes * 32; i += 256) {
+        t_fs[i] = k.fscale[i];
+        t_fb[i] = k.fshift[i];
+        t_gm[i] = k.gamma ? k.gamma[i] : 1.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    float wb[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wb[m] = (16 * h + m) < k.cout ? k.w[row * k.cout + 16 * h + m] : 0.f;
+    const float mu = k.mean[row], rs = k.rstd[row];
+    const float m1 = (float)(chan[row * 2 + 0] * inv_n), m2 = (float)(chan[row * 2 + 1] * inv_n);
+    const long long groups = k.pixels >> 5;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const f32x16 gy = head_gy_tile(k, g, row, h, wb);
+        uint32_t lw[4] = {0, 0, 0, 0};
+        float4 rsc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k.labels) lw[j] = *reinterpret_cast<const uint32_t*>(k.labels + g * 32 + 8 * j + 4 * h);
+            rsc[j] = row_scale ? *reinterpret_cast<const float4*>(row_scale + g * 32 + 8 * j + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = k.x[(g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * k.ld_x + row];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int l = (int)((lw[r >> 2] >> (8 * (r & 3))) & 255u);
+            const float t = __builtin_fmaf(xv[r], t_fs[l * 32 + row], t_fb[l * 32 + row]);
+            const float gg = gy[r] * head_act_grad(t, k.act) * t_gm[l * 32 + row];
+            const float xh = (xv[r] - mu) * rs;
+            const float4 rv = rsc[r >> 2];
+            const float sc = (r & 3) == 0 ? rv.x : ((r & 3) == 1 ? rv.y : ((r & 3) == 2 ? rv.z : rv.w));
+            dx[(g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ld_dx + row] = rs * (gg - m1 - xh * m2) * sc;
+        }
+    }
+}
+
 int grid_for_groups(long long pixels) {
     const long long blocks = ((pixels + 31) / 32 + 3) / 4;
     return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
@@ -181,4 +487,79 @@ extern "C" int cp_head1x1_wgrad_f32(const float* x, int ld_x, const float* dy, i
     if (blocks > 1024) blocks = 1024;
     CP_LAUNCH(head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, ld_x, dy, ld_dy, pixels, cout, dw);
     return cp::check_launch("cp_head1x1_wgrad_f32");
+}
+
+extern "C" int cp_head1x1_fwd_affine_f32(const float* x, int ld_x, long long pixels, const float* scale, const float* shift, const uint8_t* labels,
+                                         int classes, int act, const float* w, int cout, float* out, int ld_out, void* stream) {
+    CP_REQUIRE(x && w && out && scale && shift && pixels > 0 && cout > 0 && cout <= 32, "cp_head1x1_fwd_affine_f32: bad arguments (32 input channels, 1 <= cout <= 32)");
+    CP_REQUIRE(ld_x >= CIN && ld_x % 4 == 0 && ((uintptr_t)x & 15) == 0 && ld_out >= cout, "cp_head1x1_fwd_affine_f32: x rows must be 16-byte aligned float4 rows of >= 32 channels");
+    CP_REQUIRE(classes >= 1 && classes <= MAX_CLASSES && (classes == 1 || labels) && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+               "cp_head1x1_fwd_affine_f32: 1 <= classes <= 64, labels for the class-adaptive form, 16-byte aligned tables");
+    CP_LAUNCH(head_fwd_affine_kernel, dim3(grid_for_groups(pixels)), dim3(256), 2 * (size_t)classes * 32 * sizeof(float), (hipStream_t)stream, x, ld_x, pixels, scale, shift, labels, classes, act, w,
+              cout, out, ld_out);
+    return cp::check_launch("cp_head1x1_fwd_affine_f32");
+}
+
+extern "C" int cp_head1x1_wgrad_affine_f32(const float* x, int ld_x, const float* scale, const float* shift, const uint8_t* labels, int classes, int act,
+                                           const float* dy, int ld_dy, long long pixels, int cout, float* dw, int accumulate, void* stream) {
+    CP_REQUIRE(x && dy && dw && scale && shift && pixels > 0 && cout > 0 && cout <= 32 && ld_x >= CIN && ld_dy >= cout, "cp_head1x1_wgrad_affine_f32: bad arguments");
+    CP_REQUIRE(classes >= 1 && classes <= MAX_CLASSES && (classes == 1 || labels) && (!labels || ((uintptr_t)labels & 15) == 0) && pixels % 32 == 0,
+               "cp_head1x1_wgrad_affine_f32: 1 <= classes <= 64, 16-byte aligned labels for the class-adaptive form, pixels %% 32 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate)
+        if (hipMemsetAsync(dw, 0, sizeof(float) * CIN * cout, st) != hipSuccess) return cp::check_launch("cp_head1x1_wgrad_affine_f32 memset");
+    int blocks = grid_for_groups(pixels);
+    if (blocks > 1024) blocks = 1024;
+    const size_t lds = sizeof(float) * (4 * 16 * 64 + 2 * (size_t)classes * 32);
+    if (labels && classes > 1)
+        CP_LAUNCH(head_wgrad_affine_kernel<true>, dim3(blocks), dim3(256), lds, st, x, ld_x, scale, shift, labels, classes, act, dy, ld_dy, pixels, cout, dw);
+    else
+        CP_LAUNCH(head_wgrad_affine_kernel<false>, dim3(blocks), dim3(256), lds, st, x, ld_x, scale, shift, labels, classes, act, dy, ld_dy, pixels, cout, dw);
+    return cp::check_launch("cp_head1x1_wgrad_affine_f32");
+}
+
+static int head_bn_args(const char* fn, HeadBn& k, const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels,
+                        const float* w, int cout, const float* mean, const float* rstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
+                        const uint8_t* labels, int classes, int act) {
+    CP_REQUIRE(x && dout && w && mean && rstd && fwd_scale && fwd_shift, "%s: null pointer", fn);
+    CP_REQUIRE(pixels > 0 && pixels % 32 == 0 && cout > 0 && cout <= 32 && ld_x >= CIN, "%s: pixels must be a positive multiple of 32, 1 <= cout <= 32", fn);
+    CP_REQUIRE(dout_row_floats >= 32 && ld_dout % 4 == 0 && ((uintptr_t)dout & 15) == 0, "%s: every dout row needs 32 readable floats, 16-byte aligned", fn);
+    CP_REQUIRE(classes >= 1 && classes <= MAX_CLASSES && (classes == 1 || labels) && (!labels || ((uintptr_t)labels & 3) == 0),
+               "%s: 1 <= classes <= 64, 4-byte aligned labels for the class-adaptive form", fn);
+    k = HeadBn{x, ld_x, dout, ld_dout, pixels, w, cout, mean, rstd, gamma, fwd_scale, fwd_shift, labels, classes, act};
+    return CP_OK;
+}
+
+extern "C" int cp_head1x1_bn_bwd_reduce_f32(const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels, const float* w,
+                                            int cout, const float* mean, const float* rstd, const float* gamma, const float* fwd_scale,
+                                            const float* fwd_shift, const uint8_t* labels, int classes, int act, double* red, double* chan, void* stream) {
+    HeadBn k;
+    if (int rc = head_bn_args("cp_head1x1_bn_bwd_reduce_f32", k, x, ld_x, dout, ld_dout, dout_row_floats, pixels, w, cout, mean, rstd, gamma, fwd_scale,
+                              fwd_shift, labels, classes, act))
+        return rc;
+    CP_REQUIRE(red && chan, "cp_head1x1_bn_bwd_reduce_f32: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nred = (size_t)classes * 64;
+    if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+    if (hipMemsetAsync(chan, 0, 64 * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+    const size_t lds = (nred + 64) * sizeof(double) + 3 * (size_t)classes * 32 * sizeof(float);
+    long long blocks = ((pixels >> 5) + 31) / 32;   // a wave takes runs of 8 groups: >= 1 run per wave
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    CP_LAUNCH(head_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), lds, st, k, red, chan);
+    return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32");
+}
+
+extern "C" int cp_head1x1_bn_bwd_apply_f32(const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels, const float* w,
+                                           int cout, const float* mean, const float* rstd, const float* gamma, const float* fwd_scale,
+                                           const float* fwd_shift, const uint8_t* labels, int classes, int act, const double* chan, double global_pixels,
+                                           const float* row_scale, float* dx, int ld_dx, void* stream) {
+    HeadBn k;
+    if (int rc = head_bn_args("cp_head1x1_bn_bwd_apply_f32", k, x, ld_x, dout, ld_dout, dout_row_floats, pixels, w, cout, mean, rstd, gamma, fwd_scale,
+                              fwd_shift, labels, classes, act))
+        return rc;
+    CP_REQUIRE(chan && dx && ld_dx >= CIN && global_pixels > 0 && (!row_scale || ((uintptr_t)row_scale & 15) == 0), "cp_head1x1_bn_bwd_apply_f32: bad arguments");
+    const size_t lds = 3 * (size_t)classes * 32 * sizeof(float);
+    CP_LAUNCH(head_bn_bwd_apply_kernel, dim3(grid_for_groups(pixels)), dim3(256), lds, (hipStream_t)stream, k, chan, 1.0 / global_pixels, row_scale, dx, ld_dx);
+    return cp::check_launch("cp_head1x1_bn_bwd_apply_f32");
 }

@@ -8,6 +8,8 @@
 // (the reference gets them from tf.GradientTape, train_casapose.py:594), Keras Adam
 // (train_casapose.py:334-347, eps 1e-7).  All of them are HBM-bound: 16 B per lane per access,
 // grid-stride over a capped grid, fp64 accumulation for the statistics.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -22,16 +24,20 @@ inline int grid_for(long long n) {
 // ---------------------------------------------------------------------------------------------
 // statistics: sums[c] += sum x, sums[C + c] += sum x^2
 // A block walks rows (pixels) with stride gridDim; thread t owns channel group (t % C4) and row lane
-// (t / C4): per-thread fp32 partials over <= 64 rows, then fp64, LDS reduce, one fp64 atomic per value.
-__global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restrict__ x, long long pixels, int C, int ld,
-                                                           double* __restrict__ sums) {
+// (t / C4): fp64 partials per thread, LDS reduce, one fp64 atomic per value and block.
+// 1024-thread blocks, at most 512 of them: every block ends with 2C atomics on the SAME 2C addresses, and same-address fp64 atomics retire one
+// after the other (~9 ns each, measured with tools/debug/stats_probe.py: 2048 blocks of 256 threads spent 18 us of a 49 us launch waiting for
+// that chain; 100352 x 512: 70 -> 47 us, 401408 x 64: 49 -> 31 us at equal thread counts).
+constexpr int STAT_THREADS = 1024;
+__global__ __launch_bounds__(STAT_THREADS) void bn_stats_kernel(const float* __restrict__ x, long long pixels, int C, int ld,
+                                                                double* __restrict__ sums) {
     extern __shared__ double sred[];  // [2][C]
     const int c4n = C >> 2;
     const int lanes_per_row = c4n;              // threads covering one pixel
-    const int rows_per_pass = THREADS / lanes_per_row;  // C <= 1024
+    const int rows_per_pass = STAT_THREADS / lanes_per_row;  // C <= 4096
     const int c4 = threadIdx.x % lanes_per_row;
     const int rl = threadIdx.x / lanes_per_row;
-    for (int i = threadIdx.x; i < 2 * C; i += THREADS) sred[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * C; i += STAT_THREADS) sred[i] = 0.0;
     __syncthreads();
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (rl < rows_per_pass) {
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += THREADS) atomicAdd(&sums[i], sred[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += STAT_THREADS) atomicAdd(&sums[i], sred[i]);
 }
 
 __device__ __forceinline__ float act_fwd(float t, int act) {
@@ -88,7 +94,9 @@ __global__ void affine_act_kernel(const float* __restrict__ x, long long pixels,
 // backward of y = act(t), t = gamma[l][c]*xhat + beta[l][c], xhat = (x - mean[c]) * rstd[c]
 // reduce pass: red[(l*C + c)*2 + {0,1}] += {g, g*xhat} (g = dy*act'(t))   -> dbeta[l][c], dgamma[l][c]
 //              chan[c*2 + {0,1}]       += {g*gamma, g*gamma*xhat}           -> the two means of the BN backward
-__global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
+// (1024-thread blocks as in bn_stats_kernel were measured and lose here: 7.06 against 6.65 ms of normalisation backward per step)
+constexpr int RED_THREADS = 256;
+__global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
                                                                     long long pixels, int C, int classes, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const uint8_t* __restrict__ labels,
@@ -96,10 +104,10 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
                                                                     double* __restrict__ red, double* __restrict__ chan) {
     extern __shared__ double sred[];  // [classes*C*2] + [C*2]
     const int nred = classes * C * 2, nch = C * 2;
-    for (int i = threadIdx.x; i < nred + nch; i += THREADS) sred[i] = 0.0;
+    for (int i = threadIdx.x; i < nred + nch; i += RED_THREADS) sred[i] = 0.0;
     __syncthreads();
     const int c4n = C >> 2;
-    const int rows_per_pass = THREADS / c4n;
+    const int rows_per_pass = RED_THREADS / c4n;
     const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
     if (rl < rows_per_pass) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
@@ -162,9 +170,9 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_reduce_kernel(const float*
         flush();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nred; i += THREADS)
+    for (int i = threadIdx.x; i < nred; i += RED_THREADS)
         if (sred[i] != 0.0) atomicAdd(&red[i], sred[i]);
-    for (int i = threadIdx.x; i < nch; i += THREADS)
+    for (int i = threadIdx.x; i < nch; i += RED_THREADS)
         if (sred[nred + i] != 0.0) atomicAdd(&chan[i], sred[nred + i]);
 }
 
@@ -446,11 +454,12 @@ extern "C" int cp_bn_stats_f32(const float* x, long long pixels, int channels, i
     CP_REQUIRE(channels % 4 == 0 && channels >= 4 && channels <= 1024 && ld >= channels && ld % 4 == 0, "cp_bn_stats_f32: channels must be a multiple of 4 (<= 1024), ld >= channels");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, st) != hipSuccess) return cp::check_launch("cp_bn_stats_f32 memset");
-    const int rows_per_pass = THREADS / (channels / 4);
+    const int rows_per_pass = STAT_THREADS / (channels / 4);
     long long blocks = (pixels + rows_per_pass * 16 - 1) / (rows_per_pass * 16);
-    if (blocks > 2048) blocks = 2048;
+    static const int cap = getenv("CP_BN_STATS_BLOCKS") ? atoi(getenv("CP_BN_STATS_BLOCKS")) : 512;   // tuning aid
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    CP_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(THREADS), sizeof(double) * 2 * channels, st, x, pixels, channels, ld, sums);
+    CP_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(STAT_THREADS), sizeof(double) * 2 * channels, st, x, pixels, channels, ld, sums);
     return cp::check_launch("cp_bn_stats_f32");
 }
 
@@ -499,11 +508,12 @@ extern "C" int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* d
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr = true;
     }
-    const int rows_per_pass = THREADS / (channels / 4);
+    const int rows_per_pass = RED_THREADS / (channels / 4);
     long long blocks = (pixels + rows_per_pass * 32 - 1) / (rows_per_pass * 32);
-    if (blocks > 1024) blocks = 1024;
+    static const int cap = getenv("CP_BN_REDUCE_BLOCKS") ? atoi(getenv("CP_BN_REDUCE_BLOCKS")) : 1024;   // tuning aid
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    CP_LAUNCH(bn_act_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, x, ld_x, dy, ld_dy, pixels, channels, classes, mean, rstd,
+    CP_LAUNCH(bn_act_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), lds, st, x, ld_x, dy, ld_dy, pixels, channels, classes, mean, rstd,
               gamma, beta, labels, act, fwd_scale, fwd_shift, red, chan);
     return cp::check_launch("cp_bn_act_bwd_reduce_f32");
 }

@@ -12,6 +12,8 @@
 // x mod d) form d*d independent dilation-1 problems with zero padding at their own borders.
 // Tile id: t = ((n*d*d + sy*d + sx)*Tu + tu)*Tv + tv; planes are padded to Tp tiles (a multiple of 64) so that a GEMM
 // block never straddles two planes.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -57,8 +59,18 @@ __device__ __forceinline__ void tile_coords(int t, const WinoGeom& g, int& n, in
     sx = s - sy * g.d;
 }
 
+// pre_scale / pre_shift (per channel, may be null) + pre_act: the producer's normalisation + activation applied to every REAL pixel while it
+// is loaded -- y = act(fma(x, scale, shift)), the expression of affine_act_kernel (train_kernels.hip), so that the training step need not
+// store y for a layer whose only consumer is this transform; the zero padding stays zero.
+__device__ __forceinline__ float pre_act_f(float t, int act) {
+    if (act == CP_ACT_RELU) return fmaxf(t, 0.f);
+    if (act == CP_ACT_LEAKY01) return fmaxf(t, 0.f) - fmaxf(-0.1f * t, 0.f);
+    return t;
+}
+
+template <bool PRE>
 __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restrict__ src, int ld, int C, WinoGeom g, float* __restrict__ V, int ldv,
-                                                          int c_off) {
+                                                          int c_off, const float* __restrict__ pre_scale, const float* __restrict__ pre_shift, int pre_act) {
     const int c4n = C >> 2;
     const long long total = (long long)g.T * c4n;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -66,6 +78,11 @@ __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restric
         const int t = (int)(i / c4n);
         int n, sy, sx, tu, tv;
         tile_coords(t, g, n, sy, sx, tu, tv);
+        float4 ps = f4(1.f), pb = f4(0.f);
+        if constexpr (PRE) {
+            ps = *reinterpret_cast<const float4*>(pre_scale + c4 * 4);
+            pb = *reinterpret_cast<const float4*>(pre_shift + c4 * 4);
+        }
         float4 tt[6][6];  // (B^T d): column by column
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -76,6 +93,11 @@ __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restric
                 const int y = sy + g.d * (4 * tu + r - 1);
                 const bool ok = (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;  // outside the image (or before the sub-grid's first row/column): zero padding
                 col[r] = ok ? *reinterpret_cast<const float4*>(src + (((size_t)n * g.H + y) * g.W + x) * ld + c4 * 4) : f4(0.f);
+                if (PRE && ok) {
+                    const float4 v = col[r];
+                    col[r] = make_float4(pre_act_f(__builtin_fmaf(v.x, ps.x, pb.x), pre_act), pre_act_f(__builtin_fmaf(v.y, ps.y, pb.y), pre_act),
+                                         pre_act_f(__builtin_fmaf(v.z, ps.z, pb.z), pre_act), pre_act_f(__builtin_fmaf(v.w, ps.w, pb.w), pre_act));
+                }
             }
             float4 o[6];
             bt6(col, o);
@@ -105,14 +127,39 @@ struct WinoEpi {
     int raw_ld;
     float* out_act;
     int act_ld;
+    double* stats;   // [2][cout] or null: sum and sum of squares of the RAW output (after the residual) over the real pixels -- the batch statistics
+                     // of the normalisation layer that follows, so that the training step needs no separate pass over the tensor for them
 };
 
+template <bool STATS>
 __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restrict__ M, int cout, WinoGeom g, WinoEpi e) {
+    extern __shared__ double sstat[];   // [2][cout] when STATS
     const int c4n = cout >> 2;
     const long long total = (long long)g.T * c4n;
+    if constexpr (STATS) {
+        for (int i = threadIdx.x; i < 2 * cout; i += THREADS) sstat[i] = 0.0;
+        __syncthreads();
+    }
+    int cur_c4 = -1;
+    double ss[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    auto flush = [&]() {
+        if (cur_c4 < 0) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&sstat[cur_c4 * 4 + k], ss[k]);
+            atomicAdd(&sstat[cout + cur_c4 * 4 + k], sq[k]);
+            ss[k] = sq[k] = 0.0;
+        }
+    };
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const int t = (int)(i / c4n);
+        if constexpr (STATS) {
+            if (c4 != cur_c4) {
+                flush();
+                cur_c4 = c4;
+            }
+        }
         int n, sy, sx, tu, tv;
         tile_coords(t, g, n, sy, sx, tu, tv);
         const float* src = M + (size_t)t * cout + c4 * 4;
@@ -147,6 +194,11 @@ __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restri
                 const size_t pix = ((size_t)n * g.H + y) * g.W + x;
                 float4 v = o[j];
                 if (e.residual) v = v + *reinterpret_cast<const float4*>(e.residual + pix * e.res_ld + c4 * 4);
+                if constexpr (STATS) {   // fp64 from the first addition, like bn_stats_kernel: the two routes agree to ~1e-16, so a layer's activation
+                                         // branches do not depend on which of them produced its statistics
+                    ss[0] += v.x; ss[1] += v.y; ss[2] += v.z; ss[3] += v.w;
+                    sq[0] += (double)v.x * v.x; sq[1] += (double)v.y * v.y; sq[2] += (double)v.z * v.z; sq[3] += (double)v.w * v.w;
+                }
                 if (e.out_raw) *reinterpret_cast<float4*>(e.out_raw + pix * e.raw_ld + c4 * 4) = v;
                 if (e.out_act) {
                     if (aff && e.label) {
@@ -165,6 +217,12 @@ __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restri
                 }
             }
         }
+    }
+    if constexpr (STATS) {
+        flush();
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * cout; i += THREADS)
+            if (sstat[i] != 0.0) atomicAdd(&e.stats[i], sstat[i]);
     }
 }
 
@@ -334,26 +392,58 @@ extern "C" int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int
     return CP_OK;
 }
 
-extern "C" int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
-                                           int c_off, void* stream) {
+extern "C" int cp_wino_input_transform_pre_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
+                                               int c_off, const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
     CP_REQUIRE(src && V && channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0 && c_off >= 0 && c_off % 4 == 0 && c_off + channels <= ldv,
                "cp_wino_input_transform_f32: bad arguments");
+    CP_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr) && (((uintptr_t)pre_scale | (uintptr_t)pre_shift) & 15) == 0,
+               "cp_wino_input_transform_pre_f32: pre_scale and pre_shift come together, 16-byte aligned");
     WinoGeom g;
     CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_input_transform_f32: bad geometry");
-    CP_LAUNCH(wino_in_kernel, dim3(grid_for((long long)g.T * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv, c_off);
+    if (pre_scale)
+        CP_LAUNCH(wino_in_kernel<true>, dim3(grid_for((long long)g.T * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv,
+                  c_off, pre_scale, pre_shift, pre_act);
+    else
+        CP_LAUNCH(wino_in_kernel<false>, dim3(grid_for((long long)g.T * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv,
+                  c_off, pre_scale, pre_shift, pre_act);
     return cp::check_launch("cp_wino_input_transform_f32");
+}
+
+extern "C" int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
+                                           int c_off, void* stream) {
+    return cp_wino_input_transform_pre_f32(src, ld, channels, batch, h, w, dilation, V, ldv, c_off, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
                                             const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
                                             int out_raw_ld, float* out_act, int out_act_ld, void* stream) {
+    return cp_wino_output_transform_stats_f32(M, cout, batch, h, w, dilation, residual, residual_ld, scale, shift, epi_label, act, out_raw, out_raw_ld,
+                                              out_act, out_act_ld, nullptr, stream);
+}
+
+extern "C" int cp_wino_output_transform_stats_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                                  const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
+                                                  int out_raw_ld, float* out_act, int out_act_ld, double* stats, void* stream) {
     CP_REQUIRE(M && cout > 0 && cout % 4 == 0 && (out_raw || out_act), "cp_wino_output_transform_f32: bad arguments");
     CP_REQUIRE((scale == nullptr) == (shift == nullptr) && (!epi_label || scale), "cp_wino_output_transform_f32: scale/shift/label combination");
     CP_REQUIRE((!out_raw || out_raw_ld >= cout) && (!out_act || out_act_ld >= cout) && (!residual || residual_ld >= cout), "cp_wino_output_transform_f32: ld < cout");
     WinoGeom g;
     CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_output_transform_f32: bad geometry");
-    WinoEpi e{residual, residual_ld, scale, shift, epi_label, act, out_raw, out_raw_ld, out_act, out_act_ld};
-    CP_LAUNCH(wino_out_kernel, dim3(grid_for((long long)g.T * (cout / 4))), dim3(THREADS), 0, (hipStream_t)stream, M, cout, g, e);
+    WinoEpi e{residual, residual_ld, scale, shift, epi_label, act, out_raw, out_raw_ld, out_act, out_act_ld, stats};
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = grid_for((long long)g.T * (cout / 4));
+    size_t lds = 0;
+    if (stats) {   // fewer, longer-lived blocks: every block ends with 2 * cout fp64 atomics
+        CP_REQUIRE(cout <= 2048, "cp_wino_output_transform_stats_f32: cout <= 2048");
+        if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * cout, st) != hipSuccess) return cp::check_launch("cp_wino_output_transform_stats_f32 memset");
+        static const int cap = getenv("CP_WINO_STATS_BLOCKS") ? atoi(getenv("CP_WINO_STATS_BLOCKS")) : 1024;   // tuning aid
+        if (blocks > cap) blocks = cap;
+        lds = sizeof(double) * 2 * cout;
+    }
+    if (stats)
+        CP_LAUNCH(wino_out_kernel<true>, dim3(blocks), dim3(THREADS), lds, st, M, cout, g, e);
+    else
+        CP_LAUNCH(wino_out_kernel<false>, dim3(blocks), dim3(THREADS), 0, st, M, cout, g, e);
     return cp::check_launch("cp_wino_output_transform_f32");
 }
 

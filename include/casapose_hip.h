@@ -352,6 +352,16 @@ int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batc
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
                                  const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
                                  int out_raw_ld, float* out_act, int out_act_ld, void* stream);
+/* Training-step forms of the two transforms (round 3, fused normalisation: casapose.py:76-105 / resnet.py:78-103 are convolution ->
+ * normalisation -> activation -> convolution).  _stats: also accumulates stats[c] = sum, stats[cout + c] = sum of squares (fp64; zeroed by
+ * the call) of the RAW output over the real pixels = the batch statistics cp_bn_stats_f32 would compute from out_raw.  _pre: applies
+ * y = act(fma(x, pre_scale[c], pre_shift[c])) (cp_affine_act_f32's expression, per channel, both NULL = identity) to every real pixel as it
+ * is loaded, so the activated tensor between a normalisation layer and a Winograd layer need not be stored. */
+int cp_wino_output_transform_stats_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                       const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw, int out_raw_ld,
+                                       float* out_act, int out_act_ld, double* stats, void* stream);
+int cp_wino_input_transform_pre_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv, int c_off,
+                                    const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
 
 /* ====================================================================================
  * TRAINING PATH (train_casapose.py:494-611: forward with training=True, compute_loss,
@@ -385,6 +395,24 @@ int cp_head1x1_fwd_f32(const float* x, int ld_x, long long pixels, const float* 
 int cp_head1x1_dgrad_f32(const float* dy, int ld_dy, int dy_row_floats, long long pixels, const float* w, int cout, float* dx, int ld_dx,
                          int accumulate, void* stream);
 int cp_head1x1_wgrad_f32(const float* x, int ld_x, const float* dy, int ld_dy, long long pixels, int cout, float* dw, int accumulate, void* stream);
+
+/* Fused normalisation of decoder blocks 5 / 10 in the training step (round 3; casapose.py:76-105 is one Keras block -- convolution,
+ * (class-adaptive) normalisation, activation -- and the heads follow it, pose_models.py:546,616).  The raw convolution output x [pixels][32]
+ * stays the only stored tensor: the head's forward and weight gradient recompute y = act(fma(x, scale[l], shift[l])) (tables [classes][32],
+ * labels = NULL for classes == 1, act = CP_ACT_*), and the two passes of the normalisation backward recompute the head's data gradient
+ * g_y = dout W^T on the matrix pipe instead of reading a stored one: same red / chan / dx as cp_bn_act_bwd_reduce_f32 / _apply_f32 fed with
+ * cp_head1x1_dgrad_f32's output.  pixels % 32 == 0; every dout row has >= 32 readable floats from `dout` on (columns >= cout ignored). */
+int cp_head1x1_fwd_affine_f32(const float* x, int ld_x, long long pixels, const float* scale, const float* shift, const uint8_t* labels, int classes,
+                              int act, const float* w, int cout, float* out, int ld_out, void* stream);
+int cp_head1x1_wgrad_affine_f32(const float* x, int ld_x, const float* scale, const float* shift, const uint8_t* labels, int classes, int act,
+                                const float* dy, int ld_dy, long long pixels, int cout, float* dw, int accumulate, void* stream);
+int cp_head1x1_bn_bwd_reduce_f32(const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels, const float* w, int cout,
+                                 const float* mean, const float* rstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
+                                 const uint8_t* labels, int classes, int act, double* red, double* chan, void* stream);
+int cp_head1x1_bn_bwd_apply_f32(const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels, const float* w, int cout,
+                                const float* mean, const float* rstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
+                                const uint8_t* labels, int classes, int act, const double* chan, double global_pixels, const float* row_scale,
+                                float* dx, int ld_dx, void* stream);
 
 /* The DATA gradient needs no entry point of its own: it is cp_conv2d_fwd_f32 over dy with the kernel
  * flipped and transposed (host-side repack), pad' = dilation*(k-1) - pad, the same dilation, and, for a

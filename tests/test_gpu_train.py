@@ -223,6 +223,163 @@ def test_bn_act_forward_backward(device, hip_lib, classes, act, c):
         assert np.allclose(red.cpu().numpy().reshape(classes, c, 2)[..., 0], want, rtol=0, atol=1e-9), "d beta with dy = 1 counts the forward's own branches"
 
 
+@pytest.mark.parametrize("classes,act,cout,off", [(1, 2, 9, 0), (9, 2, 18, 32), (5, 1, 27, 32), (14, 2, 14, 0)])
+def test_fused_head_normalisation_kernels(device, hip_lib, classes, act, cout, off):
+    """cp_head1x1_{fwd,wgrad}_affine_f32 and cp_head1x1_bn_bwd_{reduce,apply}_f32 (blocks 5 / 10 -> head without a stored activation or a
+    stored head data gradient) against the separate passes they replace, and against fp64 autograd of normalise -> activate -> 1x1 head."""
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(classes * 100 + cout)
+    b, h, w, c, ldo = 2, 16, 24, 32, 64
+    n = b * h * w
+    x = (rng.standard_normal((n, c)) * 2 + 0.5).astype(np.float32)
+    lab = blob_labels(b, h, w, classes, 3).reshape(n) if classes > 1 else np.zeros(n, np.uint8)
+    gamma = (1 + 0.3 * rng.standard_normal((classes, c))).astype(np.float32)
+    beta = (0.2 * rng.standard_normal((classes, c))).astype(np.float32)
+    wk = (0.2 * rng.standard_normal((c, cout))).astype(np.float32)
+    dout = rng.standard_normal((n, ldo)).astype(np.float32)   # the other head's gradient / padding sits beside this head's columns
+    rs = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    st = torch.cuda.current_stream(device).cuda_stream
+    keep = []
+
+    def d(a):
+        keep.append(torch.from_numpy(np.ascontiguousarray(a)).to(device))
+        return keep[-1]
+
+    xd, labd, wd, doutd, rsd = d(x), d(lab), d(wk), d(dout), d(rs)
+    lp = labd.data_ptr() if classes > 1 else None
+    x64 = x.astype(np.float64)
+    meanv = x64.mean(0)
+    varv = (x64 ** 2).mean(0) - meanv ** 2
+    rstd = 1.0 / np.sqrt(varv + R.BN_EPS)
+    scale = (gamma * rstd[None]).astype(np.float32)
+    shift = (beta - gamma * (meanv * rstd)[None]).astype(np.float32)
+    scd, shd, md, rd, gd, bd = d(scale), d(shift), d(meanv.astype(np.float32)), d(rstd.astype(np.float32)), d(gamma), d(beta)
+    # ---- the separate passes -------------------------------------------------------------------------------------------
+    y = torch.empty(n, c, device=device)
+    check(lib.cp_affine_act_f32(xd.data_ptr(), n, c, c, scd.data_ptr(), shd.data_ptr(), lp, act, y.data_ptr(), c, st))
+    out0 = torch.zeros(n, 40, device=device)
+    check(lib.cp_head1x1_fwd_f32(y.data_ptr(), c, n, wd.data_ptr(), cout, out0.data_ptr(), 40, st))
+    dptr = doutd.data_ptr() + 4 * off
+    dw0 = torch.zeros(c, cout, device=device)
+    check(lib.cp_head1x1_wgrad_f32(y.data_ptr(), c, dptr, ldo, n, cout, dw0.data_ptr(), 0, st))
+    gy = torch.empty(n, c, device=device)
+    check(lib.cp_head1x1_dgrad_f32(dptr, ldo, 32, n, wd.data_ptr(), cout, gy.data_ptr(), c, 0, st))
+    red0 = torch.zeros(classes * c * 2, dtype=torch.float64, device=device)
+    chan0 = torch.zeros(c * 2, dtype=torch.float64, device=device)
+    check(lib.cp_bn_act_bwd_reduce_f32(xd.data_ptr(), c, gy.data_ptr(), c, n, c, classes, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                       scd.data_ptr(), shd.data_ptr(), red0.data_ptr(), chan0.data_ptr(), st))
+    dx0 = torch.empty(n, c, device=device)
+    check(lib.cp_bn_act_bwd_apply_f32(xd.data_ptr(), c, gy.data_ptr(), c, n, c, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(), lp, act,
+                                      scd.data_ptr(), shd.data_ptr(), chan0.data_ptr(), float(n), rsd.data_ptr(), dx0.data_ptr(), c, 0, st))
+    # ---- fused ---------------------------------------------------------------------------------------------------------
+    out1 = torch.zeros(n, 40, device=device)
+    check(lib.cp_head1x1_fwd_affine_f32(xd.data_ptr(), c, n, scd.data_ptr(), shd.data_ptr(), lp, classes, act, wd.data_ptr(), cout, out1.data_ptr(), 40, st))
+    assert torch.equal(out0, out1), "same fma, same activation, same MFMA chain: bit-identical head output"
+    dw1 = torch.full((c, cout), 3.0, device=device)
+    check(lib.cp_head1x1_wgrad_affine_f32(xd.data_ptr(), c, scd.data_ptr(), shd.data_ptr(), lp, classes, act, dptr, ldo, n, cout, dw1.data_ptr(), 1, st))
+    assert rel(dw1.cpu().numpy() - 3.0, dw0.cpu().numpy()) < 1e-5
+    red1 = torch.full((classes * c * 2,), 5.0, dtype=torch.float64, device=device)
+    chan1 = torch.full((c * 2,), 5.0, dtype=torch.float64, device=device)
+    args = (xd.data_ptr(), c, dptr, ldo, 32, n, wd.data_ptr(), cout, md.data_ptr(), rd.data_ptr(), gd.data_ptr(), scd.data_ptr(), shd.data_ptr(), lp, classes, act)
+    check(lib.cp_head1x1_bn_bwd_reduce_f32(*args, red1.data_ptr(), chan1.data_ptr(), st))
+    assert rel(red1.cpu().numpy(), red0.cpu().numpy()) < 1e-9 and rel(chan1.cpu().numpy(), chan0.cpu().numpy()) < 1e-9
+    dx1 = torch.full((n, c), 7.0, device=device)
+    check(lib.cp_head1x1_bn_bwd_apply_f32(*args, chan1.data_ptr(), float(n), rsd.data_ptr(), dx1.data_ptr(), c, st))
+    assert rel(dx1.cpu().numpy(), dx0.cpu().numpy()) < 1e-6
+    # ---- fp64 autograd of the three layers -------------------------------------------------------------------------------
+    xt = torch.tensor(x64, requires_grad=True)
+    gt, bt = torch.tensor(gamma.astype(np.float64), requires_grad=True), torch.tensor(beta.astype(np.float64), requires_grad=True)
+    wt = torch.tensor(wk.astype(np.float64), requires_grad=True)
+    mean = xt.mean(0)
+    var = ((xt - mean) ** 2).mean(0)
+    xh = (xt - mean) / torch.sqrt(var + R.BN_EPS)
+    li = torch.from_numpy(lab.astype(np.int64))
+    t = gt[li] * xh + bt[li]
+    yr = F.relu(t) if act == 1 else R.leaky_pair(t)
+    o = yr @ wt
+    assert rel(out1.cpu().numpy()[:, :cout], o.detach().numpy()) < 2e-5
+    o.backward(torch.from_numpy(dout[:, off:off + cout].astype(np.float64)))
+    assert rel(dw0.cpu().numpy(), wt.grad.numpy()) < 3e-5 and rel(dw1.cpu().numpy() - 3.0, wt.grad.numpy()) < 3e-5
+    r = red1.cpu().numpy().reshape(classes, c, 2)
+    assert rel(r[..., 0], bt.grad.numpy()) < 3e-5 and rel(r[..., 1], gt.grad.numpy()) < 3e-5
+    check(lib.cp_head1x1_bn_bwd_apply_f32(*args, chan1.data_ptr(), float(n), None, dx1.data_ptr(), c, st))
+    assert rel(dx1.cpu().numpy(), xt.grad.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize("c,cout,dil,hw", [(256, 256, 2, (15, 20)), (128, 384, 1, (12, 16)), (256, 128, 4, (9, 7))])
+def test_winograd_transforms_with_fused_normalisation(device, hip_lib, c, cout, dil, hw):
+    """cp_wino_input_transform_pre_f32 == cp_affine_act_f32 followed by the plain transform (bit for bit), and
+    cp_wino_output_transform_stats_f32's table == cp_bn_stats_f32 of the raw output it writes (ragged tiles, dilation sub-grids, residual)."""
+    lib = hip_lib
+    from casapose_amd._lib import check
+
+    rng = np.random.default_rng(c + cout)
+    b, (h, w) = 2, hw
+    n = b * h * w
+    st = torch.cuda.current_stream(device).cuda_stream
+    t, tp = C.c_int(), C.c_int()
+    check(lib.cp_wino_tiles(b, h, w, dil, C.byref(t), C.byref(tp)))
+    tp = tp.value
+    x = torch.from_numpy((rng.standard_normal((n, c)) * 2 + 0.3).astype(np.float32)).to(device)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(device)
+    sh = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).to(device)
+    for act in (1, 2, 0):
+        y = torch.empty(n, c, device=device)
+        check(lib.cp_affine_act_f32(x.data_ptr(), n, c, c, sc.data_ptr(), sh.data_ptr(), None, act, y.data_ptr(), c, st))
+        v0 = torch.zeros(36 * tp * c, device=device)
+        v1 = torch.zeros(36 * tp * c, device=device)
+        check(lib.cp_wino_input_transform_f32(y.data_ptr(), c, c, b, h, w, dil, v0.data_ptr(), c, 0, st))
+        check(lib.cp_wino_input_transform_pre_f32(x.data_ptr(), c, c, b, h, w, dil, v1.data_ptr(), c, 0, sc.data_ptr(), sh.data_ptr(), act, st))
+        assert torch.equal(v0, v1), "act %d" % act
+    m = torch.from_numpy(rng.standard_normal(36 * tp * cout).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(device)
+    for r in (None, res):
+        raw0 = torch.zeros(n, cout, device=device)
+        raw1 = torch.zeros(n, cout, device=device)
+        stats = torch.full((2 * cout,), 9.0, dtype=torch.float64, device=device)
+        rp = r.data_ptr() if r is not None else None
+        check(lib.cp_wino_output_transform_f32(m.data_ptr(), cout, b, h, w, dil, rp, cout, None, None, None, 0, raw0.data_ptr(), cout, None, cout, st))
+        check(lib.cp_wino_output_transform_stats_f32(m.data_ptr(), cout, b, h, w, dil, rp, cout, None, None, None, 0, raw1.data_ptr(), cout, None, cout,
+                                                     stats.data_ptr(), st))
+        assert torch.equal(raw0, raw1)
+        want = torch.zeros(2 * cout, dtype=torch.float64, device=device)
+        check(lib.cp_bn_stats_f32(raw0.data_ptr(), n, cout, cout, want.data_ptr(), st))
+        r64 = raw0.cpu().numpy().astype(np.float64)
+        assert rel(want.cpu().numpy(), np.concatenate([r64.sum(0), (r64 ** 2).sum(0)])) < 1e-12
+        # fp64 from the first addition on both routes: only the summation order differs
+        assert np.abs(stats.cpu().numpy() - want.cpu().numpy()).max() < 1e-12 * np.abs(r64).max() ** 2 * n
+
+
+def test_fused_normalisation_plan_equals_the_separate_passes(device, monkeypatch):
+    """TrainPlan with the fused normalisation (default) against CASAPOSE_FUSE_NORM=0: same outputs, same losses, same gradient."""
+    from casapose_amd.train_engine import BnActOp
+
+    b, h, w, k = 2, 64, 64, 5
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CASAPOSE_FUSE_NORM", fuse)
+        params, store, plan, img, lab, kpts = _setup(device, b, h, w, k)
+        fused = [op.name for op in plan.ops if isinstance(op, BnActOp) and (op.head is not None or op.stats_from is not None or op.consumer is not None)]
+        assert bool(fused) == (fuse == "1"), fused
+        if fuse == "1":
+            assert {"pv_block_5_bn", "pv_block_10_clade"} <= set(fused), fused
+        stream = torch.cuda.current_stream(device).cuda_stream
+        plan.refresh_weights(stream)
+        labd = torch.from_numpy(lab).to(device)
+        out = plan.forward(torch.from_numpy(img).to(device), cond_labels=labd).clone()
+        sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(device), 1.0, 0.5, 0.015, filter_with_segmentation=False).cpu().numpy().copy()
+        plan.backward()
+        torch.cuda.synchronize()
+        res[fuse] = (out.cpu().numpy(), sums, store.grad.cpu().numpy().copy(), {n: v.cpu().numpy().copy() for n, v in store.state.items()})
+    assert rel(res["1"][0], res["0"][0]) < 1e-5
+    assert np.allclose(res["1"][1], res["0"][1], rtol=1e-5)
+    assert rel_l2(res["1"][2], res["0"][2]) < 1e-4
+    for n in res["0"][3]:   # moving statistics
+        assert rel(res["1"][3][n], res["0"][3][n]) < 1e-5, n
+
+
 def test_resampling_adjoints(device, hip_lib):
     lib = hip_lib
     from casapose_amd._lib import check
