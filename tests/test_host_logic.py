@@ -313,3 +313,54 @@ def test_split_kernel_host_packers(hip_lib):
     assert hip_lib.cp_conv_pack_head_split_host(wh.ctypes.data, 9, dh.ctypes.data) == 0
     hh = dh.reshape(2, 64, 8)
     assert hh[1, 32 + 4, 6] == wh[8 * (2 + 1) + 4 + 2, 4] and hh[0, 20, 3] == 0.0      # q = 20 >= 9: zero
+
+
+def _unjson(v):
+    if isinstance(v, dict):
+        if "__ndarray__" in v:
+            return np.asarray(v["__ndarray__"], dtype=v["dtype"])
+        if "__tuple__" in v:
+            return tuple(_unjson(e) for e in v["__tuple__"])
+        if "__list__" in v:
+            return [_unjson(e) for e in v["__list__"]]
+    return v
+
+
+def test_config_parser_matches_the_reference_parser(tmp_path, monkeypatch):
+    """tests/golden/config_parser_ref.json holds what the REFERENCE's own parse_config() (casapose/utils/config_parser.py:7-170, executed in
+    this container by tests/golden/make_config_golden.py -- it needs no TensorFlow) returns for its config_8.ini / config_13.ini under six
+    command lines: every option must come out with the same name, type and value here."""
+    import json
+    import os
+
+    from casapose_amd.utils.config_parser import parse_config
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(root, "tests", "golden", "config_parser_ref.json")))
+    monkeypatch.chdir(root)   # `objects_to_copy_list: config/objects_to_copy.csv` is relative to the repository root, as in the reference
+    assert len(cases) == 6
+    for n, case in enumerate(cases):
+        argv = list(case["argv"])
+        if case["ini"] is not None:
+            ini = tmp_path / ("case%d.ini" % n)
+            ini.write_text("".join("[%s]\n%s\n" % (sec, "\n".join("%s: %s" % kv for kv in items.items())) for sec, items in case["ini"].items()))
+            argv[argv.index("-c") + 1] = str(ini)
+        opt = vars(parse_config(argv))
+        want = {k: _unjson(v) for k, v in case["opt"].items()}
+        assert set(opt) == set(want), (n, set(opt) ^ set(want))
+        for k, w in want.items():
+            g = opt[k]
+            if k == "manualseed" and "manualseed" not in (case["ini"] or {}).get("defaults", {}):
+                assert isinstance(g, int) and 1 <= g <= 10000   # drawn at random when absent
+                continue
+            assert type(g) is type(w), (n, k, type(g), type(w))
+            if isinstance(w, np.ndarray):
+                assert g.dtype == w.dtype and g.shape == w.shape and (g == w).all(), (n, k)
+            else:
+                assert g == w, (n, k, g, w)
+    # the two config files this repository ships carry the same options as the reference's own files
+    for n, name in ((0, "config/config_8.ini"), (1, "config/config_13.ini")):
+        opt = vars(parse_config(["-c", name]))
+        for k, w in cases[n]["opt"].items():
+            w = _unjson(w)
+            assert (opt[k] == w).all() if isinstance(w, np.ndarray) else opt[k] == w, (name, k, opt[k], w)
