@@ -509,6 +509,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra line on the fp32 MFMA (conv_mode f32) reported beside the headline")
+    ap.add_argument("--train-leg-timeout", type=int, default=300, help="seconds after which a hanging training leg is abandoned (the headline line is printed without it)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the 3-step training leg (BASELINE configs[2]) the default line reports under `training_leg`")
     ap.add_argument("--stamp", action="store_true", help="print the source / binary stamp (JSON) and exit; no GPU is touched")
     args = ap.parse_args()
@@ -741,16 +742,40 @@ def main():
             "what": "CASAPOSE_INFER_CONV_MODE=f32: every convolution on v_mfma_f32_32x32x2_f32 (the headline of rounds 1 and 2); NOT this round's headline",
             "roofline": conv_roofline(net2) if not args.no_roofline else None}
         _log("fp32-MFMA line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
-    if rank == 0 and world == 1 and not args.no_train_leg:
-        # BASELINE configs[2] beside the headline, under the driver's clock: 3 training steps (1 warm-up) at the --mode train defaults
+    if not args.no_train_leg:
+        # BASELINE configs[2] / [3] beside the headline, under the driver's clock: 3 training steps (1 warm-up) at the --mode train defaults.
+        # With N > 1 ranks this is the DATA-PARALLEL step -- every rank trains on its own 32 images, SyncBN tables and the four gradient buckets
+        # go through RCCL -- so the driver's 1 / 2 / 4 / 8-GPU runs carry a training scaling figure next to the replica-parallel headline.
+        # It annotates the headline and must never cost it: an exception is reported in place, and a watchdog ends a leg that hangs (a rank
+        # that failed while the others wait in a collective) -- rank 0 then prints the line without it.
+        import threading
+
         net = net2 = plan = None   # noqa: F841  (drop the inference plans' buffers before the training plan allocates its own)
         torch.cuda.empty_cache()
+
+        def give_up():
+            if rank == 0:
+                result["training_leg"] = {"error": "timeout: the training leg did not finish within %d s" % args.train_leg_timeout}
+                result["binary"] = binary_stamp()
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.train_leg_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
-            result["training_leg"] = {k: leg[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "losses")}
+            result["training_leg"] = {k: leg[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "losses")}
             _log("training leg done: %.2f ms/step" % leg["ms_per_step"])
         except Exception as exc:  # an annotation of the headline line: report, never fail it
             result["training_leg"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if world > 1:   # the other ranks may be waiting for this one in a collective: they leave through their own watchdogs
+                dog.cancel()
+                if rank == 0:
+                    result["binary"] = binary_stamp()
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+        dog.cancel()
     result["binary"] = binary_stamp()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)

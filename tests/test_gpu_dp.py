@@ -104,7 +104,7 @@ def test_bench_multi_rank_contract(mode, tmp_path):
     if mode == "train":
         cmd += ["--mode", "train", "--batch", "4", "--height", "64", "--width", "96"]
     else:
-        cmd += ["--batch", "2", "--height", "64", "--width", "96"]
+        cmd += ["--batch", "2", "--height", "64", "--width", "96", "--no-train-leg"]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 0)]
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
@@ -115,6 +115,42 @@ def test_bench_multi_rank_contract(mode, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
     per_step = (2 if mode == "infer" else 4) * 2
     assert abs(d["value"] - per_step / (d["ms_per_step"] / 1e3)) < 0.02 * d["value"]
+
+
+def test_bench_default_line_carries_the_dp_training_leg(tmp_path):
+    """The DEFAULT line at WORLD_SIZE = 2 (what the driver's scaling runs parse): the replica-parallel inference headline plus a `training_leg`
+    measured data-parallel over both ranks (SyncBN tables + gradient buckets all-reduced; here over gloo on one shared GPU), n_gpus = 2; and
+    the watchdog: a leg that does not finish in time is abandoned and the headline line is still printed, exactly once."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", LOCAL_RANK="0", CASAPOSE_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-optin",
+           "--batch", "2", "--height", "64", "--width", "96"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines0 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    d = json.loads(lines0[0])
+    leg = d["training_leg"]
+    assert "error" not in leg, leg
+    assert d["n_gpus"] == 2 and leg["n_gpus"] == 2 and leg["config"]["global_batch"] == 64 and leg["value"] > 0
+    assert abs(leg["value"] - 64 / (leg["ms_per_step"] / 1e3)) < 0.02 * leg["value"]
+    assert all(np.isfinite(v) for v in leg["losses"].values())
+    # watchdog (one rank is enough): 1 s is less than the training plan needs to build
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd[:2] + ["--gpus", "1"] + cmd[4:] + ["--train-leg-timeout", "1"], env=env1, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "timeout" in d["training_leg"]["error"]
 
 
 def test_bench_gpus_flag_launches_its_own_ranks():
@@ -129,7 +165,7 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["CASAPOSE_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
-           "--batch", "2", "--height", "64", "--width", "96"]
+           "--batch", "2", "--height", "64", "--width", "96", "--no-train-leg"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
