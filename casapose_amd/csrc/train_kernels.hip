@@ -76,6 +76,22 @@ __global__ void affine_act_kernel(const float* __restrict__ x, long long pixels,
                                   float* __restrict__ y, int ld_y) {
     const int c4n = C >> 2;
     const long long total = pixels * c4n;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    if (!labels && nthreads % c4n == 0) {   // a thread keeps its channel group: the two table rows are loaded once (see bn_act_bwd_apply_kernel)
+        const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+        const int c4 = (int)(i0 % c4n);
+        const float4 s = *reinterpret_cast<const float4*>(scale + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(shift + c4 * 4);
+        for (long long i = i0; i < total; i += nthreads) {
+            const long long r = i / c4n;
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
+            float4 o;
+            o.x = act_fwd(__builtin_fmaf(v.x, s.x, b.x), act); o.y = act_fwd(__builtin_fmaf(v.y, s.y, b.y), act);
+            o.z = act_fwd(__builtin_fmaf(v.z, s.z, b.z), act); o.w = act_fwd(__builtin_fmaf(v.w, s.w, b.w), act);
+            *reinterpret_cast<float4*>(y + r * ld_y + c4 * 4) = o;
+        }
+        return;
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const long long r = i / c4n;
@@ -132,39 +148,51 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const fl
         // step of a CLADE layer changed the label -> 16 LDS fp64 atomics per step (block 10: 1.37 ms against 0.79 ms without labels)
         constexpr int SUB = 8;
         const long long run = (long long)SUB * rows_per_pass;
-        for (long long rr = (long long)blockIdx.x * run; rr < pixels; rr += (long long)gridDim.x * run)
-        for (int k = 0; k < SUB; ++k) {
-            const long long r = rr + (long long)k * rows_per_pass + rl;
-            if (r >= pixels) continue;
-            const int l = labels ? labels[r] : 0;
-            if (l != cur) {
-                flush();
-                cur = l;
+        for (long long rr = (long long)blockIdx.x * run; rr < pixels; rr += (long long)gridDim.x * run) {
+            // all SUB row pairs of the run are requested before the first is used (16 loads in flight per thread instead of 2)
+            float4 xq[SUB], dq[SUB];
+            int lq[SUB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e][0] = a[e][1] = a[e][2] = a[e][3] = 0.0;
-                gm = gamma ? *reinterpret_cast<const float4*>(gamma + (size_t)l * C + c4 * 4) : make_float4(1, 1, 1, 1);
-                bt = beta ? *reinterpret_cast<const float4*>(beta + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
-                if (fscale) {
-                    fs = *reinterpret_cast<const float4*>(fscale + (size_t)l * C + c4 * 4);
-                    fb = *reinterpret_cast<const float4*>(fshift + (size_t)l * C + c4 * 4);
-                }
+            for (int k = 0; k < SUB; ++k) {
+                const long long r = rr + (long long)k * rows_per_pass + rl;
+                const bool ok = r < pixels;
+                const long long rc = ok ? r : 0;
+                xq[k] = *reinterpret_cast<const float4*>(x + rc * ld_x + c4 * 4);
+                dq[k] = *reinterpret_cast<const float4*>(dy + rc * ld_dy + c4 * 4);
+                lq[k] = ok ? (labels ? (int)labels[rc] : 0) : -1;
             }
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
-            const float4 dv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c4 * 4);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
-            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
-            const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
-            const float fss[4] = {fs.x, fs.y, fs.z, fs.w}, fbs[4] = {fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (xs[e] - mus[e]) * rss[e];
-                // the branch the FORWARD took (affine_act_kernel's own expression) when its tables are given, else recomputed from gamma / beta
-                const float t = fscale ? __builtin_fmaf(xs[e], fss[e], fbs[e]) : gms[e] * xh + bts[e];
-                const float g = ds[e] * act_grad(t, act);
-                a[e][0] += g;
-                a[e][1] += (double)g * xh;
-                a[e][2] += (double)g * gms[e];
-                a[e][3] += (double)g * gms[e] * xh;
+            for (int k = 0; k < SUB; ++k) {
+                const int l = lq[k];
+                if (l < 0) continue;
+                if (l != cur) {
+                    flush();
+                    cur = l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e][0] = a[e][1] = a[e][2] = a[e][3] = 0.0;
+                    gm = gamma ? *reinterpret_cast<const float4*>(gamma + (size_t)l * C + c4 * 4) : make_float4(1, 1, 1, 1);
+                    bt = beta ? *reinterpret_cast<const float4*>(beta + (size_t)l * C + c4 * 4) : make_float4(0, 0, 0, 0);
+                    if (fscale) {
+                        fs = *reinterpret_cast<const float4*>(fscale + (size_t)l * C + c4 * 4);
+                        fb = *reinterpret_cast<const float4*>(fshift + (size_t)l * C + c4 * 4);
+                    }
+                }
+                const float4 xv = xq[k], dv = dq[k];
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+                const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
+                const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+                const float fss[4] = {fs.x, fs.y, fs.z, fs.w}, fbs[4] = {fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xs[e] - mus[e]) * rss[e];
+                    // the branch the FORWARD took (affine_act_kernel's own expression) when its tables are given, else recomputed from gamma / beta
+                    const float t = fscale ? __builtin_fmaf(xs[e], fss[e], fbs[e]) : gms[e] * xh + bts[e];
+                    const float g = ds[e] * act_grad(t, act);
+                    a[e][0] += g;
+                    a[e][1] += (double)g * xh;
+                    a[e][2] += (double)g * gms[e];
+                    a[e][3] += (double)g * gms[e] * xh;
+                }
             }
         }
         flush();
@@ -185,6 +213,47 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ x, int ld_x, c
                                         float* __restrict__ dx, int ld_dx, int accumulate) {
     const int c4n = C >> 2;
     const long long total = pixels * c4n;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    if (!labels && nthreads % c4n == 0) {
+        // one class and a thread count that is a multiple of the channel groups: a thread keeps ITS channel group for the whole walk, so the
+        // ten table rows are loaded once instead of once per element (they shared the L1 with the x / dy stream); same expressions, same bits
+        const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+        const int c4 = (int)(i0 % c4n);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + c4 * 4);
+        const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + c4 * 4) : make_float4(1, 1, 1, 1);
+        const float4 bt = beta ? *reinterpret_cast<const float4*>(beta + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float4 fs = fscale ? *reinterpret_cast<const float4*>(fscale + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float4 fb = fscale ? *reinterpret_cast<const float4*>(fshift + c4 * 4) : make_float4(0, 0, 0, 0);
+        const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+        const float fss[4] = {fs.x, fs.y, fs.z, fs.w}, fbs[4] = {fb.x, fb.y, fb.z, fb.w};
+        float m1[4], m2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m1[e] = (float)(chan[(c4 * 4 + e) * 2 + 0] * inv_n);
+            m2[e] = (float)(chan[(c4 * 4 + e) * 2 + 1] * inv_n);
+        }
+        for (long long i = i0; i < total; i += nthreads) {
+            const long long r = i / c4n;
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c4 * 4);
+            const float4 dv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c4 * 4);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float rsc = row_scale ? row_scale[r] : 1.f;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xs[e] - mus[e]) * rss[e];
+                const float t = fscale ? __builtin_fmaf(xs[e], fss[e], fbs[e]) : gms[e] * xh + bts[e];
+                const float g = ds[e] * act_grad(t, act) * gms[e];
+                o[e] = rss[e] * (g - m1[e] - xh * m2[e]) * rsc;
+            }
+            float4* dst = reinterpret_cast<float4*>(dx + r * ld_dx + c4 * 4);
+            if (accumulate) { const float4 old = *dst; o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+            *dst = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const long long r = i / c4n;
