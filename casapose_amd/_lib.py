@@ -169,6 +169,8 @@ SYMBOLS = [
     ("cp_bn_act_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     ("cp_bn_act_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.c_double, _vp, _vp, _i, _i, _vp]),
     ("cp_maxpool3x3s2_bwd_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    ("cp_maxpool3x3s2_idx_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("cp_maxpool3x3s2_bwd_idx_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     ("cp_upsample_bilinear_x2_bwd_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_guided_upsample_x2_bwd_f32", _i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cp_gather_f32", _i, [_vp, _vp, _ll, _vp, _vp]),

@@ -540,8 +540,12 @@ extern "C" int cp_head1x1_bn_bwd_reduce_f32(const float* x, int ld_x, const floa
     CP_REQUIRE(red && chan, "cp_head1x1_bn_bwd_reduce_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const size_t nred = (size_t)classes * 64;
-    if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
-    if (hipMemsetAsync(chan, 0, 64 * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+    if (chan == red + nred) {
+        if (hipMemsetAsync(red, 0, (nred + 64) * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+    } else {
+        if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+        if (hipMemsetAsync(chan, 0, 64 * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
+    }
     const size_t lds = (nred + 64) * sizeof(double) + 3 * (size_t)classes * 32 * sizeof(float);
     long long blocks = ((pixels >> 5) + 31) / 32;   // a wave takes runs of 8 groups: >= 1 run per wave
     if (blocks > 1024) blocks = 1024;

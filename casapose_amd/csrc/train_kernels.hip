@@ -371,6 +371,95 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     }
 }
 
+// The same adjoint from the arg-max TAP INDEX the forward recorded (cp_maxpool3x3s2_idx_f32: one byte per output element, tap 0..8 in raster order,
+// first maximum wins, the zero padding takes part): no x reads at all -- per 2x2 input block the four windows' index bytes and dy values instead of
+// a 5x5 patch of x (0.60 -> ~0.25 ms at bs 32: the 411 MB input is no longer touched).
+__global__ void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
+                                       float* __restrict__ dx, int accumulate) {
+    const int c4n = C >> 2;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const long long total = (long long)B * Hb * Wb * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long t = i / c4n;
+        const int bx = (int)(t % Wb);
+        t /= Wb;
+        const int by = (int)(t % Hb);
+        const int n = (int)(t / Hb);
+        float o[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[a][b][e] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = by + wy, ox = bx + wx;
+                if (oy >= Ho || ox >= Wo) continue;
+                const size_t op = (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4;
+                const uint32_t iw = *reinterpret_cast<const uint32_t*>(idx + op);
+                const float4 g = *reinterpret_cast<const float4*>(dy + op);
+                const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int ky = 1 + a - 2 * wy, kx = 1 + b - 2 * wx;   // input (2by + a, 2bx + b) as a tap of window (oy, ox)
+                        if (ky < 0 || ky > 2 || kx < 0 || kx > 2) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((int)((iw >> (8 * e)) & 255u) == ky * 3 + kx) o[a][b][e] += gs[e];
+                    }
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int iy = 2 * by + a, ix = 2 * bx + b;
+                if (iy >= H || ix >= W) continue;
+                float4* dst = reinterpret_cast<float4*>(dx + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
+                float4 r = make_float4(o[a][b][0], o[a][b][1], o[a][b][2], o[a][b][3]);
+                if (accumulate) { const float4 old = *dst; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                *dst = r;
+            }
+    }
+}
+
+// forward that records the arg-max tap (training): same maximum as maxpool_kernel (aux_kernels.hip), first maximum in raster order
+__global__ void maxpool_idx_kernel(const float* __restrict__ src, int B, int H, int W, int C, int Ho, int Wo, float* __restrict__ dst,
+                                   uint8_t* __restrict__ idx) {
+    const int c4n = C >> 2;
+    const long long total = (long long)B * Ho * Wo * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long long pix = i / c4n;
+        const int ox = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = *reinterpret_cast<const float4*>(src + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
+                const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (vs[e] > best[e]) { best[e] = vs[e]; bi[e] = ky * 3 + kx; }
+            }
+        *reinterpret_cast<float4*>(dst + (size_t)pix * C + c4 * 4) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uint32_t*>(idx + (size_t)pix * C + c4 * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
 // bilinear x2 (half-pixel centres): dx(y,x) = sum of dy over the <=16 hi-res pixels that sample (y,x)
 __global__ void bilinear_x2_bwd_kernel(const float* __restrict__ dy, int ld_dy, int B, int H, int W, int C, float* __restrict__ dx) {
     const int c4n = C >> 2, Ho = 2 * H, Wo = 2 * W;
@@ -570,8 +659,12 @@ extern "C" int cp_bn_act_bwd_reduce_f32(const float* x, int ld_x, const float* d
     const size_t nred = (size_t)classes * channels * 2, nch = (size_t)channels * 2;
     const size_t lds = (nred + nch) * sizeof(double);
     CP_REQUIRE(lds <= 150 * 1024, "cp_bn_act_bwd_reduce_f32: classes*channels too large for the LDS reduction (%zu bytes)", lds);
-    if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
-    if (hipMemsetAsync(chan, 0, nch * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+    if (chan == red + nred) {   // one launch for both tables when the caller keeps them adjacent (the training plan does: ~30 fewer fills per step)
+        if (hipMemsetAsync(red, 0, (nred + nch) * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+    } else {
+        if (hipMemsetAsync(red, 0, nred * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+        if (hipMemsetAsync(chan, 0, nch * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_bn_act_bwd_reduce_f32 memset");
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -604,6 +697,23 @@ extern "C" int cp_maxpool3x3s2_bwd_f32(const float* x, const float* dy, int batc
     CP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long long)batch * ((h + 1) / 2) * ((w + 1) / 2) * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, x, dy,
               batch, h, w, channels, ho, wo, dx, accumulate);
     return cp::check_launch("cp_maxpool3x3s2_bwd_f32");
+}
+
+extern "C" int cp_maxpool3x3s2_idx_f32(const float* src, int batch, int h, int w, int channels, float* dst, uint8_t* idx, void* stream) {
+    CP_REQUIRE(src && dst && idx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0 && ((uintptr_t)idx & 3) == 0, "cp_maxpool3x3s2_idx_f32: bad arguments");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    CP_LAUNCH(maxpool_idx_kernel, dim3(grid_for((long long)batch * ho * wo * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, src, batch, h, w, channels,
+              ho, wo, dst, idx);
+    return cp::check_launch("cp_maxpool3x3s2_idx_f32");
+}
+
+extern "C" int cp_maxpool3x3s2_bwd_idx_f32(const uint8_t* idx, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate,
+                                           void* stream) {
+    CP_REQUIRE(idx && dy && dx && batch > 0 && h > 0 && w > 0 && channels % 4 == 0 && ((uintptr_t)idx & 3) == 0, "cp_maxpool3x3s2_bwd_idx_f32: bad arguments");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    CP_LAUNCH(maxpool_bwd_idx_kernel, dim3(grid_for((long long)batch * ((h + 1) / 2) * ((w + 1) / 2) * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, idx,
+              dy, batch, h, w, channels, ho, wo, dx, accumulate);
+    return cp::check_launch("cp_maxpool3x3s2_bwd_idx_f32");
 }
 
 extern "C" int cp_upsample_bilinear_x2_bwd_f32(const float* dy, int ld_dy, int batch, int h, int w, int channels, float* dx, void* stream) {

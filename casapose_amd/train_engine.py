@@ -751,8 +751,9 @@ class BnActOp:
         self.shift = torch.zeros(classes, C_, **f32)
         self.gamma_full = torch.ones(classes, C_, **f32)
         self.beta_full = torch.zeros(classes, C_, **f32)
-        self.red = torch.zeros(classes * C_ * 2, **f64)
-        self.chan = torch.zeros(C_ * 2, **f64)
+        self._redchan = torch.zeros(classes * C_ * 2 + C_ * 2, **f64)   # adjacent: the backward reduce zeroes both with one fill
+        self.red = self._redchan[:classes * C_ * 2]
+        self.chan = self._redchan[classes * C_ * 2:]
         st = plan.store
         self.real_c = st.offsets[beta][1][-1] if beta else C_
         self.gamma_p = st.view(gamma) if gamma else None
@@ -941,13 +942,15 @@ class TrainPlan:
         bn("bn0", x, x2s, RELU)
         pooled = new(hs[2], ws[2], 64, name="pool")
 
+        pool_idx = torch.empty(B, hs[2], ws[2], 64, dtype=torch.uint8, device=dev)   # arg-max tap per pooled element: the adjoint routes by it
+
         def pool_f(stream, src=x2s, dst=pooled):
-            check(lib.cp_maxpool3x3s2_f32(src.data.data_ptr(), B, hs[1], ws[1], 64, None, None, 0, dst.data.data_ptr(), stream), "cp_maxpool3x3s2_f32")
+            check(lib.cp_maxpool3x3s2_idx_f32(src.data.data_ptr(), B, hs[1], ws[1], 64, dst.data.data_ptr(), pool_idx.data_ptr(), stream), "cp_maxpool3x3s2_idx_f32")
 
         def pool_b(stream, src=x2s, dst=pooled):
             assert dst.has_grad
-            check(lib.cp_maxpool3x3s2_bwd_f32(src.data.data_ptr(), dst.grad.data_ptr(), B, hs[1], ws[1], 64, src.grad.data_ptr(),
-                                              1 if src.has_grad else 0, stream), "cp_maxpool3x3s2_bwd_f32")
+            check(lib.cp_maxpool3x3s2_bwd_idx_f32(pool_idx.data_ptr(), dst.grad.data_ptr(), B, hs[1], ws[1], 64, src.grad.data_ptr(),
+                                                  1 if src.has_grad else 0, stream), "cp_maxpool3x3s2_bwd_idx_f32")
             src.has_grad = True
 
         self.ops.append(FnOp(pool_f, pool_b, reads=[x2s]))

@@ -467,6 +467,11 @@ int cp_bn_act_bwd_apply_f32(const float* x, int ld_x, const float* dy, int ld_dy
  * h, w are the LOW-resolution (input) sizes for the two upsampling adjoints. */
 int cp_maxpool3x3s2_bwd_f32(const float* x, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate,
                             void* stream);
+/* The training step's pair (round 3): the forward also records the arg-max TAP (0..8, raster order, first maximum wins, zero padding takes
+ * part) of every output element in idx [batch][ho][wo][channels] (one byte each, 4-byte aligned), and the adjoint routes dy by those bytes
+ * without reading x: same dx as cp_maxpool3x3s2_bwd_f32. */
+int cp_maxpool3x3s2_idx_f32(const float* src, int batch, int h, int w, int channels, float* dst, uint8_t* idx, void* stream);
+int cp_maxpool3x3s2_bwd_idx_f32(const uint8_t* idx, const float* dy, int batch, int h, int w, int channels, float* dx, int accumulate, void* stream);
 int cp_upsample_bilinear_x2_bwd_f32(const float* dy, int ld_dy, int batch, int h, int w, int channels, float* dx, void* stream);
 int cp_guided_upsample_x2_bwd_f32(const float* dy, int ld_dy, const uint8_t* sel, int batch, int h, int w, int channels, float* dx,
                                   void* stream);

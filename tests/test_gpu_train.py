@@ -404,6 +404,23 @@ def test_resampling_adjoints(device, hip_lib):
     got = dx.cpu().numpy()
     pos = x > 0  # at exact zeros the following ReLU blocks the gradient; ties there are immaterial
     assert rel(got[pos], xt.grad.numpy()[pos]) < 1e-6
+    # the training plan's pair: forward recording the arg-max tap, adjoint routed by it (no x reads) -- same output, same dx, odd sizes too
+    for hh, ww in ((h, w), (9, 13)):
+        xo = np.maximum(rng.standard_normal((b, hh, ww, c)), 0).astype(np.float32)
+        ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        dyo = rng.standard_normal((b, ho, wo, c)).astype(np.float32)
+        y0 = torch.empty(b, ho, wo, c, device=device)
+        y1 = torch.empty(b, ho, wo, c, device=device)
+        idx = torch.empty(b, ho, wo, c, dtype=torch.uint8, device=device)
+        check(lib.cp_maxpool3x3s2_f32(d(xo).data_ptr(), b, hh, ww, c, None, None, 0, y0.data_ptr(), st))
+        check(lib.cp_maxpool3x3s2_idx_f32(d(xo).data_ptr(), b, hh, ww, c, y1.data_ptr(), idx.data_ptr(), st))
+        assert torch.equal(y0, y1) and int(idx.max()) <= 8
+        dx0 = torch.full((b, hh, ww, c), 2.0, device=device)
+        dx1 = torch.full((b, hh, ww, c), 2.0, device=device)
+        for acc in (0, 1):
+            check(lib.cp_maxpool3x3s2_bwd_f32(d(xo).data_ptr(), d(dyo).data_ptr(), b, hh, ww, c, dx0.data_ptr(), acc, st))
+            check(lib.cp_maxpool3x3s2_bwd_idx_f32(idx.data_ptr(), d(dyo).data_ptr(), b, hh, ww, c, dx1.data_ptr(), acc, st))
+            assert torch.equal(dx0, dx1)
     # bilinear x2
     x = rng.standard_normal((b, h, w, c)).astype(np.float32)
     xt = torch.tensor(x.astype(np.float64), requires_grad=True)
@@ -706,10 +723,11 @@ def _kp_case(seed, b, h, w, k):
 
 
 @pytest.mark.parametrize("conf_reg", [False, True])
-def test_keypoint_loss_and_voter_backward(device, conf_reg):
+@pytest.mark.parametrize("k", [5, 9])
+def test_keypoint_loss_and_voter_backward(device, conf_reg, k, monkeypatch):
     from casapose_amd.train_engine import ParamStore, TrainPlan, crop_to_image_affine
 
-    b, h, w, k, kp = 2, 64, 64, 5, 9  # record length k + 27 = 32 floats (the voter wants a multiple of 4)
+    b, h, w, kp = 2, 64, 64, 9  # record length k + 27 = 32 floats, or the production record of 36 (k = 9: the specialised voter kernels)
     lab, out, offsets, A, gt = _kp_case(21, b, h, w, k)
     # reference
     ot = torch.tensor(out.astype(np.float64), requires_grad=True)
@@ -736,6 +754,13 @@ def test_keypoint_loss_and_voter_backward(device, conf_reg):
     assert rel(g[..., 32:32 + 2 * kp], gr[..., k:k + 2 * kp]) < 2e-3
     assert rel(g[..., 32 + 2 * kp:32 + 3 * kp], gr[..., k + 2 * kp:]) < 2e-3
     assert np.all(g[..., :32] == 0)
+    if k == 9:   # the production-record kernels (16-byte accesses, compile-time channel positions) against the generic ones: same arithmetic
+        monkeypatch.setenv("CP_LS_GENERIC", "1")
+        plan.dout.zero_()
+        plan.kp_loss_and_grad(torch.from_numpy(lab).to(device), torch.from_numpy(gt.astype(np.float32)).to(device), Ad, kp_w, max_pixel_error=12.5,
+                              min_num=50, confidence_regularization=conf_reg, vote_with_gt=True)
+        g2 = plan.dout.cpu().numpy()
+        assert rel(g, g2) < 1e-5
 
 
 @pytest.mark.parametrize("k,bpnp", [(5, False), (14, False), (5, True)])
