@@ -411,6 +411,49 @@ class ConvOp:
             g.head_cout = g.head_out_ld = 0
             g.head_label_out, g.head_label_classes = None, 0
 
+    # ---- 1x1 / stride-1 shortcuts as plain GEMMs on the bf16 matrix pipe -----------------------------------------------------------------
+    def setup_gemm(self):
+        """The stage shortcuts with stride 1 (resnet.py:214-220 at output stride 8: stage 1, 3 and 4) are GEMMs rows x cin x cout.  In the conv modes
+        `split` / `bf16` the forward and the data gradient run on the bf16-pipe GEMM of the Winograd path (csrc/wino_gemm_split.hip: exact
+        three-way splits, or hi + mid planes in the bf16 mode) and, where cin and cout are multiples of 128, the weight gradient on its
+        transposed partner (csrc/wino_wgrad_split.hip) -- instead of the fp32-MFMA implicit-GEMM kernel (84 TFLOP/s on the 256 -> 512 shortcut).
+        CASAPOSE_SC_GEMM=0 keeps the fp32 kernels."""
+        L = self.layer
+        self.gemm = None
+        planes = conv_split_planes()
+        if not planes or os.environ.get("CASAPOSE_SC_GEMM", "1") == "0":
+            return
+        rows = self.batch * self.out_h * self.out_w
+        cin = L.sources[0][0]
+        st_, off_, ld_ = self._out_ptr_ld
+        if (L.k != 1 or self.stride != 1 or self.pad != 0 or len(self.srcs) != 1 or L.sources[0][1] != cin or self.srcs[0][1] != cin or cin % 32
+                or L.cout % 32 or rows % 128 or self.residual is not None or self.row_scale is not None or self.tap_label is not None
+                or self.head_fast or ld_ != L.cout or L.layout != 0 or self.out is None
+                or (self.dy_ptr_ld is not None and (self.dy_ptr_ld[1] != 0 or self.dy_ptr_ld[2] != L.cout))):
+            return
+        lib = _lib.load()
+        dev = L.master.device
+        idx_t = (np.arange(cin, dtype=np.int32)[None, :] * L.cout + np.arange(L.cout, dtype=np.int32)[:, None]).reshape(-1)   # [co][ci] -> master [ci][co]
+        g = dict(rows=rows, cin=cin, planes=3 if planes == 3 else 2, idx_t=torch.from_numpy(idx_t).to(dev),
+                 Uf=torch.empty(L.cout * cin, dtype=torch.float32, device=dev),
+                 Us_f=torch.empty(lib.cp_wino_split_weights_bytes(1, L.cout, cin), dtype=torch.uint8, device=dev),
+                 Us_d=torch.empty(lib.cp_wino_split_weights_bytes(1, cin, L.cout), dtype=torch.uint8, device=dev) if L.dgrad[0] is not None else None,
+                 wgrad=bool(lib.cp_wino_wgrad_split_applicable(1, rows, L.cout, cin)) and os.environ.get("CASAPOSE_WINO_WGRAD", "split") != "f32")
+        if g["wgrad"]:
+            g["dU"] = torch.empty(L.cout * cin, dtype=torch.float32, device=dev)
+        self.gemm = g
+        L.refresh_hooks.append(self._refresh_gemm)
+
+    def _refresh_gemm(self, stream: int):
+        from .engine import split_wino_weights
+
+        lib = _lib.load()
+        L, g = self.layer, self.gemm
+        check(lib.cp_gather_f32(L.master.data_ptr(), g["idx_t"].data_ptr(), g["idx_t"].numel(), g["Uf"].data_ptr(), stream), "cp_gather_f32(%s)" % L.name)
+        split_wino_weights(g["Uf"], 1, L.cout, g["cin"], out=g["Us_f"], stream=stream)          # forward: U[co][ci] = W[ci][co]
+        if g["Us_d"] is not None:
+            split_wino_weights(L.master, 1, g["cin"], L.cout, out=g["Us_d"], stream=stream)     # data gradient: U[ci][co] = W[ci][co], the master itself
+
     # ---- Winograd F(4x4,3x3) for the deep layers (csrc/wino.hip): forward and data gradient ------------------------
     def setup_winograd(self):
         """Decide which of this op's convolutions (forward, per-source data gradient) take the Winograd path and return the
@@ -514,6 +557,11 @@ class ConvOp:
               "cp_wino_output_transform_stats_f32(%s)" % self.layer.name)
 
     def forward(self, stream: int):
+        if getattr(self, "gemm", None) is not None:
+            g, d = self.gemm, self.layer.desc
+            check(_lib.load().cp_wino_gemm_split_planes_f32(self.srcs[0][0].data.data_ptr(), g["Us_f"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["cin"],
+                                                            self.layer.cout, g["planes"], stream), "cp_wino_gemm_split_planes_f32(%s)" % self.layer.name)
+            return
         if getattr(self, "wino_fwd", None) is not None:
             d = self.layer.desc
             srcs, pre = [], {}
@@ -567,6 +615,15 @@ class ConvOp:
         def split_pipe(sp):
             return ("bf16", 6.0 if sp["np"] == 3 else 1.0)
 
+        if getattr(self, "gemm", None) is not None:
+            gm = self.gemm
+            mult = 6.0 if gm["planes"] == 3 else 3.0
+            out["bf16"] += mult * direct * (2.0 if gm["Us_d"] is not None else 1.0)    # forward + data gradient
+            if gm["wgrad"]:
+                out["bf16"] += (1.0 if conv_split_planes() == 1 else 6.0) * direct
+            else:
+                out["f32"] += direct
+            return out
         if getattr(self, "wino_fwd", None) is not None:
             w = self.wino_fwd
             g = 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
@@ -655,6 +712,14 @@ class ConvOp:
             check(lib.cp_head1x1_wgrad_f32(t.data.data_ptr(), ld, dy, dy_ld, px, L.cout, L.master_grad.data_ptr(), 1 if self.accumulate_master else 0, stream),
                   "cp_head1x1_wgrad_f32(%s)" % L.name)
             return
+        if getattr(self, "gemm", None) is not None and self.gemm["wgrad"]:
+            # dU[co][ci] = sum_rows dY[row][co] A[row][ci] on the bf16 pipe, then through the transpose map into the master gradient [ci][co]
+            g = self.gemm
+            check(lib.cp_wino_wgrad_split_f32(dy, self.srcs[0][0].data.data_ptr(), g["dU"].data_ptr(), 1, g["rows"], L.cout, g["cin"],
+                                              1 if conv_split_planes() == 1 else 3, stream), "cp_wino_wgrad_split_f32(%s)" % L.name)
+            check(lib.cp_scatter_f32(g["dU"].data_ptr(), g["idx_t"].data_ptr(), g["idx_t"].numel(), L.master_grad.data_ptr(), 1 if self.accumulate_master else 0,
+                                     stream), "cp_scatter_f32(%s)" % L.name)
+            return
         if getattr(self, "wino_fwd", None) is not None:
             # weight gradient through the Winograd planes: a quarter of the MFMA work of the direct kernel (V kept from the forward)
             w = self.wino_fwd
@@ -704,6 +769,14 @@ class ConvOp:
             if ent is None:
                 continue
             t, _ = self.srcs[s]
+            if getattr(self, "gemm", None) is not None and self.gemm["Us_d"] is not None and not t.has_grad:
+                # dA[row][ci] = sum_co dY[row][co] W[ci][co]; the GEMM writes (no accumulation): the plan runs this op's backward BEFORE the
+                # other consumers of its input (TrainPlan puts the shortcut after conv1 in the tape), which then accumulate into it
+                g = self.gemm
+                check(lib.cp_wino_gemm_split_planes_f32(dy, g["Us_d"].data_ptr(), t.grad.data_ptr(), g["rows"], g["rows"], L.cout, g["cin"], g["planes"], stream),
+                      "cp_wino_gemm_split_planes_f32(dgrad %s)" % L.name)
+                t.has_grad = True
+                continue
             if s in getattr(self, "wino_dgrad", {}):  # stride 1, so the data gradient lives on the forward's input grid
                 self._wino_run(self.wino_dgrad[s], [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream)
                 t.has_grad = True
@@ -969,12 +1042,16 @@ class TrainPlan:
                     if s > 0:
                         taps[tap_names[s - 1]] = a
                     sc = new(oh, ow, f, name=base + "sc")
-                    conv(layer(base + "sc.kernel", 0, 1, f, [(cin, cin)], [True]), [(a, cin)], sc, cur_h, cur_w, stride=stride)
+                    sc_layer = layer(base + "sc.kernel", 0, 1, f, [(cin, cin)], [True])
                     shortcut = sc
                 else:
                     shortcut = xr
                 t = new(oh, ow, f)
                 conv(layer(base + "conv1.kernel", 0, 3, f, [(cin, cin)], [True]), [(a, cin)], t, cur_h, cur_w, stride=stride, dilation=dl, pad=dl)
+                if u == 0:
+                    # the shortcut comes AFTER conv1 in the tape (both read `a`): the backward then runs its data gradient first, which lets the
+                    # GEMM route write `a.grad` plainly while conv1's data gradient, running after it, accumulates through its residual input
+                    conv(sc_layer, [(a, cin)], sc, cur_h, cur_w, stride=stride)
                 t2 = new(oh, ow, f)
                 bn(base + "bn2", t, t2, RELU)
                 xn = new(oh, ow, f, name=base + "out")
@@ -1116,6 +1193,9 @@ class TrainPlan:
         # weight gradients on a second stream (CASAPOSE_WGRAD_STREAM=1; see backward())
         self.wgrad_on_side_stream = os.environ.get("CASAPOSE_WGRAD_STREAM", "0") == "1"
         self._side = torch.cuda.Stream(device=dev) if self.wgrad_on_side_stream else None
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                op.setup_gemm()
         # Winograd for the deep 3x3 layers (forward and data gradient); shared scratch sized for the largest of them
         self.use_winograd = os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
         self.wino_V = self.wino_M = None

@@ -48,6 +48,8 @@ CONV_CASES = [
     ("3x3_stride2", 3, 2, 1, 1, [(64, 64)], 128, False, (12, 16)),
     ("1x1_stride2", 1, 2, 1, 0, [(64, 64)], 128, False, (12, 16)),
     ("1x1_head", 1, 1, 1, 0, [(32, 32)], 9, False, (10, 14)),
+    ("1x1_gemm_route", 1, 1, 1, 0, [(128, 128)], 256, False, (16, 16)),       # stage shortcut: bf16-pipe GEMMs for forward, data and weight gradient
+    ("1x1_gemm_route_small", 1, 1, 1, 0, [(64, 64)], 64, False, (16, 24)),     # ... whose weight gradient stays on the fp32 kernel (64 < 128)
     ("7x7_stride2_image", 7, 2, 1, 3, [(4, 3)], 64, False, (16, 24)),
     ("3x3_winograd_dil2", 3, 1, 2, 2, [(256, 256)], 256, False, (15, 20)),
     ("3x3_winograd_two_sources", 3, 1, 1, 1, [(256, 256), (128, 128)], 128, False, (12, 16)),
@@ -95,6 +97,9 @@ def test_conv_wgrad_dgrad(device, case):
     op = ConvOp(layer, [(t, t.c) for t in tts], (out.data, 0, ldo), b, h, w, stride=stride, dilation=dil, pad=pad, tap_label=lab_t, row_scale=pn_t,
                 out=out, dy_ptr_ld=(out.grad, 0, ldo))
     stream = torch.cuda.current_stream(device).cuda_stream
+    if "gemm_route" in name:  # what TrainPlan does for the 1x1 / stride-1 shortcuts
+        op.setup_gemm()
+        assert op.gemm is not None and op.gemm["wgrad"] == ("small" not in name)
     if "winograd" in name:  # what TrainPlan does for the deep layers: Winograd forward + data gradient
         nv, nm = op.setup_winograd()
         assert nv > 0 and op.wino_fwd is not None and (len(op.wino_dgrad) >= 1 or cout < 256)  # the data gradient's K is cout
