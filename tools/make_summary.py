@@ -75,9 +75,19 @@ copy(T + "train_trace/train_kernel_stats.csv", "%s_train_kernel_stats.csv" % tag
 copy(T + "train_times.txt", "%s_train_times.txt" % tag)
 copy(T + "bench_vote.json", "%s_bench_vote.json" % tag)
 copy(T + "vote_trace/vote_kernel_stats.csv", "%s_vote_kernel_stats.csv" % tag)
-for extra in sorted(os.listdir(os.path.join(G, tag))):   # GPU suite logs written next to the profile set (tools/profile_round.sh does not run them)
+# GPU suite logs written next to the profile set (tools/profile_round.sh <tag> suites): only those of the SAME tree -- gpurun merges files into
+# gpurun_out/ without deleting older ones, so logs of an earlier tree can still lie there (gputests_stamp.json says which tree they belong to)
+gst = os.path.join(G, tag, "gputests_stamp.json")
+same_tree = os.path.exists(gst) and json.load(open(gst)).get("src_sha256") == stamp["src_sha256"]
+for extra in sorted(os.listdir(os.path.join(G, tag))):
     if extra.startswith("gputests_") and extra.endswith(".log"):
-        copy(T + extra, "%s_%s" % (tag, extra))
+        if same_tree:
+            copy(T + extra, "%s_%s" % (tag, extra))
+        else:
+            stale = os.path.join(P, "%s_%s" % (tag, extra))
+            if os.path.exists(stale):
+                os.remove(stale)
+            print("skipped %s: written on another source tree" % extra)
 git_head = subprocess.run(["git", "-C", R, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "-C", R, "status", "--porcelain", "--", "casapose_amd", "include", "bench.py"], capture_output=True, text=True).stdout.strip())
 json.dump({"tag": tag, "stamp": stamp, "git_head_when_summarised": git_head, "tracked_sources_dirty": dirty,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ONE GPU-box call that produces every artefact of a round's profile set from the SAME tree, stamped (python3 bench.py --stamp):
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'   ->   gpurun_out/<tag>/...   ->   python tools/make_summary.py r03
+#   gpurun --timeout 3600 -- 'bash tools/profile_round.sh r03 [suites]'   ->   gpurun_out/<tag>/...   ->   python tools/make_summary.py r03
 # Pieces (each its own process; the --pmc passes use --kernel-trace only, as the pool requires):
 #   bench.json                 default `python3 bench.py` (headline + roofline + fp32-MFMA line + training leg + CPU baseline)
 #   bench_bs32.json            the same at bs 32 (the batch the north star quotes its MFMA target on), no CPU baseline / training leg
@@ -37,6 +37,14 @@ rocprofv3 --kernel-trace --stats -d $O/train_trace -o train --output-format csv 
 python3 $R/tools/train_times.py > $O/train_times.txt 2>&1
 python3 $R/bench.py --mode vote --steps 20 --warmup 5 > $O/bench_vote.json 2> $O/bench_vote.err
 rocprofv3 --kernel-trace --stats -d $O/vote_trace -o vote --output-format csv -- python3 $R/bench.py --mode vote --steps 10 --warmup 3 > $O/bench_vote_profiled.json 2> $O/rocprof_vote.err
+if [ "$2" = "suites" ]; then   # the -m gpu suite per conv mode, on the same box and tree (about 4 minutes each)
+  cd $R
+  python3 bench.py --stamp > $O/gputests_stamp.json
+  python3 -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gputests_default_split.log
+  CASAPOSE_INFER_CONV_MODE=f32 python3 -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gputests_infer_conv_mode_f32.log
+  CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32 python3 -m pytest tests/test_gpu_train.py tests/test_gpu_scripts.py tests/test_gpu_dp.py -q -m gpu 2>&1 | tail -4 > $O/gputests_train_conv_mode_f32.log
+  cd /tmp
+fi
 python3 $R/bench.py --stamp > $O/stamp_end.json
 # keep the merge small: only the stats / counter summaries travel back, not the raw traces
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
