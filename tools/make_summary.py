@@ -151,7 +151,10 @@ if alone:
     md.append("Separate runs: %s.\n" % "; ".join(alone))
 tl = b.get("training_leg")
 if tl and "value" in tl:
-    md.append("Training leg inside the default line (3 steps at bs 32, 448x448): %.1f images/s, %.1f ms/step.\n" % (tl["value"], tl["ms_per_step"]))
+    tb = b.get("training_leg_bf16_convs") or {}
+    md.append("Training leg inside the default line (3 steps at bs 32, 448x448): %.1f images/s, %.1f ms/step%s.\n"
+              % (tl["value"], tl["ms_per_step"], ("; the same leg with bf16 convolution operands (BASELINE configs[2] as named): %.1f images/s, %.1f ms/step"
+                                                  % (tb["value"], tb["ms_per_step"])) if "value" in tb else ""))
 c = b.get("cpu_baseline")
 if c:
     md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s (`%s`; host has %s threads, thread probe s/image: %s).\n"
