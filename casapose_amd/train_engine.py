@@ -473,7 +473,9 @@ class ConvOp:
         # (stage3_unit1_conv1) on the Winograd path as in the inference plan: no gain on the step (510 vs 519 images/s: its weight gradient
         # falls back to the fp32 grouped GEMM), and the F(4x4,3x3) rounding of one more layer in the forward moved the config-13 gradient
         # comparison from 6e-5 to 3e-3 (the proxy-voting loss divides by |v|^2: gradients are very sensitive to the forward's last bits).
-        split_gemm = False
+        # In the bf16 conv mode (3e-2 gates) the same layer does take the Winograd path: no bf16-pipe kernel covers a dilated 3x3 directly, so it
+        # would otherwise be the one deep layer left on the fp32 MFMA (forward 0.60 ms at 99 TFLOP/s).
+        split_gemm = conv_split_planes() == 1 and self.dil > 1
 
         if all(s[0] == s[1] for s in L.sources) and wino_eligible(3, 1, self.dil, self.pad, L.sources, L.cout, split_gemm=split_gemm):
             ktot = sum(s[0] for s in L.sources)
