@@ -143,8 +143,9 @@ def test_bench_default_line_carries_the_dp_training_leg(tmp_path):
     assert d["n_gpus"] == 2 and leg["n_gpus"] == 2 and leg["config"]["global_batch"] == 64 and leg["value"] > 0
     assert abs(leg["value"] - 64 / (leg["ms_per_step"] / 1e3)) < 0.02 * leg["value"]
     assert all(np.isfinite(v) for v in leg["losses"].values())
-    bleg = d["training_leg_bf16_convs"]   # BASELINE configs[2] as named: the same leg with bf16 convolution operands
-    assert "error" not in bleg and bleg["n_gpus"] == 2 and bleg["value"] > 0 and "bf16" in bleg["dtype"] and "bf16 operands" not in leg["dtype"]
+    if "CASAPOSE_CONV_MODE" not in os.environ:   # (a suite run that pins the conv mode has no second leg)
+        bleg = d["training_leg_bf16_convs"]   # BASELINE configs[2] as named: the same leg with bf16 convolution operands
+        assert "error" not in bleg and bleg["n_gpus"] == 2 and bleg["value"] > 0 and "bf16" in bleg["dtype"] and "bf16 operands" not in leg["dtype"]
     # watchdog (one rank is enough): 1 s is less than the training plan needs to build
     env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd[:2] + ["--gpus", "1"] + cmd[4:] + ["--train-leg-timeout", "1"], env=env1, capture_output=True, text=True, timeout=600)
