@@ -118,6 +118,8 @@ SYMBOLS = [
     ("cp_conv_split_weights_f32", _i, [_vp, _ll, _i, _vp, _vp]),
     ("cp_conv_pack_head_split_host", _i, [_vp, _i, _vp]),
     ("cp_conv2d_fwd_split", _i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp]),
+    ("cp_conv_bf16_deep_applicable", _i, [C.POINTER(ConvDesc)]),
+    ("cp_conv2d_fwd_bf16_deep", _i, [C.POINTER(ConvDesc), _vp, _vp]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),
     ("cp_maxpool3x3s2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     ("cp_upsample_bilinear_x2_f32", _i, [_vp, _i, _i, _i, _i, _vp, _vp]),
