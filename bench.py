@@ -27,7 +27,8 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)",
               103: "wino_gemm_split_kernel (bf16 pipe, exact three-way split of the Winograd planes' GEMM; FLOPs counted as executed bf16 FLOPs)",
               203: "conv_hsplit_kernel<3> (bf16 pipe, exact three-way split: six bf16 products per fp32 product; FLOPs counted as executed bf16 FLOPs)",
-              201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)"}
+              201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)",
+              301: "conv_bf16d_kernel (bf16 pipe, direct 3x3 of the deep layers, operands rounded to bf16)"}
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
@@ -145,7 +146,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
                    5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel",
-                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel"}
+                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel", 301: "conv_bf16d_kernel<"}
 
 
 def binary_stamp():
@@ -624,12 +625,15 @@ def main():
         direct_flops = 0.0
         for conv in plan.convs:
             pipe = getattr(conv, "split_mode", 0)   # 3 / 1: this layer runs on the bf16 matrix pipe, csrc/conv_hsplit.hip
+            deep = getattr(conv, "deep_bf16", False)   # bf16 conv mode: csrc/conv_bf16d.hip
+            if deep:
+                pipe = 1
             if hasattr(conv, "gemm_flops") and getattr(conv, "Us", None) is not None:
                 pipe = 3                                # Winograd GEMM on the bf16 pipe (exact three-way split, or hi + mid planes in the bf16 mode)
             gemm1x1 = getattr(conv, "_gemm", None)   # 1x1 / stride-1 layer on the bf16-pipe GEMM
             if gemm1x1 is not None:
                 pipe = 3
-            tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))
+            tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (301 if deep else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc)))
             d_ = conv.desc
             t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS if pipe else PEAK_F32_MFMA_TFLOPS})
             direct_flops += conv.flops

@@ -325,7 +325,7 @@ extern "C" int cp_conv_bf16_deep_applicable(const cp_conv_desc* d) {
     if (!d || d->struct_size != (uint32_t)sizeof(cp_conv_desc)) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != d->dilation || (d->dilation != 1 && d->dilation != 2 && d->dilation != 4)) return 0;
     if (d->cout % 128 != 0 || d->cout > 1024 || d->group_rows || d->head_out || d->tap_label || d->row_scale || d->epi_label) return 0;
-    if (!d->out_raw || d->out_raw_ld % 4 || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return 0;
+    if ((!d->out_raw && !d->out_act) || (d->out_raw && d->out_raw_ld % 4) || (d->out_act && d->out_act_ld % 4) || (d->residual && d->residual_ld % 4)) return 0;
     if ((((uintptr_t)d->out_raw) | ((uintptr_t)d->out_act) | ((uintptr_t)d->residual)) & 15) return 0;
     if (d->num_sources < 1 || d->num_sources > 2) return 0;
     for (int s = 0; s < d->num_sources; ++s) {
@@ -340,7 +340,7 @@ extern "C" int cp_conv2d_fwd_bf16_deep(const cp_conv_desc* d, const void* weight
     CP_REQUIRE_DESC(d, "cp_conv2d_fwd_bf16_deep");
     CP_REQUIRE(weights_bf16, "cp_conv2d_fwd_bf16_deep: null weights");
     CP_REQUIRE(cp_conv_bf16_deep_applicable(d), "cp_conv2d_fwd_bf16_deep: outside the kernel's range (3x3 / stride 1 / pad = dilation in {1, 2, 4}, cout a multiple of 128, direct "
-                                                "sources of 16-multiple channels, raw output (+ per-channel activated output), no labels)");
+                                                "sources of 16-multiple channels, raw and / or per-channel activated output, no labels)");
     DeepK k{};
     int nch = 0;
     for (int s = 0; s < d->num_sources; ++s) {
@@ -355,7 +355,7 @@ extern "C" int cp_conv2d_fwd_bf16_deep(const cp_conv_desc* d, const void* weight
     k.W = reinterpret_cast<const unsigned char*>(weights_bf16);
     k.w_bytes = (unsigned)((size_t)(d->cout / 64) * nch * 9 * 2 * 1024);
     k.B = d->batch; k.H = d->in_h; k.Wd = d->in_w; k.Cout = d->cout;
-    const int max_ld = std::max(d->out_raw_ld, d->out_act ? d->out_act_ld : 0);
+    const int max_ld = std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0);
     CP_REQUIRE((long long)d->batch * d->in_h * d->in_w * max_ld * 4 < (1LL << 32), "cp_conv2d_fwd_bf16_deep: output spans >= 4 GiB");
     k.residual = d->residual; k.res_ld = d->residual_ld;
     k.scale = d->scale; k.shift = d->shift; k.act = d->act;

@@ -144,6 +144,7 @@ class FusedConv:
         self.head_w: Optional[torch.Tensor] = None
         self.head_cout = 0
         self._gemm: Optional[dict] = None   # set by enable_gemm_split() for the CURRENT binding only
+        self.deep_bf16 = False              # bf16 conv mode: this binding runs on csrc/conv_bf16d.hip (set by ForwardPlan)
 
     def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
         """bf16 planes of the weights for cp_conv2d_fwd_split (made once per mode; refresh=True after the fp32 image changed)."""
@@ -185,6 +186,7 @@ class FusedConv:
         """srcs: list of dicts(data=tensor, ld=int, mode=int, sel=tensor|None, pre=(scale,shift)|None)."""
         d = self.desc
         self._gemm = None   # a GEMM route decided for an earlier shape must not survive a re-bind (rows would be stale: out-of-bounds launch)
+        self.deep_bf16 = False
         eh = (self.kh - 1) * dilation + 1
         ew = (self.kw - 1) * dilation + 1
         d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -263,6 +265,9 @@ class FusedConv:
             check(lib.cp_wino_gemm_split_planes_f32(d.src[0].data, g["Us"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["k"], self.cout, g["planes"], stream),
                   "cp_wino_gemm_split_planes_f32(%s)" % self.name)
             return
+        if self.deep_bf16:
+            check(lib.cp_conv2d_fwd_bf16_deep(C.byref(self.desc), self.split_weights(1, stream).data_ptr(), stream), "cp_conv2d_fwd_bf16_deep(%s)" % self.name)
+            return
         if self.split_mode:
             if not lib.cp_conv_split_applicable(C.byref(self.desc)):
                 raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
@@ -291,6 +296,7 @@ TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
 # default arithmetic of the inference plan's convolutions (CasaposeNet(conv_mode=None)): "split" = exact three-way bf16 splits on the bf16 matrix
 # pipe for every layer the split kernels cover (fp32-equivalent), "f32" = the fp32 MFMA everywhere, "bf16" = bf16 operands (3e-2 gates)
 DEFAULT_INFER_CONV_MODE = "split"
+BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 
@@ -473,6 +479,16 @@ class ForwardPlan:
         def conv(layer: FusedConv, **kw):
             wl = net.wino_by_name.get(layer.name) if net.use_winograd else None
             plain = all(s.get("mode", _lib.SRC_DIRECT) == _lib.SRC_DIRECT and not s.get("pre") for s in kw["srcs"])
+            # bf16 conv mode: the deep 3x3 layers (cout a multiple of 128, any of the dilations, no labels) on the direct bf16-operand kernel
+            # (csrc/conv_bf16d.hip) instead of the two-plane Winograd path: measured 1.15-1.6x per layer at bs 16 (CASAPOSE_BF16_DEEP=0: Winograd)
+            if (net.conv_planes == 1 and BF16_DEEP and layer.wp_split_f32 is not None and plain and layer.kh == 3 and layer.cout % 128 == 0
+                    and kw.get("tap_label") is None and kw.get("epi_label") is None and kw.get("head_out") is None and kw.get("stride", 1) == 1):
+                layer.bind(batch=B, **kw)
+                if lib.cp_conv_bf16_deep_applicable(C.byref(layer.desc)):
+                    layer.deep_bf16 = True
+                    self.convs.append(layer)
+                    self.steps.append(layer.run)
+                    return
             if (wl is not None and plain and kw.get("tap_label") is None and kw.get("head_out") is None and kw.get("stride", 1) == 1
                     and kw.get("out_raw_ld") is None and kw.get("out_act_ld") is None and all(s["ld"] == c[0] for s, c in zip(kw["srcs"], wl.sources))):
                 _, tp = WinoConv.tiles(B, kw["in_h"], kw["in_w"], kw.get("dilation", 1))

@@ -192,8 +192,8 @@ int cp_conv_pack_head_split_host(const float* w_host, int head_cout, float* dst_
 int cp_conv2d_fwd_split(const cp_conv_desc* desc, const void* weights_split, const void* head_weights_split, int planes, void* stream);
 /* Direct convolution with bf16 OPERANDS for the deep 3x3 layers (round 3; BASELINE.json configs[2] "bf16 convs"; csrc/conv_bf16d.hip): 3x3 / stride 1,
  * pad = dilation in {1, 2, 4}, one or two direct sources of 16-multiple channels, cout a multiple of 128 (<= 512), fp32 tensors in HBM, operands
- * rounded to bf16 (nearest even) while staged, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Epilogue: + residual, out_raw (required), and
- * optionally out_act = act(raw * scale[c] + shift[c]) with per-channel tables (no labels / tap masks / heads).  weights_bf16 = the ONE-plane
+ * rounded to bf16 (nearest even) while staged, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Epilogue: + residual, out_raw and / or
+ * out_act = act(raw * scale[c] + shift[c]) with per-channel tables (no labels / tap masks / heads).  weights_bf16 = the ONE-plane
  * fragment stream of cp_conv2d_fwd_split (cp_conv_pack_weights_split_host + cp_conv_split_weights_f32(planes = 1)).  NOT fp32-equivalent:
  * gates 3e-2 of the output range against the fp32 convolution, 2e-5 against the convolution of the bf16-rounded operands. */
 int cp_conv_bf16_deep_applicable(const cp_conv_desc* desc);

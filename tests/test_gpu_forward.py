@@ -443,7 +443,11 @@ def test_forward_in_every_conv_mode(device, mode, tol, fuse):
         return
     assert len(on_pipe) >= 10, on_pipe     # stage 1 (4 layers) and decoder blocks 3-5 / 8-10, with fused upsampling / heads or without
     assert all(getattr(c, "split_mode", 0) in (0, 3 if mode == "split" else 1) for c in convs)
-    assert len(wino_split) >= 9, wino_split   # the deep layers' Winograd GEMMs on the bf16 pipe too (3 planes / hi + mid)
+    deep = [c.name for c in convs if getattr(c, "deep_bf16", False)]
+    if mode == "bf16" and deep:   # the deep layers on the direct bf16-operand kernel (csrc/conv_bf16d.hip; CASAPOSE_BF16_DEEP=0: two-plane Winograd)
+        assert len(deep) >= 9 and not wino_split, (deep, wino_split)
+    else:
+        assert len(wino_split) >= 9, wino_split   # the deep layers' Winograd GEMMs on the bf16 pipe too (3 planes / hi + mid)
 
 
 def test_default_inference_mode_is_the_fp32_equivalent_split(device):

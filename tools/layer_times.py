@@ -35,7 +35,7 @@ for c in plan.convs:
     d = c.desc
     tot_ms += ms; tot_fl += c.flops
     wino = hasattr(c, "gemm_flops")
-    print("%-34s %5s %9d %4dx%-5d %8.3f %8.1f%s" % (c.name, "W" if wino else ("P%d" % c.split_mode if getattr(c, "split_mode", 0) else t), d.batch * d.out_h * d.out_w, d.cout, c.ktot, ms, c.flops / ms / 1e9,
+    print("%-34s %5s %9d %4dx%-5d %8.3f %8.1f%s" % (c.name, "W" if wino else ("D1" if getattr(c, "deep_bf16", False) else ("P%d" % c.split_mode if getattr(c, "split_mode", 0) else t)), d.batch * d.out_h * d.out_w, d.cout, c.ktot, ms, c.flops / ms / 1e9,
                                                   "   (Winograd: effective rate of the replaced 3x3 conv)" if wino else ""))
 print("convs: %.2f ms, %.1f GFLOP, %.1f TF/s" % (tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
