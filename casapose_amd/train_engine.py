@@ -238,7 +238,12 @@ class TrainConv:
         # bf16-pipe kernel (csrc/conv_hsplit.hip) for the shallow 3x3 layers: fp32 image of its fragment stream in the arena, bf16 planes beside it
         self.split = None
         planes = conv_split_planes()
+        deep_dgrad = False
         if layout == 0 and sum(s_[0] for s_ in sources) >= 256 and cout >= 128:
+            # bf16 conv mode: the DATA gradient of these layers runs on the direct bf16-operand kernel (csrc/conv_bf16d.hip; 1.2-1.6x the two-plane
+            # Winograd path at bs 32) -- the forward stays Winograd: its transformed input V is what the weight gradient multiplies, its output
+            # transform accumulates the batch statistics and its input transform applies the normalisation (CASAPOSE_BF16_DEEP=0: Winograd everywhere)
+            deep_dgrad = planes == 1 and k == 3 and os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"
             planes = 0   # the deep ordinary 3x3 layers run as Winograd (engine.wino_eligible); partial convolutions (layout 1) of that size do not
         if planes and k == 3 and cout <= 512 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4 and (
                 ns == 1 or (sources[1][0] == 4 and cout <= 32) or sources[1][0] % 16 == 0):
@@ -280,14 +285,16 @@ class TrainConv:
                 ent["idx_halo"] = torch.from_numpy(imap).to(dev)
                 ent["w_halo"] = store.pack_alloc(imap, off)
             ent["split"] = None
-            if planes and k == 3 and cr <= 512 and cr % 4 == 0:
+            ent["deep"] = deep_dgrad and cr % 128 == 0 and cr <= 512 and cpad % 16 == 0
+            if (planes or ent["deep"]) and k == 3 and cr <= 512 and cr % 4 == 0:
+                planes_d = planes or 1
                 nfl = lib.cp_conv_split_weight_floats(cr, 1, dch)
 
                 def pack_ds(src, dst, dch=dch, dre=dre, cr=cr):
                     check(lib.cp_conv_pack_weights_split_host(src.ctypes.data, 0, cr, 1, dch, dre, dst.ctypes.data), "pack dgrad split " + key)
 
                 imap = _index_map(pack_ds, np.ascontiguousarray(sub), nfl)
-                ent["split"] = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes,
+                ent["split"] = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes_d * 1024, dtype=torch.uint8, device=dev), np=planes_d,
                                     idx=torch.from_numpy(imap).to(dev))
             self.dgrad.append(ent)
             c0 += cr
@@ -651,7 +658,9 @@ class ConvOp:
         for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
             if ent is None:
                 continue
-            if s in getattr(self, "wino_dgrad", {}):
+            if ent.get("deep") and ent["split"] is not None:
+                out["bf16"] += 2.0 * float(self.batch * self.in_h * self.in_w) * L.k * L.k * ent["cin"] * cr
+            elif s in getattr(self, "wino_dgrad", {}):
                 w = self.wino_dgrad[s]
                 out[wino_pipe] += wino_mult * 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
             else:
@@ -779,6 +788,14 @@ class ConvOp:
                       "cp_wino_gemm_split_planes_f32(dgrad %s)" % L.name)
                 t.has_grad = True
                 continue
+            if ent.get("deep") and ent["split"] is not None:
+                g = ent["desc"]
+                g.src[0].data, g.src[0].ld = dy, dy_ld
+                g.residual = t.grad.data_ptr() if t.has_grad else None
+                if lib.cp_conv_bf16_deep_applicable(C.byref(g)):
+                    check(lib.cp_conv2d_fwd_bf16_deep(C.byref(g), ent["split"]["planes"].data_ptr(), stream), "dgrad bf16 deep(%s)" % L.name)
+                    t.has_grad = True
+                    continue
             if s in getattr(self, "wino_dgrad", {}):  # stride 1, so the data gradient lives on the forward's input grid
                 self._wino_run(self.wino_dgrad[s], [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream)
                 t.has_grad = True
