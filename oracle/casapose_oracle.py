@@ -550,6 +550,9 @@ def casapose_c_gcu5(p, img, seg_input=None, return_intermediates=False, variant=
 # --------------------------------------------------------------------------------------
 
 
+TF_PINV_RCOND = 10.0 * 2 * np.finfo(np.float64).eps   # tf.linalg.pinv(a, rcond=None) on a [2,2] fp64 matrix
+
+
 def softplus(x):
     return np.logaddexp(0.0, x)
 
@@ -637,7 +640,9 @@ def ls_voting(seg, direct, conf, num_points=9, filter_estimates=False, hot_overr
         for bi in range(b):
             for j in range(num_points):
                 mat = np.array([[s00[bi, j], s01[bi, j]], [s01[bi, j], s11[bi, j]]])
-                sol = np.linalg.pinv(mat).dot(np.array([t0[bi, j], t1[bi, j]]))
+                # tf.linalg.pinv's documented default cut-off, 10 * max(rows, cols) * eps of the dtype (fp64 here: voting_layers_2d.py:111-116),
+                # NOT NumPy's 1e-15: a direction field that is parallel to one part in 3e15 is rank 1 for TensorFlow
+                sol = np.linalg.pinv(mat, rcond=TF_PINV_RCOND).dot(np.array([t0[bi, j], t1[bi, j]]))
                 out[bi, o, j] = (sol * h).astype(np.float32)
     return out
 

@@ -380,7 +380,8 @@ def ls_voting(labels: torch.Tensor, dirs: torch.Tensor, conf: torch.Tensor, obje
         m = (labels == o + 1).to(dt)[..., None, None]
         A = (R * m[..., None]).sum(dim=(1, 2))                         # [b,kp,2,2]
         t = (q * m).sum(dim=(1, 2))                                    # [b,kp,2]
-        out.append((torch.linalg.pinv(A) @ t[..., None])[..., 0] * h)
+        # tf.linalg.pinv's default cut-off 10 * max(rows, cols) * eps (voting_layers_2d.py:116), not torch's 1e-15
+        out.append((torch.linalg.pinv(A, rtol=10.0 * 2 * torch.finfo(dt).eps) @ t[..., None])[..., 0] * h)
     return torch.stack(out, dim=1)
 
 

@@ -7,6 +7,7 @@ with Keras' group / dataset / attribute layout restated from keras/saving/hdf5_f
 `save_attributes_to_hdf5_group`; the variable ORDER inside the nested backbone stays an assumption, h5_weights.keras_backbone_layer_order.)
 
     /opt/conda/bin/python3.9 tests/golden/make_h5py_golden.py write  tests/golden/h5py_keras_layout.h5   # fixture: h5py writes, our reader parses
+    /opt/conda/bin/python3.9 tests/golden/make_h5py_golden.py write_many tests/golden/h5py_many_groups.h5    # 73 top-level + 64 nested groups: multi-node group B-trees
     /opt/conda/bin/python3.9 tests/golden/make_h5py_golden.py verify <file written by h5_weights.write_keras_h5> <seed | params.npz>   # h5py reads OUR writer
 
 `write` stores a reduced layer set (the full network is 59 MB): backbone layers nested under `model` (conv0, bn_data, bn0, one residual
@@ -82,6 +83,43 @@ def write(path, seed=20):
     print(json.dumps({"path": path, "seed": seed, "h5py": h5py.__version__, "hdf5": h5py.version.hdf5_version, "datasets": len(datasets)}))
 
 
+# ---- many groups: more children per group than one symbol-table node holds (libhdf5 splits a group's entries over several SNODs above 8)
+MANY_TOP, MANY_NESTED = 73, 64
+
+
+def many_group_items(seed=40):
+    """path -> array for a Keras-LAYOUT file of tiny datasets: 72 top-level layer groups (one dataset each, nested under the layer's own name
+    as Keras does: '<layer>/<layer>/kernel:0') plus one group `model` holding 64 nested layer groups of two datasets each."""
+    items = {}
+    for i in range(MANY_TOP - 1):
+        name = "layer_%03d" % i
+        items["%s/%s/kernel:0" % (name, name)] = tensor(seed, name, (1 + i % 3, 2))
+    for i in range(MANY_NESTED):
+        name = "stage_%03d_bn" % i
+        items["model/%s/gamma:0" % name] = tensor(seed, name + "g", (3,))
+        items["model/%s/beta:0" % name] = tensor(seed, name + "b", (3,))
+    return items
+
+
+def write_many(path, seed=40):
+    import h5py
+
+    items = many_group_items(seed)
+    layers = sorted({k.split("/")[0] for k in items})
+    with h5py.File(path, "w") as f:
+        f.attrs["layer_names"] = np.asarray([n.encode() for n in layers])
+        f.attrs["backend"] = "tensorflow"
+        f.attrs["keras_version"] = "2.9.0"
+        for layer in layers:
+            g = f.create_group(layer)
+            names = sorted(k[len(layer) + 1:] for k in items if k.split("/")[0] == layer)
+            g.attrs["weight_names"] = np.asarray([n.encode() for n in names])
+            for n in names:
+                val = items["%s/%s" % (layer, n)]
+                g.create_dataset(n, val.shape, dtype=val.dtype)[:] = val
+    print("wrote", path, os.path.getsize(path), "bytes,", len(layers), "top-level groups,", len(items), "datasets")
+
+
 def verify(path, seed):
     """h5py / libhdf5 reads a file written by OUR writer (h5_weights.write_keras_h5 on params(seed), or on the arrays of an .npz when `seed`
     is a path): every dataset bit-equal, the attributes as Keras' loader reads them (load_attributes_from_hdf5_group:
@@ -111,6 +149,8 @@ def verify(path, seed):
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "write":
         write(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+    elif len(sys.argv) >= 3 and sys.argv[1] == "write_many":
+        write_many(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "verify":
         verify(sys.argv[2], int(sys.argv[3]) if sys.argv[3].isdigit() else sys.argv[3])
     else:

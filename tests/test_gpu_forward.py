@@ -144,6 +144,24 @@ def test_ls_voting_matches_oracle(device):
     assert np.abs(got3 - ref3).max() < 0.05 and np.abs(ref3 - ref).max() > 1e-3
 
 
+def test_ls_voting_rank_cutoff_is_tensorflows(device):
+    """tf.linalg.pinv's default cut-off (10 * 2 * eps = 4.4e-15 of the largest singular value, voting_layers_2d.py:116) against NumPy's 1e-15:
+    a two-pixel object whose system is diag(2.6e-15, 1) * 20 must come out rank one (minimum-norm: y = 0); one decade up it is regular.
+    The construction and the analytic answers are test_oracle_kat.py::test_ls_voting_rank_cutoff_is_tensorflows_not_numpys."""
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+    from test_oracle_kat import _two_pixel_field
+
+    for conf_b, regular in ((-30.6, False), (-28.0, True)):
+        seg, direct, conf, (ya, xa), (yb, xb) = _two_pixel_field(conf_b)
+        rec = torch.from_numpy(np.concatenate([seg, direct, conf], -1)).to(device)
+        s, d, c = torch.split(rec, [2, 18, 9], dim=3)
+        got = CoordLSVotingWeighted(name="v", num_classes=2, num_points=9)([s, d, c]).cpu().numpy()[0, 0]
+        ref = O.ls_voting(seg, direct, conf)[0, 0]
+        assert np.abs(got - ref).max() < 1e-3, (conf_b, got, ref)
+        assert np.allclose(got[:, 1], xa + 0.5, atol=1e-3)
+        assert np.allclose(got[:, 0], yb + 0.5 if regular else 0.0, atol=1e-3)
+
+
 def test_ls_voting_sums_and_empty_objects(device):
     """fp64 accumulators against the oracle; objects with no pixels give zeros (pinv(0)=0)."""
     from casapose_amd import ops

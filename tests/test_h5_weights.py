@@ -174,3 +174,20 @@ def test_h5py_reads_files_written_by_our_writer(tmp_path):
     assert subprocess.run([CONDA_PY, os.path.join(GOLDEN, "make_h5py_golden.py"), "write", again], capture_output=True).returncode == 0
     a, b = H.read_h5(again), H.read_h5(os.path.join(GOLDEN, "h5py_keras_layout.h5"))
     assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_reader_parses_many_group_file_written_by_h5py():
+    """tests/golden/h5py_many_groups.h5 (make_h5py_golden.py write_many): 73 top-level layer groups and 64 nested groups under `model`, tiny
+    datasets.  libhdf5 keeps at most 8 entries per symbol-table node, so both the root group and `model` are B-trees over SEVERAL nodes --
+    the layout a full Keras weight file has (71 layers + 62 nested backbone layers) and the reduced fixture above never reaches."""
+    mk = _maker()
+    want = mk.many_group_items(40)
+    path = os.path.join(GOLDEN, "h5py_many_groups.h5")
+    got = {k.lstrip("/"): v for k, v in H.read_h5(path).items()}   # read_h5 keys are absolute paths
+    assert len(want) == 200 and set(got) == set(want)
+    assert all(got[k].dtype == np.float32 and got[k].shape == want[k].shape and np.array_equal(got[k], want[k]) for k in want)
+    attrs = H.read_attrs(path)
+    tops = sorted({k.split("/")[0] for k in want})
+    assert len(tops) == mk.MANY_TOP and attrs["/"]["layer_names"] == [t.encode() for t in tops]
+    assert len(attrs["/model"]["weight_names"]) == 2 * mk.MANY_NESTED
+    assert attrs["/layer_071"]["weight_names"] == [b"layer_071/kernel:0"]

@@ -212,6 +212,130 @@ def test_largest_component_filter():
     assert O.label_components_4(diag).max() == 2   # 4-connectivity: diagonal neighbours are separate
 
 
+# ------------------------------------------- independent pins (round 4): published algorithms available in this image ----------
+def _blobs(rng, h, w, n, rmax):
+    img = np.zeros((h, w), bool)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n):
+        cy, cx, ry, rx = rng.integers(0, h), rng.integers(0, w), rng.integers(1, rmax), rng.integers(1, rmax)
+        img |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+    return img
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_label_components_4_equals_scipy_ndimage_label(seed):
+    """tfa.image.connected_components (voting_layers_2d.py:51-56) documents 4-connectivity and ids in row-major order of each component's
+    first pixel; scipy.ndimage.label with its default cross-shaped structure is an independent implementation of exactly that, so the
+    id maps must be EQUAL, not merely equivalent up to renaming."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(seed)
+    img = _blobs(rng, 48, 64, 14, 9) if seed % 2 == 0 else rng.random((48, 64)) < (0.35 + 0.1 * seed)   # blobs / salt-and-pepper near the percolation point
+    lab, n = ndi.label(img)
+    mine = O.label_components_4(img)
+    assert mine.max() == n
+    assert np.array_equal(mine, lab)
+    firsts = [np.flatnonzero(mine.ravel() == i)[0] for i in range(1, n + 1)]
+    assert firsts == sorted(firsts)   # raster order of first pixels, the property the top_k tie rule below depends on
+
+
+def _filter_via_scipy(hot, min_size=50, rank=1):
+    """voting_layers_2d.py:58-76 restated on top of scipy's labelling instead of the oracle's: bincount with minlength, bins < 50 zeroed,
+    top_k (descending, ties to the lower index), component `rank` of that order kept."""
+    import scipy.ndimage as ndi
+
+    lab, _ = ndi.label(hot > 0)
+    counts = np.bincount(lab.ravel(), minlength=rank + 1)
+    counts = np.where(counts < min_size, 0, counts)
+    order = sorted(range(counts.size), key=lambda i: (-counts[i], i))
+    return ((lab == order[rank]) & (hot > 0)).astype(hot.dtype)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("rank", [1, 2])
+def test_largest_component_filter_equals_scipy_based_restatement(seed, rank):
+    pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(100 + seed)
+    if seed < 4:
+        hot = _blobs(rng, 40, 56, 3 + seed, 4 + seed).astype(np.float32)      # few blobs: sub-threshold (< 50 px) components and mixtures
+    elif seed < 6:
+        hot = np.zeros((40, 56), np.float32)                                   # exact size ties: two 8x8 squares, then two 5x5 (both < 50)
+        s = 8 if seed == 4 else 5
+        hot[2:2 + s, 30:30 + s] = 1
+        hot[20:20 + s, 4:4 + s] = 1
+    else:
+        hot = (rng.random((40, 56)) < 0.5).astype(np.float32)                 # many tiny components, possibly none >= 50
+    assert np.array_equal(O.largest_component_filter(hot, rank=rank), _filter_via_scipy(hot, rank=rank))
+
+
+def test_largest_component_background_smaller_than_object():
+    """The reference ASSUMES the background bin is the largest (voting_layers_2d.py:67); when an object covers more than half of the map the
+    object's component is rank 0 and the background id 0 is 'kept' -- multiplied by hot == 0 afterwards, i.e. nothing survives."""
+    hot = np.ones((20, 20), np.float32)
+    hot[0:5, 0:5] = 0
+    assert O.largest_component_filter(hot).sum() == 0
+    assert _filter_via_scipy(hot).sum() == 0
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_rodrigues_equals_scipy_rotation(seed):
+    """cv2.Rodrigues / geometry_utils.py:206-236 against scipy.spatial.transform.Rotation, both directions, including the
+    small-angle branch and angles next to pi."""
+    Rot = pytest.importorskip("scipy.spatial.transform").Rotation
+    from casapose_amd.pose_estimation import pnp
+
+    rng = np.random.default_rng(seed)
+    for scale in (1e-9, 1e-4, 0.3, 2.0, np.pi - 1e-3):
+        axis = rng.standard_normal(3)
+        rvec = axis / np.linalg.norm(axis) * scale
+        R = pnp.rodrigues(rvec)
+        assert np.allclose(R, Rot.from_rotvec(rvec).as_matrix(), atol=1e-12)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        back = pnp.rodrigues_inverse(R)
+        assert np.allclose(back, Rot.from_matrix(R).as_rotvec(), atol=1e-7 if scale > 3 else 1e-9)
+        assert np.allclose(back, rvec, atol=1e-7 if scale > 3 else 1e-9)
+    assert np.array_equal(pnp.rodrigues(np.zeros(3)), np.eye(3))
+
+
+def _two_pixel_field(conf_b):
+    """One object of two pixels: pixel A votes along y with weight softplus(20) ~ 20, pixel B along x with weight softplus(conf_b).
+    The accumulated 2x2 system is diag(w_B, w_A) exactly (R = w (I - n n^T), voting_layers_2d.py:92-94)."""
+    h, w, k = 8, 12, 2
+    seg = np.zeros((1, h, w, k), np.float32)
+    seg[..., 0] = 1.0
+    direct = np.zeros((1, h, w, 18), np.float32)
+    conf = np.zeros((1, h, w, 9), np.float32)
+    (ya, xa), (yb, xb) = (2, 3), (5, 9)
+    seg[0, ya, xa] = seg[0, yb, xb] = (0.0, 1.0)
+    direct[0, ya, xa, 0::2] = 1.0     # (dy, dx) = (1, 0): constrains x only
+    direct[0, yb, xb, 1::2] = 1.0     # (0, 1): constrains y only
+    conf[0, ya, xa], conf[0, yb, xb] = 20.0, conf_b
+    return seg, direct, conf, (ya, xa), (yb, xb)
+
+
+def test_ls_voting_rank_cutoff_is_tensorflows_not_numpys():
+    """tf.linalg.pinv(rcond=None) cuts singular values at 10 * max(rows, cols) * eps = 4.4e-15 of the largest (voting_layers_2d.py:116);
+    NumPy's default is 1e-15.  A system with sigma_min / sigma_max = 2.6e-15 lies between the two: TensorFlow solves it as RANK ONE
+    (minimum-norm solution: the unconstrained coordinate is 0), NumPy's default would invert it (the coordinate of pixel B)."""
+    seg, direct, conf, (ya, xa), (yb, xb) = _two_pixel_field(-30.6)
+    wa, wb = np.logaddexp(0, 20.0), np.exp(-30.6)
+    assert 1e-15 < wb / wa < O.TF_PINV_RCOND
+    kp = O.ls_voting(seg, direct, conf)[0, 0]
+    assert np.allclose(kp[:, 1], xa + 0.5, atol=1e-4)          # x from pixel A's line
+    assert np.array_equal(kp[:, 0], np.zeros(9, np.float32))  # y: cut off, NOT yb + 0.5
+    # one decade above the cut-off the same construction is a regular system and the second pixel decides y
+    seg, direct, conf, (ya, xa), (yb, xb) = _two_pixel_field(-28.0)
+    assert np.exp(-28.0) / wa > O.TF_PINV_RCOND
+    kp = O.ls_voting(seg, direct, conf)[0, 0]
+    assert np.allclose(kp[:, 1], xa + 0.5, atol=1e-4) and np.allclose(kp[:, 0], yb + 0.5, atol=1e-4)
+    # the training oracle's voter takes the same decision
+    import torch_train_ref as R
+
+    seg, direct, conf, (ya, xa), _ = _two_pixel_field(-30.6)
+    lab = torch.from_numpy(seg.argmax(-1))
+    kpt = R.ls_voting(lab, torch.from_numpy(direct.astype(np.float64)), torch.from_numpy(conf.astype(np.float64)), 1)[0, 0].numpy()
+    assert np.allclose(kpt[:, 1], xa + 0.5, atol=1e-4) and np.allclose(kpt[:, 0], 0.0, atol=1e-9)
+
+
 def test_full_forward_shapes_and_mask_conditioning():
     p = O.init_params(3, 27, seed=1, dtype=np.float64)
     img = np.random.default_rng(0).uniform(-1, 1, (1, 32, 48, 3))
