@@ -497,6 +497,9 @@ def launch_ranks(args):
     return max(abs(p.wait()) for p in procs)
 
 
+TRAIN_LEG_FAILED_EXIT = 3   # exit status when the training leg hung (watchdog) or failed with other ranks possibly waiting in a collective
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["infer", "train", "vote"], default="infer",
@@ -696,7 +699,7 @@ def main():
             "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2), "direct_equivalent_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 2),
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
-                            "(separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.sh), not measured by this run",
+                            "(separate rocprofv3 --pmc passes of this command, tools/profile_round.sh), not measured by this run",
             "dominant_family": {"kernel": TILE_NAMES.get(dom, "conv_f32_kernel"), "achieved": round(ach, 3), "frac": round(ach / d["peak"], 4), "peak": d["peak"],
                                 "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                                 "algorithmic_bytes_per_launch": round(d.get("bytes", 0.0) / d["launches"])},
@@ -763,7 +766,9 @@ def main():
                 result["training_leg_bf16_convs" if "training_leg" in result else "training_leg"] = err
                 result["binary"] = binary_stamp()
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            # a process that has touched the GPU and is stuck in a launch or a collective cannot be unwound: leave through _exit, and with a
+            # NON-ZERO code -- the line above carries the headline and the error annotation, the exit status says that the run did not finish
+            os._exit(TRAIN_LEG_FAILED_EXIT)
 
         dog = threading.Timer(args.train_leg_timeout, give_up)
         dog.daemon = True
@@ -793,7 +798,7 @@ def main():
                 if rank == 0:
                     result["binary"] = binary_stamp()
                     print(json.dumps(result), flush=True)
-                os._exit(0)
+                os._exit(TRAIN_LEG_FAILED_EXIT)
         dog.cancel()
     result["binary"] = binary_stamp()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -332,7 +332,10 @@ extern "C" int cp_conv_bf16_deep_applicable(const cp_conv_desc* d) {
         const cp_conv_source& in = d->src[s];
         if (in.pre_scale || in.pre_shift || in.mode != CP_SRC_DIRECT) return 0;
         if (in.channels % 16 != 0 || in.ld % 4 != 0 || (((uintptr_t)in.data) & 15)) return 0;
+        if ((long long)d->batch * d->in_h * d->in_w * in.ld * 4 >= (1LL << 31)) return 0;
     }
+    const int max_ld = std::max(std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0), d->residual ? d->residual_ld : 0);
+    if ((long long)d->batch * d->in_h * d->in_w * max_ld * 4 >= (1LL << 31)) return 0;   // 32-bit range-checked addressing with 0x80000000 as "absent"
     return 1;
 }
 
@@ -355,8 +358,9 @@ extern "C" int cp_conv2d_fwd_bf16_deep(const cp_conv_desc* d, const void* weight
     k.W = reinterpret_cast<const unsigned char*>(weights_bf16);
     k.w_bytes = (unsigned)((size_t)(d->cout / 64) * nch * 9 * 2 * 1024);
     k.B = d->batch; k.H = d->in_h; k.Wd = d->in_w; k.Cout = d->cout;
-    const int max_ld = std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0);
-    CP_REQUIRE((long long)d->batch * d->in_h * d->in_w * max_ld * 4 < (1LL << 32), "cp_conv2d_fwd_bf16_deep: output spans >= 4 GiB");
+    // absent lanes / absent tensors are addressed at byte offset 0x80000000 (OOB in the kernel): that is only out of range for tensors below 2 GiB
+    const int max_ld = std::max(std::max(d->out_raw ? d->out_raw_ld : 0, d->out_act ? d->out_act_ld : 0), d->residual ? d->residual_ld : 0);
+    CP_REQUIRE((long long)d->batch * d->in_h * d->in_w * max_ld * 4 < (1LL << 31), "cp_conv2d_fwd_bf16_deep: an output or the residual spans >= 2 GiB");
     k.residual = d->residual; k.res_ld = d->residual_ld;
     k.scale = d->scale; k.shift = d->shift; k.act = d->act;
     k.out_raw = d->out_raw; k.raw_ld = d->out_raw_ld; k.out_act = d->out_act; k.act_ld = d->out_act_ld;

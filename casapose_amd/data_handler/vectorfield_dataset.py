@@ -134,13 +134,14 @@ def _shared_random_seed() -> int:
     seed = int(np.random.SeedSequence().entropy % (1 << 31))
     try:
         import torch.distributed as dist
-
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            box = [seed]
-            dist.broadcast_object_list(box, src=0)
-            seed = int(box[0])
-    except Exception:  # no process group: a single process keeps its own draw
-        pass
+    except ImportError:  # no torch.distributed in this interpreter: a single process keeps its own draw
+        return seed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # a failing collective must NOT be swallowed: ranks that kept their own seeds would draw different epoch permutations and their
+        # shard slices would no longer partition the global batch (and the other ranks would hang in the broadcast)
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = int(box[0])
     return seed
 
 

@@ -237,7 +237,7 @@ class TrainConv:
             self.wp_halo = store.pack_alloc(imap, off)
         # bf16-pipe kernel (csrc/conv_hsplit.hip) for the shallow 3x3 layers: fp32 image of its fragment stream in the arena, bf16 planes beside it
         self.split = None
-        planes = conv_split_planes()
+        planes = self.mode_planes = conv_split_planes()   # read ONCE per layer: the backward and the accounting reuse it (bench.py changes the variable between plans)
         deep_dgrad = False
         if layout == 0 and sum(s_[0] for s_ in sources) >= 256 and cout >= 128:
             # bf16 conv mode: the DATA gradient of these layers runs on the direct bf16-operand kernel (csrc/conv_bf16d.hip; 1.2-1.6x the two-plane
@@ -427,7 +427,7 @@ class ConvOp:
         CASAPOSE_SC_GEMM=0 keeps the fp32 kernels."""
         L = self.layer
         self.gemm = None
-        planes = conv_split_planes()
+        planes = self.layer.mode_planes
         if not planes or os.environ.get("CASAPOSE_SC_GEMM", "1") == "0":
             return
         rows = self.batch * self.out_h * self.out_w
@@ -482,7 +482,7 @@ class ConvOp:
         # comparison from 6e-5 to 3e-3 (the proxy-voting loss divides by |v|^2: gradients are very sensitive to the forward's last bits).
         # In the bf16 conv mode (3e-2 gates) the same layer does take the Winograd path: no bf16-pipe kernel covers a dilated 3x3 directly, so it
         # would otherwise be the one deep layer left on the fp32 MFMA (forward 0.60 ms at 99 TFLOP/s).
-        split_gemm = conv_split_planes() == 1 and self.dil > 1
+        split_gemm = self.layer.mode_planes == 1 and self.dil > 1
 
         if all(s[0] == s[1] for s in L.sources) and wino_eligible(3, 1, self.dil, self.pad, L.sources, L.cout, split_gemm=split_gemm):
             ktot = sum(s[0] for s in L.sources)
@@ -557,7 +557,7 @@ class ConvOp:
         if w.get("Us") is not None:
             # CASAPOSE_CONV_MODE=bf16: hi + mid planes only (three products, not fp32-equivalent: that mode's gates are 3e-2); else the exact split
             check(lib.cp_wino_gemm_split_planes_f32(V.data_ptr(), w["Us"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"],
-                                                    2 if conv_split_planes() == 1 else 3, stream), "cp_wino_gemm_split_planes_f32(%s)" % self.layer.name)
+                                                    2 if self.layer.mode_planes == 1 else 3, stream), "cp_wino_gemm_split_planes_f32(%s)" % self.layer.name)
         else:
             check(lib.cp_wino_gemm_f32(V.data_ptr(), w["U"].data_ptr(), self._wM.data_ptr(), 36 * w["tp"], w["tp"], w["ktot"], w["cout"], stream),
                   "cp_wino_gemm_f32(%s)" % self.layer.name)
@@ -619,7 +619,7 @@ class ConvOp:
         m_out = float(self.batch * self.out_h * self.out_w)
         cin = sum(s[1] for s in L.sources)
         direct = 2.0 * m_out * L.k * L.k * cin * L.cout
-        wino_pipe, wino_mult = ("bf16", 3.0 if conv_split_planes() == 1 else 6.0) if TRAIN_WINO_GEMM_SPLIT else ("f32", 1.0)
+        wino_pipe, wino_mult = ("bf16", 3.0 if self.layer.mode_planes == 1 else 6.0) if TRAIN_WINO_GEMM_SPLIT else ("f32", 1.0)
 
         def split_pipe(sp):
             return ("bf16", 6.0 if sp["np"] == 3 else 1.0)
@@ -629,7 +629,7 @@ class ConvOp:
             mult = 6.0 if gm["planes"] == 3 else 3.0
             out["bf16"] += mult * direct * (2.0 if gm["Us_d"] is not None else 1.0)    # forward + data gradient
             if gm["wgrad"]:
-                out["bf16"] += (1.0 if conv_split_planes() == 1 else 6.0) * direct
+                out["bf16"] += (1.0 if self.layer.mode_planes == 1 else 6.0) * direct
             else:
                 out["f32"] += direct
             return out
@@ -638,7 +638,7 @@ class ConvOp:
             g = 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
             out[wino_pipe] += wino_mult * g      # forward GEMM
             if self.wino_wgrad_split():          # weight gradient: grouped GEMM over the 36 planes, exact splits on the bf16 pipe or fp32 MFMA
-                out["bf16"] += (1.0 if conv_split_planes() == 1 else 6.0) * g
+                out["bf16"] += (1.0 if self.layer.mode_planes == 1 else 6.0) * g
             else:
                 out["f32"] += g
         else:
@@ -686,7 +686,7 @@ class ConvOp:
     def wgrad_planes(self) -> int:
         """3 / 1 when this op's weight gradient runs on the bf16 matrix pipe (CASAPOSE_CONV_MODE split / bf16 and a descriptor that
         cp_conv2d_wgrad_split covers: 3x3 / stride 1 / pad 1, 32-multiple sources + optional image, cout % 32 == 0), else 0 = fp32 MFMA."""
-        planes = conv_split_planes()
+        planes = self.layer.mode_planes
         if not planes or getattr(self, "wino_fwd", None) is not None:
             return 0
         return planes if _lib.load().cp_conv_wgrad_split_applicable(C.byref(self.layer.desc)) else 0
@@ -727,7 +727,7 @@ class ConvOp:
             # dU[co][ci] = sum_rows dY[row][co] A[row][ci] on the bf16 pipe, then through the transpose map into the master gradient [ci][co]
             g = self.gemm
             check(lib.cp_wino_wgrad_split_f32(dy, self.srcs[0][0].data.data_ptr(), g["dU"].data_ptr(), 1, g["rows"], L.cout, g["cin"],
-                                              1 if conv_split_planes() == 1 else 3, stream), "cp_wino_wgrad_split_f32(%s)" % L.name)
+                                              1 if self.layer.mode_planes == 1 else 3, stream), "cp_wino_wgrad_split_f32(%s)" % L.name)
             check(lib.cp_scatter_f32(g["dU"].data_ptr(), g["idx_t"].data_ptr(), g["idx_t"].numel(), L.master_grad.data_ptr(), 1 if self.accumulate_master else 0,
                                      stream), "cp_scatter_f32(%s)" % L.name)
             return
@@ -741,7 +741,7 @@ class ConvOp:
             if self.wino_wgrad_split():   # the grouped GEMM dU[p] = dM[p]^T V[p] on the bf16 matrix pipe (exact splits; csrc/wino_wgrad_split.hip)
                 # exact splits (fp32-equivalent) by default; CASAPOSE_CONV_MODE=bf16 rounds the operands of this GEMM to bf16 like the other weight gradients
                 check(lib.cp_wino_wgrad_split_f32(wM.data_ptr(), w["V"].data_ptr(), w["dU"].data_ptr(), 36, w["tp"], cout, w["ktot"],
-                                                  1 if conv_split_planes() == 1 else 3, stream),
+                                                  1 if self.layer.mode_planes == 1 else 3, stream),
                       "cp_wino_wgrad_split_f32(%s)" % L.name)
             else:
                 check(lib.cp_conv2d_wgrad_f32(C.byref(w["wdesc"]), wM.data_ptr(), cout, w["dU"].data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(wino %s)" % L.name)

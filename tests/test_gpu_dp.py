@@ -149,7 +149,7 @@ def test_bench_default_line_carries_the_dp_training_leg(tmp_path):
     # watchdog (one rank is enough): 1 s is less than the training plan needs to build
     env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd[:2] + ["--gpus", "1"] + cmd[4:] + ["--train-leg-timeout", "1"], env=env1, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])   # bench.TRAIN_LEG_FAILED_EXIT: the line is printed, the status says the leg hung
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])

@@ -11,6 +11,8 @@
 #   layer_times*.txt           per-layer table, default and f32
 #   bench_train*.json, train_trace/, train_times.txt      the training step (default, CASAPOSE_CONV_MODE=f32 / bf16)
 #   bench_vote.json, vote_trace/                           the voting stage alone
+set -u
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=${1:-r03}
