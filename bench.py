@@ -697,6 +697,13 @@ def main():
             "per_pipe": pipes, "winograd_transform_ms_per_step": round(transform_ms, 3),
             "all_conv_ms_per_step": round(conv_ms, 3), "launches_per_step": len(plan.convs),
             "direct_equivalent_gflop_per_step": round(direct_flops / 1e9, 2), "direct_equivalent_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 2),
+            # the OTHER reading of the same measurement (round-3 verdict): `frac` above prices EXECUTED FLOPs (six bf16 products per fp32 product on the
+            # split layers, the Winograd GEMMs as run); `useful_*` prices the convolutions the network DEFINES (2*M*k*k*Cin*Cout each, 177 GFLOP per
+            # image) over the same convolution time, against the rate at which the bf16 pipe could deliver fp32-equivalent products at best
+            # (dense bf16 peak / 6 products)
+            "useful_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 2),
+            "useful_frac_of_fp32_equiv_peak": round(direct_flops / (conv_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
+            "fp32_equiv_peak": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
                             "(separate rocprofv3 --pmc passes of this command, tools/profile_round.sh), not measured by this run",
