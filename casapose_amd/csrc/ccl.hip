@@ -137,25 +137,55 @@ __global__ void ccl_flatten_count(const uint8_t* __restrict__ lab, int* __restri
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long n_iter = (total + stride - 1) / stride;
     const int lane = threadIdx.x & 63;
+    __shared__ int blk_root, blk_cnt;
     for (long long it = 0; it < n_iter; ++it) {
         const long long i = it * stride + blockIdx.x * (long long)blockDim.x + threadIdx.x;
         int r = -1;
+        bool is_root = false;
         if (i < total && lab[i]) {
             r = find_root(parent, (int)i);
             parent[i] = r;
-            if (r == (int)i) {   // a component root: rare (one per component), so a plain atomic slot claim
-                const long long n = i / hw;
-                roots[n * hw + atomicAdd(&nroots[n], 1)] = (int)i;
-            }
+            is_root = r == (int)i;
         }
+        // component roots claim slots of their image's list with ONE atomic per (wave, image): on a salt-and-pepper label map (an untrained
+        // network, bench.py's synthetic weights) every other pixel is a root and a per-root atomic on the image's counter serialised the pass
+        // (152 us against 34 us on blob-shaped masks).  The order of the list is free: ccl_select takes maxima over keys that carry the index.
+        unsigned long long rt = __ballot(is_root);
+        while (rt) {
+            const int leader = __builtin_ctzll(rt);
+            const long long n0 = __shfl(is_root ? i / hw : -1, leader);
+            const unsigned long long grp = __ballot(is_root && i / hw == n0);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&nroots[n0], (int)__popcll(grp));
+            base = __shfl(base, leader);
+            if (is_root && i / hw == n0) roots[n0 * hw + base + (int)__popcll(grp & ((1ull << lane) - 1ull))] = (int)i;
+            rt &= ~grp;
+        }
+        // a component that covers a large part of the image (one class winning everywhere: again the untrained network) would still receive one
+        // global atomic per wave on ONE address; the block therefore collects the pixels of ONE root per iteration -- the root of its first
+        // labelled pixel -- in LDS and sends them with a single atomic
+        if (threadIdx.x == 0) { blk_root = -1; blk_cnt = 0; }
+        __syncthreads();
+        if (r >= 0) atomicCAS(&blk_root, -1, r);
+        __syncthreads();
+        const int br = blk_root;
         unsigned long long todo = __ballot(r >= 0);
-        while (todo) {
+        for (int round = 0; todo; ++round) {
+            if (round == 4) {   // many distinct roots in this wave (noise): the addresses differ, plain atomics do not collide
+                if ((todo >> lane) & 1ull) atomicAdd(&count[r], 1);
+                break;
+            }
             const int leader = __builtin_ctzll(todo);
             const int r0 = __shfl(r, leader);
             const unsigned long long same = __ballot(r == r0);
-            if (lane == leader) atomicAdd(&count[r0], (int)__popcll(same));
+            if (lane == leader) {
+                if (r0 == br) atomicAdd(&blk_cnt, (int)__popcll(same));
+                else atomicAdd(&count[r0], (int)__popcll(same));
+            }
             todo &= ~same;
         }
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_cnt) atomicAdd(&count[br], blk_cnt);
     }
 }
 

@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr bool PARTIAL = (MODE & HS_PARTIAL) != 0;
     constexpr bool BILINEAR = (MODE & HS_BILINEAR) != 0;   // source 0 is read at half resolution through a x2 half-pixel bilinear filter
     constexpr bool SEL = (MODE & HS_SEL) != 0;             // source 0 is read at half resolution through the guided-upsampling selection map
-    constexpr int NV = BILINEAR ? 4 : 1;
+    constexpr int NV = 1;   // (round 3 fetched the four bilinear taps of source 0 from global memory: NV = 4; now a low-resolution tile is staged in LDS)
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NPROD = (NP == 3) ? 6 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
@@ -165,6 +166,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     unsigned short* labh = reinterpret_cast<unsigned short*>(smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B);   // [2 tile parities][HP]: label | 0xff00 outside the image
     unsigned char* wst = smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B + 4 * HP;                                // [2 stages][GROUP_B] weight groups
     unsigned char* hwl = wst + 2 * GROUP_B;                                                                   // [2 steps][NP][1 KB] fused-head weights
+    // BILINEAR: source 0 is stored at half resolution; the (TH/2 + 2) x (32/2 + 2) source pixels a tile's halo interpolates from are staged
+    // as fp32 ([2 stages][LOW_P pixels][16 channels]) and the four taps of every halo pixel come from there -- a slice costs 432 16-byte
+    // global loads per block instead of 5440 (round 3: four taps per halo pixel from L2, which is what made the fused form slower than
+    // a materialised upsampled tensor on the 32-channel layers)
+    constexpr int LOW_R = HR / 2 + 1, LOW_C = COLS / 2 + 1, LOW_P = LOW_R * LOW_C;   // 6 x 18 = 108 source pixels
+    constexpr int LOW_B = LOW_P * 64;
+    unsigned char* lowb = hwl + 2 * NP * 1024;   // [2 stages][LOW_P][64 B]
     const bool head = (TN == 1) && p.head_out != nullptr;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,7 +231,6 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         float4 lv[NIT][NV];
         float4 liv[NIMG];
         int selb[NIT];       // SEL: the selection byte of this element's pixel (constant over the slices of a tile)
-        int lpar[NIT];       // BILINEAR: parity bits (y & 1) << 1 | (x & 1) << 2 of the element's pixel in the tile being fetched
         const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
                                                                               SEL ? p.lab_bytes : 0u, 0x00020000);
         auto issue_sel = [&](const TilePos& tp) {
@@ -247,18 +254,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
                 const unsigned pixel = (unsigned)((n * p.H + y) * p.Wd + x);
                 eo1[it] = inb ? (pixel * (unsigned)p.s[1].ld + (unsigned)q4) * 4u : OOB;
-                if constexpr (BILINEAR) {   // half-pixel centres: output row y reads source rows (y-1)/2 and (y+1)/2 (clamped), weights 0.75 / 0.25
-                    lpar[it] = ((y & 1) << 1) | ((x & 1) << 2);
-                    const int Hs = p.s[0].Hs, Ws = p.s[0].Ws, sld = p.s[0].ld;
-                    int ys = (y >> 1) - ((y & 1) ? 0 : 1), xs = (x >> 1) - ((x & 1) ? 0 : 1);
-                    const int y1 = min(ys + 1, Hs - 1), x1 = min(xs + 1, Ws - 1);
-                    ys = max(ys, 0);
-                    xs = max(xs, 0);
-                    const int nb = n * Hs * Ws;
-                    eo0[it][0] = inb ? (unsigned)(((nb + ys * Ws + xs) * sld + q4) * 4) : OOB;
-                    eo0[it][1] = inb ? (unsigned)(((nb + ys * Ws + x1) * sld + q4) * 4) : OOB;
-                    eo0[it][2] = inb ? (unsigned)(((nb + y1 * Ws + xs) * sld + q4) * 4) : OOB;
-                    eo0[it][3] = inb ? (unsigned)(((nb + y1 * Ws + x1) * sld + q4) * 4) : OOB;
+                if constexpr (BILINEAR) {
+                    eo0[it][0] = OOB;   // source 0 goes through the low-resolution LDS tile (bilinear loader below)
                 } else if constexpr (SEL) {
                     const int sl = selb[it];
                     eo0[it][0] = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * p.s[0].ld + q4) * 4) : OOB;
@@ -267,12 +264,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
             }
         };
-        bool slice_src0 = true;   // BILINEAR: the slice in flight belongs to source 0 (needs the interpolation)
         auto issue_slice = [&](const TilePos& tp, int c) {
             (void)tp;
             const int si = c >= p.nch0 ? 1 : 0;
             const int cs = (c - (si ? p.nch0 : 0)) * 64;   // uniform byte offset of the slice's first channel
-            slice_src0 = si == 0;
 #ifdef HS_NOLOAD
             if (p.B > 0) return;   // timing experiment
 #endif
@@ -295,17 +290,6 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             for (int it = 0; it < NIT; ++it) {
                 if (e_hy[it] >= 0x4000) continue;
                 float4 val = lv[it][0];
-                if constexpr (BILINEAR) {
-                    if (slice_src0) {
-                        const float fy = (lpar[it] & 2) ? 0.25f : 0.75f, fx = (lpar[it] & 4) ? 0.25f : 0.75f;
-                        const float gy = 1.f - fy, gx = 1.f - fx;
-                        const float4 v01 = lv[it][1], v10 = lv[it][2], v11 = lv[it][3];
-                        val.x = (val.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
-                        val.y = (val.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
-                        val.z = (val.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
-                        val.w = (val.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
-                    }
-                }
                 if constexpr (NP == 3) {
                     uint2 a, b, c;
                     split4(val, a, b, c);
@@ -414,6 +398,165 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 2u * NP * 1024u, 0x00020000);
             for (unsigned o = (unsigned)tid * 16u; o < 2u * NP * 1024u; o += 256u * 16u)
                 *reinterpret_cast<u32x4*>(hwl + o) = __builtin_amdgcn_raw_buffer_load_b128(rsh, (int)o, 0, 0);
+        }
+        if constexpr (BILINEAR) {
+            // ---------------------------------------------- loaders, source 0 at half resolution -----------------------------------------
+            // Slice s (global index) is multiplied in phase s.  Its halo stage is written in phase s - 1: a DIRECT slice (source 1) from the
+            // registers its loads were issued into in phase s - 2 (as in the generic loader); a BILINEAR slice by interpolation from the
+            // low-resolution stage s & 1, which was stored in phase s - 2 from loads issued in phase s - 3.  Three cursors walk the block's
+            // slice list one, two and three slices ahead of the consumers.
+            constexpr int NLO = (LOW_P * 4 + 255) / 256;
+            struct Cur { TilePos t; int c, k, s; };   // tile, slice within the tile, tile index of this block, global slice index
+            auto step = [&](Cur& u) {
+                ++u.s;
+                if (++u.c == nslices) { u.c = 0; ++u.k; next_tile(u.t); }
+            };
+            bool l_ok[NLO];
+            int l_r[NLO], l_c[NLO];
+            unsigned l_lds[NLO];
+#pragma unroll
+            for (int it = 0; it < NLO; ++it) {
+                const int idx = it * 256 + tid, pix = idx >> 2;
+                l_ok[it] = pix < LOW_P;
+                l_r[it] = pix / LOW_C;
+                l_c[it] = pix % LOW_C;
+                l_lds[it] = (unsigned)(pix * 64 + (idx & 3) * 16);
+            }
+            unsigned h_low[NIT];   // LDS offset of tap (0, 0) of this thread's halo elements inside a low-resolution stage
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) h_low[it] = (unsigned)(((e_hy[it] >> 1) * LOW_C + (e_hx[it] >> 1)) * 64 + (tid & 3) * 16);
+            float4 llow[NLO];
+            unsigned elo[NLO];
+            int elo_k = -1, eo1_k = -1;
+            auto issue_low = [&](const Cur& u) {
+                if (u.k != elo_k) {   // first low-resolution slice of a tile: the tile's source offsets (edge-clamped, as the reference's resize)
+                    elo_k = u.k;
+                    const int n = u.t.n % p.B, ys0 = u.t.ty * (TH / 2) - 1, xs0 = u.t.tx * 16 - 1;
+                    const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
+#pragma unroll
+                    for (int it = 0; it < NLO; ++it) {
+                        const int ys = min(max(ys0 + l_r[it], 0), Hs - 1), xs = min(max(xs0 + l_c[it], 0), Ws - 1);
+                        elo[it] = l_ok[it] ? (unsigned)((((n * Hs + ys) * Ws + xs) * p.s[0].ld + q4) * 4) : OOB;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NLO; ++it) llow[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)elo[it], u.c * 64, 0));
+            };
+            auto store_low = [&](int stage) {
+#pragma unroll
+                for (int it = 0; it < NLO; ++it)
+                    if (l_ok[it]) *reinterpret_cast<float4*>(lowb + stage * LOW_B + l_lds[it]) = llow[it];
+            };
+            auto interp = [&](const Cur& u) {   // low-resolution stage u.s & 1 -> halo stage u.s & 1
+                const unsigned char* lo = lowb + (u.s & 1) * LOW_B;
+                unsigned char* h = halo + (u.s & 1) * (NP * PLANE_B);
+                const int y0 = u.t.ty * TH - 1, x0 = u.t.tx * 32 - 1;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (e_hy[it] >= 0x4000) continue;
+                    const int y = y0 + e_hy[it], x = x0 + e_hx[it];
+                    const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+                    // half-pixel centres: halo row hy (image row y0 + hy, y0 odd) blends source rows hy / 2 and hy / 2 + 1 of the stage with
+                    // weights 0.75 / 0.25 (hy even) or 0.25 / 0.75 (hy odd); the expression is the one of round 3's global-tap version
+                    const float fy = (e_hy[it] & 1) ? 0.75f : 0.25f, fx = (e_hx[it] & 1) ? 0.75f : 0.25f;
+                    const float gy = 1.f - fy, gx = 1.f - fx;
+                    const float4 v00 = *reinterpret_cast<const float4*>(lo + h_low[it]), v01 = *reinterpret_cast<const float4*>(lo + h_low[it] + 64);
+                    const float4 v10 = *reinterpret_cast<const float4*>(lo + h_low[it] + LOW_C * 64), v11 = *reinterpret_cast<const float4*>(lo + h_low[it] + LOW_C * 64 + 64);
+                    float4 val;
+                    val.x = (v00.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
+                    val.y = (v00.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
+                    val.z = (v00.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
+                    val.w = (v00.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
+                    if (!inb) val = make_float4(0.f, 0.f, 0.f, 0.f);   // the convolution's zero padding is applied to the UPSAMPLED map
+                    if constexpr (NP == 3) {
+                        uint2 a, b, c;
+                        split4(val, a, b, c);
+                        *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
+                        *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
+                        *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
+                    } else {
+                        *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(val);
+                    }
+                }
+            };
+            auto issue_direct = [&](const Cur& u) {
+                if (u.k != eo1_k) {
+                    eo1_k = u.k;
+                    tile_offsets(u.t);
+                }
+                issue_slice(u.t, u.c);
+            };
+            // B-step of a slice (two phases before it is multiplied): low-resolution registers -> LDS, or the direct slice's loads; the tile's
+            // image / label halo rides with its first slice
+            auto step_b = [&](const Cur& u) {
+                if (u.s >= total_slices) return;
+                if (u.c == 0) {
+                    if (has_img) issue_img(u.t);
+                    if (has_lab_l) issue_lab(u.t);
+                }
+                if (u.c < p.nch0) store_low(u.s & 1);
+                else issue_direct(u);
+            };
+            // A-step (one phase before): the halo stage
+            auto step_a = [&](const Cur& u) {
+                if (u.s >= total_slices) return;
+                if (u.c < p.nch0) interp(u);
+                else store_slice(u.s & 1);
+                if (u.c == 0) {
+                    if (has_img) store_img(u.k & 1);
+                    if (has_lab_l) store_lab(u.k & 1);
+                }
+            };
+            auto step_c = [&](const Cur& u) {
+                if (u.s < total_slices && u.c < p.nch0) issue_low(u);
+            };
+            Cur ca{first, 0, 0, 0};
+            issue_low(ca);          // slice 0 is always a source-0 slice
+            if (has_img) issue_img(ca.t);
+            if (has_lab_l) issue_lab(ca.t);
+            store_low(0);
+            Cur cb = ca;
+            step(cb);               // slice 1
+            step_c(cb);
+            issue_w(0);
+            CP_BARRIER();           // (the consumers run the same extra barrier) low-resolution stage 0 is complete
+            step_a(ca);             // interpolate slice 0, store tile 0's image / label halo
+            store_w(0);
+            if (cb.s < total_slices) {   // slice 1: its B-step without the extras of slice 0's tile being issued twice
+                if (cb.c == 0) {
+                    if (has_img) issue_img(cb.t);
+                    if (has_lab_l) issue_lab(cb.t);
+                }
+                if (cb.c < p.nch0) store_low(1);
+                else issue_direct(cb);
+            }
+            Cur cc = cb;
+            step(cc);               // slice 2
+            step_c(cc);
+            if (total_groups > 1) issue_w(1);
+            CP_BARRIER();
+            // from here: ca = slice gs + 1, cb = gs + 2, cc = gs + 3 at the first group of slice gs
+            ca = cb;
+            cb = cc;
+            step(cc);
+            int lg = 0;
+            for (int gg = 0; gg < total_groups; ++gg) {
+                if (gg + 1 < total_groups) {
+                    store_w((gg + 1) & 1);
+                    if (gg + 2 < total_groups) issue_w(gg + 2);
+                }
+                if (lg < nslices * GPS && lg % GPS == 0) {   // first group of a slice
+                    step_a(ca);
+                    step_b(cb);
+                    step_c(cc);
+                    step(ca);
+                    step(cb);
+                    step(cc);
+                }
+                if (++lg == ngroups_tile) lg = 0;
+                CP_BARRIER();
+            }
+            return;
         }
         issue_tile_extras();
         issue_slice(ftile, 0);
@@ -632,6 +775,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 
     // ------------------------------------------------------------------ pipeline ---------------------------------------------------------
     TilePos ctile = first;
+    if constexpr (BILINEAR) CP_BARRIER();   // the loaders' hand-over of the first low-resolution stage (their interpolation reads other threads' stores)
     CP_BARRIER();   // slice 0, the first weight group (and the first tile's image / label halo) are in LDS
     int gs = 0, gg = 0;   // global slice / group counters
     for (int k = 0; k < my_tiles; ++k) {
@@ -756,8 +900,9 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_per_pass = k.B * k.tiles_y * k.tiles_x;
     k.ntiles = k.passes * k.tiles_per_pass;
     // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
-    const size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : TN == 2 ? 3 : 1) * TN * NP * 1024 +
-                       (size_t)2 * NP * 1024;   // + the fused head's weights
+    size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : TN == 2 ? 3 : 1) * TN * NP * 1024 +
+                 (size_t)2 * NP * 1024;   // + the fused head's weights
+    if (MODE & HS_BILINEAR) lds += (size_t)2 * ((HR / 2 + 1) * (COLS / 2 + 1)) * 64;   // + two low-resolution stages of source 0
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -299,6 +299,7 @@ DEFAULT_INFER_CONV_MODE = "split"
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
+MATERIALISE_BILINEAR = os.environ.get("CASAPOSE_MATERIALISE_BILINEAR", "0") == "1"
 
 
 def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
@@ -586,10 +587,11 @@ class ForwardPlan:
                 src0 = prev
                 mode = _lib.SRC_DIRECT
                 if up:
-                    # on the bf16 pipe the 32-output-channel layers (blocks 4, 5) are too short on MFMA work per loaded element to hide a
-                    # four-tap interpolation in the loader waves (measured: 0.77 / 1.29 ms fused against 0.46 / 0.63 ms direct), so the x2
-                    # bilinear tensor is materialised for them (one streaming pass, 0.12 / 0.25 ms)
-                    if fuse_upsample and not (net.conv_planes and dims[i] <= 32):
+                    # round 3 materialised the x2 bilinear tensor for the 32-output-channel layers (blocks 4, 5) on the bf16 pipe: four taps per
+                    # halo pixel from global memory did not fit their loaders (0.77 / 1.29 ms fused against 0.46 / 0.63 ms direct).  The loaders
+                    # now stage the half-resolution tile in LDS and interpolate from there (csrc/conv_hsplit.hip), so the fused form is the
+                    # default everywhere; CASAPOSE_MATERIALISE_BILINEAR=1 restores the separate streaming pass (A/B measurements)
+                    if fuse_upsample and not (net.conv_planes and dims[i] <= 32 and MATERIALISE_BILINEAR):
                         mode = _lib.SRC_BILINEAR_X2
                     else:
                         big = new(B, hs[l], ws[l], prev_c)

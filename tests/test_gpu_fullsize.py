@@ -139,18 +139,8 @@ def test_full_size_ransac_voting_recovers_exact_keypoints(device):
     assert np.abs(got[..., ::-1] - kpts).max() < 5e-2  # the RANSAC voter returns (x, y)
 
 
-@pytest.mark.parametrize("mode,tol", [("split", 0.02), ("bf16", 0.02)])
-def test_full_size_training_gradient_is_the_directional_derivative(device, monkeypatch, mode, tol):
-    """BASELINE.json configs[2] size (bs = 32, 448x448, K = 9): the analytic gradient of the whole step (forward with batch statistics,
-    CE + vertex + proxy losses, backward through 28 convolutions incl. the Winograd layers) must predict the change of the loss along
-    its own direction: (L(theta + e d) - L(theta - e d)) / 2e = g . d, with d = g / |g|.  In the training plan's default mode (exact
-    bf16 splits, fp32-equivalent) and in CASAPOSE_CONV_MODE=bf16 -- configs[2]'s "bf16 convs" -- where the loss itself is the bf16-rounded
-    network's (measured ratios 0.9998 and 1.0006)."""
-    from casapose_amd.train_engine import ParamStore, TrainPlan
-
-    monkeypatch.setenv("CASAPOSE_CONV_MODE", mode)
-
-    b, h, w = 32, 448, 448
+def _config2_batch(device, b, h, w):
+    """parameters + one synthetic batch at BASELINE.json configs[2]'s shape: ellipse objects on a 3x3 grid, keypoints inside them"""
     rng = np.random.default_rng(21)
     params = O.init_params(K, V, seed=5, dtype=np.float32)
     lab = np.zeros((b, h, w), np.uint8)
@@ -165,7 +155,21 @@ def test_full_size_training_gradient_is_the_directional_derivative(device, monke
             kpts[n, o, :, 0] = cy + rng.uniform(-ry, ry, 9)
             kpts[n, o, :, 1] = cx + rng.uniform(-rx, rx, 9)
     img = torch.from_numpy(rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)).to(device)
-    labd, kpd = torch.from_numpy(lab).to(device), torch.from_numpy(kpts).to(device)
+    return params, img, torch.from_numpy(lab).to(device), torch.from_numpy(kpts).to(device)
+
+
+@pytest.mark.parametrize("mode,tol", [("split", 0.02), ("bf16", 0.02)])
+def test_full_size_training_gradient_is_the_directional_derivative(device, monkeypatch, mode, tol):
+    """BASELINE.json configs[2] size (bs = 32, 448x448, K = 9): the analytic gradient of the whole step (forward with batch statistics,
+    CE + vertex + proxy losses, backward through 28 convolutions incl. the Winograd layers) must predict the change of the loss along
+    its own direction: (L(theta + e d) - L(theta - e d)) / 2e = g . d, with d = g / |g|.  In the training plan's default mode (exact
+    bf16 splits, fp32-equivalent) and in CASAPOSE_CONV_MODE=bf16 -- configs[2]'s "bf16 convs" -- where the loss itself is the bf16-rounded
+    network's (measured ratios 0.9998 and 1.0006)."""
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    monkeypatch.setenv("CASAPOSE_CONV_MODE", mode)
+    b, h, w = 32, 448, 448
+    params, img, labd, kpd = _config2_batch(device, b, h, w)
     store = ParamStore(params, device)
     plan = TrainPlan(store, K, V, b, h, w)
     plan.update_moving = False
@@ -194,3 +198,78 @@ def test_full_size_training_gradient_is_the_directional_derivative(device, monke
     fd = (lp - lm) / (2 * eps)
     print("%s mode: directional derivative %.6g vs |g| %.6g (ratio %.4f), loss %.6g" % (mode, fd, gn, fd / gn, l0))
     assert abs(fd - gn) < tol * gn, "directional derivative %.6g vs |g| %.6g (loss %.6g)" % (fd, gn, l0)
+
+
+# bounds of the bf16 conv mode's GRADIENT at the configs[2] shape against the fp32-equivalent mode on the same parameters and batch (round-3
+# verdict: the 799 images/s leg "rides on an ungated gradient").  Measured values are printed by the test; DESIGN.md section 2 quotes them.
+# Measured on MI355X (round 4): cosine 0.99643, relative L2 0.0845; per variable median 0.161, 90 % 0.302, worst 0.374 (stage2_unit1_bn1.beta: the
+# small per-channel reductions are the cancellation-prone ones); directional ratio 1.0000.
+BF16_GRAD_COSINE_MIN = 0.99          # whole flat gradient
+BF16_GRAD_REL_L2_MAX = 0.12          # whole flat gradient
+BF16_GRAD_VAR_MEDIAN_MAX = 0.22      # per-variable relative L2: median over the 90 variables
+BF16_GRAD_VAR_WORST_MAX = 0.50       # ... and the worst variable
+BF16_GRAD_DIRECTION_RATIO = (0.98, 1.02)   # fp32-equivalent loss along the bf16 gradient's direction / (g_split . d)
+
+
+def test_full_size_bf16_gradient_against_the_fp32_equivalent_mode(device, monkeypatch):
+    """BASELINE.json configs[2] AS NAMED ("bs=32 bf16 convs", 448x448, K = 9): the gradient the bf16 conv mode hands to Adam, compared with the
+    fp32-equivalent mode's on the same parameters and batch -- flat cosine and relative L2, per-variable relative L2 (median and worst of the
+    90 variables), and the cross directional derivative: moving along the BF16 gradient's direction d must change the FP32-EQUIVALENT loss
+    by g_split . d (finite differences of the exact-split forward), i.e. the bf16 gradient is a descent direction of the loss the other mode
+    optimises, with the predicted slope."""
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    b, h, w = 32, 448, 448
+    params, img, labd, kpd = _config2_batch(device, b, h, w)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    wts = (1.0, 0.5, 0.015)
+    grads, plans = {}, {}
+    for mode in ("split", "bf16"):
+        monkeypatch.setenv("CASAPOSE_CONV_MODE", mode)
+        store = ParamStore(params, device)
+        plan = TrainPlan(store, K, V, b, h, w)
+        plan.update_moving = False
+        plan.refresh_weights(stream)
+        plan.forward(img, cond_labels=labd)
+        plan.loss_and_grad(labd, labd, kpd, *wts, filter_with_segmentation=False)
+        plan.backward()
+        torch.cuda.synchronize()
+        grads[mode] = store.grad.double().clone()
+        if mode == "split":
+            plans[mode] = (store, plan)
+        else:
+            names = {n: store.grad_view(n).double().flatten().clone() for n in store.offsets}
+            del plan, store
+            torch.cuda.empty_cache()
+    store, plan = plans["split"]
+    gs, gb = grads["split"], grads["bf16"]
+    cos = float(gs @ gb / (gs.norm() * gb.norm()))
+    rel = float((gs - gb).norm() / gs.norm())
+    per = {}
+    for n in store.offsets:
+        a = store.grad_view(n).double().flatten()
+        per[n] = float((names[n] - a).norm() / max(float(a.norm()), 1e-30))
+    vals = sorted(per.values())
+    worst = max(per, key=per.get)
+
+    def loss():
+        plan.refresh_weights(stream)
+        plan.forward(img, cond_labels=labd)
+        s_ = plan.loss_and_grad(labd, labd, kpd, *wts, filter_with_segmentation=False).clone()
+        return float(wts[0] * s_[0] + wts[1] * s_[1] + wts[2] * s_[2])
+
+    d = (gb / gb.norm()).float()
+    theta0 = store.theta.clone()
+    eps = 2e-3
+    store.theta.copy_(theta0 + eps * d)
+    lp = loss()
+    store.theta.copy_(theta0 - eps * d)
+    lm = loss()
+    store.theta.copy_(theta0)
+    fd, pred = (lp - lm) / (2 * eps), float(gs @ d.double())
+    print("bf16 vs fp32-equivalent gradient at bs 32, 448x448: cosine %.5f, relative L2 %.4f; per variable: median %.4f, 90 %% %.4f, worst %.4f (%s); "
+          "fp32-equivalent loss along the bf16 direction: %.6g measured vs %.6g predicted (ratio %.4f)"
+          % (cos, rel, vals[len(vals) // 2], vals[int(0.9 * len(vals))], vals[-1], worst, fd, pred, fd / pred))
+    assert cos >= BF16_GRAD_COSINE_MIN and rel <= BF16_GRAD_REL_L2_MAX, (cos, rel)
+    assert vals[len(vals) // 2] <= BF16_GRAD_VAR_MEDIAN_MAX and vals[-1] <= BF16_GRAD_VAR_WORST_MAX, (vals[len(vals) // 2], worst, vals[-1])
+    assert pred > 0 and BF16_GRAD_DIRECTION_RATIO[0] <= fd / pred <= BF16_GRAD_DIRECTION_RATIO[1], (fd, pred)

@@ -148,6 +148,34 @@ def test_fused_upsampling_sources(device, mode, tol):
 
 
 @pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("c0,c1,cout,hw", [(16, 0, 32, (144, 320)), (32, 4, 32, (136, 288)), (48, 32, 32, (72, 608)), (32, 16, 64, (152, 304)), (64, 64, 64, (40, 48))])
+def test_bilinear_source_from_the_staged_low_resolution_tile(device, mode, tol, c0, c1, cout, hw):
+    """Round 4: the loaders stage the half-resolution tile of source 0 in LDS and interpolate the halo from it.  Shapes with MORE tiles than
+    blocks (a block walks several tiles: the three slice cursors cross tile borders), one-slice tiles (16 channels: every slice starts a
+    tile), bilinear slices followed by direct slices / by the image block, ragged right and bottom edges, both cout widths."""
+    from casapose_amd import ops
+
+    rng = np.random.default_rng(c0 + c1 + cout)
+    b, (h, w) = 2, hw
+    low = rng.standard_normal((b, h // 2, w // 2, c0))
+    srcs, real, full = [dev(low, device)], [c0], [O.upsample_bilinear_x2(low)]
+    if c1 == 4:
+        img = rng.uniform(-1, 1, (b, h, w, 3))
+        srcs.append(ops.pad_channels_3to4(dev(img, device)))
+        real.append(3)
+        full.append(img)
+    elif c1:
+        skip = rng.standard_normal((b, h, w, c1))
+        srcs.append(dev(skip, device))
+        real.append(c1)
+        full.append(skip)
+    cin = sum(real)
+    wk = rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)
+    raw, _ = ops.conv2d_fused(srcs, wk.astype(np.float32), pad=1, real_channels=real, modes=[2] + [0] * (len(srcs) - 1), tile_hint=mode)
+    close(raw, O.conv2d(np.concatenate(full, 3), wk, pad=1), rtol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
 @pytest.mark.parametrize("q", [9, 27, 32])
 def test_fused_head(device, mode, tol, q):
     """the 1x1 head (pv_final_conv_segmentation / _vertex) fused into the epilogue of a 32-channel layer, on the same matrix pipe"""

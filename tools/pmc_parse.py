@@ -1,14 +1,15 @@
 import csv, collections, sys, os
 d = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else 'conv_f32'   # substring of the kernel name to aggregate
 agg = collections.defaultdict(list)
 for p in ('p1', 'p2'):
     f = os.path.join(d, p, p + '_counter_collection.csv')
     for r in csv.DictReader(open(f)):
-        if 'conv_f32' in r['Kernel_Name']:
+        if KERNEL in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 m = {k: sum(v[1:]) / len(v[1:]) for k, v in agg.items()}
 kt = list(csv.DictReader(open(os.path.join(d, 'p1', 'p1_kernel_trace.csv'))))
-dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in kt if 'conv_f32' in r['Kernel_Name']][1:]
+dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in kt if KERNEL in r['Kernel_Name']][1:]
 us = sum(dur) / len(dur)
 cyc = m['GRBM_GUI_ACTIVE'] / 8
 print(open(os.path.join(d, 'plain.log')).read().strip())
