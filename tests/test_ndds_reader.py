@@ -154,3 +154,91 @@ def test_reader_on_the_reference_s_own_model_files(tmp_path):
     for n in names:
         assert meshes[n]["diameter"] == info[n]["diameter"] and meshes[n]["keypoints"].shape == (9, 3)
         assert np.allclose(meshes[n]["keypoints"], read_vertices(os.path.join(src, n + "_keypoints.ply")))
+
+
+# --------------------------------------------------------------------------------------------------
+# the per-frame format against the REFERENCE'S OWN reader code (round-3 verdict, row f2)
+# --------------------------------------------------------------------------------------------------
+def _frame_meshes(tmp_path):
+    """<meshes>/<obj>/<obj>.ply + <obj>_keypoints.ply + models_info.json: the reference's keypoint files, and as the model the eight corners of
+    the models_info bounding box (so that `volume` is the same box the golden generator handed to the reference's code)"""
+    import json
+    import os
+    import shutil
+
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data", "lm_models_eval")
+    info = json.load(open(os.path.join(src, "models_info.json")))
+    d = tmp_path / "models"
+    for n in ("obj_000001", "obj_000005", "obj_000009", "obj_000012"):
+        os.makedirs(d / n)
+        shutil.copy(os.path.join(src, n + "_keypoints.ply"), d / n / (n + "_keypoints.ply"))
+        b = info[n]
+        lo = np.array([b["min_x"], b["min_y"], b["min_z"]])
+        hi = lo + [b["size_x"], b["size_y"], b["size_z"]]
+        v = [[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]
+        with open(d / n / (n + ".ply"), "w") as f:
+            f.write("ply\nformat ascii 1.0\nelement vertex 8\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+            f.write("\n".join("%r %r %r" % tuple(float(c) for c in r) for r in v) + "\n")
+    shutil.copy(os.path.join(src, "models_info.json"), d / "models_info.json")
+    return str(d)
+
+
+def test_frame_reader_equals_the_reference_reader_code(tmp_path):
+    """tests/golden/ndds_frame/: a frame written by hand with the keys the reference's reader dereferences; tests/golden/ndds_frame_ref.json: what
+    the reference's OWN `load_json_minimal` / `load_json_classes` / `load_json_camera` / `apply_preprocessing` (vectorfield_dataset.py:291-631,
+    extracted with `ast` and executed by tests/golden/make_ndds_frame_golden.py) return for it.  The frame holds: two instances of one class, the
+    first below the 0.10 visibility cut; an object whose keypoints fall left of the centre crop; an object without `px_count_all`; a class
+    outside the objects of interest; an object of interest that is absent; a fixed model transform with a scale and one with a translation.
+    Every field of the batch tuple is compared."""
+    import json
+    import os
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = json.load(open(os.path.join(G, "ndds_frame_ref.json")))
+    names = ref["names"]
+    meshes = _frame_meshes(tmp_path)
+    root = os.path.join(G, "ndds_frame", "data")
+    for case in ref["cases"]:
+        ds = VectorfieldDataset(root, meshes, objectsofinterest=names, color_input=True, noise=0, brightness=0, contrast=0, random_translation=(0, 0),
+                                random_rotation=0, random_crop=False, visibility_filter=case["visibility_filter"])
+        assert len(ds) == 1
+        b = next(ds.generate_dataset(1, 1, 0, tuple(case["imagesize"]), case["cropratio"], 1, len(names), shuffle=False)[0])
+        if "raises" in case:
+            # two VISIBLE instances of one class: the reference's lists go ragged at max_instance_count = 1 and it raises (recorded in the golden);
+            # this reader keeps the first instance in file order instead -- a documented difference, on input the reference does not accept
+            assert "IndexError" in case["raises"]
+            data = ds.load_json_minimal(ds.imgs[0][2])
+            assert data["objectClasses"]["obj_000005"] == [1, 2]
+            continue
+        oc = len(names)
+        close = lambda got, want, tol=1e-4: np.allclose(np.asarray(got, np.float64), np.asarray(want, np.float64), rtol=0, atol=tol)  # noqa: E731
+        assert close(b["target_vert"][0], case["keypoints2d"], 2e-3)           # (y, x) in crop pixels; -1000 for absent objects
+        assert close(b["keypoints3d"][0], case["keypoints3d"])                 # fixed model transform applied (scale 0.1 / translation)
+        assert close(b["cuboid3d"][0], case["cuboid3d"], 1e-3)
+        assert close(b["cam_mat"][0], case["camera_data"])
+        assert close(b["diameters"][0], case["diameters"])                     # models_info diameter x |first column of the fixed transform|; -1 absent
+        assert close(b["offsets"][0], case["offsets"], 0)
+        assert close(b["poses_gt"][0], case["transform_mats"])
+        assert close(b["pixel_gt_count"][0], case["pixel_gt_count"], 0)        # int(px * scale + 0.5); 0 without the key
+        assert b["image_id"][0] == case["image_id"][0] == "lmo_test_000002_000017"
+        # labels: the reference hands [segmentation id, index + 1] pairs to its TF relabelling; this reader applies them
+        seg = np.asarray(b["filtered_seg"][0, :, :, 0])
+        kp = np.asarray(case["keypoints2d"])
+        for o, (sid, new) in enumerate(case["new_labels"]):
+            if new == 0:
+                assert not (seg == o + 1).any()
+                continue
+            y, x = int(round(kp[o, 0, 0, 0])), int(round(kp[o, 0, 0, 1]))       # the blob is centred on keypoint 0
+            if 0 <= y < seg.shape[0] and 0 <= x < seg.shape[1]:
+                assert seg[y, x] == new == o + 1
+        assert b["target_seg"].shape == (1, case["imagesize"][0], case["imagesize"][1], oc + 1)
+        # the parsed frame itself
+        data = ds.load_json_minimal(ds.imgs[0][2])
+        mini = case["load_json_minimal"]
+        assert data["objectClasses"] == mini["objectClasses"] and data["px_count_all"] == mini["px_count_all"]
+        assert close(data["poses_loc"], mini["poses_loc"])
+    path = ds.imgs[0][4]
+    assert ds.class_labels[path] == ref["load_json_classes"]["labels"]
+    for n, m in ref["load_json_classes"]["fixed"].items():
+        assert np.allclose(ds.fixed_transformations[path][n], m)
+    assert np.allclose(ds.camera_data[path], ref["load_json_camera"])
