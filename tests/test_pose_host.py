@@ -214,3 +214,40 @@ def test_bpnp_reprojection_loss_gradient_by_finite_differences():
                 num[0, o, j, a] = (f(coords + d)[0] - f(coords - d)[0]) / 2e-3
     m = num != 0
     assert np.abs(g[m] - num[m]).max() < 2e-2 * np.abs(num[m]).max()
+
+
+# --------------------------------------------------------------------------------------------------
+# host geometry against the REFERENCE'S OWN NumPy functions (tests/golden/make_geometry_golden.py executes them; round 4)
+# --------------------------------------------------------------------------------------------------
+def test_host_geometry_equals_the_reference_functions():
+    """crop -> image transform (ransac_voting.py:71-89 through map_offsets' argument order), its inverse (geometry_utils.py:7-34), projection
+    (:161-170), quaternion -> pose (geometry_utils.py:144-181, both quaternion orders), fixed-transform application (:48-57) and the 2-D rotation
+    matrix (:37-45): golden outputs of the reference's code on random inputs, including rotation / translation jitter and scales != 1."""
+    import json
+    import os
+
+    from casapose_amd.data_handler import vectorfield_dataset as VD
+    from casapose_amd.pose_estimation import pose_evaluation as PE
+    from casapose_amd.train_engine import crop_to_image_affine, project_keypoints
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry_ref.json")))
+    for c in ref["transform_points_back"]:
+        pts, off = np.asarray(c["points_xy"]), np.asarray(c["offsets"])
+        got = PE.transform_points_back(pts, off)
+        assert np.allclose(got, c["image_xy"], atol=2e-3), np.abs(got - c["image_xy"]).max()       # the reference computes in float32
+        A = crop_to_image_affine(off[None])[0].reshape(2, 3).astype(np.float64)                     # the same map as one 2x3 matrix (training path)
+        assert np.allclose(pts @ A[:, :2].T + A[:, 2], c["image_xy"], atol=5e-3)
+    for c, back in zip(ref["apply_offsets_round_trip"], ref["transform_points_back"]):
+        assert np.allclose(c["crop_xy"], back["points_xy"], atol=5e-3)      # consistency of the golden itself: image -> crop inverts crop -> image
+    for c in ref["project"]:
+        xy, cam = PE.project(np.asarray(c["xyz"]), np.asarray(c["K"]), np.asarray(c["RT"]))
+        assert np.allclose(xy, c["xy"], atol=1e-3) and np.allclose(cam, c["xyz_cam"], atol=1e-3)
+        assert np.allclose(project_keypoints(np.asarray(c["xyz"]), np.asarray(c["K"]), np.asarray(c["RT"])), c["xy"], atol=1e-3)
+    for c in ref["quaternion_matrix"]:
+        assert np.allclose(VD.quaternion_matrix(c["q_xyzw"], c["t"]), c["RT"], atol=1e-12)
+        assert np.allclose(VD.quaternion_matrix(c["q_xyzw"], c["t"], wxyz_input=True), c["RT_wxyz_input"], atol=1e-12)
+        assert np.allclose(VD.quaternion_matrix(c["q_xyzw"]), c["R"], atol=1e-12)
+    t = ref["transform_points"]
+    assert np.allclose(VD.transform_points(np.asarray(t["points"]), np.asarray(t["M"])), t["out"], atol=1e-12)
+    for c in ref["get_rotation_matrix_2D"]:
+        assert np.allclose(VD.get_rotation_matrix_2D(c["center"], c["angle"]), c["M"], atol=1e-4)
