@@ -229,6 +229,98 @@ __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restri
     }
 }
 
+// Output transform of layer A fused with the input transform of layer B (round 4): where a Winograd convolution's activated output feeds
+// nothing but the next Winograd convolution of the SAME geometry (the conv1 -> conv2 / conv2 -> next unit's conv1 chains of stages 3 and 4,
+// resnet.py:57-113), the activated map makes no round trip through HBM: a block owns ONE sub-grid of one image (dilation d: the pixels with
+// equal (y mod d, x mod d) -- an independent dilation-1 problem, so the 6x6 patches of its tiles never leave it) and CS channels; it computes
+// Y = A^T M A + epilogue for its Tu x Tv tiles, keeps act(Y) in LDS with the zero ring of the NEXT convolution's padding, and writes
+// V' = B^T d B of layer B from there.  The raw output (a residual for later) and the activated map (when something else reads it too) are
+// still stored on request.  Thread = (tile, channel quad).
+template <int CS4, int MAXT>
+__global__ __launch_bounds__(MAXT) void wino_out_in_kernel(const float* __restrict__ M, int cout, WinoGeom g, WinoEpi e, float* __restrict__ V, int ldv, int c_off) {
+    extern __shared__ __attribute__((aligned(16))) float4 sub[];   // [(4 Tu + 2)][(4 Tv + 2)][CS4]
+    const int RW = 4 * g.Tv + 2, RH = 4 * g.Tu + 2;
+    const int slices = (cout / 4 + CS4 - 1) / CS4;
+    const int slice = blockIdx.x % slices, sg = blockIdx.x / slices;     // sg = n * d * d + sy * d + sx
+    const int s = sg % (g.d * g.d), n = sg / (g.d * g.d);
+    const int sy = s / g.d, sx = s - sy * g.d;
+    const int c4l = threadIdx.x % CS4, tl = threadIdx.x / CS4;
+    const int c4 = slice * CS4 + c4l;
+    const bool live = tl < g.Tu * g.Tv && c4 < cout / 4;
+    const int tu = tl / g.Tv, tv = tl - tu * g.Tv;
+    for (int i = threadIdx.x; i < RH * RW * CS4; i += blockDim.x) sub[i] = f4(0.f);   // the ring and the rows / columns beyond the image stay zero
+    __syncthreads();
+    const int t = (sg * g.Tu + tu) * g.Tv + tv;
+    if (live) {
+        const float* src = M + (size_t)t * cout + c4 * 4;
+        const size_t plane = (size_t)g.Tp * cout;
+        float4 tt[4][6];  // A^T m, column by column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 col[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const float4*>(src + (size_t)(r * 6 + j) * plane);
+            float4 o[4];
+            at6(col, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tt[r][j] = o[r];
+        }
+        float4 sc = f4(1.f), sh = f4(0.f);
+        if (e.scale) {
+            sc = *reinterpret_cast<const float4*>(e.scale + c4 * 4);
+            sh = *reinterpret_cast<const float4*>(e.shift + c4 * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            at6(tt[r], o);
+            const int y = sy + g.d * (4 * tu + r);
+            if (y >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = sx + g.d * (4 * tv + j);
+                if (x >= g.W) continue;
+                const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+                float4 v = o[j];
+                if (e.residual) v = v + *reinterpret_cast<const float4*>(e.residual + pix * e.res_ld + c4 * 4);
+                if (e.out_raw) *reinterpret_cast<float4*>(e.out_raw + pix * e.raw_ld + c4 * 4) = v;
+                float4 w = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);   // wino_out_kernel's expression
+                if (e.act == CP_ACT_RELU) {
+                    w = make_float4(fmaxf(w.x, 0.f), fmaxf(w.y, 0.f), fmaxf(w.z, 0.f), fmaxf(w.w, 0.f));
+                } else if (e.act == CP_ACT_LEAKY01) {
+                    w = make_float4(fmaxf(w.x, 0.f) - fmaxf(-0.1f * w.x, 0.f), fmaxf(w.y, 0.f) - fmaxf(-0.1f * w.y, 0.f),
+                                    fmaxf(w.z, 0.f) - fmaxf(-0.1f * w.z, 0.f), fmaxf(w.w, 0.f) - fmaxf(-0.1f * w.w, 0.f));
+                }
+                if (e.out_act) *reinterpret_cast<float4*>(e.out_act + pix * e.act_ld + c4 * 4) = w;
+                sub[((4 * tu + r + 1) * RW + 4 * tv + j + 1) * CS4 + c4l] = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float4 tt[6][6];  // (B^T d): column by column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 col[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = sub[((4 * tu + r) * RW + 4 * tv + j) * CS4 + c4l];
+            float4 o[6];
+            bt6(col, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tt[r][j] = o[r];
+        }
+        float* dst = V + (size_t)t * ldv + c_off + c4 * 4;
+        const size_t plane = (size_t)g.Tp * ldv;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float4 o[6];
+            bt6(tt[r], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
+        }
+    }
+}
+
 // U[p][o][k_off + c] = (G g G^T)[p] on the device, g read from the MASTER weights through strides so that one kernel serves
 // the forward layout (HWIO or IHWO) and the flipped / transposed data-gradient layout; run after every optimizer step.
 __global__ void wino_weight_kernel(const float* __restrict__ w, long long s_ky, long long s_kx, long long s_in, long long s_out, int flip, int channels,
@@ -452,6 +544,55 @@ extern "C" int cp_wino_output_transform_stats_f32(const float* M, int cout, int 
     return cp::check_launch("cp_wino_output_transform_f32");
 }
 
+
+// block shape of the fused transform: 32 channels per block (8 quads, 128-byte segments of every M / V row) when a sub-grid's tiles x 8 fit 256
+// threads and its padded map 64 KB of LDS (60x80 at dilation 4: 4 x 5 tiles); else 16 channels (4 quads) with up to 384 threads and 96 KB
+// (the 30x40 sub-grids of dilation 2: 8 x 10 tiles); 0 = not applicable (dilation 1 at this size: one sub-grid is the whole image)
+static int out_in_quads(const WinoGeom& g) {
+    const int tiles = g.Tu * g.Tv;
+    const size_t px = (size_t)(4 * g.Tu + 2) * (4 * g.Tv + 2);
+    if (tiles * 8 <= 256 && px * 8 * 16 <= 64 * 1024) return 8;
+    if (tiles * 4 <= 384 && px * 4 * 16 <= 96 * 1024) return 4;
+    return 0;
+}
+
+extern "C" int cp_wino_output_input_applicable(int batch, int h, int w, int dilation, int cout) {
+    WinoGeom g;
+    if (make_geom(batch, h, w, dilation, g) != CP_OK || cout <= 0 || cout % 4) return 0;
+    // measured (bs 16, 60x80): the 32-channel form saves 0.13 ms over the three stage-4 pairs; the 16-channel form (64-byte segments of every M / V
+    // row) LOSES 0.1 ms on the stage-3 pairs against the two separate passes -- so only the former is used unless CP_WINO_OUT_IN_MIN_QUADS=4
+    static const int max_quads = getenv("CP_WINO_OUT_IN_MIN_QUADS") ? atoi(getenv("CP_WINO_OUT_IN_MIN_QUADS")) : 8;
+    const int q = out_in_quads(g);
+    return q >= max_quads ? 1 : 0;
+}
+
+extern "C" int cp_wino_output_input_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                                  const float* scale, const float* shift, int act, float* out_raw, int out_raw_ld, float* out_act,
+                                                  int out_act_ld, float* V, int ldv, int c_off, void* stream) {
+    CP_REQUIRE(M && V && cout > 0 && cout % 4 == 0 && c_off >= 0 && c_off % 4 == 0 && c_off + cout <= ldv, "cp_wino_output_input_transform_f32: bad arguments");
+    CP_REQUIRE((scale == nullptr) == (shift == nullptr), "cp_wino_output_input_transform_f32: scale and shift come together");
+    CP_REQUIRE((!out_raw || out_raw_ld >= cout) && (!out_act || out_act_ld >= cout) && (!residual || residual_ld >= cout), "cp_wino_output_input_transform_f32: ld < cout");
+    WinoGeom g;
+    CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_output_input_transform_f32: bad geometry");
+    const int quads = out_in_quads(g);
+    CP_REQUIRE(quads > 0, "cp_wino_output_input_transform_f32: a sub-grid of %dx%d at dilation %d does not fit one block (cp_wino_output_input_applicable)", h, w, dilation);
+    WinoEpi e{residual, residual_ld, scale, shift, nullptr, act, out_raw, out_raw_ld, out_act, out_act_ld, nullptr};
+    const int slices = (cout / 4 + quads - 1) / quads;
+    const int threads = (g.Tu * g.Tv * quads + 63) / 64 * 64;
+    const size_t lds = (size_t)(4 * g.Tu + 2) * (4 * g.Tv + 2) * quads * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_out_in_kernel<8, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_out_in_kernel<4, 384>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid(batch * dilation * dilation * slices);
+    if (quads == 8)
+        CP_LAUNCH((wino_out_in_kernel<8, 256>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off);
+    else
+        CP_LAUNCH((wino_out_in_kernel<4, 384>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off);
+    return cp::check_launch("cp_wino_output_input_transform_f32");
+}
 
 extern "C" int cp_wino_transform_weights_f32(const float* w, long long stride_ky, long long stride_kx, long long stride_in, long long stride_out,
                                              int flip, int channels, int cout, int ldk, int k_off, float* U, void* stream) {

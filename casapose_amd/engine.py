@@ -300,6 +300,7 @@ BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode:
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 MATERIALISE_BILINEAR = os.environ.get("CASAPOSE_MATERIALISE_BILINEAR", "0") == "1"
+WINO_FUSE_OUT_IN = os.environ.get("CASAPOSE_WINO_FUSE_OUT_IN", "1") != "0"   # A/B switch of the fused output -> input transform
 
 
 def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
@@ -390,10 +391,18 @@ class WinoConv:
         for b0, nb, tp in self.chunks():
             off = 0
             for (cpad, _), s in zip(self.sources, self.srcs):
+                if getattr(self, "skip_input", False):   # the producer's fused output -> input transform has written V already
+                    break
                 check(lib.cp_wino_input_transform_f32(at(s["data"], b0, s["ld"]), s["ld"], cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
                                                       stream), "cp_wino_input_transform_f32(%s)" % self.name)
                 off += cpad
             self.run_gemm(stream, tp)
+            nxt = getattr(self, "fuse_next", None)
+            if nxt is not None:   # Y = A^T M A + epilogue, then straight into the next layer's V (the activated map stays on chip)
+                check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
+                                                             _ptr(e["scale"]), _ptr(e["shift"]), e["act"], at(e["out_raw"], b0, self.cout), self.cout, None, self.cout,
+                                                             self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
+                continue
             check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
                                                    _ptr(e["scale"]), _ptr(e["shift"]), at(e["epi_label"], b0, 1, 1), e["act"], at(e["out_raw"], b0, self.cout),
                                                    self.cout, at(e["out_act"], b0, self.cout), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
@@ -477,7 +486,9 @@ class ForwardPlan:
 
         self.wino_V = self.wino_M = None
 
-        def conv(layer: FusedConv, **kw):
+        def conv(layer: FusedConv, act_private: bool = False, **kw):
+            """act_private: nothing but the NEXT convolution of the plan reads this layer's activated output (lets two consecutive Winograd
+            layers hand it over on chip: WinoConv.fuse_next)"""
             wl = net.wino_by_name.get(layer.name) if net.use_winograd else None
             plain = all(s.get("mode", _lib.SRC_DIRECT) == _lib.SRC_DIRECT and not s.get("pre") for s in kw["srcs"])
             # bf16 conv mode: the deep 3x3 layers (cout a multiple of 128, any of the dilations, no labels) on the direct bf16-operand kernel
@@ -500,7 +511,7 @@ class ForwardPlan:
                     self.wino_M = torch.empty(nm, **f32)
                 self._wino_pending.append((wl, dict(batch=B, in_h=kw["in_h"], in_w=kw["in_w"], dilation=kw.get("dilation", 1), srcs=kw["srcs"],
                                                     residual=kw.get("residual"), scale=kw.get("scale"), shift=kw.get("shift"), epi_label=kw.get("epi_label"),
-                                                    act=kw.get("act", 0), out_raw=kw.get("out_raw"), out_act=kw.get("out_act"))))
+                                                    act=kw.get("act", 0), out_raw=kw.get("out_raw"), out_act=kw.get("out_act")), bool(act_private)))
                 self.convs.append(wl)
                 self.steps.append(wl.run)
                 return
@@ -550,7 +561,7 @@ class ForwardPlan:
                     shortcut = sc
                 else:
                     shortcut = x_raw
-                conv(L[base + "conv1"], in_h=cur_h, in_w=cur_w, stride=stride, dilation=d, pad=d,
+                conv(L[base + "conv1"], in_h=cur_h, in_w=cur_w, stride=stride, dilation=d, pad=d, act_private=True,   # t feeds conv2 only
                      srcs=[dict(data=a, ld=cin)], scale=bn2[0], shift=bn2[1], act=_lib.ACT_RELU, out_act=t)
                 if u == 0:
                     nxt = P["stage%d_unit2_bn1" % (s + 1)]
@@ -559,7 +570,9 @@ class ForwardPlan:
                     nxt = P["stage%d_unit1_bn1" % (s + 2)] if s < 3 else P["bn1"]
                     x_raw = None
                 a_next = new(B, oh, ow, f)
-                conv(L[base + "conv2"], in_h=oh, in_w=ow, dilation=d, pad=d, srcs=[dict(data=t, ld=f)],
+                # unit 1's activated output feeds unit 2's conv1 only (its shortcut is the RAW sum); unit 2's also feeds the next stage's 1x1
+                # shortcut / the decoders / the backbone's taps
+                conv(L[base + "conv2"], in_h=oh, in_w=ow, dilation=d, pad=d, srcs=[dict(data=t, ld=f)], act_private=(u == 0),
                      residual=shortcut, out_raw=x_raw, scale=nxt[0], shift=nxt[1], act=_lib.ACT_RELU, out_act=a_next)
                 self._bufs += [t, shortcut, a_next]
                 a, cur_h, cur_w, cin = a_next, oh, ow, f
@@ -712,8 +725,21 @@ class ForwardPlan:
         self._bind_winograd()
 
     def _bind_winograd(self):
-        for wl, kw in self._wino_pending:
+        lib = _lib.load()
+        for wl, kw, _ in self._wino_pending:
             wl.bind(V=self.wino_V, M=self.wino_M, **kw)
+            wl.fuse_next, wl.skip_input = None, False
+        # consecutive Winograd layers A -> B of one geometry where B's only source is A's activated output and nothing else reads it: A's output
+        # transform writes B's transformed input directly (cp_wino_output_input_transform_f32); the activated map is not stored
+        for (a, ka, private), (b, kb, _) in zip(self._wino_pending, self._wino_pending[1:]):
+            if not (WINO_FUSE_OUT_IN and private and WINO_CHUNK == 0 and not WINO_GROUPED_CONV):
+                continue
+            ia, ib = self.steps.index(a.run), self.steps.index(b.run)
+            same = all(ka[k] == kb[k] for k in ("batch", "in_h", "in_w", "dilation"))
+            if (ib == ia + 1 and same and len(kb["srcs"]) == 1 and kb["srcs"][0]["data"] is ka["out_act"] and ka["out_act"] is not None
+                    and ka["epi_label"] is None and b.ktot == a.cout
+                    and lib.cp_wino_output_input_applicable(ka["batch"], ka["in_h"], ka["in_w"], ka["dilation"], a.cout)):
+                a.fuse_next, b.skip_input = b, True
         self._wino_pending = []
 
     def _bilinear_step(self, src, dst, sh, sw, c):

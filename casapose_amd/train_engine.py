@@ -959,6 +959,7 @@ class TrainPlan:
                 self.GRAD_LD = (seg_dim + ver_dim + 31) // 32 * 32
             self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
+        self.comm_timing = None   # start_comm_timing()
         self._buckets = None
         self._pending: List = []
         self.update_moving = True
@@ -1317,8 +1318,47 @@ class TrainPlan:
     # ---- distributed hooks ---------------------------------------------------------------------------
     def all_reduce_stats(self, table: torch.Tensor, local_pixels: int) -> int:
         """SUM the fp64 statistic table over the replicas; returns the global pixel count."""
-        parallel.all_reduce_sum_(table, self.group, self.world_size)
+        if self.comm_timing is not None and self.group is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            parallel.all_reduce_sum_(table, self.group, self.world_size)
+            e1.record()
+            self.comm_timing["syncbn"].append((e0, e1))
+        else:
+            parallel.all_reduce_sum_(table, self.group, self.world_size)
         return local_pixels * self.world_size
+
+    # ---- communication accounting (bench.py --mode train with N > 1 ranks; tests/test_gpu_dp.py) ------------------
+    def start_comm_timing(self):
+        """From the next step on, bracket every collective the step WAITS for with events on the compute stream: the 58 SyncBN table
+        all-reduces (blocking: the next kernel needs the global statistics) and the wait for the gradient buckets in all_reduce_grads()
+        (whatever of their exchange the backward did not cover).  comm_report() turns them into milliseconds per step."""
+        self.comm_timing = {"syncbn": [], "grad_wait": [], "steps": 0}
+
+    def comm_report(self) -> dict:
+        """{"syncbn_ms", "syncbn_calls", "grad_wait_ms", "exposed_ms", "grad_total_ms", "grad_hidden_ms", "grad_bytes"} per step.  exposed =
+        time the compute stream spent inside / waiting for collectives; grad_total = the same gradient buckets all-reduced back to back on an
+        idle GPU (measured here, after the steps), so grad_hidden = grad_total - grad_wait is what the overlap with the backward bought."""
+        t = self.comm_timing
+        torch.cuda.synchronize(self.store.device)
+        steps = max(t["steps"], 1)
+        bn = sum(a.elapsed_time(b) for a, b in t["syncbn"]) / steps
+        gw = sum(a.elapsed_time(b) for a, b in t["grad_wait"]) / steps
+        total, nbytes = 0.0, 0
+        if self.group is not None and self._buckets:
+            scratch = torch.zeros_like(self.store.grad)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                hs = [parallel.all_reduce_sum_async(scratch[a:e], self.group) for _, a, e in self._buckets]
+                for h in hs:
+                    h.wait()
+                e1.record()
+                e1.synchronize()
+                total = e0.elapsed_time(e1)   # the last repetition (the first pays RCCL's lazy set-up)
+            nbytes = 4 * scratch.numel()
+        return {"syncbn_ms": round(bn, 4), "syncbn_calls": len(t["syncbn"]) // steps, "grad_wait_ms": round(gw, 4), "exposed_ms": round(bn + gw, 4),
+                "grad_total_ms": round(total, 4), "grad_hidden_ms": round(max(total - gw, 0.0), 4), "grad_bytes": nbytes}
 
     # ---- one step ------------------------------------------------------------------------------------
     def refresh_weights(self, stream: int):
@@ -1489,12 +1529,20 @@ class TrainPlan:
 
     def all_reduce_grads(self):
         """Complete the gradient exchange started by backward() (or run it as one all-reduce if none is pending)."""
+        timed = self.comm_timing is not None and self.group is not None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if getattr(self, "_pending", None):
             for h in self._pending:
                 h.wait()
             self._pending = []
         else:
             parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
+        if timed:
+            e1.record()
+            self.comm_timing["grad_wait"].append((e0, e1))
+            self.comm_timing["steps"] += 1
 
     def train_step(self, img, labels_ce, labels_fg, keypoints_yx, lr: float, cond_labels=None, weights=(1.0, 1.0, 1.0),
                    filter_with_segmentation=True, kp_args: Optional[dict] = None):

@@ -360,6 +360,16 @@ int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batc
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
                                  const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
                                  int out_raw_ld, float* out_act, int out_act_ld, void* stream);
+/* Output transform of one Winograd layer FUSED with the input transform of the next (round 4): Y = A^T M A, + residual, raw store (optional),
+ * t = act(Y * scale[c] + shift[c]) (per channel; optional activated store), then V[p][t][c_off + c] = (B^T t B)[p] of the consumer -- for two
+ * Winograd convolutions of the same (batch, h, w, dilation) where the consumer's only source is this activated output (the residual-unit chains
+ * of resnet.py:57-113 in inference).  The activated map never goes to HBM unless out_act is given.  One block owns a whole sub-grid (the pixels
+ * with equal (y mod d, x mod d)) x 32 channels (60x80 at dilation 4: 4 x 5 tiles) or x 16 channels (the 30x40 sub-grids of dilation 2);
+ * cp_wino_output_input_applicable says whether a geometry fits one of the two block shapes, otherwise the two separate transforms are used. */
+int cp_wino_output_input_applicable(int batch, int h, int w, int dilation, int cout);
+int cp_wino_output_input_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
+                                       const float* scale, const float* shift, int act, float* out_raw, int out_raw_ld, float* out_act,
+                                       int out_act_ld, float* V, int ldv, int c_off, void* stream);
 /* Training-step forms of the two transforms (round 3, fused normalisation: casapose.py:76-105 / resnet.py:78-103 are convolution ->
  * normalisation -> activation -> convolution).  _stats: also accumulates stats[c] = sum, stats[cout + c] = sum of squares (fp64; zeroed by
  * the call) of the RAW output over the real pixels = the batch statistics cp_bn_stats_f32 would compute from out_raw.  _pre: applies

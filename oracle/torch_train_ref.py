@@ -452,3 +452,109 @@ def keypoint_reprojection_loss(coords_yx: torch.Tensor, gt_xy: torch.Tensor, aff
         cl = torch.where(ms > 0, cs / torch.where(ms > 0, ms, torch.ones_like(ms)), torch.zeros_like(cs))
         loss = loss + torch.abs(cl - 0.7).mean()
     return loss
+
+
+# --------------------------------------------------------------------------------------
+#  inference-only fast path of the SAME graph (bench.py's CPU baseline, round 4)
+# --------------------------------------------------------------------------------------
+def prepare_inference(p: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Constant folding for forward_infer_fast: every (Sync)BatchNormalization becomes one per-channel affine (scale, shift); every CLADE layer a
+    per-class table of them; convolution kernels go to OIHW channels-last once; the partial convolutions' [Cin,3,3,Cout] weights to ONE
+    1x1 kernel with 9*Cout outputs (tap-major).  Values only -- the arithmetic per output element is the reference's, re-associated."""
+    q: Dict[str, torch.Tensor] = {}
+    for k, v in p.items():
+        if k.endswith(".moving_variance"):
+            n = k[: -len(".moving_variance")]
+            rstd = 1.0 / torch.sqrt(v + BN_EPS)
+            g, b = p.get(n + ".gamma"), p.get(n + ".beta")
+            scale = rstd if g is None else g * rstd                   # CLADE: gamma [classes, C] -> table [classes, C]
+            shift = -p[n + ".moving_mean"] * scale
+            q[n + ".scale"], q[n + ".shift"] = scale.contiguous(), (shift if b is None else shift + b).contiguous()
+        elif k.endswith(".kernel"):
+            q[k] = v.permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+        elif k.endswith(".weights"):                                  # IHWO -> [9*Cout, Cin, 1, 1], output channel = tap * Cout + o
+            cin, _, _, cout = v.shape
+            q[k] = v.permute(1, 2, 3, 0).reshape(9 * cout, cin, 1, 1).contiguous(memory_format=torch.channels_last)
+    return q
+
+
+def forward_infer_fast(q: Dict[str, torch.Tensor], img: torch.Tensor) -> torch.Tensor:
+    """casapose_c_gcu5 inference with the estimated mask (forward_train(..., labels=None, training=False)) as a CPU program someone would
+    actually run: NCHW tensors in channels-last memory end to end (oneDNN's native layout, no per-layer permutes), folded normalisation
+    (one fused multiply-add per layer), in-place activations, and the partial convolution as ONE 1x1 convolution to 9*Cout tap planes
+    followed by nine masked shifted accumulations on the OUTPUT side (the tap mask is a per-pixel scalar, so (m x) W = m (x W), and every
+    decoder layer has Cout <= Cin).  img [B,H,W,3] -> [B,H,W,K+ver_dim]."""
+    def affine(name, x, act):   # act: 0 none, 1 relu, 2 leaky pair relu(t) - relu(-0.1 t) = leaky_relu(t, 0.1)
+        y = torch.addcmul(q[name + ".shift"].view(1, -1, 1, 1), x, q[name + ".scale"].view(1, -1, 1, 1))
+        return F.relu_(y) if act == 1 else (F.leaky_relu_(y, 0.1) if act == 2 else y)
+
+    def conv(name, x, stride=1, dil=1, pad=0):
+        return F.conv2d(x, q[name + ".kernel"], stride=stride, dilation=dil, padding=pad)
+
+    x = img.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    img_c = x
+    x = conv("conv0", affine("bn_data", x, 0), stride=2, pad=3)
+    x2s = affine("bn0", x, 1)
+    x = F.max_pool2d(F.pad(x2s, (1, 1, 1, 1)), 3, 2)
+    taps = []
+    for s in range(4):
+        d = STAGE_DILATION[s]
+        for u in range(2):
+            base = "stage%d_unit%d_" % (s + 1, u + 1)
+            stride = STAGE_STRIDE[s] if u == 0 else 1
+            a = affine(base + "bn1", x, 1)
+            shortcut = conv(base + "sc", a, stride=stride) if u == 0 else x
+            y = affine(base + "bn2", conv(base + "conv1", a, stride=stride, dil=d, pad=d), 1)
+            x = conv(base + "conv2", y, dil=d, pad=d).add_(shortcut)
+            if u == 0 and s > 0:
+                taps.append(a)
+    x32s = affine("bn1", x, 1)
+    x4s, x8s, _ = taps
+    skips = [None, x8s, x4s, x2s, img_c]
+    d1 = None
+    for i in range(5):
+        n = "pv_block_%d" % (i + 1)
+        inp = x32s if i == 0 else torch.cat([d1, skips[i]], dim=1)
+        y = affine(n + "_bn", conv(n + "_conv2d", inp, pad=1), 1 if i == 0 else 2)
+        d1 = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=False) if 0 < i < 4 else y
+    logits = conv("pv_final_conv_segmentation", d1)
+    labs = labels_pyramid(torch.argmax(logits, dim=1))               # [B,H,W] int64 and its three [::2, ::2] levels
+    lvl = [3, 3, 2, 1, 0]
+
+    def partial(name, x, lab):
+        b, _, h, w = x.shape
+        zp = F.conv2d(F.pad(x, (1, 1, 1, 1)), q[name + ".weights"])  # [B, 9*Cout, H+2, W+2]: the zero ring of x gives the zero ring of the tap planes
+        cout = zp.shape[1] // 9
+        lp = F.pad(lab + 1, (1, 1, 1, 1))                            # 0 = outside the image
+        out = torch.zeros(b, cout, h, w, dtype=x.dtype).contiguous(memory_format=torch.channels_last)
+        cnt = torch.zeros(b, 1, h, w, dtype=x.dtype)
+        for t in range(9):
+            ky, kx = divmod(t, 3)
+            m = (lp[:, ky:ky + h, kx:kx + w] == (lab + 1)).to(x.dtype).unsqueeze(1)
+            cnt += m
+            out.addcmul_(zp[:, t * cout:(t + 1) * cout, ky:ky + h, kx:kx + w], m)
+        return out.mul_(9.0 / cnt)
+
+    d2 = None
+    for i in range(5):
+        n = "pv_block_%d" % (i + 6)
+        lab = labs[lvl[i]]
+        inp = x32s if i == 0 else torch.cat([d2, skips[i]], dim=1)
+        y = partial(n + "_prepare_conv2d", inp, lab)
+        sc = q[n + "_clade.scale"][lab].permute(0, 3, 1, 2)          # per-label rows of the folded CLADE table
+        sh = q[n + "_clade.shift"][lab].permute(0, 3, 1, 2)
+        y = torch.addcmul(sh, y, sc)
+        y = F.relu_(y) if i == 0 else F.leaky_relu_(y, 0.1)
+        if 0 < i < 4:
+            hi = labs[lvl[i] - 1]
+            if i in (1, 2, 3):                                        # guided upsampling (casapose_c_gcu5: blocks 7-9)
+                sel = guided_select(lab, hi)
+                b, c, h2, w2 = y.shape
+                yy, xx = torch.meshgrid(torch.arange(2 * h2), torch.arange(2 * w2), indexing="ij")
+                sy = torch.clamp(yy[None] // 2 + sel // 2, max=h2 - 1)
+                sx = torch.clamp(xx[None] // 2 + sel % 2, max=w2 - 1)
+                bi = torch.arange(b)[:, None, None]
+                y = y.permute(0, 2, 3, 1)[bi, sy, sx, :].permute(0, 3, 1, 2)
+        d2 = y
+    vertex = conv("pv_final_conv_vertex", d2)
+    return torch.cat([logits, vertex], dim=1).permute(0, 2, 3, 1)

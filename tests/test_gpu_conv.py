@@ -2,6 +2,8 @@
 against the fp64 NumPy oracle, on seeded inputs small enough for the oracle to finish in
 seconds.  Tolerance: fp32 MFMA accumulation vs fp64 -> max|diff| <= 1e-4 * max|ref|
 (indexing mistakes produce O(1) relative errors)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -346,3 +348,48 @@ def test_split_bf16_gemm_is_fp32_equivalent(device):
         e3 = float(((M3.cpu().double() - ref).abs() / bound).max())
         assert 1e-7 < e3 < 4e-5, (rows, n, k, e3)
         del scale
+
+
+@pytest.mark.parametrize("h,w,dil,cout", [(60, 80, 4, 512), (56, 56, 4, 256), (15, 20, 1, 64), (30, 37, 2, 96), (9, 7, 4, 32), (60, 80, 2, 64)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_fused_winograd_output_input_transform_equals_the_two_passes(device, h, w, dil, cout, with_residual):
+    """cp_wino_output_input_transform_f32 (round 4): output transform + epilogue of one Winograd layer and input transform of the next in one
+    launch -- against cp_wino_output_transform_f32 followed by cp_wino_input_transform_f32 on the stored activated map.  The raw and the
+    activated output must be BIT-EQUAL (same expressions); the transformed input V to the last bits (the compiler contracts the B^T d B sums
+    into FMAs differently in the two kernels: <= 2e-6 of the largest |V|); ragged sub-grids (rows / columns beyond the image inside the last
+    tiles) and the zero ring of the next convolution's padding included."""
+    from casapose_amd import _lib
+
+    lib = _lib.load()
+    b = 2
+    # (60, 80, 2): 8 x 10 tiles per sub-grid -> the 16-channel block shape, which the plan does not select (cp_wino_output_input_applicable says
+    # no: it measured slower than the two passes) but the entry point still serves
+    assert lib.cp_wino_output_input_applicable(b, h, w, dil, cout) == (0 if (h, w, dil) == (60, 80, 2) else 1)
+    st = torch.cuda.current_stream().cuda_stream
+    t, tp = C.c_int(0), C.c_int(0)
+    _lib.check(lib.cp_wino_tiles(b, h, w, dil, C.byref(t), C.byref(tp)))
+    g = torch.Generator(device="cpu").manual_seed(h * w + cout)
+    M = torch.randn(36, tp.value, cout, generator=g).to(device)
+    res = torch.randn(b, h, w, cout, generator=g).to(device) if with_residual else None
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
+    raw0, act0 = torch.empty(b, h, w, cout, device=device), torch.empty(b, h, w, cout, device=device)
+    V0 = torch.full((36, tp.value, cout), float("nan"), device=device)
+    rp = res.data_ptr() if res is not None else None
+    _lib.check(lib.cp_wino_output_transform_f32(M.data_ptr(), cout, b, h, w, dil, rp, cout, scale.data_ptr(), shift.data_ptr(), None, 1, raw0.data_ptr(), cout,
+                                                act0.data_ptr(), cout, st))
+    _lib.check(lib.cp_wino_input_transform_f32(act0.data_ptr(), cout, cout, b, h, w, dil, V0.data_ptr(), cout, 0, st))
+    raw1, act1 = torch.empty_like(raw0), torch.empty_like(act0)
+    V1 = torch.full_like(V0, float("nan"))
+    _lib.check(lib.cp_wino_output_input_transform_f32(M.data_ptr(), cout, b, h, w, dil, rp, cout, scale.data_ptr(), shift.data_ptr(), 1, raw1.data_ptr(), cout,
+                                                      act1.data_ptr(), cout, V1.data_ptr(), cout, 0, st))
+    torch.cuda.synchronize()
+    T = t.value
+    assert torch.equal(raw0, raw1) and torch.equal(act0, act1)
+    vmax = float(V0[:, :T].abs().max())
+    assert torch.isfinite(V1[:, :T]).all() and float((V0[:, :T] - V1[:, :T]).abs().max()) <= 2e-6 * vmax
+    # without the optional stores, into a channel slice of a wider V
+    V2 = torch.zeros(36, tp.value, cout + 32, device=device)
+    _lib.check(lib.cp_wino_output_input_transform_f32(M.data_ptr(), cout, b, h, w, dil, rp, cout, scale.data_ptr(), shift.data_ptr(), 1, None, cout, None, cout,
+                                                      V2.data_ptr(), cout + 32, 32, st))
+    torch.cuda.synchronize()
+    assert float((V2[:, :T, 32:] - V0[:, :T]).abs().max()) <= 2e-6 * vmax and not V2[:, :, :32].any()

@@ -115,6 +115,10 @@ def test_bench_multi_rank_contract(mode, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
     per_step = (2 if mode == "infer" else 4) * 2
     assert abs(d["value"] - per_step / (d["ms_per_step"] / 1e3)) < 0.02 * d["value"]
+    if mode == "train":   # the communication account of the data-parallel step (round 4): what the compute stream waited for, per step
+        c = d["comm"]
+        assert c["syncbn_calls"] == 57 and c["syncbn_ms"] > 0 and c["grad_total_ms"] > 0 and c["grad_bytes"] > 0
+        assert abs(d["comm_exposed_ms"] - (c["syncbn_ms"] + c["grad_wait_ms"])) < 1e-3 and d["comm_exposed_ms"] < d["ms_per_step"]
 
 
 def test_bench_default_line_carries_the_dp_training_leg(tmp_path):
@@ -256,3 +260,72 @@ def test_bench_train_over_rccl_world_one():
         assert len(lines) == 1
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 2
+
+
+# --------------------------------------------------------------------------------------------------
+# two ranks on two GPUs over RCCL: runs the moment a second GPU exists (the test boxes have one)
+# --------------------------------------------------------------------------------------------------
+def _rccl2_worker(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.environ.pop("CASAPOSE_DIST_BACKEND", None)
+    os.environ.pop("CASAPOSE_DIST_FORCE", None)
+    import torch.distributed as dist
+
+    from casapose_amd import parallel
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    r, local, w = parallel.init_from_env("nccl")
+    assert dist.get_backend() == "nccl" and (r, w) == (rank, world)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    parallel.barrier_sync(dev)
+    params, img, lab, kpts = _data()
+    b, e = parallel.shard_range(B, rank, world)
+    plan = TrainPlan(ParamStore(params, dev), K, 27, e - b, H, W, group=dist.group.WORLD, world_size=world)
+    plan.refresh_weights(torch.cuda.current_stream(dev).cuda_stream)
+    _run(plan, dev, img[b:e], lab[b:e], kpts[b:e])           # warm-up: RCCL's lazy communicator set-up
+    plan.start_comm_timing()
+    out, sums, grad = _run(plan, dev, img[b:e], lab[b:e], kpts[b:e])
+    comm = plan.comm_report()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), out=out, sums=sums, grad=grad, comm=np.array([comm[k] for k in sorted(comm)], np.float64),
+             comm_keys=np.array(sorted(comm)))
+    parallel.barrier_sync(dev)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_on_two_gpus(tmp_path):
+    """world_size = 2, backend nccl (= RCCL), one rank per GPU: the protocol of test_two_ranks_reproduce_the_whole_batch over the real ring --
+    57 fp64 SyncBN table all-reduces (29 forward + 28 backward: bn_data has no input gradient), four asynchronous gradient buckets overlapped
+    with the backward -- plus the communication account bench.py
+    prints (`comm`: blocking SyncBN time, exposed and hidden part of the gradient exchange).  SKIPS on a box with one GPU; needs no new code on
+    the day a second GPU is there (round-3 verdict item 6)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d): RCCL refuses two ranks on one device; the gloo two-rank test and the world-1 RCCL test "
+                    "above cover the protocol and the RCCL calls" % torch.cuda.device_count())
+    from casapose_amd.train_engine import ParamStore, TrainPlan
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rccl2_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    device = torch.device("cuda:0")
+    params, img, lab, kpts = _data()
+    plan = TrainPlan(ParamStore(params, device), K, 27, B, H, W)
+    plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+    out, sums, grad = _run(plan, device, img, lab, kpts)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    got = np.concatenate([r0["out"], r1["out"]])
+    assert np.abs(got - out).max() <= 1e-4 * np.abs(out).max()                       # SyncBN: the sharded forward equals the whole-batch forward
+    assert np.array_equal(r0["grad"], r1["grad"])                                     # both ranks hold the same SUM
+    assert np.linalg.norm(r0["grad"] / 2 - grad) <= 1e-3 * np.linalg.norm(grad)       # per-replica mean losses, SUM reduction
+    comm = dict(zip([str(k) for k in r0["comm_keys"]], r0["comm"]))
+    print("two-rank RCCL step: %s" % comm)
+    assert comm["syncbn_calls"] == 57 and comm["grad_bytes"] == 4 * grad.size
+    assert comm["syncbn_ms"] > 0 and comm["grad_total_ms"] > 0 and comm["exposed_ms"] >= comm["syncbn_ms"]

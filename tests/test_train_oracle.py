@@ -52,6 +52,24 @@ def test_inference_mode_of_the_torch_restatement_equals_the_numpy_oracle():
     assert np.abs(got - O.ls_voting(seg, direct, conf)).max() < 1e-3
 
 
+def test_fast_cpu_inference_path_equals_the_plain_restatement():
+    """bench.py's CPU baseline (round 4) times `forward_infer_fast` -- folded normalisation, channels-last, the partial convolution as a 1x1
+    convolution to tap planes + masked accumulation.  In fp64 it must equal the plain restatement's inference forward (which the test above
+    ties to the NumPy oracle) to re-association error: batch 2, two sizes, and -- same seed and size as above -- the NumPy oracle directly."""
+    for b, h, w, seed in ((2, 40, 56, 11), (1, 32, 48, 1237)):
+        params = O.init_params(9, 27, seed=seed, dtype=np.float64)
+        img = np.random.default_rng(5 if seed == 1237 else 6).uniform(-1, 1, (b, h, w, 3))
+        p = R.to_torch(params, requires_grad=False)
+        with torch.no_grad():
+            out_f = R.forward_infer_fast(R.prepare_inference(p), torch.from_numpy(img)).numpy()
+            out_t = R.forward_train(p, torch.from_numpy(img), None, training=False).numpy()
+        assert out_f.shape == out_t.shape == (b, h, w, 36)
+        assert np.abs(out_f - out_t).max() < 1e-9 * max(1.0, np.abs(out_t).max())
+        if seed == 1237:
+            out_n = O.casapose_c_gcu5(params, img)
+            assert np.abs(out_f - out_n).max() < 1e-9 * max(1.0, np.abs(out_n).max())
+
+
 def test_functional_loss_restatements_agree_with_the_training_oracle():
     """oracle/loss_functions_ref.py (the reference's FUNCTIONS with their own signatures) against oracle/torch_train_ref.losses (the merged
     compute_loss the training tests use): vertex and proxy terms through smooth_l1_loss / proxy_voting_loss_v2 on get_all_vectorfields'
