@@ -110,7 +110,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
                     if sizes.max() >= 50:
                         keep[bi][cc == 1 + int(sizes.argmax())] = o
         with torch.no_grad():
-            return R.ls_voting(torch.from_numpy(keep), out[..., seg_dim:seg_dim + 2 * kp], out[..., seg_dim + 2 * kp:], objects)
+            return R.ls_voting_fast(torch.from_numpy(keep), out[..., seg_dim:seg_dim + 2 * kp], out[..., seg_dim + 2 * kp:], objects)
 
     # threads: all host cores unless that is slower than 32 threads on this graph (a 2-socket, 256-thread host loses time in the thread
     # pool on the small layers); one bs-1 forward each decides, and `cores` below reports the count actually used

@@ -558,3 +558,30 @@ def forward_infer_fast(q: Dict[str, torch.Tensor], img: torch.Tensor) -> torch.T
         d2 = y
     vertex = conv("pv_final_conv_vertex", d2)
     return torch.cat([logits, vertex], dim=1).permute(0, 2, 3, 1)
+
+
+def ls_voting_fast(labels: torch.Tensor, dirs: torch.Tensor, conf: torch.Tensor, objects: int) -> torch.Tensor:
+    """ls_voting (CoordLSVotingWeighted.calc, voting_layers_2d.py:83-122) as ONE pass: the five distinct entries of w (I - n n^T) and of its
+    product with the pixel centre are formed per pixel and keypoint in the input precision, accumulated per OBJECT in fp64 with index_add
+    (the reference's fp64 reduce_sum over the masked map, :110-111), then the 2x2 systems are solved with TensorFlow's pinv cut-off.
+    labels [B,H,W] int (0 = background), dirs [B,H,W,2*kp] (dy,dx), conf [B,H,W,kp] -> [B,objects,kp,2] (y,x) pixels.  No autograd."""
+    b, h, w, kp = conf.shape
+    dt = dirs.dtype
+    wgt = F.softplus(conf)
+    d = dirs.reshape(b, h, w, kp, 2)
+    nrm = torch.sqrt((d * d).sum(-1, keepdim=True))
+    n = torch.where(nrm > 0, d / torch.where(nrm > 0, nrm, torch.ones_like(nrm)), torch.zeros_like(d))
+    ny, nx = n[..., 0], n[..., 1]
+    r00, r01, r11 = (1.0 - ny * ny) * wgt, (-ny * nx) * wgt, (1.0 - nx * nx) * wgt
+    cy = ((torch.arange(h, dtype=dt) + 0.5) / h).view(1, h, 1, 1)
+    cx = ((torch.arange(w, dtype=dt) + 0.5) / h).view(1, 1, w, 1)
+    terms = torch.stack([r00, r01, r11, r00 * cy + r01 * cx, r01 * cy + r11 * cx], dim=-1).reshape(b, h * w, kp * 5).double()
+    idx = labels.reshape(b, h * w).to(torch.int64)
+    acc = torch.zeros(b, objects + 1, kp * 5, dtype=torch.float64)
+    for i in range(b):
+        acc[i].index_add_(0, idx[i], terms[i])
+    s = acc[:, 1:].reshape(b, objects, kp, 5)
+    A = torch.stack([torch.stack([s[..., 0], s[..., 1]], -1), torch.stack([s[..., 1], s[..., 2]], -1)], -2)
+    t = s[..., 3:5]
+    sol = (torch.linalg.pinv(A, rtol=10.0 * 2 * torch.finfo(torch.float64).eps) @ t[..., None])[..., 0] * h
+    return sol.to(dt)

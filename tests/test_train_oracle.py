@@ -50,6 +50,9 @@ def test_inference_mode_of_the_torch_restatement_equals_the_numpy_oracle():
     seg, direct, conf, labels, _ = O.synthetic_voting_inputs(1, 40, 60, num_obj=8, seed=3)
     got = R.ls_voting(torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(direct.astype(np.float64)), torch.from_numpy(conf.astype(np.float64)), 8).numpy()
     assert np.abs(got - O.ls_voting(seg, direct, conf)).max() < 1e-3
+    # the one-pass form bench.py's CPU baseline times (index_add per object instead of a masked reduction per object)
+    fast = R.ls_voting_fast(torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(direct), torch.from_numpy(conf), 8).numpy()
+    assert np.abs(fast - O.ls_voting(seg, direct, conf)).max() < 1e-3
 
 
 def test_fast_cpu_inference_path_equals_the_plain_restatement():
