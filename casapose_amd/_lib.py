@@ -101,6 +101,8 @@ SYMBOLS = [
     ("cp_conv_desc_size", C.c_size_t, []),
     ("cp_conv_source_size", C.c_size_t, []),
     ("cp_device_count", _i, []),
+    ("cp_set_persistent_blocks", _i, [_i]),
+    ("cp_get_persistent_blocks", _i, []),
     ("cp_mfma_probe_workspace_bytes", C.c_size_t, []),
     ("cp_mfma_probe", _i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("cp_conv_ktot", _i, [_i, _i, _i, C.POINTER(_i)]),

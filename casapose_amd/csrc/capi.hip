@@ -1,6 +1,7 @@
 // Library-level entry points of include/casapose_hip.h: error reporting and probing.
 #include "common.h"
 
+#include <cstdlib>
 #include <string>
 
 namespace {
@@ -17,6 +18,24 @@ void set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 }  // namespace cp
+
+namespace cp {
+int& persistent_blocks_ref() {
+    static int n = [] {
+        const char* e = getenv("CASAPOSE_PERSIST_BLOCKS");
+        const int v = e ? atoi(e) : 256;
+        return (v < 8 || v > 256 || v % 8) ? 256 : v;
+    }();
+    return n;
+}
+}  // namespace cp
+
+extern "C" int cp_set_persistent_blocks(int blocks) {
+    CP_REQUIRE(blocks >= 8 && blocks <= 256 && blocks % 8 == 0, "cp_set_persistent_blocks: a multiple of 8 in [8, 256] (one block per CU, whole XCD rows)");
+    cp::persistent_blocks_ref() = blocks;
+    return CP_OK;
+}
+extern "C" int cp_get_persistent_blocks(void) { return cp::persistent_blocks_ref(); }
 
 extern "C" const char* cp_last_error(void) { return g_last_error.c_str(); }
 extern "C" int cp_version(void) { return CP_ABI_VERSION; }

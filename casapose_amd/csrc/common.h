@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "casapose_hip.h"
 
@@ -43,6 +44,12 @@ inline int check_launch(const char* what) {
                fn ": descriptor is null or its struct_size (%u) is not this library's sizeof(cp_conv_desc) = %u (ABI %d); rebuild the " \
                   "caller against include/casapose_hip.h",                                                                           \
                (d) ? (unsigned)(d)->struct_size : 0u, (unsigned)sizeof(cp_conv_desc), CP_ABI_VERSION)
+
+// Blocks of a persistent launch (one block per CU: 256).  cp_set_persistent_blocks / CASAPOSE_PERSIST_BLOCKS = a smaller multiple of 8 leaves CUs
+// free for a kernel of ANOTHER stream: the two-stream forward (engine.py) runs the HBM-bound passes of one half-batch beside the matrix-pipe
+// kernels of the other.
+int& persistent_blocks_ref();   // capi.hip
+inline int persistent_blocks() { return persistent_blocks_ref(); }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks b, b+8, b+16, ... land on the same
 // XCD (observed dispatch, MI355X_MICROARCH.md), so give each XCD one contiguous run of

@@ -908,7 +908,7 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int grid = std::min(256, k.ntiles);
+    const int grid = std::min(cp::persistent_blocks(), k.ntiles);
     CP_LAUNCH((conv_hsplit_kernel<TN, NP, MODE>), dim3(grid), dim3(512), lds, st, k);
     return cp::check_launch("cp_conv2d_fwd_split");
 }

@@ -315,8 +315,8 @@ extern "C" int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (planes == 3) CP_LAUNCH(wino_gemm_split_kernel<3>, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
-    else CP_LAUNCH(wino_gemm_split_kernel<2>, dim3(256), dim3(512), lds, (hipStream_t)stream, g);
+    if (planes == 3) CP_LAUNCH(wino_gemm_split_kernel<3>, dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
+    else CP_LAUNCH(wino_gemm_split_kernel<2>, dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
     return cp::check_launch("cp_wino_gemm_split_f32");
 }
 

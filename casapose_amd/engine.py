@@ -300,7 +300,12 @@ BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode:
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 MATERIALISE_BILINEAR = os.environ.get("CASAPOSE_MATERIALISE_BILINEAR", "0") == "1"
-WINO_FUSE_OUT_IN = os.environ.get("CASAPOSE_WINO_FUSE_OUT_IN", "1") != "0"   # A/B switch of the fused output -> input transform
+WINO_FUSE_OUT_IN = os.environ.get("CASAPOSE_WINO_FUSE_OUT_IN", "1") != "0"
+# two-stream forward (CasaposeNet._forward_two_streams): half-batches pipelined over a matrix-pipe stream and an HBM stream
+TWO_STREAM = os.environ.get("CASAPOSE_TWO_STREAM", "0") == "1"
+TWO_STREAM_BLOCKS = int(os.environ.get("CASAPOSE_TWO_STREAM_BLOCKS", "224"))   # blocks of the persistent kernels while both streams run
+TWO_STREAM_MODE = os.environ.get("CASAPOSE_TWO_STREAM_MODE", "half")   # "half": a stream per half-batch; "tag": a stream per kernel class
+TWO_STREAM_SKEW = float(os.environ.get("CASAPOSE_TWO_STREAM_SKEW", "0.4"))     # fraction of its steps the first half runs ahead   # A/B switch of the fused output -> input transform
 
 
 def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
@@ -406,6 +411,41 @@ class WinoConv:
             check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
                                                    _ptr(e["scale"]), _ptr(e["shift"]), at(e["epi_label"], b0, 1, 1), e["act"], at(e["out_raw"], b0, self.cout),
                                                    self.cout, at(e["out_act"], b0, self.cout), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
+
+    def micro_steps(self):
+        """[(tag, fn(stream))] of one run(): "H" = HBM-bound transform passes, "M" = the matrix-pipe GEMM (the two-stream forward puts them on
+        different streams).  Only without batch chunking (one chunk)."""
+        lib = _lib.load()
+        e = self.epi
+        tp = self.tiles(self.batch, self.h, self.w, self.dil)[1]
+        out: List = []
+
+        def t_in(stream):
+            off = 0
+            for (cpad, _), s in zip(self.sources, self.srcs):
+                check(lib.cp_wino_input_transform_f32(s["data"].data_ptr(), s["ld"], cpad, self.batch, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
+                                                      stream), "cp_wino_input_transform_f32(%s)" % self.name)
+                off += cpad
+
+        def t_gemm(stream):
+            self.run_gemm(stream, tp)
+
+        def t_out(stream):
+            nxt = getattr(self, "fuse_next", None)
+            if nxt is not None:
+                check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
+                                                             _ptr(e["scale"]), _ptr(e["shift"]), e["act"], _ptr(e["out_raw"]), self.cout, None, self.cout,
+                                                             self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
+            else:
+                check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
+                                                       _ptr(e["scale"]), _ptr(e["shift"]), _ptr(e["epi_label"]), e["act"], _ptr(e["out_raw"]), self.cout,
+                                                       _ptr(e["out_act"]), self.cout, stream), "cp_wino_output_transform_f32(%s)" % self.name)
+
+        if not getattr(self, "skip_input", False):
+            out.append(("H", t_in))
+        out.append(("M", t_gemm))
+        out.append(("H", t_out))
+        return out
 
     def run_gemm(self, stream: int, tp: Optional[int] = None):
         lib = _lib.load()
@@ -785,6 +825,30 @@ class ForwardPlan:
             step(stream)
         return [self.taps[n] for n in ("x2s", "x4s", "x8s", "x16s", "x32s")]
 
+    def micro_steps(self, img: torch.Tensor, out: torch.Tensor):
+        """The launches of run(img, out=out) with the estimated mask as a list of (tag, fn(stream)): "M" = matrix-pipe kernels (convolutions, the
+        Winograd GEMMs), "H" = HBM-bound passes (Winograd transforms, pooling, label pyramid, resampling, channel padding).  Binds `out`."""
+        lib = _lib.load()
+        B, h, w = self.batch, self.h, self.w
+        if tuple(img.shape) != (B, h, w, 3) or img.dtype != torch.float32 or not img.is_contiguous():
+            raise ValueError("image must be a contiguous float32 [%d,%d,%d,3] tensor" % (B, h, w))
+        if WINO_CHUNK or WINO_GROUPED_CONV:
+            raise ValueError("the two-stream forward does not combine with CASAPOSE_WINO_CHUNK / CASAPOSE_WINO_GROUPED_CONV")
+        self.out = out
+        for layer, off, field in self._out_bound:
+            setattr(layer.desc, field, out.data_ptr() + 4 * off)
+        self.seg_input_ptr = None
+        steps = [("H", lambda stream: check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4"))]
+        for st in self.steps:
+            owner = getattr(st, "__self__", None)
+            if isinstance(owner, WinoConv):
+                steps += owner.micro_steps()
+            elif isinstance(owner, FusedConv):
+                steps.append(("M", st))
+            else:
+                steps.append(("H", st))
+        return steps
+
     def run(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         lib = _lib.load()
         B, h, w = self.batch, self.h, self.w
@@ -848,10 +912,14 @@ class CasaposeNet:
         self.conv_mode = mode
         self.conv_planes = {"f32": 0, "split": 3, "bf16": 1}[mode]
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
+        self._twin: Optional["CasaposeNet"] = None   # the second half-batch's layer objects (two-stream forward)
+        self._streams = None
         self.set_params(params)
 
     def set_params(self, params: Dict[str, np.ndarray]):
         self.params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
+        if getattr(self, "_twin", None) is not None:
+            self._twin.set_params(params)
         dev = self.device
         p = self.params
         tabs: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -932,4 +1000,85 @@ class CasaposeNet:
 
     def forward(self, img: torch.Tensor, seg_input: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         b, h, w, _ = img.shape
+        if TWO_STREAM and seg_input is None and not self.pvnet and b >= 2 and b % 2 == 0 and not (WINO_CHUNK or WINO_GROUPED_CONV):
+            return self._forward_two_streams(img, out)
         return self.plan(b, h, w).run(img, seg_input, out)
+
+    def _forward_two_streams(self, img: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+        """The batch as two halves software-pipelined over TWO HIP streams (round 4): matrix-pipe kernels ("M": convolutions, Winograd GEMMs)
+        on one stream, HBM-bound passes ("H": Winograd transforms, pooling, label pyramid, resampling) on the other, events where a half's
+        chain changes stream.  The persistent "M" kernels are launched with TWO_STREAM_BLOCKS (224 of 256) blocks, so the "H" kernels of one
+        half find free CUs while the other half's convolution runs: measured on the stage-4 shapes GEMM 0.325 ms + transforms 0.121 ms alone,
+        0.364 ms together.  Each half has its own CasaposeNet (descriptors and buffers live in the layer objects; the weights
+        are duplicated: 59 MB); results are those of two independent half-batch forwards -- the network has no cross-image term."""
+        b, h, w, _ = img.shape
+        hb = b // 2
+        if self._twin is None:
+            self._twin = CasaposeNet(self.params, self.seg_dim, self.ver_dim, self.device, decoder_dims=self.decoder_dims, fuse_upsample=self.fuse_upsample,
+                                     fuse_heads=self.fuse_heads, partial=self.partial, guided=self.guided, use_winograd=self.use_winograd,
+                                     bilinear=self.bilinear, pvnet=False, shared=self.shared, reuse_first=self.reuse_first, skips2=self.skips2,
+                                     conv_mode=self.conv_mode)
+            self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        if out is None:
+            out = torch.empty(b, h, w, self.seg_dim + self.ver_dim, dtype=torch.float32, device=img.device)
+        plans = [self.plan(hb, h, w), self._twin.plan(hb, h, w)]
+        seqs = [plans[0].micro_steps(img[:hb], out[:hb]), plans[1].micro_steps(img[hb:], out[hb:])]
+        lib = _lib.load()
+        cur = torch.cuda.current_stream(self.device)
+        streams = {"M": self._streams[0], "H": self._streams[1]}
+        for s_ in streams.values():
+            s_.wait_stream(cur)
+        old_blocks = lib.cp_get_persistent_blocks()
+        check(lib.cp_set_persistent_blocks(min(old_blocks, TWO_STREAM_BLOCKS)), "cp_set_persistent_blocks")
+        try:
+            pos, last = [0, 0], [None, None]   # next micro-step / (tag, event) of the last issued step per half
+            lead = int(TWO_STREAM_SKEW * len(seqs[0]))
+            if TWO_STREAM_MODE == "half":
+                # one in-order stream per HALF (no cross-stream waits inside a chain): the hardware runs whatever of the two queues fits;
+                # half 1 starts when half 0 has passed `lead` steps, so that its transform-heavy encoder meets half 0's convolution-only decoders
+                s0, s1 = self._streams
+                gate = None
+                for k_, (tag, fn) in enumerate(seqs[0]):
+                    fn(s0.cuda_stream)
+                    if k_ + 1 == lead:
+                        gate = torch.cuda.Event()
+                        gate.record(s0)
+                    if k_ + 1 >= lead and pos[1] < len(seqs[1]):     # keep both queues fed: one step of half 1 per step of half 0
+                        if pos[1] == 0 and gate is not None:
+                            s1.wait_event(gate)
+                        seqs[1][pos[1]][1](s1.cuda_stream)
+                        pos[1] += 1
+                while pos[1] < len(seqs[1]):
+                    seqs[1][pos[1]][1](s1.cuda_stream)
+                    pos[1] += 1
+                pos[0] = len(seqs[0])
+
+            def issue(k):
+                tag, fn = seqs[k][pos[k]]
+                st = streams[tag]
+                if last[k] is not None and last[k][0] != tag:
+                    st.wait_event(last[k][1])                   # this half's previous step ran on the other stream
+                fn(st.cuda_stream)
+                pos[k] += 1
+                ev = None
+                if pos[k] < len(seqs[k]) and seqs[k][pos[k]][0] != tag:   # the next step of this half changes stream: it will wait for this one
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                last[k] = (tag, ev)
+
+            # "tag" mode: matrix-pipe kernels on one stream, HBM-bound passes on the other, events where a half's chain changes stream; half 0
+            # runs ahead by `lead` steps, then the two lists are issued alternately -- the streams serialise equal tags in issue order
+            for _ in range(lead if pos[0] == 0 else 0):
+                issue(0)
+            while pos[0] < len(seqs[0]) or pos[1] < len(seqs[1]):
+                for k in (1, 0):
+                    if pos[k] < len(seqs[k]):
+                        issue(k)
+        finally:
+            check(lib.cp_set_persistent_blocks(old_blocks), "cp_set_persistent_blocks")
+        for s_ in streams.values():
+            cur.wait_stream(s_)
+        if len(_LABEL_CACHE) > 8:
+            _LABEL_CACHE.clear()
+        _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), torch.cat([plans[0].labels[0], plans[1].labels[0]]), out._version)
+        return out

@@ -42,6 +42,12 @@ int cp_version(void);
 /* sizeof(cp_conv_desc) / sizeof(cp_conv_source) as this library was compiled: a binder checks them against its own declaration at load time */
 size_t cp_conv_desc_size(void);
 size_t cp_conv_source_size(void);
+/* Blocks of the PERSISTENT convolution / GEMM launches (csrc/conv_hsplit.hip, csrc/wino_gemm_split.hip): 256 = one per CU (default; the
+ * environment variable CASAPOSE_PERSIST_BLOCKS sets the initial value).  A smaller multiple of 8 leaves whole CUs free, so that an HBM-bound
+ * kernel launched on ANOTHER stream runs beside the matrix-pipe kernel instead of behind it -- the two-stream forward of the host layer sets 224
+ * around its launches.  Process-wide, read at launch time on the calling thread. */
+int cp_set_persistent_blocks(int blocks);
+int cp_get_persistent_blocks(void);
 /* number of visible gfx950 devices (0 on a CPU-only host); never initialises a context */
 int cp_device_count(void);
 /* Matrix-pipe probe (measurement aid, bench.py): one launch of a bare MFMA stream on every SIMD -- which = 0: v_mfma_f32_32x32x2_f32,

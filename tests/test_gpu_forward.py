@@ -535,3 +535,45 @@ def test_gemm_route_does_not_survive_a_shape_change(device):
         rows8 = b * (h // 8) * (w // 8)   # the stage-3 / stage-4 shortcuts run at 1/8 resolution
         assert ("stage4_unit1_sc" in routed) == (rows8 % 128 == 0) and ("stage3_unit1_sc" in routed) == (rows8 % 128 == 0), (routed, rows8)
         assert rel_err(outs["split"][..., :k], outs["f32"][..., :k]) < 1e-4, (b, h, w)
+
+
+@pytest.mark.parametrize("mode", ["half", "tag"])
+def test_two_stream_forward_equals_the_single_stream_forward(device, monkeypatch, mode):
+    """CASAPOSE_TWO_STREAM=1 (round 4, opt-in -- measured no faster): the batch as two halves over two HIP streams, either a stream per
+    half or a stream per kernel class with events between them, persistent kernels launched with fewer blocks.  The network has no cross-image
+    term and every kernel computes a tile the same way whatever the grid, so the output must be BIT-EQUAL to the one-stream forward, the cached
+    label map must serve the filtered voter, and the block count must be restored afterwards."""
+    from casapose_amd import _lib, engine
+    from casapose_amd.pose_estimation.voting_layers_2d import CoordLSVotingWeighted
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    k, v, b, h, w = 5, 27, 4, 64, 96
+    params = O.init_params(k, v, seed=3, dtype=np.float32)
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, device=device)
+    net.set_parameters(params)
+    img = torch.from_numpy(np.random.default_rng(4).uniform(-1, 1, (b, h, w, 3)).astype(np.float32)).to(device)
+    voter = CoordLSVotingWeighted(name="v", num_classes=k, num_points=9, filter_estimates=True)
+
+    def run():
+        out = net([img], training=False)
+        s, d, c = torch.split(out, [k, 18, 9], dim=3)
+        kp = voter([s, d, c])
+        torch.cuda.synchronize()
+        return out.clone(), kp.clone()
+
+    one, kp_one = run()
+    lib = _lib.load()
+    before = lib.cp_get_persistent_blocks()
+    monkeypatch.setattr(engine, "TWO_STREAM", True)
+    monkeypatch.setattr(engine, "TWO_STREAM_MODE", mode)
+    for _ in range(2):
+        two, kp_two = run()
+        assert torch.equal(one, two) and torch.equal(kp_one, kp_two)
+    assert lib.cp_get_persistent_blocks() == before
+    # new parameters reach the second half's layer objects too
+    params2 = O.init_params(k, v, seed=8, dtype=np.float32)
+    net.set_parameters(params2)
+    two2, _ = run()
+    monkeypatch.setattr(engine, "TWO_STREAM", False)
+    one2, _ = run()
+    assert torch.equal(one2, two2) and not torch.equal(one2, one)

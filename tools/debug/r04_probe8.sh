@@ -1,0 +1,5 @@
+set -u
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04i; mkdir -p $O
+for pb in 256 224 192 160 128; do CASAPOSE_PERSIST_BLOCKS=$pb timeout 300 python tools/debug/two_stream_probe.py >> $O/two_stream.txt 2>&1; done
+grep persist $O/two_stream.txt
