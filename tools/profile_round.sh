@@ -12,7 +12,7 @@
 #   bench_train*.json, train_trace/, train_times.txt      the training step (default, CASAPOSE_CONV_MODE=f32 / bf16)
 #   bench_vote.json, vote_trace/                           the voting stage alone
 set -u
-: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}"
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun (GRAFT_REPO_ROOT = root of the snapshot)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=${1:-r03}
