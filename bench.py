@@ -28,7 +28,8 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               103: "wino_gemm_split_kernel (bf16 pipe, exact three-way split of the Winograd planes' GEMM; FLOPs counted as executed bf16 FLOPs)",
               203: "conv_hsplit_kernel<3> (bf16 pipe, exact three-way split: six bf16 products per fp32 product; FLOPs counted as executed bf16 FLOPs)",
               201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)",
-              301: "conv_bf16d_kernel (bf16 pipe, direct 3x3 of the deep layers, operands rounded to bf16)"}
+              301: "conv_bf16d_kernel (bf16 pipe, direct 3x3 of the deep layers, operands rounded to bf16)",
+              208: "conv_stem_split_kernel (bf16 pipe, the 7x7/s2 stem as exact three-way splits or bf16 operands)"}
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
@@ -151,7 +152,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
                    5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel",
-                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel", 301: "conv_bf16d_kernel<"}
+                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel", 301: "conv_bf16d_kernel<", 208: "conv_stem_split_kernel<"}
 
 
 def binary_stamp():
@@ -255,7 +256,7 @@ def _dtype_note():
     bf16 matrix pipe -- each fp32 operand is split into three bf16 terms (8+8+8 significand bits), six bf16 x bf16 products (each exact in fp32)
     are accumulated in fp32; the three dropped terms are <= 2^-24 of the product, the rounding an fp32 multiply makes itself, and the measured
     error against fp64 is at or below the fp32 MFMA's (tests/test_gpu_hsplit.py, test_gpu_conv.py).  Tensors stay fp32 in HBM.  Layers the split
-    kernels do not cover (stem, strided / dilated 3x3, a few 1x1) run on v_mfma_f32_32x32x2_f32.  CASAPOSE_INFER_CONV_MODE=f32 puts every layer
+    kernels do not cover (strided 3x3, a few 1x1) run on v_mfma_f32_32x32x2_f32.  CASAPOSE_INFER_CONV_MODE=f32 puts every layer
     there; =bf16 rounds operands to bf16 (not fp32-equivalent)."""
     from casapose_amd import engine
 
@@ -265,7 +266,7 @@ def _dtype_note():
         return "bf16 operands / f32 accumulate in the 3x3 layers off the Winograd path, Winograd GEMMs on hi + mid bf16 planes, f32 elsewhere (NOT fp32-equivalent)"
     if mode == "split":
         return ("f32 (fp32-equivalent: exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six exact products per fp32 product, fp32 accumulate, for the 3x3 / "
-                "stride-1 layers%s; stem / strided / dilated layers on v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))
+                "stride-1 layers, the 7x7 stem%s; strided 3x3 / 1x1 layers on v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))
     return "f32 (v_mfma_f32_32x32x2_f32 in every convolution%s)" % ("; Winograd GEMMs as exact 3-way bf16 splits" if wino == "split" else "")
 
 
@@ -648,7 +649,10 @@ def main():
             gemm1x1 = getattr(conv, "_gemm", None)   # 1x1 / stride-1 layer on the bf16-pipe GEMM
             if gemm1x1 is not None:
                 pipe = 3
-            tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (301 if deep else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc)))
+            stem_split = getattr(conv, "stem_split", 0)   # conv0 on the bf16 matrix pipe, csrc/conv_stem_split.hip
+            if stem_split:
+                pipe = stem_split
+            tile = (103 if pipe else 100) if (hasattr(conv, "gemm_flops") or gemm1x1 is not None) else (301 if deep else (208 if stem_split else (200 + pipe if pipe else lib.cp_conv_selected_tile(conv.desc))))
             d_ = conv.desc
             t = per_tile.setdefault(tile, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS if pipe else PEAK_F32_MFMA_TFLOPS})
             direct_flops += conv.flops

@@ -153,6 +153,9 @@ SYMBOLS = [
     ("cp_wino_wgrad_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    ("cp_conv_stem_split_weight_floats", _i, []),
+    ("cp_conv_pack_weights_stem_split_host", _i, [_vp, _i, _i, _vp]),
+    ("cp_conv2d_fwd_stem_split", _i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     ("cp_wino_output_input_applicable", _i, [_i, _i, _i, _i, _i]),
     ("cp_wino_output_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_stats_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),

@@ -109,6 +109,8 @@ class FusedConv:
         if tuple(w.shape) != expect:
             raise ValueError("%s: kernel shape %s, expected %s" % (name, w.shape, expect))
         self.wp = None
+        self.wp_stem_split_f32 = None
+        self.stem_split = 0     # 3 / 1: this binding runs the stem on the bf16 matrix pipe (set by ForwardPlan)
         if all(s[0] == 4 or s[0] % 32 == 0 for s in sources):   # (16-multiple sources exist only for the bf16-pipe kernel below)
             packed = np.empty((cout, self.ktot), dtype=np.float32)
             check(lib.cp_conv_pack_weights_host(w.ctypes.data, layout, kh, kw, cout, ns, chans, real, packed.ctypes.data),
@@ -127,6 +129,10 @@ class FusedConv:
             ph = np.empty(25 * 2 * 64 * 4, dtype=np.float32)
             check(lib.cp_conv_pack_weights_stem_host(w.ctypes.data, layout, sources[0][1], ph.ctypes.data), "cp_conv_pack_weights_stem_host(%s)" % name)
             self.wp_halo = torch.from_numpy(ph).to(device)
+            if want_split:   # the same layer on the bf16 matrix pipe (csrc/conv_stem_split.hip): fp32 image of its fragment stream
+                ps = np.empty(lib.cp_conv_stem_split_weight_floats(), dtype=np.float32)
+                check(lib.cp_conv_pack_weights_stem_split_host(w.ctypes.data, layout, sources[0][1], ps.ctypes.data), "cp_conv_pack_weights_stem_split_host(%s)" % name)
+                self.wp_stem_split_f32 = torch.from_numpy(ps).to(device)
         # third packing: the fp32 image of the fragment stream of csrc/conv_hsplit.hip (3x3 / cout <= 512 in passes of 64 / 16-multiple sources [+ image]);
         # its bf16 planes (3 = exact split, 1 = plain bf16) are made on the device when a mode asks for them
         self.wp_split_f32 = None
@@ -147,12 +153,13 @@ class FusedConv:
         self.deep_bf16 = False              # bf16 conv mode: this binding runs on csrc/conv_bf16d.hip (set by ForwardPlan)
 
     def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
-        """bf16 planes of the weights for cp_conv2d_fwd_split (made once per mode; refresh=True after the fp32 image changed)."""
+        """bf16 planes of the weights for cp_conv2d_fwd_split / cp_conv2d_fwd_stem_split (made once per mode)."""
         if planes not in self._split_planes:
             lib = _lib.load()
-            out = torch.empty(self.wp_split_f32.numel() // 512 * planes * 1024, dtype=torch.uint8, device=self.wp_split_f32.device)
+            image = self.wp_split_f32 if self.wp_split_f32 is not None else self.wp_stem_split_f32
+            out = torch.empty(image.numel() // 512 * planes * 1024, dtype=torch.uint8, device=image.device)
             st = torch.cuda.current_stream(out.device).cuda_stream if stream is None else stream
-            check(lib.cp_conv_split_weights_f32(self.wp_split_f32.data_ptr(), self.wp_split_f32.numel(), planes, out.data_ptr(), st), "cp_conv_split_weights_f32")
+            check(lib.cp_conv_split_weights_f32(image.data_ptr(), image.numel(), planes, out.data_ptr(), st), "cp_conv_split_weights_f32")
             self._split_planes[planes] = out
         return self._split_planes[planes]
 
@@ -268,6 +275,10 @@ class FusedConv:
         if self.deep_bf16:
             check(lib.cp_conv2d_fwd_bf16_deep(C.byref(self.desc), self.split_weights(1, stream).data_ptr(), stream), "cp_conv2d_fwd_bf16_deep(%s)" % self.name)
             return
+        if self.stem_split:
+            check(lib.cp_conv2d_fwd_stem_split(C.byref(self.desc), self.split_weights(self.stem_split, stream).data_ptr(), self.stem_split, stream),
+                  "cp_conv2d_fwd_stem_split(%s)" % self.name)
+            return
         if self.split_mode:
             if not lib.cp_conv_split_applicable(C.byref(self.desc)):
                 raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
@@ -301,6 +312,7 @@ BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode:
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
 MATERIALISE_BILINEAR = os.environ.get("CASAPOSE_MATERIALISE_BILINEAR", "0") == "1"
 WINO_FUSE_OUT_IN = os.environ.get("CASAPOSE_WINO_FUSE_OUT_IN", "1") != "0"
+STEM_SPLIT = os.environ.get("CASAPOSE_STEM_SPLIT", "1") != "0"   # A/B switch: conv0 on csrc/conv_stem_split.hip in the split / bf16 conv modes
 # two-stream forward (CasaposeNet._forward_two_streams): half-batches pipelined over a matrix-pipe stream and an HBM stream
 TWO_STREAM = os.environ.get("CASAPOSE_TWO_STREAM", "0") == "1"
 TWO_STREAM_BLOCKS = int(os.environ.get("CASAPOSE_TWO_STREAM_BLOCKS", "224"))   # blocks of the persistent kernels while both streams run
@@ -559,8 +571,12 @@ class ForwardPlan:
             # conv mode (CASAPOSE_INFER_CONV_MODE / CasaposeNet(conv_mode=...), default "split"): the 3x3 / stride-1 layers off the Winograd path on the
             # bf16 matrix pipe (csrc/conv_hsplit.hip), 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside
             # its range (stem, strided and dilated layers, ...) keep the fp32-MFMA kernels
+            layer.stem_split = 0
             if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
                 layer.split_mode = net.conv_planes
+            elif (net.conv_planes and STEM_SPLIT and layer.wp_stem_split_f32 is not None and kw.get("stride", 1) == 2 and kw.get("pad", 0) == 3
+                  and kw.get("dilation", 1) == 1 and lib.cp_conv_selected_tile(C.byref(layer.desc)) == _lib.TILE_STEM):
+                layer.stem_split = net.conv_planes   # conv0 on the bf16 matrix pipe (exact split / bf16 operands), csrc/conv_stem_split.hip
             elif net.conv_planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
                 layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), 3 if net.conv_planes == 3 else 2)
             self.convs.append(layer)

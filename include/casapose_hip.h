@@ -366,6 +366,14 @@ int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batc
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
                                  const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw,
                                  int out_raw_ld, float* out_act, int out_act_ld, void* stream);
+/* The ResNet stem (conv0: 7x7 / stride 2 / pad 3, one 4-channel source, cout 64 -- the range of the CP_TILE_STEM kernel) on the bf16 matrix
+ * pipe (csrc/conv_stem_split.hip, round 4): planes = 3 exact three-way bf16 splits (fp32-equivalent), planes = 1 bf16 operands.  Same descriptor
+ * as cp_conv2d_fwd_f32 (input affine on real pixels, per-channel affine + activation epilogue, raw / activated outputs).  Weights:
+ * cp_conv_pack_weights_stem_split_host (HOST: HWIO / IHWO kernel -> fp32 image of the fragment stream, cp_conv_stem_split_weight_floats()
+ * floats), then cp_conv_split_weights_f32(image, floats, planes, out) on the device (floats / 512 * planes * 1024 bytes). */
+int cp_conv_stem_split_weight_floats(void);
+int cp_conv_pack_weights_stem_split_host(const float* w_host, int layout, int real_channels, float* dst_host);
+int cp_conv2d_fwd_stem_split(const cp_conv_desc* d, const void* weights_split, int planes, void* stream);
 /* Output transform of one Winograd layer FUSED with the input transform of the next (round 4): Y = A^T M A, + residual, raw store (optional),
  * t = act(Y * scale[c] + shift[c]) (per channel; optional activated store), then V[p][t][c_off + c] = (B^T t B)[p] of the consumer -- for two
  * Winograd convolutions of the same (batch, h, w, dilation) where the consumer's only source is this activated output (the residual-unit chains

@@ -4,6 +4,8 @@
   planes = 1 (operands rounded to bf16): the bf16 gate of SURVEY 8(d), 3e-2 relative.
 Every operand / epilogue mode the kernel covers: one and two sources, the 4-channel image source, ragged tiles (16-row x 32-column
 tiles), partial-convolution tap mask with 9/count, CLADE table + leaky pair, residual, dual outputs."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -236,3 +238,44 @@ def test_out_of_range_layers_are_refused(device):
     w2 = rng.standard_normal((3, 3, 64, 32)) * 0.1
     with pytest.raises(_lib.CasaposeHipError):
         ops.conv2d_fused([dev(x, device)], w2.astype(np.float32), pad=2, dilation=2, tile_hint=SPLIT3)   # dilated
+
+
+@pytest.mark.parametrize("planes,tol", [(3, 1e-4), (1, 3e-2)])
+@pytest.mark.parametrize("hw", [(64, 96), (37, 70), (480, 640)])
+def test_stem_on_the_bf16_pipe(device, planes, tol, hw):
+    """csrc/conv_stem_split.hip (round 4): conv0 -- 7x7 / stride 2 / pad 3, bn_data as an affine on the real pixels (the padding stays zero),
+    bn0 + ReLU epilogue, raw and activated outputs -- as exact three-way bf16 splits (the fp32 gate) or with bf16 operands, against the fp64
+    oracle; odd sizes (ragged tiles, halo rows beyond the image), and the full-size map (more tiles than blocks)."""
+    from casapose_amd import _lib
+    from casapose_amd.engine import FusedConv
+
+    lib = _lib.load()
+    rng = np.random.default_rng(hw[0] + planes)
+    b, (h, w) = (1 if hw[0] > 100 else 2), hw
+    img = rng.uniform(-1, 1, (b, h, w, 3))
+    wk = rng.standard_normal((7, 7, 3, 64)) / np.sqrt(147.0)
+    ps, pb = rng.uniform(0.5, 1.5, 3), rng.standard_normal(3) * 0.3
+    sc, sh = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.2
+    layer = FusedConv("conv0", wk.astype(np.float32), 0, 7, 7, 64, [(4, 3)], device)
+    from casapose_amd import ops
+
+    img4 = ops.pad_channels_3to4(dev(img, device))
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    raw, act = torch.empty(b, oh, ow, 64, device=device), torch.empty(b, oh, ow, 64, device=device)
+    pre = (dev(np.r_[ps, 1.0], device), dev(np.r_[pb, 0.0], device))
+    layer.bind(batch=b, in_h=h, in_w=w, stride=2, pad=3, srcs=[dict(data=img4, ld=4, pre=pre)], scale=dev(sc, device), shift=dev(sh, device),
+               act=_lib.ACT_RELU, out_raw=raw, out_act=act)
+    assert lib.cp_conv_selected_tile(C.byref(layer.desc)) == _lib.TILE_STEM
+    layer.stem_split = planes
+    layer.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = O.conv2d(img * ps + pb, wk, stride=2, pad=3)   # zero padding AFTER the affine: O.conv2d pads the affine image with zeros
+    close(raw, ref, rtol=tol)
+    close(act, np.maximum(ref * sc + sh, 0.0), rtol=tol)
+    if planes == 3:   # and it is the fp32-MFMA stem kernel's result to fp32 rounding
+        layer.stem_split = 0
+        raw2 = torch.empty_like(raw)
+        layer.desc.out_raw = raw2.data_ptr()
+        layer.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert float((raw - raw2).abs().max()) <= 2e-5 * float(raw2.abs().max())
