@@ -486,17 +486,6 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
                 issue_slice(u.t, u.c);
             };
-            // B-step of a slice (two phases before it is multiplied): low-resolution registers -> LDS, or the direct slice's loads; the tile's
-            // image / label halo rides with its first slice
-            auto step_b = [&](const Cur& u) {
-                if (u.s >= total_slices) return;
-                if (u.c == 0) {
-                    if (has_img) issue_img(u.t);
-                    if (has_lab_l) issue_lab(u.t);
-                }
-                if (u.c < p.nch0) store_low(u.s & 1);
-                else issue_direct(u);
-            };
             // A-step (one phase before): the halo stage
             auto step_a = [&](const Cur& u) {
                 if (u.s >= total_slices) return;
@@ -540,14 +529,24 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             cb = cc;
             step(cc);
             int lg = 0;
+            // (stores before issues inside a phase, as in the generic loop below: a wait then only meets loads that are a phase old)
             for (int gg = 0; gg < total_groups; ++gg) {
-                if (gg + 1 < total_groups) {
-                    store_w((gg + 1) & 1);
-                    if (gg + 2 < total_groups) issue_w(gg + 2);
+                const bool more_w = gg + 1 < total_groups;
+                if (more_w) store_w((gg + 1) & 1);
+                const bool slice_phase = lg < nslices * GPS && lg % GPS == 0;   // first group of a slice
+                if (slice_phase) {
+                    step_a(ca);                                                  // interpolation / direct halo store (+ image / label halo stores)
+                    if (cb.s < total_slices && cb.c < p.nch0) store_low(cb.s & 1);
                 }
-                if (lg < nslices * GPS && lg % GPS == 0) {   // first group of a slice
-                    step_a(ca);
-                    step_b(cb);
+                if (more_w && gg + 2 < total_groups) issue_w(gg + 2);
+                if (slice_phase) {
+                    if (cb.s < total_slices) {
+                        if (cb.c == 0) {
+                            if (has_img) issue_img(cb.t);
+                            if (has_lab_l) issue_lab(cb.t);
+                        }
+                        if (cb.c >= p.nch0) issue_direct(cb);
+                    }
                     step_c(cc);
                     step(ca);
                     step(cb);
@@ -574,23 +573,32 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         if (total_groups > 1) issue_w(1);
         CP_BARRIER();
         int gs = 0, lg = 0;   // global slice counter / group index within the tile of the group being multiplied
+        // Order inside a phase (round 4): every STORE (registers -> LDS) first, every ISSUE (global -> registers) after them, so that a vmcnt wait
+        // before a store can only meet loads that are a whole phase old (the loads sit behind uniform branches; if the compiler cannot count
+        // them it waits with vmcnt(0)).  Measured against the old order (weight loads of group gg + 2 issued before the halo store): 1509 vs
+        // 1506-1514 images/s -- no difference, the hand-over was not exposed; the order is kept because it cannot be the worse one.
+        constexpr bool kStoresFirst = true;
         for (int gg = 0; gg < total_groups; ++gg) {
-            if (gg + 1 < total_groups) {
+            const bool more_w = gg + 1 < total_groups;
+            if (more_w) {
                 store_w((gg + 1) & 1);                             // weight stage read last during group gg - 1
-                if (gg + 2 < total_groups) issue_w(gg + 2);
+                if (!kStoresFirst && gg + 2 < total_groups) issue_w(gg + 2);
             }
+            bool fetch = false;
             if (lg < nslices * GPS && lg % GPS == 0) {             // first group of slice gs
                 if (gs + 1 < total_slices) {
                     store_slice((gs + 1) & 1);                     // halo stage read last during slice gs - 1
                     store_tile_extras();
-                    if (issued < total_slices) {
-                        advance();
-                        issue_tile_extras();
-                        issue_slice(ftile, fc);
-                        ++issued;
-                    }
+                    fetch = issued < total_slices;
                 }
                 ++gs;
+            }
+            if (kStoresFirst && more_w && gg + 2 < total_groups) issue_w(gg + 2);
+            if (fetch) {
+                advance();
+                issue_tile_extras();
+                issue_slice(ftile, fc);
+                ++issued;
             }
             if (++lg == ngroups_tile) lg = 0;
             CP_BARRIER();
