@@ -255,6 +255,17 @@ class TrainConv:
             imap = _index_map(pack_split, hwio, nfl)
             self.split = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes,
                               idx=torch.from_numpy(imap).to(dev))
+        elif planes and k == 7 and cout == 64 and ns == 1 and sources[0][0] == 4 and os.environ.get("CASAPOSE_STEM_SPLIT", "1") != "0":
+            # the stem on the bf16 matrix pipe (csrc/conv_stem_split.hip, round 4): same bookkeeping as the 3x3 layers -- fp32 image of the fragment
+            # stream in the arena (re-gathered with every weight refresh), bf16 planes beside it; the weight gradient stays on the fp32 kernel
+            nfl = lib.cp_conv_stem_split_weight_floats()
+
+            def pack_stem_split(src, dst):
+                check(lib.cp_conv_pack_weights_stem_split_host(src.ctypes.data, 0, sources[0][1], dst.ctypes.data), "pack stem split " + key)
+
+            imap = _index_map(pack_stem_split, hwio, nfl)
+            self.split = dict(f32=store.pack_alloc(imap, off), planes=torch.empty(nfl // 512 * planes * 1024, dtype=torch.uint8, device=dev), np=planes,
+                              idx=torch.from_numpy(imap).to(dev), stem=True)
         # data-gradient packs: per source that needs a gradient, the flipped / transposed kernel
         self.dgrad: List[Optional[dict]] = []
         cpad = (cout + 31) // 32 * 32
@@ -599,7 +610,13 @@ class ConvOp:
                                          st_.data_ptr() + 4 * off, old_, stream), "cp_head1x1_fwd_f32(%s)" % self.layer.name)
             return
         sp = self.layer.split
-        if sp is not None:
+        if sp is not None and sp.get("stem"):
+            if getattr(self, "_stem_fwd", None) is None:   # stride 2 / pad 3 / one 4-channel source: the range of the stem kernels
+                self._stem_fwd = lib.cp_conv_selected_tile(C.byref(self.layer.desc)) == _lib.TILE_STEM
+            if self._stem_fwd:
+                check(lib.cp_conv2d_fwd_stem_split(C.byref(self.layer.desc), sp["planes"].data_ptr(), sp["np"], stream), "cp_conv2d_fwd_stem_split(%s)" % self.layer.name)
+                return
+        elif sp is not None:
             if getattr(self, "_split_fwd", None) is None:
                 self._split_fwd = bool(lib.cp_conv_split_applicable(C.byref(self.layer.desc)))
             if self._split_fwd:
@@ -642,7 +659,7 @@ class ConvOp:
             else:
                 out["f32"] += g
         else:
-            if L.split is not None and lib.cp_conv_split_applicable(C.byref(L.desc)):
+            if L.split is not None and (lib.cp_conv_split_applicable(C.byref(L.desc)) or (L.split.get("stem") and getattr(self, "_stem_fwd", True))):
                 pipe, mult = split_pipe(L.split)
                 out[pipe] += mult * direct
             else:
