@@ -66,8 +66,39 @@ def main():
     p = rng.normal(size=(5, 3))
     out["transform_points"] = {"points": p.tolist(), "M": M.tolist(), "out": np.asarray(gu["transform_points"](p, M)).tolist()}
     out["get_rotation_matrix_2D"] = [{"center": [320.0, 240.0], "angle": a, "M": np.asarray(gu["get_rotation_matrix_2D"]((320.0, 240.0), a)).tolist()} for a in (0, 15, -33)]
+    out["loss_weight_handler"] = loss_weight_golden()
+    rn = extract("casapose/pose_models/models/resnet.py", ["handle_block_names"])       # resnet.py:20-26: the layer-name stems of the residual units
+    out["block_names"] = [[s_, b_] + list(rn["handle_block_names"](s_, b_)) for s_ in range(4) for b_ in range(2)]
     json.dump(out, open(os.path.join(HERE, "geometry_ref.json"), "w"), indent=1)
     print("wrote", os.path.join(HERE, "geometry_ref.json"))
+
+
+
+
+def loss_weight_golden():
+    """LossWeightHandler.__init__ / clamp / update (utils/learning_rate_schedules.py:62-109; plain Python, the class statement itself does not
+    touch TensorFlow): the per-epoch loss-weight schedule, executed for a few constructor calls and update() sequences."""
+    tree = ast.parse(open(os.path.join(REF, "casapose", "utils", "learning_rate_schedules.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LossWeightHandler")
+    cls.body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("__init__", "clamp", "update")]
+    ns = {}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "learning_rate_schedules.py (reference, extracted)", "exec"), ns)
+    H = ns["LossWeightHandler"]
+    cases = [dict(args=[], kw={}, updates=3),
+             dict(args=[1.0, 0.5, 0.015, 0.007], kw={}, updates=2),                                                      # config_8.ini's weights, positional
+             dict(args=[], kw=dict(mask_loss_weight=2.0, mask_loss_factor=1.5, vertex_loss_weight=8.0, vertex_loss_factor=1.2, proxy_loss_weight=0.02,
+                                   proxy_loss_factor=1.3, kp_loss_weight=0.1, kp_loss_factor=0.5, kp_loss_borders=(0.04, 2.5),
+                                   filter_vertex_with_segmentation=True), updates=6),
+             dict(args=[1.0, 1.0, 0.01, 1.0, 0.9, 0.9, 0.9, 0.9, (0.5, 2.5), (0.7, 10.0), (0.009, 0.025), (0.0, 2.5), True, True], kw={}, updates=4)]
+    out = []
+    for c in cases:
+        h = H(*c["args"], **c["kw"])
+        trace = []
+        for _ in range(c["updates"] + 1):
+            trace.append([h.mask_loss_weight, h.vertex_loss_weight, h.proxy_loss_weight, h.kp_loss_weight])
+            h.update()
+        out.append({"args": c["args"], "kw": c["kw"], "trace": trace, "flags": [h.filter_vertex_with_segmentation, h.filter_high_proxy_errors]})
+    return out
 
 
 if __name__ == "__main__":

@@ -48,7 +48,7 @@ def reference_functions():
     assert want <= set(ns)
     tree = ast.parse(open(os.path.join(REF, "casapose", "data_handler", "vectorfield_dataset.py")).read())
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "VectorfieldDataset")
-    want = {"load_json_minimal", "load_json_classes", "load_json_camera", "apply_preprocessing"}
+    want = {"load_json_minimal", "load_json_classes", "load_json_camera", "apply_preprocessing", "load_image_data"}
     mod = ast.Module(body=[n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
     # the one compatibility edit: the reference targets NumPy 1.x, where the dtype alias "unicode_" exists (:485); NumPy 2 spells it "str_"
     for node in ast.walk(mod):
@@ -56,6 +56,18 @@ def reference_functions():
             node.value = "str_"
     exec(compile(mod, "vectorfield_dataset.py (reference, extracted)", "exec"), ns)
     assert want <= set(ns)
+    # file discovery and the train / validation split file: utils/dataset_utils.py load_split (:462-475), write_json_split (:478-493) and the
+    # JSON writer they use, utils/io_utils.py to_json (:9-51) -- plus the names load_image_data takes from its module's imports
+    import glob
+    from itertools import compress
+    from os.path import exists
+
+    ns.update(glob=glob, compress=compress, exists=exists)
+    for path, names in (("casapose/utils/io_utils.py", {"to_json"}), ("casapose/utils/dataset_utils.py", {"load_split", "write_json_split"})):
+        tree = ast.parse(open(os.path.join(REF, path)).read())
+        mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names], type_ignores=[])
+        exec(compile(mod, path + " (reference, extracted)", "exec"), ns)
+        assert names <= set(ns)
     return ns
 
 
@@ -130,6 +142,58 @@ def write_frame(ns):
     return kps
 
 
+def discovery_golden(ns, Ref):
+    """load_image_data (:682-746) on a small tree under tests/golden/ndds_frame/discovery/: two leaf folders; images as .png, .jpg (the reader
+    falls back png -> bmp -> jpg), a seg.png without its .json (skipped), an image without a seg.png (never seen).  Then the same with the
+    TRAIN and the VALIDATION half of a split file that the reference's write_json_split / to_json wrote (copied into the fixture as
+    split_settings_written_by_reference.json: the test installs it as _split_settings.json in a temporary copy of the tree)."""
+    import shutil
+    import tempfile
+
+    from PIL import Image
+
+    root = os.path.join(FRAME_ROOT, "discovery")
+    shutil.rmtree(root, ignore_errors=True)
+    tiny = Image.fromarray(np.zeros((4, 6, 3), np.uint8))
+    seg = Image.fromarray(np.zeros((4, 6), np.uint8))
+    leaves = {"sceneA/000001": ["000000.png", "000001.png", "000002.jpg", "000003.png", "000004.png"], "sceneB": ["000010.jpg", "000011.png"]}
+    for leaf, files in leaves.items():
+        d = os.path.join(root, leaf)
+        os.makedirs(d)
+        shutil.copy(os.path.join(SCENE, "_object_settings.json"), d)
+        shutil.copy(os.path.join(SCENE, "_camera_settings.json"), d)
+        for f in files:
+            stem = f.split(".")[0]
+            tiny.save(os.path.join(d, f))
+            seg.save(os.path.join(d, stem + ".seg.png"))
+            json.dump({"objects": []}, open(os.path.join(d, stem + ".json"), "w"))
+    d = os.path.join(root, "sceneA", "000001")
+    seg.save(os.path.join(d, "000005.seg.png"))                     # no image, no json: skipped
+    tiny.save(os.path.join(d, "000006.png"))                        # no seg.png: never listed
+    seg.save(os.path.join(d, "000007.seg.png"))
+    tiny.save(os.path.join(d, "000007.png"))                        # image + seg but no json: skipped
+    gold = {"root": os.path.relpath(root, HERE)}
+
+    def run(tree, **flags):
+        r = Ref()
+        r.use_train_split, r.use_validation_split, r.train_validation_split = flags.get("train", False), flags.get("val", False), 0.6
+        imgs = []
+        for name in sorted(os.listdir(tree)):                         # load_data (:95-106) walks os.listdir(root); order is the file system's
+            imgs += r.load_image_data(tree + "/" + name)[0]
+        return sorted([os.path.relpath(i[0], tree), i[1], os.path.relpath(i[2], tree), os.path.relpath(i[3], tree), os.path.relpath(i[4], tree)] for i in imgs)
+
+    gold["all"] = run(root)
+    with tempfile.TemporaryDirectory() as tmp:
+        tree = os.path.join(tmp, "d")
+        shutil.copytree(root, tree)
+        np.random.seed(7)
+        gold["train"] = run(tree, train=True)                          # writes _split_settings.json in every leaf (write_json_split)
+        gold["val"] = run(tree, val=True)                              # re-reads them (load_split)
+        for leaf in leaves:
+            shutil.copy(os.path.join(tree, leaf, "_split_settings.json"), os.path.join(root, leaf, "split_settings_written_by_reference.json"))
+    return gold
+
+
 class Reader:
     """the state apply_preprocessing dereferences on `self` (vectorfield_dataset.py:60-130), filled by the reference's own loaders"""
 
@@ -139,7 +203,7 @@ def main():
         sys.exit("needs the reference tree at %s" % REF)
     ns = reference_functions()
     kps = write_frame(ns)
-    Ref = type("RefReader", (Reader,), {n: ns[n] for n in ("load_json_minimal", "load_json_classes", "load_json_camera", "apply_preprocessing")})
+    Ref = type("RefReader", (Reader,), {n: ns[n] for n in ("load_json_minimal", "load_json_classes", "load_json_camera", "apply_preprocessing", "load_image_data")})
     info = json.load(open(os.path.join(HERE, "ref_data", "lm_models_eval", "models_info.json")))
     rng = np.random.default_rng(0)
     out = {"frame": os.path.relpath(SCENE, HERE), "names": NAMES, "cases": [],
@@ -175,6 +239,7 @@ def main():
         minimal = r.load_json_minimal(os.path.join(SCENE, "000017.json"))
         case["load_json_minimal"] = {"objectClasses": minimal["objectClasses"], "px_count_all": minimal["px_count_all"],
                                      "poses_loc": np.asarray(minimal["poses_loc"]).tolist(), "n_keypoints2d": [len(k) for k in minimal["keypoints2d"]]}
+    out["discovery"] = discovery_golden(ns, Ref)
     out["load_json_classes"] = {"labels": labels, "fixed": {k: np.asarray(v).tolist() for k, v in fixed.items()}}
     out["load_json_camera"] = np.asarray(r.camera_data[SCENE]).tolist()
     json.dump(out, open(os.path.join(HERE, "ndds_frame_ref.json"), "w"), indent=1)

@@ -364,3 +364,47 @@ def test_config_parser_matches_the_reference_parser(tmp_path, monkeypatch):
         for k, w in cases[n]["opt"].items():
             w = _unjson(w)
             assert (opt[k] == w).all() if isinstance(w, np.ndarray) else opt[k] == w, (name, k, opt[k], w)
+
+
+def test_loss_weight_handler_equals_the_reference_class():
+    """`LossWeightHandler.__init__` / `clamp` / `update` of the reference (learning_rate_schedules.py:62-109) are plain Python: executed by
+    tests/golden/make_geometry_golden.py (extracted with `ast`), their weight traces over several update() calls -- defaults, config_8.ini's
+    weights passed positionally, growing / shrinking factors hitting both borders, all fourteen positional arguments -- pin this
+    repository's table-driven restatement (same constructor signature, same attributes)."""
+    import json
+    import os
+
+    from casapose_amd.utils.learning_rate_schedules import LossWeightHandler
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry_ref.json")))["loss_weight_handler"]
+    assert len(ref) == 4
+    for c in ref:
+        args = [tuple(a) if isinstance(a, list) else a for a in c["args"]]
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c["kw"].items()}
+        h = LossWeightHandler(*args, **kw)
+        for row in c["trace"]:
+            assert [h.mask_loss_weight, h.vertex_loss_weight, h.proxy_loss_weight, h.kp_loss_weight] == row
+            h.update()
+        assert [h.filter_vertex_with_segmentation, h.filter_high_proxy_errors] == c["flags"]
+
+
+def test_residual_unit_layer_names_equal_the_reference_helper():
+    """`handle_block_names` (resnet.py:20-26, executed by the golden generator) gives the stems the reference appends '1' / '2' to (resnet.py:78-103:
+    bn_name + '1', conv_name + '1', bn_name + '2', conv_name + '2', sc_name): the Keras layer names -- and with them the variable names of a
+    weight file -- that the oracle's parameter dictionary, the HDF5 writer's backbone order and the engines use."""
+    import json
+    import os
+
+    import casapose_oracle as O
+    from casapose_amd.utils import h5_weights as H
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry_ref.json")))["block_names"]
+    convs = {n for n, _, _, _ in O.encoder_conv_specs()}
+    bns = {n for n, _, _ in O.encoder_bn_specs()}
+    order = H.keras_backbone_layer_order()
+    for stage, block, conv_name, bn_name, relu_name, sc_name in ref:
+        assert conv_name + "1" in convs and conv_name + "2" in convs and bn_name + "1" in bns and bn_name + "2" in bns
+        assert (sc_name in convs) == (block == 0)                      # the 1x1 shortcut exists in the first unit of a stage only (cut = 'post')
+        i = order.index(bn_name + "1")
+        assert order[i:i + 4] == [bn_name + "1", conv_name + "1", bn_name + "2", conv_name + "2"]
+    assert len(convs) == 1 + 4 * (2 * 2 + 1) and len(ref) == 8

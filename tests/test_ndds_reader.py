@@ -242,3 +242,35 @@ def test_frame_reader_equals_the_reference_reader_code(tmp_path):
     for n, m in ref["load_json_classes"]["fixed"].items():
         assert np.allclose(ds.fixed_transformations[path][n], m)
     assert np.allclose(ds.camera_data[path], ref["load_json_camera"])
+
+
+def test_file_discovery_and_split_files_equal_the_reference_code(tmp_path):
+    """`load_image_data` (vectorfield_dataset.py:682-746), `load_split` / `write_json_split` (dataset_utils.py:462-493) and `to_json`
+    (io_utils.py:9-51), executed by tests/golden/make_ndds_frame_golden.py on the tree tests/golden/ndds_frame/discovery: which frames are
+    found (png -> bmp -> jpg fall-back, a frame needs image + seg.png + json, leaf folders only), the five fields stored per frame, and which
+    of them the TRAIN and the VALIDATION side of a split file select -- with split files the reference's own writer produced (the split
+    applies to the sorted `*seg.png` list BEFORE the existence checks, so a skipped frame still consumes a split entry)."""
+    import json
+    import os
+    import shutil
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(G, "ndds_frame_ref.json")))["discovery"]
+    tree = str(tmp_path / "d")
+    shutil.copytree(os.path.join(G, gold["root"]), tree)
+    meshes = _frame_meshes(tmp_path)
+
+    def found(**kw):
+        ds = VectorfieldDataset(tree, meshes, objectsofinterest=["obj_000001"], random_crop=False, **kw)
+        return sorted([os.path.relpath(i[0], tree), i[1], os.path.relpath(i[2], tree), os.path.relpath(i[3], tree), os.path.relpath(i[4], tree)] for i in ds.imgs)
+
+    assert found() == gold["all"] and len(gold["all"]) == 7
+    for leaf in ("sceneA/000001", "sceneB"):   # install the split files written by the reference's write_json_split / to_json
+        shutil.move(os.path.join(tree, leaf, "split_settings_written_by_reference.json"), os.path.join(tree, leaf, "_split_settings.json"))
+    assert found(use_train_split=True, train_validation_split=0.6) == gold["train"]
+    assert found(use_validation_split=True, train_validation_split=0.6) == gold["val"]
+    assert sorted(gold["train"] + gold["val"]) == gold["all"]
+    # another ratio than the stored one: a new split is drawn and stored (load_split :467-471); sizes follow int(n * ratio)
+    n_train = len(found(use_train_split=True, train_validation_split=0.5))
+    stored = json.load(open(os.path.join(tree, "sceneA/000001", "_split_settings.json")))["split"][0]
+    assert stored["ratio"] == 0.5 and sum(stored["values"]) == int(7 * 0.5) and len(stored["values"]) == 7 and 0 < n_train <= 4
