@@ -68,6 +68,11 @@ def main():
     out["get_rotation_matrix_2D"] = [{"center": [320.0, 240.0], "angle": a, "M": np.asarray(gu["get_rotation_matrix_2D"]((320.0, 240.0), a)).tolist()} for a in (0, 15, -33)]
     out["loss_weight_handler"] = loss_weight_golden()
     rn = extract("casapose/pose_models/models/resnet.py", ["handle_block_names"])       # resnet.py:20-26: the layer-name stems of the residual units
+    # the model registry (pose_models/models_factory.py:9-35): the KEYS and the class each key names, read off the dict literal's syntax tree
+    # (its values are attribute references into TensorFlow modules and cannot be evaluated here)
+    tree = ast.parse(open(os.path.join(REF, "casapose", "pose_models", "models_factory.py")).read())
+    reg = next(n for n in ast.walk(tree) if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "_models")
+    out["registry"] = [[k.value, v.attr] for k, v in zip(reg.value.keys, reg.value.values)]
     out["block_names"] = [[s_, b_] + list(rn["handle_block_names"](s_, b_)) for s_ in range(4) for b_ in range(2)]
     json.dump(out, open(os.path.join(HERE, "geometry_ref.json"), "w"), indent=1)
     print("wrote", os.path.join(HERE, "geometry_ref.json"))

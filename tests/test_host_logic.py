@@ -408,3 +408,21 @@ def test_residual_unit_layer_names_equal_the_reference_helper():
         i = order.index(bn_name + "1")
         assert order[i:i + 4] == [bn_name + "1", conv_name + "1", bn_name + "2", conv_name + "2"]
     assert len(convs) == 1 + 4 * (2 * 2 + 1) and len(ref) == 8
+
+
+def test_model_registry_equals_the_reference_registry():
+    """The keys of `ModelsFactory._models` and the class each key names (pose_models/models_factory.py:9-35, read off the dict literal's syntax
+    tree by the golden generator) against this repository's registry: same 18 names in the same order, each bound to a callable of the same
+    name (`Classifiers.get(name)` is the drop-in entry the reference's scripts use, tfkeras.py:6-17)."""
+    import json
+    import os
+
+    from casapose_amd.pose_models.models_factory import ModelsFactory
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry_ref.json")))["registry"]
+    mine = ModelsFactory()
+    assert mine.models_names() == [k for k, _ in ref] and len(ref) == 18
+    for key, cls_name in ref:
+        assert mine.models[key].__name__ == cls_name, (key, mine.models[key].__name__, cls_name)
+    with pytest.raises(ValueError, match="No such model"):
+        mine.get("casapose_does_not_exist")
