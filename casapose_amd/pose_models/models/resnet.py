@@ -91,7 +91,7 @@ def _deeper(name):
         raise NotImplementedError("model `%s` is registered by the reference (resnet.py:335-343) but no model of the pose-estimation path uses it; "
                                   "only resnet18 is built for MI355X" % name)
 
-    ctor.__name__ = name
+    ctor.__name__ = name.replace("resnet", "ResNet")   # the reference's function names (resnet.py:386-431)
     return ctor
 
 
