@@ -111,7 +111,15 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     if (producer) {
-        const int col4 = tid & 7, rbase = tid >> 3;  // 32 rows x 8 float4 per pass, four passes per operand
+        // 32 rows x 8 float4 per pass, four passes per operand.  A 16-lane group of a ds_write_b64 covers two rows: with consecutive rows (stride 80 B
+        // = 20 banks) their 16-dword spans overlap on four banks (SQ_LDS_BANK_CONFLICT = one extra cycle per store, profiles/r04_pmc_gemm_isolated.txt);
+        // rows r and r + 4 (80 dwords apart = 16 banks) do not: the eight row slots of a wave take rows 0, 4, 1, 5, 2, 6, 3, 7
+        const int col4 = tid & 7;
+#ifdef WS_ROWS_CONSECUTIVE
+        const int rbase = tid >> 3;
+#else
+        const int rslot = tid >> 3, rbase = (rslot & ~7) | (((rslot & 7) >> 1) + 4 * (rslot & 1));
+#endif
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
         float4 areg[4];
         unsigned aoff[4];
