@@ -25,12 +25,15 @@ TILE_NAMES = {1: "conv_f32_kernel<2,2,2,2> (128x128)", 2: "conv_f32_kernel<2,2,1
               7: "conv_halo_kernel (LDS-resident 4-row halo tile, cout <= 64)",
               8: "conv_stem_kernel (7x7/s2 stem, LDS-resident input halo)",
               100: "wino_gemm_kernel (persistent 64x64 grouped GEMM of the Winograd planes)",
-              103: "wino_gemm_split_kernel (bf16 pipe, exact three-way split of the Winograd planes' GEMM; FLOPs counted as executed bf16 FLOPs)",
+              103: "wino_gemm_split_kernel (bf16 / fp16 pipe: the Winograd planes' GEMM as exact three-way bf16 splits or fp16 two-way splits; FLOPs counted as executed 2-byte FLOPs)",
               203: "conv_hsplit_kernel<3> (bf16 pipe, exact three-way split: six bf16 products per fp32 product; FLOPs counted as executed bf16 FLOPs)",
+              218: "conv_hsplit_kernel<2> (fp16 pipe, two-way split: three fp16 products per fp32 product; FLOPs counted as executed fp16 FLOPs)",
               201: "conv_hsplit_kernel<1> (bf16 pipe, operands rounded to bf16)",
               301: "conv_bf16d_kernel (bf16 pipe, direct 3x3 of the deep layers, operands rounded to bf16)",
               208: "conv_stem_split_kernel (bf16 pipe, the 7x7/s2 stem as exact three-way splits or bf16 operands)"}
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16; v_mfma_f32_32x32x16_f16 has the same rate)
+# executed 2-byte products per fp32 product by `planes` code: exact bf16 split, hi + mid bf16 planes, fp16 two-way split (CP_PLANES_F16X2), bf16 operands
+PRODUCTS = {3: 6.0, 2: 3.0, 0x12: 3.0, 1: 1.0}
 
 
 def _log(msg):
@@ -72,7 +75,7 @@ def _median_rate(fn, images, warmup=3, timed=10, budget_s=12.0):
     return images / ts[len(ts) // 2], len(ts)
 
 
-def cpu_baseline(h, w, seg_dim, ver_dim, batch):
+def cpu_baseline(h, w, seg_dim, ver_dim, batch, accuracy=None):
     """CPU restatement (PyTorch-CPU, oneDNN), NOT TensorFlow: the reference's TF-CPU path cannot run here, so the
     number beside the GPU is the oracle's torch restatement of the same inference graph (oracle/torch_train_ref.forward_train with
     training=False and the estimated mask) in fp32 on all host cores, as BASELINE.md 3 / SURVEY 8(d) prescribe: warm-up, then the
@@ -143,7 +146,22 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
         _log("cpu baseline: bs %d forward %.3f images/s, with voting %.3f" % (bs, fwd, both))
         legs["bs%d" % bs] = {"forward_images_per_s": round(fwd, 3), "forward_plus_filter_plus_ls_images_per_s": round(both, 3), "timed_iterations": [n1, n2]}
     best = max(v["forward_plus_filter_plus_ls_images_per_s"] for v in legs.values())
-    return {"value": round(best, 3), "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
+    acc = None
+    if accuracy and accuracy["logits"]:
+        # the checker's other job in this leg: ONE image of the bench batch through the same network (the bench's parameters) in fp64 on the CPU;
+        # the segmentation logits of every arithmetic the GPU ran in this line against it (max |difference| / max |logit|).  Logits only: the
+        # vector fields are conditioned on the arg-max label map, which random weights put on ties.
+        t0 = time.perf_counter()
+        p64 = R.to_torch({k: np.asarray(v) for k, v in accuracy["params"].items()}, dtype=torch.float64, requires_grad=False)
+        with torch.no_grad():
+            ref = R.forward_infer_fast(R.prepare_inference(p64), torch.from_numpy(accuracy["image"]).double())[..., :seg_dim].numpy()
+        den = float(np.abs(ref).max())
+        acc = {"what": "max |segmentation logit - fp64 logit| / max |fp64 logit| for image 0 of the bench batch, per convolution arithmetic run in this line "
+                       "(fp64 = the CPU restatement in double precision with the bench's parameters)",
+               "per_conv_mode": {m: float("%.3g" % (float(np.abs(v.astype(np.float64) - ref).max()) / den)) for m, v in accuracy["logits"].items()},
+               "seconds": round(time.perf_counter() - t0, 1)}
+        _log("cpu baseline: fp64 accuracy check %s" % acc["per_conv_mode"])
+    return {"value": round(best, 3), "accuracy_vs_fp64": acc, "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
             "what": "CPU restatement (PyTorch-CPU fp32, oneDNN, %d threads), not TensorFlow" % threads, "cpu": _cpu_model_name(),
             "thread_probe_s_per_image": {str(k): round(v, 3) for k, v in timing.items()},
             "sample": "%dx%d, %s: warm-up + median of <= 10 timed iterations per leg (time-boxed); value = best forward + "
@@ -152,7 +170,7 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch):
 
 TILE_PMC_PREFIX = {1: "conv_f32_kernel<2, 2, 2, 2,", 2: "conv_f32_kernel<2, 2, 1, 2,", 3: "conv_f32_kernel<2, 2, 2, 1,", 4: "conv_f32_kernel<4, 1, 1, 1,",
                    5: "conv_f32_kernel<2, 2, 1, 1,", 6: "conv_f32_kernel<4, 1, 2, 1,", 7: "conv_halo_kernel<", 8: "conv_stem_kernel", 100: "wino_gemm_kernel",
-                   203: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel", 301: "conv_bf16d_kernel<", 208: "conv_stem_split_kernel<"}
+                   203: "conv_hsplit_kernel<", 218: "conv_hsplit_kernel<", 201: "conv_hsplit_kernel<", 103: "wino_gemm_split_kernel", 301: "conv_bf16d_kernel<", 208: "conv_stem_split_kernel<"}
 
 
 def binary_stamp():
@@ -264,6 +282,11 @@ def _dtype_note():
     wino = os.environ.get("CASAPOSE_WINO_GEMM", "")
     if mode == "bf16":
         return "bf16 operands / f32 accumulate in the 3x3 layers off the Winograd path, Winograd GEMMs on hi + mid bf16 planes, f32 elsewhere (NOT fp32-equivalent)"
+    if mode == "f16x2":
+        return ("f32 (fp32-level: every fp32 operand as an fp16 pair hi = rn(x), lo = rn(x - hi) -- reproduced to 2^-24 -- and the three products hi*hi, hi*lo, lo*hi, "
+                "each exact, accumulated in fp32 on v_mfma_f32_32x32x16_f16; weights pre-scaled by a power of two; measured error against fp64 at or below the fp32 "
+                "MFMA's (tests/test_gpu_f16x2.py, `accuracy_vs_fp64` in this line); for the 3x3 / stride-1 layers, the 7x7 stem%s; strided 3x3 / 1x1 layers on "
+                "v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))
     if mode == "split":
         return ("f32 (fp32-equivalent: exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16, six exact products per fp32 product, fp32 accumulate, for the 3x3 / "
                 "stride-1 layers, the 7x7 stem%s; strided 3x3 / 1x1 layers on v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))
@@ -662,7 +685,7 @@ def main():
                 gemm_ms = timed(lambda: conv.run_gemm(stream))
                 whole_ms = timed(lambda: conv.run(stream))
                 t["ms"] += gemm_ms
-                t["flops"] += conv.gemm_flops * ((3.0 if getattr(conv, "planes", 3) == 2 else 6.0) if pipe == 3 else 1.0)
+                t["flops"] += conv.gemm_flops * (PRODUCTS[getattr(conv, "planes", 3)] if pipe == 3 else 1.0)
                 t["launches"] += 1
                 t["bytes"] += 4.0 * (36.0 * conv.Tp * (conv.ktot + conv.cout) + conv.U.numel())
                 wino["layers"] += 1
@@ -672,11 +695,11 @@ def main():
                 continue
             if gemm1x1 is not None:
                 t["ms"] += timed(lambda: conv.run(stream))
-                t["flops"] += conv.flops * (6.0 if gemm1x1["planes"] == 3 else 3.0)
+                t["flops"] += conv.flops * PRODUCTS[gemm1x1["planes"]]
                 t["launches"] += 1
                 continue
             t["ms"] += timed(lambda: conv.run(stream))
-            t["flops"] += conv.flops * (6.0 if pipe == 3 else 1.0)   # the exact split executes six bf16 products per fp32 product
+            t["flops"] += conv.flops * PRODUCTS.get(pipe, 1.0)   # the exact split executes six bf16 products per fp32 product, the fp16 split three
             t["launches"] += 1
             # algorithmic HBM bytes: every operand once (sources at their stored resolution, packed weights, outputs)
             byt = 4.0 * (conv.wp.numel() if conv.wp is not None else 0)
@@ -706,8 +729,8 @@ def main():
         return {
             "bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": round(weighted * peak, 3), "frac": round(weighted, 4),
             "frac_definition": "time-weighted mean over all convolution time (incl. the Winograd transform passes, which execute no FLOPs) of each kernel "
-                               "family's EXECUTED FLOP rate / the dense peak of the matrix pipe it runs on (fp32 MFMA %.1f, bf16 MFMA %.0f TFLOP/s; an exact "
-                               "three-way split executes six bf16 FLOPs per fp32 FLOP); `achieved` = frac x `peak` of the pipe that holds most of the time (%s)"
+                               "family's EXECUTED FLOP rate / the dense peak of the matrix pipe it runs on (fp32 MFMA %.1f, bf16 / fp16 MFMA %.0f TFLOP/s; an exact "
+                               "three-way bf16 split executes six 2-byte FLOPs per fp32 FLOP, the fp16 two-way split three); `achieved` = frac x `peak` of the pipe that holds most of the time (%s)"
                                % (PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS, main_pipe),
             "kernel": "all convolution launches of the forward (conv_hsplit / wino_gemm_split / conv_halo / wino_gemm / conv_f32 / conv_stem kernels + Winograd transform passes)",
             "per_pipe": pipes, "winograd_transform_ms_per_step": round(transform_ms, 3),
@@ -718,8 +741,10 @@ def main():
             # image) over the same convolution time, against the rate at which the bf16 pipe could deliver fp32-equivalent products at best
             # (dense bf16 peak / 6 products)
             "useful_tflops": round(direct_flops / (conv_ms * 1e-3) / 1e12, 2),
-            "useful_frac_of_fp32_equiv_peak": round(direct_flops / (conv_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
-            "fp32_equiv_peak": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
+            # (dense 2-byte peak / products per fp32 product of this conv mode: 6 for the exact bf16 split, 3 for the fp16 two-way split)
+            "useful_frac_of_fp32_equiv_peak": round(direct_flops / (conv_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / PRODUCTS.get(net_._net.conv_planes, 6.0)), 4),
+            "fp32_equiv_peak": round(PEAK_BF16_MFMA_TFLOPS / PRODUCTS.get(net_._net.conv_planes, 6.0), 1),
+            "products_per_fp32_product": PRODUCTS.get(net_._net.conv_planes, 1.0),
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_unit": "bytes per launch of the dominant family, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the COMMITTED profile profiles/r0N_pmc_traffic.json "
                             "(separate rocprofv3 --pmc passes of this command, tools/profile_round.sh), not measured by this run",
@@ -742,36 +767,50 @@ def main():
         except Exception as exc:  # the probe is an annotation: never fail the bench line over it
             result["roofline"]["sustained_on_this_box"] = {"error": str(exc)}
     _log("roofline section done")
-    if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode == "split":
-        # the same workload on the fp32 MFMA everywhere (conv_mode="f32": v_mfma_f32_32x32x2_f32 in every convolution, the round-1/2 headline) --
-        # measured in the same run and reported BESIDE the headline with its own roofline, so that the two arithmetic routes can be compared
+    accuracy = {"params": params, "image": img[:1].cpu().numpy(), "logits": {}} if rank == 0 else None
+    if rank == 0:
+        accuracy["logits"][net._net.conv_mode] = net([img[:1]], training=False)[..., :seg_dim].cpu().numpy()
+    if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode in ("split", "f16x2"):
+        # the same workload in the other fp32 arithmetics, measured in the same run and reported BESIDE the headline, each with its own roofline:
+        # conv_mode="f32" (v_mfma_f32_32x32x2_f32 in every convolution, the round-1/2 headline) and -- when the headline is the fp16 two-way split --
+        # conv_mode="split" (exact three-way bf16 splits, the round-3 / early round-4 headline).  Their logits for one image go to the CPU leg,
+        # which compares every mode with an fp64 evaluation of the same network (`accuracy_vs_fp64`).
         ref_logits = net([img], training=False)[..., :seg_dim].clone()
+        headline_mode = net._net.conv_mode
         net = None
         torch.cuda.empty_cache()
-        net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None, base_model="resnet18", device=dev,
-                                                  seed=1237, conv_mode="f32")
-        net2.set_parameters(params)
+        for other, key, what in (("f32", "exact_fp32_mfma", "CASAPOSE_INFER_CONV_MODE=f32: every convolution on v_mfma_f32_32x32x2_f32 (the headline of rounds 1 and 2); NOT this round's headline"),
+                                 ("split", "exact_bf16_split", "CASAPOSE_INFER_CONV_MODE=split: exact three-way bf16 splits, six products per fp32 product (the headline of round 3); NOT this round's headline")):
+            if other == headline_mode:
+                continue
+            net2 = Classifiers.get("casapose_c_gcu5")(ver_dim=ver_dim, seg_dim=seg_dim, input_shape=(H, W, 3), weights=None, base_model="resnet18", device=dev,
+                                                      seed=1237, conv_mode=other)
+            net2.set_parameters(params)
 
-        def step2():
-            out = net2([img], training=False)
-            s_, d_, c_ = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
-            return voter([s_, d_, c_])
+            def step2():
+                out = net2([img], training=False)
+                s_, d_, c_ = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
+                return voter([s_, d_, c_])
 
-        for _ in range(args.warmup):
-            step2()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step2()
-        torch.cuda.synchronize(dev)
-        dt2 = time.perf_counter() - t1
-        result["exact_fp32_mfma"] = {
-            "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
-            # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)
-            "max_logit_difference_vs_headline_rel": float("%.3g" % float((net2([img], training=False)[..., :seg_dim] - ref_logits).abs().max() / ref_logits.abs().max())),
-            "what": "CASAPOSE_INFER_CONV_MODE=f32: every convolution on v_mfma_f32_32x32x2_f32 (the headline of rounds 1 and 2); NOT this round's headline",
-            "roofline": conv_roofline(net2) if not args.no_roofline else None}
-        _log("fp32-MFMA line done: %.3f ms/step" % (1e3 * dt2 / args.steps))
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step2()
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t1
+            accuracy["logits"][other] = net2([img[:1]], training=False)[..., :seg_dim].cpu().numpy()
+            result[key] = {
+                "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
+                # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)
+                "max_logit_difference_vs_headline_rel": float("%.3g" % float((net2([img], training=False)[..., :seg_dim] - ref_logits).abs().max() / ref_logits.abs().max())),
+                "what": what,
+                "roofline": conv_roofline(net2) if not args.no_roofline else None}
+            _log("%s line done: %.3f ms/step" % (key, 1e3 * dt2 / args.steps))
+            net2 = None
+            torch.cuda.empty_cache()
+        del ref_logits
     if not args.no_train_leg:
         # BASELINE configs[2] / [3] beside the headline, under the driver's clock: 3 training steps (1 warm-up) at the --mode train defaults.
         # With N > 1 ranks this is the DATA-PARALLEL step -- every rank trains on its own 32 images, SyncBN tables and the four gradient buckets
@@ -825,7 +864,7 @@ def main():
         dog.cancel()
     result["binary"] = binary_stamp()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B)
+        result["cpu_baseline"] = cpu_baseline(H, W, seg_dim, ver_dim, B, accuracy)
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():

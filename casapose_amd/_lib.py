@@ -86,12 +86,13 @@ class ConvDesc(C.Structure):
 
 
 ABI_VERSION = 300  # CP_ABI_VERSION of include/casapose_hip.h
+PLANES_F16X2 = 0x12  # CP_PLANES_F16X2: the fp16 two-way split (three products, fp32-level accuracy)
 
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_256x32, TILE_HALO, TILE_STEM = range(9)
 # host-side selectors (never passed to the library): the bf16-pipe kernel of csrc/conv_hsplit.hip with 3 planes (exact fp32 split) / 1 plane (bf16)
-TILE_SPLIT3, TILE_BF16 = 100, 101
+TILE_SPLIT3, TILE_BF16, TILE_F16X2 = 100, 101, 102
 
 # every symbol include/casapose_hip.h declares: (name, restype, argtypes)
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -120,6 +121,8 @@ SYMBOLS = [
     ("cp_conv_split_weights_f32", _i, [_vp, _ll, _i, _vp, _vp]),
     ("cp_conv_pack_head_split_host", _i, [_vp, _i, _vp]),
     ("cp_conv2d_fwd_split", _i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp]),
+    ("cp_conv_split_weights_scaled_f32", _i, [_vp, _ll, _i, C.c_float, _vp, _vp]),
+    ("cp_conv2d_fwd_split_scaled", _i, [C.POINTER(ConvDesc), _vp, _vp, _i, C.c_float, C.c_float, _vp]),
     ("cp_conv_bf16_deep_applicable", _i, [C.POINTER(ConvDesc)]),
     ("cp_conv2d_fwd_bf16_deep", _i, [C.POINTER(ConvDesc), _vp, _vp]),
     ("cp_pad_channels_3to4", _i, [_vp, _vp, _ll, _vp]),
@@ -145,6 +148,9 @@ SYMBOLS = [
     ("cp_wino_gemm_split_planes_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_split_weights_bytes", C.c_size_t, [_i, _i, _i]),
     ("cp_wino_split_weights_f32", _i, [_vp, _i, _i, _i, _vp, _vp]),
+    ("cp_f16x2_weight_scale", C.c_float, [C.c_float]),
+    ("cp_wino_split_weights_scaled_f32", _i, [_vp, _i, _i, _i, _i, C.c_float, _vp, _vp]),
+    ("cp_wino_gemm_split_scaled_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _vp]),
     ("cp_wino_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     ("cp_wino_transform_weights_f32", _i, [_vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),
     ("cp_wino_dy_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -156,6 +162,7 @@ SYMBOLS = [
     ("cp_conv_stem_split_weight_floats", _i, []),
     ("cp_conv_pack_weights_stem_split_host", _i, [_vp, _i, _i, _vp]),
     ("cp_conv2d_fwd_stem_split", _i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
+    ("cp_conv2d_fwd_stem_split_scaled", _i, [C.POINTER(ConvDesc), _vp, _i, C.c_float, _vp]),
     ("cp_wino_output_input_applicable", _i, [_i, _i, _i, _i, _i]),
     ("cp_wino_output_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_stats_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),

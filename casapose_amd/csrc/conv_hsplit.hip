@@ -2,6 +2,9 @@
 //   NP = 3  fp32-EQUIVALENT: every fp32 operand is split exactly into three bf16 terms (hi, mid, lo: 8 + 8 + 8 significand bits) and the
 //           six products lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (the scheme of
 //           wino_gemm_split.hip; the three dropped products are <= 2^-24 of the full product -- the rounding an fp32 multiply makes anyway);
+//   NP = 2  fp32-LEVEL with half the MFMAs: the fp16 two-way split of split_f16.h (hi = rn_f16(x), lo = rn_f16(x - hi): the operand to 2^-24;
+//           products lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16).  The weights arrive multiplied by a power of two (their low parts stay
+//           normal numbers); the epilogue multiplies the accumulators by its inverse (HSplitK::descale, exact).
 //   NP = 1  plain bf16 operands (round to nearest even), fp32 accumulation -- "bf16 convolutions" of BASELINE.json configs[2].
 // Activations and outputs stay fp32 in HBM; the split / conversion happens once per staged halo pixel.
 //
@@ -18,8 +21,10 @@
 // Accumulators are transposed as in conv_halo.hip (MFMA A = weights, B = pixels): lane = pixel, so the partial-conv tap mask, 9/count,
 // the CLADE table row, residual and stores are per lane with four consecutive channels in four consecutive registers.
 #include "common.h"
+#include "split_f16.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -75,6 +80,7 @@ struct HSplitK {
     int head_cout, head_ld;
     uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
     int head_lab_classes;
+    float descale, head_descale;   // NP = 2: 1 / (power of two the conv / head weights were multiplied by); 1 otherwise
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -110,8 +116,40 @@ __device__ __forceinline__ uint2 round4(const float4 v) {
     return make_uint2(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]));
 }
 
+// planes of one float4 at `dst`, `dst + stride`, ...: the exact bf16 split (3), the fp16 two-way split (2) or rounded bf16 (1)
 template <int NP>
-__global__ void hsplit_weights_kernel(const float* __restrict__ src, long long nfrag, unsigned char* __restrict__ dst) {
+__device__ __forceinline__ void store_planes(unsigned char* dst, unsigned stride, const float4 val) {
+    if constexpr (NP == 3) {
+        uint2 a, b, c;
+        split4(val, a, b, c);
+        *reinterpret_cast<uint2*>(dst) = a;
+        *reinterpret_cast<uint2*>(dst + stride) = b;
+        *reinterpret_cast<uint2*>(dst + 2 * stride) = c;
+    } else if constexpr (NP == 2) {
+        uint2 a, b;
+        cp::split4h(val, a, b);
+        *reinterpret_cast<uint2*>(dst) = a;
+        *reinterpret_cast<uint2*>(dst + stride) = b;
+    } else {
+        *reinterpret_cast<uint2*>(dst) = round4(val);
+    }
+}
+
+// (weight plane, pixel plane) of product t, smallest terms first.  NP = 3: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; NP = 2: lo*hi, hi*lo, hi*hi
+template <int NP> __device__ __forceinline__ constexpr int prod_w(int t) {
+    return NP == 1 ? 0 : NP == 2 ? (t == 0 ? 1 : 0) : ((t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0);
+}
+template <int NP> __device__ __forceinline__ constexpr int prod_p(int t) {
+    return NP == 1 ? 0 : NP == 2 ? (t == 1 ? 1 : 0) : ((t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0);
+}
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_np(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, a), __builtin_bit_cast(cp::f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NP>
+__global__ void hsplit_weights_kernel(const float* __restrict__ src, long long nfrag, float scale, unsigned char* __restrict__ dst) {
     // src: [fragment][64 lanes][8 floats] -> dst: [fragment][plane][64 lanes][8 bf16]
     const long long total = nfrag * 64;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -126,6 +164,12 @@ __global__ void hsplit_weights_kernel(const float* __restrict__ src, long long n
             *reinterpret_cast<uint4*>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             *reinterpret_cast<uint4*>(d + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
             *reinterpret_cast<uint4*>(d + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else if constexpr (NP == 2) {
+            uint2 h0, l0, h1, l1;
+            cp::split4h(make_float4(v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale), h0, l0);
+            cp::split4h(make_float4(v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale), h1, l1);
+            *reinterpret_cast<uint4*>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(d + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         } else {
             const uint2 a = round4(v0), b = round4(v1);
             *reinterpret_cast<uint4*>(d) = make_uint4(a.x, a.y, b.x, b.y);
@@ -148,7 +192,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr bool SEL = (MODE & HS_SEL) != 0;             // source 0 is read at half resolution through the guided-upsampling selection map
     constexpr int NV = 1;   // (round 3 fetched the four bilinear taps of source 0 from global memory: NV = 4; now a low-resolution tile is staged in LDS)
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int NPROD = (NP == 3) ? 6 : 1;
+    static_assert(NP == 1 || NP == 2 || NP == 3, "1 = bf16, 2 = fp16 two-way split, 3 = exact bf16 split");
+    constexpr int NPROD = (NP == 3) ? 6 : (NP == 2) ? 3 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
     constexpr int GT = (TN == 1) ? 9 : (TN == 2) ? 3 : 1;   // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice),
                                                             // a third of it for the 64-channel ones, one tap for 128 channels per pass (LDS budget)
@@ -211,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     const int ngroups_tile = nslices * GPS + (has_img ? 1 : 0);   // weight groups per tile: GPS per slice + the image block
     const int total_groups = my_tiles * ngroups_tile;
 
+    if constexpr (NP == 2) cp::f16_overflow_clamps();
     if (loader) {
         // ------------------------------------------------------------------ loaders ------------------------------------------------------
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
@@ -289,16 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (e_hy[it] >= 0x4000) continue;
-                float4 val = lv[it][0];
-                if constexpr (NP == 3) {
-                    uint2 a, b, c;
-                    split4(val, a, b, c);
-                    *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
-                    *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
-                    *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
-                } else {
-                    *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(val);
-                }
+                store_planes<NP>(h + e_lds[it], PLANE_B, lv[it][0]);
             }
         };
         auto issue_img = [&](const TilePos& tp) {
@@ -316,15 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             for (int it = 0; it < NIMG; ++it) {
                 const int pix = it * 256 + tid;
                 if (pix >= HP) continue;
-                if constexpr (NP == 3) {
-                    uint2 a, b, c;
-                    split4(liv[it], a, b, c);
-                    *reinterpret_cast<uint2*>(h + pix * 8) = a;
-                    *reinterpret_cast<uint2*>(h + IPLANE_B + pix * 8) = b;
-                    *reinterpret_cast<uint2*>(h + 2 * IPLANE_B + pix * 8) = c;
-                } else {
-                    *reinterpret_cast<uint2*>(h + pix * 8) = round4(liv[it]);
-                }
+                store_planes<NP>(h + pix * 8, IPLANE_B, liv[it]);
             }
         };
         const bool has_lab_l = PARTIAL || p.clade;
@@ -468,15 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     val.z = (v00.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
                     val.w = (v00.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
                     if (!inb) val = make_float4(0.f, 0.f, 0.f, 0.f);   // the convolution's zero padding is applied to the UPSAMPLED map
-                    if constexpr (NP == 3) {
-                        uint2 a, b, c;
-                        split4(val, a, b, c);
-                        *reinterpret_cast<uint2*>(h + e_lds[it]) = a;
-                        *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[it]) = b;
-                        *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[it]) = c;
-                    } else {
-                        *reinterpret_cast<uint2*>(h + e_lds[it]) = round4(val);
-                    }
+                    store_planes<NP>(h + e_lds[it], PLANE_B, val);
                 }
             };
             auto issue_direct = [&](const Cur& u) {
@@ -664,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
             float f = 1.f;
             if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
+            if constexpr (NP == 2) f *= p.descale;   // the weights' power-of-two scale, undone exactly
             float4 keep[4];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -734,6 +756,12 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                             px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
                             px[1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
                             px[2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                        } else if constexpr (NP == 2) {
+                            uint2 h0, l0, h1, l1;
+                            cp::split4h(keep[2 * m], h0, l0);
+                            cp::split4h(keep[2 * m + 1], h1, l1);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
                         } else {
                             const uint2 a = round4(keep[2 * m]), b = round4(keep[2 * m + 1]);
                             px[0] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
@@ -743,10 +771,12 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         for (int sidx = 0; sidx < NP; ++sidx) hw[sidx] = *reinterpret_cast<const bf16x8*>(hwl + (unsigned)(m * NP + sidx) * 1024u + wlane);
 #pragma unroll
                         for (int t6 = 0; t6 < NPROD; ++t6) {
-                            const int sw = (NP == 1) ? 0 : ((t6 == 0) ? 2 : (t6 == 1) ? 0 : (t6 == 2) ? 1 : (t6 == 3) ? 1 : 0);
-                            const int sp = (NP == 1) ? 0 : ((t6 == 0) ? 0 : (t6 == 1) ? 2 : (t6 == 2) ? 1 : (t6 == 3) ? 0 : (t6 == 4) ? 1 : 0);
-                            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw[sw], px[sp], a2, 0, 0, 0);
+                            a2 = mfma_np<NP>(hw[prod_w<NP>(t6)], px[prod_p<NP>(t6)], a2);
                         }
+                    }
+                    if constexpr (NP == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) a2[e] *= p.head_descale;
                     }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -773,11 +803,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     auto mfma_sub = [&](int aslot, int wslot, int j) {
 #pragma unroll
         for (int t = 0; t < NPROD; ++t) {
-            // (weight plane, pixel plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-            const int sw = (NP == 1) ? 0 : ((t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0);
-            const int sp = (NP == 1) ? 0 : ((t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[wslot][sw], fa[aslot][r][sp], acc[r][j], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) acc[r][j] = mfma_np<NP>(fw[wslot][prod_w<NP>(t)], fa[aslot][r][prod_p<NP>(t)], acc[r][j]);
         }
     };
 
@@ -839,6 +866,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                             if constexpr (R2 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R2, 0);
                             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if constexpr (NP == 2) {
+                            // 2 x 3 MFMAs: the next sub-step's / tap's reads between the first and the second pair
+                            constexpr int NR = (sub + 1 < GSUB ? NP : 0) + ((FAS == 2 && j == 0 && st + 1 < GT) ? 2 * NP : 0);
+                            constexpr int R0 = (NR + 1) / 2, R1 = NR - R0;
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if constexpr (R0 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R0, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if constexpr (R1 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
 #endif
@@ -969,7 +1006,7 @@ extern "C" int cp_conv_split_weight_floats(int cout, int num_sources, const int*
 }
 
 extern "C" size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels, int planes) {
-    return (size_t)split_fragments(cout, num_sources, channels) * (size_t)planes * 1024;
+    return (size_t)split_fragments(cout, num_sources, channels) * (size_t)(planes & 15) * 1024;   // CP_PLANES_F16X2 = 0x12: two planes
 }
 
 // HOST: Keras-layout kernel -> the fp32 image of the fragment stream, [step][cout block][64 lanes][8 k]:
@@ -1020,16 +1057,24 @@ extern "C" int cp_conv_pack_weights_split_host(const float* w, int layout, int c
     return CP_OK;
 }
 
-extern "C" int cp_conv_split_weights_f32(const float* packed, long long floats, int planes, void* out, void* stream) {
-    CP_REQUIRE(packed && out && floats > 0 && floats % 512 == 0 && (planes == 1 || planes == 3), "cp_conv_split_weights_f32: bad arguments");
+extern "C" int cp_conv_split_weights_scaled_f32(const float* packed, long long floats, int planes, float scale, void* out, void* stream) {
+    CP_REQUIRE(packed && out && floats > 0 && floats % 512 == 0 && (planes == 1 || planes == 3 || planes == CP_PLANES_F16X2), "cp_conv_split_weights_f32: bad arguments");
     CP_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0, "cp_conv_split_weights_f32: pointers must be 16-byte aligned");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (scale > 0.f && std::isfinite(scale)) : scale == 1.f, "cp_conv_split_weights_scaled_f32: a scale other than 1 goes with CP_PLANES_F16X2 only");
     const long long nfrag = floats / 512;
     const int blocks = (int)std::min<long long>((nfrag * 64 + 255) / 256, 4096);
     if (planes == 3)
-        CP_LAUNCH(hsplit_weights_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, reinterpret_cast<unsigned char*>(out));
+        CP_LAUNCH(hsplit_weights_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, 1.f, reinterpret_cast<unsigned char*>(out));
+    else if (planes == CP_PLANES_F16X2)
+        CP_LAUNCH(hsplit_weights_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, scale, reinterpret_cast<unsigned char*>(out));
     else
-        CP_LAUNCH(hsplit_weights_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, reinterpret_cast<unsigned char*>(out));
+        CP_LAUNCH(hsplit_weights_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, nfrag, 1.f, reinterpret_cast<unsigned char*>(out));
     return cp::check_launch("cp_conv_split_weights_f32");
+}
+
+extern "C" int cp_conv_split_weights_f32(const float* packed, long long floats, int planes, void* out, void* stream) {
+    CP_REQUIRE(planes == 1 || planes == 3, "cp_conv_split_weights_f32: planes must be 1 or 3 (CP_PLANES_F16X2 needs cp_conv_split_weights_scaled_f32)");
+    return cp_conv_split_weights_scaled_f32(packed, floats, planes, 1.f, out, stream);
 }
 
 // HOST: [1][1][32][head_cout] (HWIO) 1x1 kernel -> the fp32 image of the fused head's two fragments, [2 steps][64 lanes][8]:
@@ -1047,8 +1092,17 @@ extern "C" int cp_conv_pack_head_split_host(const float* w, int head_cout, float
 }
 
 extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_split, const void* head_weights_split, int planes, void* stream) {
+    CP_REQUIRE(planes == 1 || planes == 3, "cp_conv2d_fwd_split: planes must be 1 or 3 (CP_PLANES_F16X2 needs cp_conv2d_fwd_split_scaled)");
+    return cp_conv2d_fwd_split_scaled(d, weights_split, head_weights_split, planes, 1.f, 1.f, stream);
+}
+
+extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* weights_split, const void* head_weights_split, int planes, float w_descale,
+                                          float head_descale, void* stream) {
     CP_REQUIRE_DESC(d, "cp_conv2d_fwd_split");
-    CP_REQUIRE(weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_split: bad arguments");
+    CP_REQUIRE(weights_split && (planes == 1 || planes == 3 || planes == CP_PLANES_F16X2), "cp_conv2d_fwd_split: bad arguments");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (w_descale > 0.f && std::isfinite(w_descale) && head_descale > 0.f && std::isfinite(head_descale))
+                                         : (w_descale == 1.f && head_descale == 1.f),
+               "cp_conv2d_fwd_split_scaled: descale factors other than 1 go with CP_PLANES_F16X2 only");
     CP_REQUIRE(cp_conv_split_applicable(d), "cp_conv2d_fwd_split: this convolution is outside the kernel's range (3x3 / stride 1 / pad 1, cout <= 512 and a multiple of 4, sources "
                                             "of 16-multiple channels + optional trailing 4-channel source; source 0 direct, bilinear x2 or guided x2)");
     CP_REQUIRE(d->out_raw || d->out_act || d->head_out, "cp_conv2d_fwd_split: no output");
@@ -1092,13 +1146,17 @@ extern "C" int cp_conv2d_fwd_split(const cp_conv_desc* d, const void* weights_sp
     k.head_w = d->head_out ? reinterpret_cast<const unsigned char*>(head_weights_split) : nullptr;
     k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
+    k.descale = w_descale; k.head_descale = head_descale;
+    const int np = planes & 15;
     const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0);
     const int tn = split_tn(d->cout);
     hipStream_t st = (hipStream_t)stream;
-#define CP_HS(TN_, NP_, M_) if (tn == TN_ && planes == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
+#define CP_HS(TN_, NP_, M_) if (tn == TN_ && np == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
 #define CP_HS4(TN_, NP_) CP_HS(TN_, NP_, 0) CP_HS(TN_, NP_, HS_BILINEAR) CP_HS(TN_, NP_, HS_PARTIAL) CP_HS(TN_, NP_, HS_PARTIAL | HS_SEL)
     CP_HS4(1, 3)
     CP_HS4(2, 3)
+    CP_HS4(1, 2)
+    CP_HS4(2, 2)
     CP_HS4(1, 1)
     CP_HS4(2, 1)
 #undef CP_HS4

@@ -1,6 +1,8 @@
 // The ResNet stem (`conv0`, resnet.py:248-249: 7x7 / stride 2 / pad 3, 4-channel image -> 64 channels, input batch-norm as a per-channel affine on
 // the real pixels, bn0 + ReLU in the epilogue) on the bf16 matrix pipe -- the arithmetic modes of conv_hsplit.hip:
 //   NP = 3  fp32-EQUIVALENT: every fp32 operand split exactly into three bf16 terms, six products accumulated in fp32;
+//   NP = 2  fp32-LEVEL: the fp16 two-way split of split_f16.h, three products on v_mfma_f32_32x32x16_f16 (weights pre-multiplied by a power of two,
+//           accumulators multiplied by StemSK::descale);
 //   NP = 1  bf16 operands (round to nearest even), fp32 accumulation.
 // conv_stem.hip runs the layer on v_mfma_f32_32x32x2_f32: 200 MFMAs of 64 cycles per 32-pixel row and 64 output channels.  Here K = 49 taps x 4
 // channels is walked in 13 steps of FOUR taps (k = 8 * half + 4 * (tap & 1) + channel: lane half 0 takes taps 4s, 4s+1, half 1 taps 4s+2, 4s+3;
@@ -11,6 +13,8 @@
 //     life of the block -- six 16-byte fragments per step and wave from L1 would need the full L1 rate of a CU;
 //   * accumulators transposed (MFMA A = weights, B = pixels): lane = pixel, 16-byte epilogue accesses (conv_stem.hip's epilogue).
 #include "common.h"
+#include <cmath>
+#include "split_f16.h"
 
 #include <algorithm>
 
@@ -41,6 +45,7 @@ struct StemSK {
     float* out_raw; int raw_ld;
     float* out_act; int act_ld;
     int B, H, Wd, Ho, Wo, tiles_y, tiles_x, ntiles;
+    float descale;           // NP = 2: 1 / (the power of two the weights were multiplied by); 1 otherwise
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -79,7 +84,7 @@ template <int NP>
 __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][NP][PLANE_B] halo planes | [13][2][NP][1 KB] weights
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int NPROD = (NP == 3) ? 6 : 1;
+    constexpr int NPROD = (NP == 3) ? 6 : (NP == 2) ? 3 : 1;
     constexpr unsigned W_BYTES = NSTEP * 2 * NP * 1024u;
     unsigned char* halo = smem;
     unsigned char* wl = smem + 2 * NP * PLANE_B;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
     };
 
     if (producer) {
+        if constexpr (NP == 2) cp::f16_overflow_clamps();
         const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.img_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, W_BYTES, 0x00020000);
         for (unsigned o = (unsigned)tid * 16u; o < W_BYTES; o += 256u * 16u)   // the resident weight fragments
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
                     *reinterpret_cast<uint2*>(h + e_lds[i]) = a;
                     *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[i]) = b;
                     *reinterpret_cast<uint2*>(h + 2 * PLANE_B + e_lds[i]) = c;
+                } else if constexpr (NP == 2) {
+                    uint2 a, b;
+                    cp::split4h(r, a, b);
+                    *reinterpret_cast<uint2*>(h + e_lds[i]) = a;
+                    *reinterpret_cast<uint2*>(h + PLANE_B + e_lds[i]) = b;
                 } else {
                     *reinterpret_cast<uint2*>(h + e_lds[i]) = ss_round4(r);
                 }
@@ -206,10 +217,16 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
 #pragma unroll
             for (int t = 0; t < NPROD; ++t) {
                 // (weight plane, pixel plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi -- smallest terms first
-                const int sw = (NP == 1) ? 0 : ((t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0);
-                const int sp = (NP == 1) ? 0 : ((t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0);
+                // NP = 2: lo*hi, hi*lo, hi*hi
+                const int sw = (NP == 1) ? 0 : (NP == 2) ? (t == 0 ? 1 : 0) : ((t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : 0);
+                const int sp = (NP == 1) ? 0 : (NP == 2) ? (t == 1 ? 1 : 0) : ((t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s & 1][j][sw], fa[s & 1][sp], acc[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (NP == 2)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, fw[s & 1][j][sw]), __builtin_bit_cast(cp::f16x8_t, fa[s & 1][sp]), acc[j], 0, 0, 0);
+                    else
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s & 1][j][sw], fa[s & 1][sp], acc[j], 0, 0, 0);
+                }
             }
         }
         // ---- epilogue: lane = pixel; register r of block j = channel j*32 + (r&3) + 8*(r>>2) + 4*half (conv_stem.hip) ----
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int ch = j * 32 + g4 * 8 + half * 4;
                 float4 v = make_float4(acc[j][g4 * 4 + 0], acc[j][g4 * 4 + 1], acc[j][g4 * 4 + 2], acc[j][g4 * 4 + 3]);
+                if constexpr (NP == 2) { v.x *= p.descale; v.y *= p.descale; v.z *= p.descale; v.w *= p.descale; }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(pok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
                 float4 t = v;
                 if (p.scale) {
@@ -289,8 +307,15 @@ extern "C" int cp_conv_pack_weights_stem_split_host(const float* w, int layout, 
 }
 
 extern "C" int cp_conv2d_fwd_stem_split(const cp_conv_desc* d, const void* weights_split, int planes, void* stream) {
+    CP_REQUIRE(planes == 1 || planes == 3, "cp_conv2d_fwd_stem_split: planes must be 1 or 3 (CP_PLANES_F16X2 needs cp_conv2d_fwd_stem_split_scaled)");
+    return cp_conv2d_fwd_stem_split_scaled(d, weights_split, planes, 1.f, stream);
+}
+
+extern "C" int cp_conv2d_fwd_stem_split_scaled(const cp_conv_desc* d, const void* weights_split, int planes, float w_descale, void* stream) {
     CP_REQUIRE_DESC(d, "cp_conv2d_fwd_stem_split");
-    CP_REQUIRE(weights_split && (planes == 1 || planes == 3), "cp_conv2d_fwd_stem_split: bad arguments");
+    CP_REQUIRE(weights_split && (planes == 1 || planes == 3 || planes == CP_PLANES_F16X2), "cp_conv2d_fwd_stem_split: bad arguments");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (w_descale > 0.f && std::isfinite(w_descale)) : w_descale == 1.f,
+               "cp_conv2d_fwd_stem_split_scaled: a descale factor other than 1 goes with CP_PLANES_F16X2 only");
     cp_conv_desc probe = *d;
     probe.weights_halo = reinterpret_cast<const float*>(weights_split);   // stem_applicable only asks that a second packing exists
     CP_REQUIRE(cp::stem_applicable(&probe), "cp_conv2d_fwd_stem_split: not the stem convolution (7x7 / stride 2 / pad 3, one 4-channel source, cout 64, no labels / residual / head)");
@@ -309,5 +334,7 @@ extern "C" int cp_conv2d_fwd_stem_split(const cp_conv_desc* d, const void* weigh
     k.B = d->batch; k.H = d->in_h; k.Wd = d->in_w; k.Ho = d->out_h; k.Wo = d->out_w;
     k.tiles_y = (k.Ho + TH - 1) / TH; k.tiles_x = (k.Wo + TW - 1) / TW;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
+    k.descale = w_descale;
+    if (planes == CP_PLANES_F16X2) return launch_stem_split<2>(k, (hipStream_t)stream);
     return planes == 3 ? launch_stem_split<3>(k, (hipStream_t)stream) : launch_stem_split<1>(k, (hipStream_t)stream);
 }

@@ -1,0 +1,38 @@
+// Two-way fp16 split of fp32 operands for the bf16/fp16 matrix pipe ("f16x2": three products instead of the six of the exact bf16 split).
+//     hi = rn_f16(x),   lo = rn_f16(x - hi)            (x - hi is exact in fp32: at most 13 significant bits, |x - hi| <= 2^-12 |x|)
+// so |x - hi - lo| <= 2^-11 * 2^-12 |x| / 2 = 2^-24 |x|: the operand is reproduced to half an fp32 ulp, as long as `lo` is a NORMAL fp16
+// number (|x| >= 2^-2) or -- fp16 subnormals are honoured by v_cvt_pk_f16_f32 and by v_mfma_f32_32x32x16_f16 on gfx950, measured with
+// tools/debug/f16_probe.hip -- to an absolute 2^-25 below that.  The products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator
+// (11 x 11 bits); the dropped lo*lo is <= 2^-24 of the product.  Range: fp16 ends at 65504; with MODE.FP16_OVFL set a conversion clamps
+// instead of producing inf and lo takes 11 bits of the remainder: no inf / NaN, the error of such an operand grows to <= 2^-12 of it (beyond
+// 131008: saturation).  Graceful, not fp32-level: the callers keep their operands inside the range.
+// WEIGHTS are multiplied by a power of two first (cp_f16x2_weight_scale: max |w| -> [2^11, 2^12)) so that their low parts are normal numbers;
+// the kernels multiply the accumulators by the inverse (exact).  Activations are used as they are: every convolution input of this network
+// is a normalised (BN / CLADE + activation) tensor or the normalised image.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cp {
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// clamp fp16 overflows to +-65504 for the rest of the wave's life (conversions only; the MFMA accumulates in fp32)
+__device__ __forceinline__ void f16_overflow_clamps() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory"); }
+
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2_t x = {a, b};
+    const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+    const f32x2_t r = x - __builtin_convertvector(h, f32x2_t);
+    const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ void split4h(const float4 v, uint2& hi, uint2& lo) {
+    split2h(v.x, v.y, hi.x, lo.x);
+    split2h(v.z, v.w, hi.y, lo.y);
+}
+
+}  // namespace cp

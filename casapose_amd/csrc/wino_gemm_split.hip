@@ -14,8 +14,10 @@
 // chunk ahead (issued unconditionally: a branch around the loads makes the compiler's wait counts conservative).  One persistent block per
 // CU.  Measured 178-195 TFLOP/s-equivalent against 115-120 for the fp32 MFMA kernel = ~1.1 PFLOP/s of bf16 MFMA work.  Variants measured within 3 %: all six planes staged in LDS (182); fp32 in LDS, split in the consumers (149).
 #include "common.h"
+#include "split_f16.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -57,10 +59,13 @@ struct SplitK {
     int rows, N, K, group_rows, nchunks, tiles_m, tiles_n;
     int nb32;                 // 32-column blocks per group (N rounded up to 128, / 32)
     unsigned a_bytes, b_bytes;
+    float c_scale;            // F16: 1 / (the power of two the weights were multiplied by before their split)
 };
 
-// pre-split one weight row segment: thread = (group, 32-column block, k16 step, lane)
-__global__ void split_weights_kernel(const float* __restrict__ U, int groups, int n, int k, int nb32, unsigned char* __restrict__ out) {
+// pre-split one weight row segment: thread = (group, 32-column block, k16 step, lane).  F16: planes 0 / 1 = hi / lo of the fp16 two-way split of
+// U * scale (split_f16.h), plane 2 unused (the three-plane stride is kept so that both layouts address alike)
+template <bool F16>
+__global__ void split_weights_kernel(const float* __restrict__ U, int groups, int n, int k, int nb32, float scale, unsigned char* __restrict__ out) {
     const long long total = (long long)groups * nb32 * (k / 16) * 64;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
@@ -76,20 +81,31 @@ __global__ void split_weights_kernel(const float* __restrict__ U, int groups, in
             v0 = *reinterpret_cast<const float4*>(src);
             v1 = *reinterpret_cast<const float4*>(src + 4);
         }
-        uint2 h0, m0, l0, h1, m1, l1;
-        split4(v0, h0, m0, l0);
-        split4(v1, h1, m1, l1);
         unsigned char* dst = out + ((((size_t)g * nb32 + jb) * (k / 16) + ks) * 3) * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-        *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        if constexpr (F16) {
+            uint2 h0, l0, h1, l1;
+            cp::split4h(make_float4(v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale), h0, l0);
+            cp::split4h(make_float4(v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale), h1, l1);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+            uint2 h0, m0, l0, h1, m1, l1;
+            split4(v0, h0, m0, l0);
+            split4(v1, h1, m1, l1);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+            *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
     }
 }
 
 // NPL = 3: the exact three-way split (six products, fp32-equivalent).  NPL = 2: hi + mid planes only (16 significand bits per operand, products
-// hi*hi, hi*mid, mid*hi): half the MFMAs, for the bf16 conv modes whose gates are 3e-2 -- NOT fp32-equivalent.
-template <int NPL>
+// hi*hi, hi*mid, mid*hi): half the MFMAs, for the bf16 conv modes whose gates are 3e-2 -- NOT fp32-equivalent.  NPL = 2 with F16: the fp16
+// two-way split of split_f16.h (operands reproduced to 2^-24, products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16): fp32-level accuracy
+// with half the MFMAs of the exact bf16 split; the weights come pre-multiplied by a power of two, the accumulators are multiplied by c_scale.
+template <int NPL, bool F16>
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
+    static_assert(!F16 || NPL == 2, "the fp16 split has two planes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE stages][3 splits][128 rows][80 B]
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     if (producer) {
+        if constexpr (F16) cp::f16_overflow_clamps();
         // 32 rows x 8 float4 per pass, four passes per operand.  A 16-lane group of a ds_write_b64 covers two rows: with consecutive rows (stride 80 B
         // = 20 banks) their 16-dword spans overlap on four banks (SQ_LDS_BANK_CONFLICT = one extra cycle per store, profiles/r04_pmc_gemm_isolated.txt);
         // rows r and r + 4 (80 dwords apart = 16 banks) do not: the eight row slots of a wave take rows 0, 4, 1, 5, 2, 6, 3, 7
@@ -146,7 +163,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 h, m, l;
-                split4(areg[i], h, m, l);
+                if constexpr (F16) cp::split4h(areg[i], h, m);
+                else split4(areg[i], h, m, l);
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB) = h;
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + SPLIT_BYTES) = m;
                 if constexpr (NPL == 3) *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
@@ -233,7 +251,10 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i][sa], fb[par][ks][j][sb], acc[i][j], 0, 0, 0);
+                    if constexpr (F16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, fa[slot][i][sa]), __builtin_bit_cast(cp::f16x8_t, fb[par][ks][j][sb]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i][sa], fb[par][ks][j][sb], acc[i][j], 0, 0, 0);
         }
     };
     int it = 0, q = 0;
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                     float* dst = p.C + (size_t)(tm * BM + wm * 64 + i * 32 + kh * 4) * p.N + col;
                     if (col < p.N) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][j][r];
+                        for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = F16 ? acc[i][j][r] * p.c_scale : acc[i][j][r];
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -291,18 +312,36 @@ extern "C" size_t cp_wino_split_weights_bytes(int groups, int n, int k) {
     return (size_t)groups * nb32 * (k / 16) * 3 * 1024;
 }
 
-extern "C" int cp_wino_split_weights_f32(const float* U, int groups, int n, int k, void* out, void* stream) {
+extern "C" float cp_f16x2_weight_scale(float max_abs) {
+    // the power of two that brings max |w| into [2^11, 2^12): low parts of all but vanishing weights are normal fp16 numbers, 16x headroom to 65504
+    if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.f;
+    int e = 0;
+    (void)std::frexp(max_abs, &e);   // max_abs = m * 2^e, m in [0.5, 1)
+    return std::ldexp(1.f, std::min(std::max(12 - e, -100), 100));
+}
+
+extern "C" int cp_wino_split_weights_scaled_f32(const float* U, int groups, int n, int k, int planes, float scale, void* out, void* stream) {
     CP_REQUIRE(U && out && groups > 0 && n > 0 && k > 0 && k % 32 == 0, "cp_wino_split_weights_f32: bad arguments (K must be a multiple of 32)");
     CP_REQUIRE(((uintptr_t)U & 15) == 0 && ((uintptr_t)out & 15) == 0, "cp_wino_split_weights_f32: pointers must be 16-byte aligned");
+    CP_REQUIRE(planes == 3 || planes == 2 || planes == CP_PLANES_F16X2, "cp_wino_split_weights_scaled_f32: planes must be 3, 2 or CP_PLANES_F16X2");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (scale > 0.f && std::isfinite(scale)) : scale == 1.f, "cp_wino_split_weights_scaled_f32: a scale other than 1 goes with CP_PLANES_F16X2 only");
     const int nb32 = ((n + 127) / 128) * 4;
     const long long total = (long long)groups * nb32 * (k / 16) * 64;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-    CP_LAUNCH(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, groups, n, k, nb32, reinterpret_cast<unsigned char*>(out));
+    if (planes == CP_PLANES_F16X2)
+        CP_LAUNCH(split_weights_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, groups, n, k, nb32, scale, reinterpret_cast<unsigned char*>(out));
+    else
+        CP_LAUNCH(split_weights_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, groups, n, k, nb32, 1.f, reinterpret_cast<unsigned char*>(out));
     return cp::check_launch("cp_wino_split_weights_f32");
 }
 
-extern "C" int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream) {
-    CP_REQUIRE(planes == 3 || planes == 2, "cp_wino_gemm_split_planes_f32: planes must be 3 (exact split) or 2 (hi + mid)");
+extern "C" int cp_wino_split_weights_f32(const float* U, int groups, int n, int k, void* out, void* stream) {
+    return cp_wino_split_weights_scaled_f32(U, groups, n, k, 3, 1.f, out, stream);
+}
+
+extern "C" int cp_wino_gemm_split_scaled_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, float c_scale, void* stream) {
+    CP_REQUIRE(planes == 3 || planes == 2 || planes == CP_PLANES_F16X2, "cp_wino_gemm_split_planes_f32: planes must be 3 (exact split), 2 (hi + mid) or CP_PLANES_F16X2");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (c_scale > 0.f && std::isfinite(c_scale)) : c_scale == 1.f, "cp_wino_gemm_split_scaled_f32: a scale other than 1 goes with CP_PLANES_F16X2 only");
     CP_REQUIRE(V && Usplit && M, "cp_wino_gemm_split_f32: null pointer");
     CP_REQUIRE(rows > 0 && group_rows > 0 && rows % group_rows == 0 && group_rows % 128 == 0, "cp_wino_gemm_split_f32: rows must be whole groups of a multiple of 128 rows");
     CP_REQUIRE(k > 0 && k % 32 == 0 && n > 0, "cp_wino_gemm_split_f32: K must be a multiple of 32");
@@ -316,18 +355,26 @@ extern "C" int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit,
     g.tiles_m = rows / BM; g.tiles_n = (n + BN - 1) / BN;
     g.nb32 = g.tiles_n * 4;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+    g.c_scale = c_scale;
     const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (planes == 3) CP_LAUNCH(wino_gemm_split_kernel<3>, dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
-    else CP_LAUNCH(wino_gemm_split_kernel<2>, dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
+    if (planes == 3) CP_LAUNCH((wino_gemm_split_kernel<3, false>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
+    else if (planes == 2) CP_LAUNCH((wino_gemm_split_kernel<2, false>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
+    else CP_LAUNCH((wino_gemm_split_kernel<2, true>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
     return cp::check_launch("cp_wino_gemm_split_f32");
 }
 
+extern "C" int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream) {
+    CP_REQUIRE(planes == 3 || planes == 2, "cp_wino_gemm_split_planes_f32: planes must be 3 (exact split) or 2 (hi + mid)");
+    return cp_wino_gemm_split_scaled_f32(V, Usplit, M, rows, group_rows, k, n, planes, 1.f, stream);
+}
+
 extern "C" int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, void* stream) {
-    return cp_wino_gemm_split_planes_f32(V, Usplit, M, rows, group_rows, k, n, 3, stream);
+    return cp_wino_gemm_split_scaled_f32(V, Usplit, M, rows, group_rows, k, n, 3, 1.f, stream);
 }

@@ -137,6 +137,7 @@ class FusedConv:
         # its bf16 planes (3 = exact split, 1 = plain bf16) are made on the device when a mode asks for them
         self.wp_split_f32 = None
         self._split_planes: Dict[int, torch.Tensor] = {}
+        self._descale: Dict[int, float] = {}
         self.split_mode = 0
         split_ok = (kh == 3 and kw == 3 and cout <= 512 and cout % 4 == 0 and sources[0][0] % 16 == 0 and sources[0][0] != 4
                     and (ns == 1 or (sources[1][0] == 4 and cout <= 32) or sources[1][0] % 16 == 0))
@@ -152,26 +153,26 @@ class FusedConv:
         self._gemm: Optional[dict] = None   # set by enable_gemm_split() for the CURRENT binding only
         self.deep_bf16 = False              # bf16 conv mode: this binding runs on csrc/conv_bf16d.hip (set by ForwardPlan)
 
-    def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
-        """bf16 planes of the weights for cp_conv2d_fwd_split / cp_conv2d_fwd_stem_split (made once per mode)."""
-        if planes not in self._split_planes:
-            lib = _lib.load()
-            image = self.wp_split_f32 if self.wp_split_f32 is not None else self.wp_stem_split_f32
-            out = torch.empty(image.numel() // 512 * planes * 1024, dtype=torch.uint8, device=image.device)
-            st = torch.cuda.current_stream(out.device).cuda_stream if stream is None else stream
-            check(lib.cp_conv_split_weights_f32(image.data_ptr(), image.numel(), planes, out.data_ptr(), st), "cp_conv_split_weights_f32")
-            self._split_planes[planes] = out
-        return self._split_planes[planes]
-
-    def head_split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
-        key = -planes
+    def _make_planes(self, key: int, image: torch.Tensor, planes: int, stream: Optional[int]) -> torch.Tensor:
+        """2-byte operand planes of an fp32 fragment image: 3 = exact bf16 split, 1 = bf16, PLANES_F16X2 = the fp16 two-way split of image * 2^e (the
+        inverse factor is kept in _descale[key]: the kernels multiply their accumulators by it)."""
         if key not in self._split_planes:
             lib = _lib.load()
-            out = torch.empty(2 * planes * 1024, dtype=torch.uint8, device=self.head_w_split_f32.device)
+            out = torch.empty(image.numel() // 512 * (planes & 15) * 1024, dtype=torch.uint8, device=image.device)
             st = torch.cuda.current_stream(out.device).cuda_stream if stream is None else stream
-            check(lib.cp_conv_split_weights_f32(self.head_w_split_f32.data_ptr(), 1024, planes, out.data_ptr(), st), "cp_conv_split_weights_f32(head)")
+            scale = float(lib.cp_f16x2_weight_scale(float(image.abs().max()))) if planes == _lib.PLANES_F16X2 else 1.0
+            check(lib.cp_conv_split_weights_scaled_f32(image.data_ptr(), image.numel(), planes, scale, out.data_ptr(), st), "cp_conv_split_weights_scaled_f32")
             self._split_planes[key] = out
+            self._descale[key] = 1.0 / scale
         return self._split_planes[key]
+
+    def split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
+        """operand planes of the weights for cp_conv2d_fwd_split / cp_conv2d_fwd_stem_split (made once per mode)."""
+        image = self.wp_split_f32 if self.wp_split_f32 is not None else self.wp_stem_split_f32
+        return self._make_planes(planes, image, planes, stream)
+
+    def head_split_weights(self, planes: int, stream: Optional[int] = None) -> torch.Tensor:
+        return self._make_planes(-planes, self.head_w_split_f32, planes, stream)
 
     def attach_head(self, kernel_1x1: np.ndarray):
         """Fuse a following 1x1 convolution (HWIO [1,1,32,q], no bias / activation) into this layer's epilogue."""
@@ -227,12 +228,12 @@ class FusedConv:
         d.out_raw_ld = out_raw_ld if out_raw_ld is not None else self.cout
         d.out_act = _ptr(out_act)
         d.out_act_ld = out_act_ld if out_act_ld is not None else self.cout
-        # tile_hint TILE_SPLIT3 / TILE_BF16 (Python-side values): run on csrc/conv_hsplit.hip when the layer is in its range
+        # tile_hint TILE_SPLIT3 / TILE_BF16 / TILE_F16X2 (Python-side values): run on csrc/conv_hsplit.hip when the layer is in its range
         self.split_mode = 0
-        if tile_hint in (_lib.TILE_SPLIT3, _lib.TILE_BF16):
+        if tile_hint in (_lib.TILE_SPLIT3, _lib.TILE_BF16, _lib.TILE_F16X2):
             if self.wp_split_f32 is None:
                 raise _lib.CasaposeHipError("%s: the bf16-pipe kernel covers 3x3 / cout <= 512 / 16-multiple sources only" % self.name)
-            self.split_mode = 3 if tile_hint == _lib.TILE_SPLIT3 else 1
+            self.split_mode = {_lib.TILE_SPLIT3: 3, _lib.TILE_BF16: 1, _lib.TILE_F16X2: _lib.PLANES_F16X2}[tile_hint]
             tile_hint = 0
         d.tile_hint = tile_hint
         d.head_weights = _ptr(self.head_w) if head_out is not None else None
@@ -260,7 +261,11 @@ class FusedConv:
         if not ok:
             return False
         U = torch.from_numpy(np.ascontiguousarray(kernel_hwio.reshape(cin, self.cout).T[None])).to(torch.float32).to(self.wp.device if self.wp is not None else "cuda")
-        self._gemm = dict(Us=split_wino_weights(U, 1, self.cout, cin), rows=rows, k=cin, planes=planes)
+        if planes == _lib.PLANES_F16X2:
+            Us, c_scale = split_wino_weights_f16x2(U, 1, self.cout, cin)
+        else:
+            Us, c_scale = split_wino_weights(U, 1, self.cout, cin), 1.0
+        self._gemm = dict(Us=Us, rows=rows, k=cin, planes=planes, c_scale=c_scale)
         return True
 
     def run(self, stream: int):
@@ -269,22 +274,24 @@ class FusedConv:
         if g is not None:
             d = self.desc
             assert g["rows"] == d.batch * d.out_h * d.out_w, "%s: GEMM route bound for another shape" % self.name
-            check(lib.cp_wino_gemm_split_planes_f32(d.src[0].data, g["Us"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["k"], self.cout, g["planes"], stream),
-                  "cp_wino_gemm_split_planes_f32(%s)" % self.name)
+            check(lib.cp_wino_gemm_split_scaled_f32(d.src[0].data, g["Us"].data_ptr(), d.out_raw, g["rows"], g["rows"], g["k"], self.cout, g["planes"], g["c_scale"],
+                                                    stream), "cp_wino_gemm_split_scaled_f32(%s)" % self.name)
             return
         if self.deep_bf16:
             check(lib.cp_conv2d_fwd_bf16_deep(C.byref(self.desc), self.split_weights(1, stream).data_ptr(), stream), "cp_conv2d_fwd_bf16_deep(%s)" % self.name)
             return
         if self.stem_split:
-            check(lib.cp_conv2d_fwd_stem_split(C.byref(self.desc), self.split_weights(self.stem_split, stream).data_ptr(), self.stem_split, stream),
+            wsp = self.split_weights(self.stem_split, stream)
+            check(lib.cp_conv2d_fwd_stem_split_scaled(C.byref(self.desc), wsp.data_ptr(), self.stem_split, self._descale[self.stem_split], stream),
                   "cp_conv2d_fwd_stem_split(%s)" % self.name)
             return
         if self.split_mode:
             if not lib.cp_conv_split_applicable(C.byref(self.desc)):
                 raise _lib.CasaposeHipError("%s: descriptor outside the range of cp_conv2d_fwd_split" % self.name)
             head = self.head_split_weights(self.split_mode, stream).data_ptr() if self.desc.head_out else None
-            check(lib.cp_conv2d_fwd_split(C.byref(self.desc), self.split_weights(self.split_mode, stream).data_ptr(), head, self.split_mode, stream),
-                  "cp_conv2d_fwd_split(%s)" % self.name)
+            wsp = self.split_weights(self.split_mode, stream)
+            check(lib.cp_conv2d_fwd_split_scaled(C.byref(self.desc), wsp.data_ptr(), head, self.split_mode, self._descale[self.split_mode],
+                                                 self._descale[-self.split_mode] if head else 1.0, stream), "cp_conv2d_fwd_split(%s)" % self.name)
             return
         check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)
 
@@ -304,9 +311,13 @@ WINO_GROUPED_CONV = os.environ.get("CASAPOSE_WINO_GROUPED_CONV", "0") == "1"
 WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
 WINO_GEMM_F32 = os.environ.get("CASAPOSE_WINO_GEMM", "") == "f32"
 TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
-# default arithmetic of the inference plan's convolutions (CasaposeNet(conv_mode=None)): "split" = exact three-way bf16 splits on the bf16 matrix
-# pipe for every layer the split kernels cover (fp32-equivalent), "f32" = the fp32 MFMA everywhere, "bf16" = bf16 operands (3e-2 gates)
-DEFAULT_INFER_CONV_MODE = "split"
+# default arithmetic of the inference plan's convolutions (CasaposeNet(conv_mode=None)):
+#   "f16x2" (default since round 4) = every fp32 operand as an fp16 pair hi + lo (reproduced to 2^-24), the three exact products hi*hi, hi*lo, lo*hi
+#           accumulated in fp32 on the fp16 matrix pipe, for every layer the split kernels cover: fp32-LEVEL -- against fp64 its error is at or below
+#           the fp32 MFMA's on the GEMM, on single convolutions and on the whole network (tests/test_gpu_f16x2.py) -- with half the MFMAs of "split";
+#   "split" = exact three-way bf16 splits, six products (fp32-equivalent for any finite operand, no range conditions: the round-3 default);
+#   "f32"   = the fp32 MFMA everywhere;   "bf16" = bf16 operands (3e-2 gates)
+DEFAULT_INFER_CONV_MODE = "f16x2"
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
@@ -328,6 +339,17 @@ def split_wino_weights(U: torch.Tensor, groups: int, n: int, k: int, out: Option
     st = torch.cuda.current_stream(U.device).cuda_stream if stream is None else stream
     check(lib.cp_wino_split_weights_f32(U.data_ptr(), groups, n, k, out.data_ptr(), st), "cp_wino_split_weights_f32")
     return out
+
+
+def split_wino_weights_f16x2(U: torch.Tensor, groups: int, n: int, k: int, stream: Optional[int] = None):
+    """cp_wino_split_weights_scaled_f32 with CP_PLANES_F16X2: the fp16 two-way split of U * 2^e (e from max |U|: csrc/split_f16.h).  Returns the
+    plane buffer and c_scale = 2^-e, the factor cp_wino_gemm_split_scaled_f32 multiplies its accumulators by."""
+    lib = _lib.load()
+    out = torch.empty(lib.cp_wino_split_weights_bytes(groups, n, k), dtype=torch.uint8, device=U.device)
+    st = torch.cuda.current_stream(U.device).cuda_stream if stream is None else stream
+    scale = float(lib.cp_f16x2_weight_scale(float(U.abs().max())))
+    check(lib.cp_wino_split_weights_scaled_f32(U.data_ptr(), groups, n, k, _lib.PLANES_F16X2, scale, out.data_ptr(), st), "cp_wino_split_weights_scaled_f32")
+    return out, 1.0 / scale
 
 
 class WinoConv:
@@ -355,7 +377,11 @@ class WinoConv:
         self.U = torch.from_numpy(U).to(device)
         # pre-split bf16 planes of the opt-in GEMM; split_planes = 2 (the bf16 conv mode): hi + mid planes only, three products, NOT fp32-equivalent
         self.planes = split_planes or 3
-        self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if (WINO_GEMM_SPLIT or split_planes) else None
+        self.c_scale = 1.0
+        if self.planes == _lib.PLANES_F16X2:   # the fp16 two-way split: weights times a power of two, the GEMM undoes it
+            self.Us, self.c_scale = split_wino_weights_f16x2(self.U, 36, cout, self.ktot)
+        else:
+            self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if (WINO_GEMM_SPLIT or split_planes) else None
         self.desc = ConvDesc()  # the grouped GEMM
         self._keep: List = []
 
@@ -469,8 +495,8 @@ class WinoConv:
             check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(wino %s)" % self.name)
         else:
             if self.Us is not None:
-                check(lib.cp_wino_gemm_split_planes_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, self.planes,
-                                                        stream), "cp_wino_gemm_split_planes_f32(%s)" % self.name)
+                check(lib.cp_wino_gemm_split_scaled_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, self.planes,
+                                                        self.c_scale, stream), "cp_wino_gemm_split_scaled_f32(%s)" % self.name)
             else:
                 check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
                       "cp_wino_gemm_f32(%s)" % self.name)
@@ -578,7 +604,7 @@ class ForwardPlan:
                   and kw.get("dilation", 1) == 1 and lib.cp_conv_selected_tile(C.byref(layer.desc)) == _lib.TILE_STEM):
                 layer.stem_split = net.conv_planes   # conv0 on the bf16 matrix pipe (exact split / bf16 operands), csrc/conv_stem_split.hip
             elif net.conv_planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
-                layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), 3 if net.conv_planes == 3 else 2)
+                layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), net.conv_planes if net.conv_planes in (3, _lib.PLANES_F16X2) else 2)
             self.convs.append(layer)
             self.steps.append(layer.run)
 
@@ -923,10 +949,10 @@ class CasaposeNet:
         self.fuse_heads = fuse_heads
         self.use_winograd = use_winograd and os.environ.get("CASAPOSE_NO_WINOGRAD", "0") != "1"
         mode = conv_mode if conv_mode is not None else os.environ.get("CASAPOSE_INFER_CONV_MODE", DEFAULT_INFER_CONV_MODE)
-        if mode not in ("f32", "split", "bf16"):
-            raise ValueError("conv_mode must be f32, split or bf16 (got %r)" % mode)
+        if mode not in ("f32", "split", "f16x2", "bf16"):
+            raise ValueError("conv_mode must be f32, split, f16x2 or bf16 (got %r)" % mode)
         self.conv_mode = mode
-        self.conv_planes = {"f32": 0, "split": 3, "bf16": 1}[mode]
+        self.conv_planes = {"f32": 0, "split": 3, "f16x2": _lib.PLANES_F16X2, "bf16": 1}[mode]
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self._twin: Optional["CasaposeNet"] = None   # the second half-batch's layer objects (two-stream forward)
         self._streams = None
@@ -963,7 +989,7 @@ class CasaposeNet:
         def add(name, key, layout, k, cout, sources, stride=1, dil=1, pad=None, partial=False):
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev, want_split=bool(self.conv_planes))
             pad = dil * (k // 2) if pad is None else pad
-            planes = 2 if self.conv_mode == "bf16" else (3 if self.conv_mode == "split" and not WINO_GEMM_F32 else None)
+            planes = 2 if self.conv_mode == "bf16" else (self.conv_planes if self.conv_mode in ("split", "f16x2") and not WINO_GEMM_F32 else None)
             if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout, split_gemm=bool(planes) or WINO_GEMM_SPLIT):
                 Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev, split_planes=planes)
 

@@ -186,6 +186,8 @@ int cp_conv_selected_tile(const cp_conv_desc* desc);
  * (cp_conv_split_weight_floats floats); cp_conv_split_weights_f32 turns that image into the bf16 planes
  * (cp_conv_split_weight_bytes bytes) on the device -- one gather + one launch re-packs after an optimizer step.
  * ---------------------------------------------------------------------------------- */
+enum { CP_PLANES_F16X2 = 0x12 };   /* `planes` code of the fp16 two-way split (two planes; see cp_wino_gemm_split_scaled_f32) */
+float cp_f16x2_weight_scale(float max_abs);   /* the power of two that brings max |w| into [2^11, 2^12) */
 int cp_conv_split_applicable(const cp_conv_desc* desc);   /* 1 if cp_conv2d_fwd_split covers this descriptor */
 int cp_conv_split_weight_floats(int cout, int num_sources, const int* channels);
 size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels, int planes);
@@ -196,6 +198,12 @@ int cp_conv_split_weights_f32(const float* packed, long long floats, int planes,
  * makes its planes.  head_weights_split may be NULL when desc->head_out is NULL. */
 int cp_conv_pack_head_split_host(const float* w_host, int head_cout, float* dst_host);
 int cp_conv2d_fwd_split(const cp_conv_desc* desc, const void* weights_split, const void* head_weights_split, int planes, void* stream);
+/* planes = CP_PLANES_F16X2 (see cp_wino_gemm_split_scaled_f32 below for the arithmetic): the weight image is multiplied by `scale` (a power of two,
+ * cp_f16x2_weight_scale(max |w|)) before its fp16 split, the convolution multiplies its accumulators by w_descale = 1 / scale (the fused head's by
+ * head_descale, the inverse of the head image's scale).  With planes = 1 / 3 the factors must be 1 and the calls equal the two above. */
+int cp_conv_split_weights_scaled_f32(const float* packed, long long floats, int planes, float scale, void* out, void* stream);
+int cp_conv2d_fwd_split_scaled(const cp_conv_desc* desc, const void* weights_split, const void* head_weights_split, int planes, float w_descale,
+                               float head_descale, void* stream);
 /* Direct convolution with bf16 OPERANDS for the deep 3x3 layers (round 3; BASELINE.json configs[2] "bf16 convs"; csrc/conv_bf16d.hip): 3x3 / stride 1,
  * pad = dilation in {1, 2, 4}, one or two direct sources of 16-multiple channels, cout a multiple of 128 (<= 512), fp32 tensors in HBM, operands
  * rounded to bf16 (nearest even) while staged, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Epilogue: + residual, out_raw and / or
@@ -339,6 +347,17 @@ int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int row
 /* planes = 3: the above.  planes = 2: hi + mid planes only (16 significand bits per operand; products hi*hi, hi*mid, mid*hi): half the MFMAs, NOT
  * fp32-equivalent -- for the bf16 conv modes (BASELINE.json configs[2]; gates 3e-2).  Same pre-split weights. */
 int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream);
+/* planes = CP_PLANES_F16X2: the fp16 TWO-way split (csrc/split_f16.h): hi = rn_f16(x), lo = rn_f16(x - hi) reproduce an fp32 operand to 2^-24
+ * relative (half an fp32 ulp) and the three products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16 -- fp32-level
+ * accuracy (measured against fp64 beside the fp32 MFMA and the exact bf16 split: tests/test_gpu_f16x2.py) with HALF the MFMAs of
+ * the exact bf16 split.  fp16's range is handled by scaling: the weights are multiplied by a power of two before their split
+ * (cp_f16x2_weight_scale(max |w|): max -> [2^11, 2^12), so that the low parts are normal numbers) and the kernel multiplies its accumulators by
+ * c_scale = 1 / scale (exact); activations are used as they are: fp32-level for max |v| in [1, 65504]; below, the low parts
+ * become subnormal (absolute 2^-25: the error degrades as 2^-25 / max |v|); above, conversions clamp at +-65504 and the error grows to 2^-12 of the
+ * operand -- never inf / NaN.  The split-weight buffer has the size and layout of the three-plane one (planes 0 / 1 used). */
+int cp_wino_split_weights_scaled_f32(const float* U, int groups, int n, int k, int planes, float scale, void* out, void* stream);
+int cp_wino_gemm_split_scaled_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, float c_scale,
+                                  void* stream);
 int cp_wino_pack_weights_host(const float* w_hwio, int cin_total, int cout, int c_begin, int channels, int real_channels, int ldk,
                               int k_off, float* dst);
 /* device version of the weight transform (training: after every optimizer step): g(ky,kx,c,o) is read at
@@ -374,6 +393,8 @@ int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int
 int cp_conv_stem_split_weight_floats(void);
 int cp_conv_pack_weights_stem_split_host(const float* w_host, int layout, int real_channels, float* dst_host);
 int cp_conv2d_fwd_stem_split(const cp_conv_desc* d, const void* weights_split, int planes, void* stream);
+/* planes = CP_PLANES_F16X2: as cp_conv2d_fwd_split_scaled (weights from cp_conv_split_weights_scaled_f32 with the same power-of-two scale) */
+int cp_conv2d_fwd_stem_split_scaled(const cp_conv_desc* desc, const void* weights_split, int planes, float w_descale, void* stream);
 /* Output transform of one Winograd layer FUSED with the input transform of the next (round 4): Y = A^T M A, + residual, raw store (optional),
  * t = act(Y * scale[c] + shift[c]) (per channel; optional activated store), then V[p][t][c_off + c] = (B^T t B)[p] of the consumer -- for two
  * Winograd convolutions of the same (batch, h, w, dilation) where the consumer's only source is this activated output (the residual-unit chains

@@ -1,0 +1,136 @@
+"""GPU parity of the fp16 two-way split ("f16x2", csrc/split_f16.h): three exact products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16 instead of
+the six of the exact bf16 split.  The claim to pin: fp32-LEVEL accuracy -- against fp64, the error of every f16x2 kernel stays within a small
+factor of the error the fp32 MFMA kernel of the same operation makes on the same data (both accumulate in fp32; the split adds an operand
+perturbation of <= 2^-24 relative), including badly scaled weights (the power-of-two weight scale) and large activations (the clamp at 65504 with the
+low part taking the remainder); activations whose maximum is below 1 degrade gracefully (subnormal low parts: absolute 2^-25)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm_errors(device, V, U, group):
+    from casapose_amd import _lib
+    from casapose_amd._lib import check
+    from casapose_amd.engine import split_wino_weights, split_wino_weights_f16x2
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream(device).cuda_stream
+    rows, k = V.shape
+    n = U.shape[1]
+    Vd, Ud = V.to(device), U.to(device)
+    M = [torch.empty(rows, n, device=device) for _ in range(3)]
+    check(lib.cp_wino_gemm_f32(Vd.data_ptr(), Ud.data_ptr(), M[0].data_ptr(), rows, group, k, n, st), "fp32")
+    Us = split_wino_weights(Ud, rows // group, n, k)
+    check(lib.cp_wino_gemm_split_f32(Vd.data_ptr(), Us.data_ptr(), M[1].data_ptr(), rows, group, k, n, st), "bf16x3")
+    Uh, c_scale = split_wino_weights_f16x2(Ud, rows // group, n, k)
+    check(lib.cp_wino_gemm_split_scaled_f32(Vd.data_ptr(), Uh.data_ptr(), M[2].data_ptr(), rows, group, k, n, _lib.PLANES_F16X2, c_scale, st), "f16x2")
+    ref = torch.cat([V[i * group:(i + 1) * group].double() @ U[i].double().T for i in range(rows // group)])
+    bound = torch.cat([V[i * group:(i + 1) * group].double().abs() @ U[i].double().abs().T for i in range(rows // group)]).clamp_min(1e-300)
+    out = []
+    for m in M:
+        e = (m.cpu().double() - ref).abs() / bound
+        out.append((float(e.max()), float(e.pow(2).mean().sqrt())))
+    return out   # (max, rms) relative to sum |v||u| for fp32 MFMA, exact bf16 split, f16x2
+
+
+@pytest.mark.parametrize("rows,group,n,k,vs,us", [
+    (256, 128, 128, 64, 1.0, 1.0),
+    (3 * 384, 384, 256, 512, 1.0, 0.02),       # small weights: without the power-of-two scale their low parts would be subnormal
+    (2 * 128, 128, 132, 32, 30.0, 5.0),
+    (256, 128, 64, 256, 1e-3, 1e-4),           # tiny activations: low parts subnormal (absolute 2^-25): graceful degradation, see below
+    (256, 128, 64, 128, 3000.0, 300.0),        # Winograd-domain magnitudes
+])
+def test_f16x2_gemm_has_fp32_level_error(device, rows, group, n, k, vs, us):
+    g = torch.Generator().manual_seed(rows + n + k)
+    V = torch.randn(rows, k, generator=g) * vs
+    U = torch.randn(rows // group, n, k, generator=g) * us
+    (f_max, f_rms), (b_max, b_rms), (h_max, h_rms) = _gemm_errors(device, V, U, group)
+    print("fp32 MFMA max %.2e rms %.2e | bf16x3 max %.2e rms %.2e | f16x2 max %.2e rms %.2e" % (f_max, f_rms, b_max, b_rms, h_max, h_rms))
+    amax = float(V.abs().max())
+    if amax < 1.0:
+        # activations are not scaled: below 2^-2 the low parts are subnormal, i.e. absolute 2^-25 instead of relative 2^-24 -- the error degrades
+        # gracefully to 2^-25 / max |v| of the largest terms (the network's convolution inputs are normalised tensors, max >= 1)
+        assert h_max <= 2.0 ** -25 / amax * 1.5, (amax, h_max)
+        return
+    assert h_max < 2e-6, (f_max, b_max, h_max)
+    assert h_max <= 2.0 * f_max + 1e-7 and h_rms <= 2.0 * f_rms + 2e-8, ((f_max, f_rms), (h_max, h_rms))
+
+
+def test_f16x2_gemm_operands_beyond_the_fp16_range(device):
+    """|v| up to 1.3e5, mixed with ordinary values: the conversion CLAMPS at 65504 (MODE.FP16_OVFL) and the low part takes what it can of the
+    remainder (11 bits of it) -- no inf / NaN, the error of such an operand grows to <= 2^-12 of it: graceful, not fp32-level.  The network never
+    gets there (normalised activations); the contract is stated in csrc/split_f16.h."""
+    g = torch.Generator().manual_seed(3)
+    V = torch.randn(256, 64, generator=g)
+    V[::7, ::5] = 1.0e5
+    V[3::11, 1::3] = -1.3e5
+    U = torch.randn(2, 128, 64, generator=g) * 0.1
+    (f_max, _), _, (h_max, _) = _gemm_errors(device, V, U, 128)
+    assert np.isfinite(h_max) and h_max <= 2.0 ** -12, (f_max, h_max)
+    V2 = V.clamp(-6.0e4, 6.0e4)   # inside the range: fp32-level again
+    (f_max, _), _, (h_max, _) = _gemm_errors(device, V2, U, 128)
+    assert h_max <= 2.0 * f_max + 1e-7 and h_max < 2e-6, (f_max, h_max)
+
+
+def test_f16x2_weight_scale_is_a_power_of_two_bringing_the_maximum_below_4096():
+    from casapose_amd import _lib
+
+    lib = _lib.load()
+    for m in (1e-6, 0.013, 0.5, 1.0, 3.9, 4096.0, 1e9):
+        s = lib.cp_f16x2_weight_scale(m)
+        assert 2048.0 <= m * s < 4096.0 and np.log2(s) == round(np.log2(s)), (m, s)
+    assert lib.cp_f16x2_weight_scale(0.0) == 1.0
+
+
+@pytest.mark.parametrize("sx,sw", [(1.0, 1.0), (30.0, 0.01), (1.0, 1e-4), (300.0, 1e3)])
+def test_f16x2_convolution_against_the_fp32_mfma_kernel(device, sx, sw):
+    """csrc/conv_hsplit.hip with CP_PLANES_F16X2 beside the fp32-MFMA halo kernel on the same fp32 operands, both against fp64: the two-way split
+    must stay within twice the fp32 kernel's error (the weights' power-of-two scale makes it independent of the weights' magnitude)."""
+    import casapose_oracle as O
+    from casapose_amd import ops
+    from test_gpu_conv import dev
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 32, 64, 64)) * sx
+    w = rng.standard_normal((3, 3, 64, 64)) / 24.0 * sw
+    ref32 = O.conv2d(x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64), pad=1)
+    scale = np.abs(ref32).max()
+    got = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=102)[0].cpu().numpy().astype(np.float64)
+    f32 = ops.conv2d_fused([dev(x, device)], w.astype(np.float32), pad=1, tile_hint=7)[0].cpu().numpy().astype(np.float64)
+    e_h, e_f = np.abs(got - ref32).max() / scale, np.abs(f32 - ref32).max() / scale
+    r_h, r_f = np.sqrt(np.mean((got - ref32) ** 2)) / scale, np.sqrt(np.mean((f32 - ref32) ** 2)) / scale
+    print("sx %g sw %g: f16x2 max %.2e rms %.2e | fp32 MFMA max %.2e rms %.2e" % (sx, sw, e_h, r_h, e_f, r_f))
+    assert e_h < 2e-6 and e_h <= 2.0 * e_f + 2e-7 and r_h <= 2.0 * r_f + 2e-8, (sx, sw, e_h, e_f, r_h, r_f)
+
+
+def test_f16x2_network_error_beside_the_other_modes(device):
+    """The whole forward (28 convolution layers, Winograd GEMMs, partial convolutions, CLADE, fused heads) in conv_mode f32 (fp32 MFMA everywhere),
+    split (exact bf16 three-way split) and f16x2, each against the fp64 oracle: the two-way split's error must be of the fp32 modes' size
+    (<= 1.5 x the larger of the two + 1e-6 of the range) -- what "fp32-level" means at the network's outputs."""
+    import casapose_oracle as O
+    from test_gpu_forward import build, rel_err
+
+    b, h, w, k, v = 2, 64, 96, 5, 27
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)
+    lab = np.zeros((b, h, w), np.int64)
+    lab[:, 8:40, 10:50] = 1
+    lab[:, 30:60, 40:90] = 2
+    lab[0, 5:20, 60:80] = 3
+    lab[1, 44:62, 4:30] = 4
+    seg = O.onehot_from_labels(lab, k, np.float32)
+    errs = {}
+    ref = None
+    for mode in ("f32", "split", "f16x2"):
+        net, p64 = build(device, k, v, h, w, seg_input=True, fuse_upsample=True, fuse_heads=True, conv_mode=mode)
+        if ref is None:
+            ref = O.casapose_c_gcu5(p64, img.astype(np.float64), seg_input=seg.astype(np.float64))
+        got = net([img, seg], training=False).cpu().numpy().astype(np.float64)
+        errs[mode] = (rel_err(got[..., :k], ref[..., :k]), rel_err(got[..., k:], ref[..., k:]))
+    print("network error vs fp64 (segmentation, vector field): %s" % errs)
+    for i in range(2):
+        assert errs["f16x2"][i] <= 1.5 * max(errs["f32"][i], errs["split"][i]) + 1e-6, errs

@@ -431,7 +431,7 @@ def test_load_weights_from_keras_h5(device, tmp_path):
     assert np.array_equal(got["conv0.kernel"], other["conv0.kernel"]) and np.array_equal(got["pv_block_6_clade.gamma"], params["pv_block_6_clade.gamma"])
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("split", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("split", 1e-3), ("f16x2", 1e-3), ("bf16", 3e-2)])
 @pytest.mark.parametrize("fuse", [True, False])
 def test_forward_in_every_conv_mode(device, mode, tol, fuse):
     """conv_mode="split" (the inference default since round 3): the 3x3 layers off the Winograd path run as exact three-way bf16 splits
@@ -460,7 +460,7 @@ def test_forward_in_every_conv_mode(device, mode, tol, fuse):
         assert not on_pipe and not wino_split and net._net.conv_mode == "f32"
         return
     assert len(on_pipe) >= 10, on_pipe     # stage 1 (4 layers) and decoder blocks 3-5 / 8-10, with fused upsampling / heads or without
-    assert all(getattr(c, "split_mode", 0) in (0, 3 if mode == "split" else 1) for c in convs)
+    assert all(getattr(c, "split_mode", 0) in (0, {"split": 3, "f16x2": _lib.PLANES_F16X2, "bf16": 1}[mode]) for c in convs)
     deep = [c.name for c in convs if getattr(c, "deep_bf16", False)]
     if mode == "bf16" and deep:   # the deep layers on the direct bf16-operand kernel (csrc/conv_bf16d.hip; CASAPOSE_BF16_DEEP=0: two-plane Winograd)
         assert len(deep) >= 9 and not wino_split, (deep, wino_split)
@@ -468,15 +468,17 @@ def test_forward_in_every_conv_mode(device, mode, tol, fuse):
         assert len(wino_split) >= 9, wino_split   # the deep layers' Winograd GEMMs on the bf16 pipe too (3 planes / hi + mid)
 
 
-def test_default_inference_mode_is_the_fp32_equivalent_split(device):
+def test_default_inference_mode_is_the_fp32_level_fp16_split(device):
     from casapose_amd import engine
 
     import os
 
     if os.environ.get("CASAPOSE_INFER_CONV_MODE"):
         pytest.skip("the environment overrides the default conv mode for this run")
+    from casapose_amd import _lib
+
     net, _ = build(device, 5, 27, 64, 96)
-    assert engine.DEFAULT_INFER_CONV_MODE == "split" and net._net.conv_mode == "split" and net._net.conv_planes == 3
+    assert engine.DEFAULT_INFER_CONV_MODE == "f16x2" and net._net.conv_mode == "f16x2" and net._net.conv_planes == _lib.PLANES_F16X2
 
 
 def test_bare_resnet18_backbone_taps(device, tmp_path):

@@ -1,7 +1,8 @@
 """GPU parity of the bf16-pipe 3x3 kernel (csrc/conv_hsplit.hip) against the fp64 oracle:
   planes = 3 (exact three-way bf16 split, six products): the SAME gate as the fp32-MFMA kernels (1e-4 of the tensor's range; measured
              error is at the fp32 round-off level), over 12 orders of magnitude of operand scale;
-  planes = 1 (operands rounded to bf16): the bf16 gate of SURVEY 8(d), 3e-2 relative.
+  planes = 1 (operands rounded to bf16): the bf16 gate of SURVEY 8(d), 3e-2 relative;
+  F16X2 (fp16 two-way split, three products; round 4): the fp32 gate again -- its error against the fp32 kernels' is pinned in test_gpu_f16x2.py.
 Every operand / epilogue mode the kernel covers: one and two sources, the 4-channel image source, ragged tiles (16-row x 32-column
 tiles), partial-convolution tap mask with 9/count, CLADE table + leaky pair, residual, dual outputs."""
 import ctypes as C
@@ -14,8 +15,8 @@ import casapose_oracle as O
 from test_gpu_conv import _labels, close, dev
 
 pytestmark = pytest.mark.gpu
-SPLIT3, BF16 = 100, 101
-MODES = [(SPLIT3, 1e-4), (BF16, 3e-2)]
+SPLIT3, BF16, F16X2 = 100, 101, 102
+MODES = [(SPLIT3, 1e-4), (BF16, 3e-2), (F16X2, 1e-4)]   # F16X2: the fp16 two-way split (round 4), the fp32 gate
 
 
 @pytest.mark.parametrize("mode,tol", MODES)
@@ -240,7 +241,7 @@ def test_out_of_range_layers_are_refused(device):
         ops.conv2d_fused([dev(x, device)], w2.astype(np.float32), pad=2, dilation=2, tile_hint=SPLIT3)   # dilated
 
 
-@pytest.mark.parametrize("planes,tol", [(3, 1e-4), (1, 3e-2)])
+@pytest.mark.parametrize("planes,tol", [(3, 1e-4), (1, 3e-2), (0x12, 1e-4)])
 @pytest.mark.parametrize("hw", [(64, 96), (37, 70), (480, 640)])
 def test_stem_on_the_bf16_pipe(device, planes, tol, hw):
     """csrc/conv_stem_split.hip (round 4): conv0 -- 7x7 / stride 2 / pad 3, bn_data as an affine on the real pixels (the padding stays zero),
@@ -272,7 +273,7 @@ def test_stem_on_the_bf16_pipe(device, planes, tol, hw):
     ref = O.conv2d(img * ps + pb, wk, stride=2, pad=3)   # zero padding AFTER the affine: O.conv2d pads the affine image with zeros
     close(raw, ref, rtol=tol)
     close(act, np.maximum(ref * sc + sh, 0.0), rtol=tol)
-    if planes == 3:   # and it is the fp32-MFMA stem kernel's result to fp32 rounding
+    if planes in (3, 0x12):   # and it is the fp32-MFMA stem kernel's result to fp32 rounding
         layer.stem_split = 0
         raw2 = torch.empty_like(raw)
         layer.desc.out_raw = raw2.data_ptr()
