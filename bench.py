@@ -264,6 +264,9 @@ def _dtype_note_train():
     note = "f32"
     if parts:
         note += " (%s as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)" % " and ".join(parts)
+    if conv == "split" and os.environ.get("CASAPOSE_TRAIN_FWD", "split") == "f16x2":
+        note += ("; FORWARD launches of those groups as fp16 two-way splits on v_mfma_f32_32x32x16_f16 (three exact products per fp32 product, fp32-level error: "
+                 "tests/test_gpu_f16x2.py), backward launches as exact bf16 splits")
     if conv == "bf16":
         note = "bf16 operands / f32 accumulate in the forward / data gradient / weight gradient of the 3x3 layers off the Winograd path; " + note + " elsewhere"
     return note

@@ -955,7 +955,9 @@ def test_config13_bpnp_step_at_448_matches_autograd(device):
     # term divides by |v|^2 of a random-initialised direction field, so a few pixels with |v| ~ 1e-3 dominate the gradient and turn the
     # forward's 1e-5 into per cents (tools/debug/grad_per_variable.py at 224x224: 8e-3 worst with fp32 MFMA and direct kernels only, 3.6e-3
     # with the exact splits) -- that mode is gated at 1e-2 here and at 1e-3 on the better-conditioned shapes of the tests above.
-    gate = 1e-3 if os.environ.get("CASAPOSE_CONV_MODE", "split") == "split" else 1e-2
+    # CASAPOSE_TRAIN_FWD=f16x2 (opt-in: the forward in the fp16 two-way split, fp32-LEVEL rather than exact) lands where the fp32 MFMA does: 4.4e-3 worst.
+    exact = os.environ.get("CASAPOSE_CONV_MODE", "split") == "split" and os.environ.get("CASAPOSE_TRAIN_FWD", "split") != "f16x2"
+    gate = 1e-3 if exact else 1e-2
     bad = {n: e for n, e in worst.items() if e > gate}
     assert not bad, "gradient mismatch (relative L2): %s" % sorted(bad.items(), key=lambda t: -t[1])[:10]
     # ---- the host BPnP gradient itself, by central differences on two visible objects of THIS scene ----

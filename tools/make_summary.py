@@ -60,17 +60,20 @@ for old in [f for f in os.listdir(P) if f.startswith(tag + "_")]:   # nothing of
 copy(T + "bench.json", "%s_bench.json" % tag)
 copy(T + "bench_bs32.json", "%s_bench_bs32.json" % tag)
 copy(T + "bench_f32.json", "%s_bench_infer_f32.json" % tag)
+copy(T + "bench_split.json", "%s_bench_infer_split.json" % tag)
 copy(T + "bench_bf16.json", "%s_bench_infer_bf16.json" % tag)
 copy(T + "bench_profiled.json", "%s_bench_profiled.json" % tag)
 copy(T + "trace/bench_kernel_stats.csv", "%s_bench_kernel_stats.csv" % tag)
 copy(T + "layer_times.txt", "%s_layer_times.txt" % tag)
 copy(T + "layer_times_f32.txt", "%s_layer_times_conv_mode_f32.txt" % tag)
+copy(T + "layer_times_split.txt", "%s_layer_times_conv_mode_split.txt" % tag)
 copy(T + "pmc_traffic/traffic.json", "%s_pmc_traffic.json" % tag)
 copy(T + "pmc_traffic/summary.txt", "%s_pmc_traffic.txt" % tag)
 copy(T + "pmc_mfma/summary.txt", "%s_pmc_mfma.txt" % tag)
 copy(T + "bench_train.json", "%s_bench_train.json" % tag)
 copy(T + "bench_train_f32.json", "%s_bench_train_conv_mode_f32.json" % tag)
 copy(T + "bench_train_bf16.json", "%s_bench_train_conv_mode_bf16.json" % tag)
+copy(T + "bench_train_fwd_f16x2.json", "%s_bench_train_fwd_f16x2.json" % tag)
 copy(T + "train_trace/train_kernel_stats.csv", "%s_train_kernel_stats.csv" % tag)
 copy(T + "train_times.txt", "%s_train_times.txt" % tag)
 copy(T + "bench_vote.json", "%s_bench_vote.json" % tag)
@@ -153,8 +156,19 @@ if o:
               "frac %.3f of %.1f (MFMA families alone %.3f); largest logit difference between the two forwards %.1e (relative).\n"
               % (o["value"], o["ms_per_step"], orf.get("frac", float("nan")), orf.get("peak", float("nan")),
                  (orf.get("per_pipe", {}).get("f32", {}) or {}).get("frac_of_its_peak", float("nan")), o.get("max_logit_difference_vs_headline_rel", float("nan"))))
+o2 = b.get("exact_bf16_split")
+if o2:
+    orf = o2.get("roofline") or {}
+    md.append("Same run with exact three-way bf16 splits (`exact_bf16_split`, conv mode `split`, the headline of round 3): **%.1f images/s**, %.2f ms/step, roofline "
+              "frac %.3f; largest logit difference from the headline forward %.1e (relative).\n"
+              % (o2["value"], o2["ms_per_step"], orf.get("frac", float("nan")), o2.get("max_logit_difference_vs_headline_rel", float("nan"))))
+acc = (b.get("cpu_baseline") or {}).get("accuracy_vs_fp64")
+if acc:
+    md.append("Accuracy inside the same line (`cpu_baseline.accuracy_vs_fp64`): %s -- %s.\n" % (json.dumps(acc["per_conv_mode"]), acc["what"]))
+md.append("`useful_tflops` %.1f = %.3f of the fp32-level peak of this arithmetic (%.0f TFLOP/s = dense 2-byte peak / %d products per fp32 product).\n"
+          % (rf["useful_tflops"], rf["useful_frac_of_fp32_equiv_peak"], rf["fp32_equiv_peak"], int(rf.get("products_per_fp32_product", 6))))
 alone = []
-for name, label in (("bench_infer_f32.json", "`CASAPOSE_INFER_CONV_MODE=f32` as its own run"), ("bench_infer_bf16.json", "`=bf16` (operands rounded to bf16, NOT fp32-equivalent)")):
+for name, label in (("bench_infer_f32.json", "`CASAPOSE_INFER_CONV_MODE=f32` as its own run"), ("bench_infer_split.json", "`=split` (exact three-way bf16 splits)"), ("bench_infer_bf16.json", "`=bf16` (operands rounded to bf16, NOT fp32-equivalent)")):
     x = load(name)
     if x:
         alone.append("%s %.0f images/s (%.2f ms, frac %.3f)" % (label, x["value"], x["ms_per_step"], x["roofline"]["frac"]))
@@ -177,7 +191,7 @@ if os.path.exists(mf):
 tf = os.path.join(P, "%s_pmc_traffic.txt" % tag)
 if os.path.exists(tf):
     md.append("HBM traffic per launch (`%s_pmc_traffic.txt`, first rows):\n\n```\n%s\n```\n" % (tag, "\n".join(open(tf).read().splitlines()[:16])))
-for name, label in (("layer_times.txt", "default (split)"), ("layer_times_conv_mode_f32.txt", "`CASAPOSE_INFER_CONV_MODE=f32`")):
+for name, label in (("layer_times.txt", "default (f16x2)"), ("layer_times_conv_mode_split.txt", "`CASAPOSE_INFER_CONV_MODE=split`"), ("layer_times_conv_mode_f32.txt", "`CASAPOSE_INFER_CONV_MODE=f32`")):
     p_ = os.path.join(P, "%s_%s" % (tag, name))
     if os.path.exists(p_):
         md.append("Per-layer times, %s: `%s_%s`." % (label, tag, name))
@@ -190,7 +204,8 @@ md.append("\n## Training step (BASELINE configs[2]: bs 32, 448x448, K = 9; `pyth
 tr = t["roofline"]
 extra = []
 for name, label in (("bench_train_conv_mode_f32.json", "`CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32` (fp32 MFMA everywhere)"),
-                    ("bench_train_conv_mode_bf16.json", "`CASAPOSE_CONV_MODE=bf16` (operands rounded to bf16)")):
+                    ("bench_train_conv_mode_bf16.json", "`CASAPOSE_CONV_MODE=bf16` (operands rounded to bf16)"),
+                    ("bench_train_fwd_f16x2.json", "`CASAPOSE_TRAIN_FWD=f16x2` (opt-in: forward launches as fp16 two-way splits, backward exact)")):
     x = load(name)
     if x:
         extra.append("%s: %.0f images/s (%.1f ms)" % (label, x["value"], x["ms_per_step"]))
