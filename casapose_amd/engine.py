@@ -513,16 +513,23 @@ class WinoConv:
         return sum(2.0 * 36 * tp * self.ktot * self.cout for _, _, tp in self.chunks())
 
 
+WINO_DIRECT_UNDILATED_128 = os.environ.get("CASAPOSE_WINO_DIRECT_128", "")   # "" = by conv mode (f16x2: yes), "0" / "1" force (A/B)
 WINO_MIN_K = int(os.environ.get("CASAPOSE_WINO_MIN_K", "0"))      # 0 = the measured defaults below
 WINO_MIN_COUT = int(os.environ.get("CASAPOSE_WINO_MIN_COUT", "128"))
 
 
-def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int, split_gemm: bool = False) -> bool:
+def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequence[Tuple[int, int]], cout: int, split_gemm: bool = False,
+                  f16x2: bool = False) -> bool:
     """Measured on MI355X (profiles/): the 4x MFMA saving beats the two transform passes once the GEMM is deep and wide enough -- K >= 256 with
     the fp32-MFMA GEMM; K >= 128 when the GEMM runs on the bf16 pipe (split_gemm: the dilated 128 -> 256 layer stage3_unit1_conv1, which no
-    split kernel covers directly, 0.43 -> 0.17 ms at bs 16; the three 128 -> 128 stage-2 layers 0.37 -> 0.36 ms)."""
+    split kernel covers directly, 0.43 -> 0.17 ms at bs 16; the three 128 -> 128 stage-2 layers 0.37 -> 0.36 ms).  f16x2 (three products per fp32
+    product): the UNDILATED 128-channel layers are faster on the direct split kernel (stage 2: 0.27 against 0.30 ms, 1882 against 1872 images/s) --
+    their Winograd GEMM is HBM-bound on V and M -- so K >= 256 again for them; the dilated 128 -> 256 layer has no direct kernel and stays."""
     k = sum(s[0] for s in sources)
     min_k = WINO_MIN_K or (128 if split_gemm else 256)
+    direct_128 = f16x2 if WINO_DIRECT_UNDILATED_128 == "" else WINO_DIRECT_UNDILATED_128 == "1"
+    if direct_128 and dilation == 1 and split_gemm and not WINO_MIN_K:
+        min_k = 256
     return kh == 3 and stride == 1 and pad == dilation and k >= min_k and k % 32 == 0 and cout >= WINO_MIN_COUT and cout % 4 == 0
 
 
@@ -990,7 +997,7 @@ class CasaposeNet:
             L[name] = FusedConv(name, p[key], layout, k, k, cout, sources, dev, want_split=bool(self.conv_planes))
             pad = dil * (k // 2) if pad is None else pad
             planes = 2 if self.conv_mode == "bf16" else (self.conv_planes if self.conv_mode in ("split", "f16x2") and not WINO_GEMM_F32 else None)
-            if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout, split_gemm=bool(planes) or WINO_GEMM_SPLIT):
+            if self.use_winograd and not partial and wino_eligible(k, stride, dil, pad, sources, cout, split_gemm=bool(planes) or WINO_GEMM_SPLIT, f16x2=self.conv_mode == "f16x2"):
                 Wn[name] = WinoConv(name, p[key] if layout == 0 else np.transpose(p[key], (1, 2, 0, 3)), cout, sources, dev, split_planes=planes)
 
         add("conv0", "conv0.kernel", 0, 7, 64, [(4, 3)])

@@ -1,4 +1,5 @@
 set -u
+export CASAPOSE_GEMM_ONE=${CASAPOSE_GEMM_ONE:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_gemm; rm -rf $O; mkdir -p $O
 for shape in "512 512" "256 256" "128 128"; do
