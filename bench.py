@@ -286,7 +286,7 @@ def _dtype_note():
     if mode == "bf16":
         return "bf16 operands / f32 accumulate in the 3x3 layers off the Winograd path, Winograd GEMMs on hi + mid bf16 planes, f32 elsewhere (NOT fp32-equivalent)"
     if mode == "f16x2":
-        return ("f32 (fp32-level: every fp32 operand as an fp16 pair hi = rn(x), lo = rn(x - hi) -- reproduced to 2^-24 -- and the three products hi*hi, hi*lo, lo*hi, "
+        return ("f32 (fp32-level: every fp32 operand as an fp16 pair hi = rn(x), lo = rn(x - hi) -- reproduced to within one fp32 ulp, 0.75 x 2^-24 rms -- and the three products hi*hi, hi*lo, lo*hi, "
                 "each exact, accumulated in fp32 on v_mfma_f32_32x32x16_f16; weights pre-scaled by a power of two; measured error against fp64 at or below the fp32 "
                 "MFMA's (tests/test_gpu_f16x2.py, `accuracy_vs_fp64` in this line); for the 3x3 / stride-1 layers, the 7x7 stem%s; strided 3x3 / 1x1 layers on "
                 "v_mfma_f32_32x32x2_f32; tensors fp32 in HBM)" % ("" if wino == "f32" else " and the Winograd GEMMs"))

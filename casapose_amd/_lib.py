@@ -138,6 +138,7 @@ SYMBOLS = [
     ("cp_ccl_filter_labels", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("cp_ccl_workspace_bytes", C.c_size_t, [_i, _i, _i, _i]),
     ("cp_ransac_vote_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("cp_ransac_vote_seeded_f32", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_ulonglong, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("cp_ransac_workspace_bytes", C.c_size_t, [_i, _i, _i, _i, _i, _i]),
     ("cp_guided_match_mask", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("cp_guided_bilinear_upsample_x2_f32", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

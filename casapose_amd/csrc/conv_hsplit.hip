@@ -2,7 +2,7 @@
 //   NP = 3  fp32-EQUIVALENT: every fp32 operand is split exactly into three bf16 terms (hi, mid, lo: 8 + 8 + 8 significand bits) and the
 //           six products lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (the scheme of
 //           wino_gemm_split.hip; the three dropped products are <= 2^-24 of the full product -- the rounding an fp32 multiply makes anyway);
-//   NP = 2  fp32-LEVEL with half the MFMAs: the fp16 two-way split of split_f16.h (hi = rn_f16(x), lo = rn_f16(x - hi): the operand to 2^-24;
+//   NP = 2  fp32-LEVEL with half the MFMAs: the fp16 two-way split of split_f16.h (hi = rn_f16(x), lo = rn_f16(x - hi): the operand to one fp32 ulp;
 //           products lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16).  The weights arrive multiplied by a power of two (their low parts stay
 //           normal numbers); the epilogue multiplies the accumulators by its inverse (HSplitK::descale, exact).
 //   NP = 1  plain bf16 operands (round to nearest even), fp32 accumulation -- "bf16 convolutions" of BASELINE.json configs[2].

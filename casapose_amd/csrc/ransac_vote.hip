@@ -16,8 +16,9 @@
 //      remaining rounds);
 //   5. refinement: fp64 normal-equation sums over the winners' inliers, 2x2 solve, with the
 //      reference's "all keypoints invertible, cond < 1e6, else return the winners" rule.
-// Random numbers: the caller supplies 31-bit uniform draws (tests inject them; the Python wrapper
-// generates them with torch); a draw d selects pixel d % tn.
+// Random numbers: either the caller supplies 31-bit uniform draws (cp_ransac_vote_f32: tests inject them) or the library makes them from a 64-bit
+// seed with a counter-based generator (cp_ransac_vote_seeded_f32, round 4: no draw tensor -- 94 MB per call at the reference's settings -- and the
+// random thinning of objects above max_num pixels, ransac_voting.py:295-301, happens inside the compaction); a draw d selects pixel d % tn.
 #include "common.h"
 
 #include <type_traits>
@@ -36,8 +37,23 @@ struct ObjState {        // one per (image, object)
     float win_pts[KP][2];
 };
 
+// counter-based random numbers (splitmix64 finaliser of seed + counter * golden ratio): 64 well-mixed bits per (seed, counter), no state
+__device__ __forceinline__ unsigned long long mix64(unsigned long long seed, unsigned long long ctr) {
+    unsigned long long z = seed + (ctr + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// thinning predicate of one pixel: kept with probability thr / 2^32 (thr = 0xffffffff: always); the same decision in both compaction passes
+__device__ __forceinline__ bool thin_keep(const unsigned* __restrict__ thr, size_t io, unsigned long long seed, unsigned long long pixel_id) {
+    if (thr == nullptr) return true;
+    const unsigned t = thr[io];
+    return t == 0xffffffffu || (unsigned)(mix64(seed ^ 0x7468696E6E696E67ull, pixel_id) >> 32) < t;
+}
+
 // ---- 1. compaction -------------------------------------------------------------------------
-__global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int objects, int* __restrict__ rowcnt) {
+__global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int objects, int* __restrict__ rowcnt,
+                                const unsigned* __restrict__ thr, unsigned long long seed) {
     // one wave per (image,row); rowcnt[(img*objects+o)*H + y]
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -48,11 +64,24 @@ __global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, i
         int c = 0;
         for (int x0 = 0; x0 < W; x0 += 64) {
             int x = x0 + lane;
-            bool m = x < W && p[x] == o;
+            bool m = x < W && p[x] == o && thin_keep(thr, (size_t)img * objects + (o - 1), seed, ((unsigned long long)img * H + y) * W + x);
             c += __popcll(__ballot(m));
         }
         if (lane == 0) rowcnt[((size_t)img * objects + (o - 1)) * H + y] = c;
     }
+}
+
+// thinning thresholds: one wave per (image, object) sums the row counts; above max_num pixels every pixel is kept with probability max_num / count
+// (ransac_voting.py:295-301: selection = uniform < max_num / foreground_num)
+__global__ void thin_threshold_kernel(const int* __restrict__ rowcnt, int H, int n_obj_total, int max_num, unsigned* __restrict__ thr) {
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n_obj_total) return;
+    int c = 0;
+    for (int y = lane; y < H; y += 64) c += rowcnt[(size_t)i * H + y];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) thr[i] = c > max_num ? (unsigned)((double)max_num / (double)c * 4294967296.0) : 0xffffffffu;
 }
 
 __global__ void rowscan_kernel(int* __restrict__ rowcnt, int H, int n_obj_total, int min_num, ObjState* __restrict__ st) {
@@ -88,7 +117,7 @@ __global__ void rowscan_kernel(int* __restrict__ rowcnt, int H, int n_obj_total,
 }
 
 __global__ void compact_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int objects, const int* __restrict__ rowstart,
-                               int* __restrict__ pixlist, int list_stride) {
+                               int* __restrict__ pixlist, int list_stride, const unsigned* __restrict__ thr, unsigned long long seed) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B * H) return;
@@ -99,7 +128,7 @@ __global__ void compact_kernel(const uint8_t* __restrict__ lab, int B, int H, in
         int base = rowstart[io * H + y];
         for (int x0 = 0; x0 < W; x0 += 64) {
             int x = x0 + lane;
-            bool m = x < W && p[x] == o;
+            bool m = x < W && p[x] == o && thin_keep(thr, io, seed, ((unsigned long long)img * H + y) * W + x);
             unsigned long long bal = __ballot(m);
             if (m) {
                 int rank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -123,7 +152,7 @@ __device__ __forceinline__ void pixel_record(const float* __restrict__ vertex, i
 
 __global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_off, int H, int W, int objects, const int* __restrict__ pixlist,
                               int list_stride, const int32_t* __restrict__ draws, int hyp, const ObjState* __restrict__ st,
-                              float* __restrict__ hyp_pts, int n_obj_total, int* __restrict__ counts) {
+                              float* __restrict__ hyp_pts, int n_obj_total, int* __restrict__ counts, unsigned long long seed, int round) {
     // one thread per (image*object, h, v)
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long per = (long long)hyp * KP;
@@ -135,9 +164,18 @@ __global__ void hypgen_kernel(const float* __restrict__ vertex, int ld, int dir_
     counts[i] = 0;   // this round's inlier counter of (object, hypothesis, keypoint): same index space (a separate zeroing launch before)
     const int img = io / objects;
     const int v = hv % KP;
-    const int32_t* d = draws + ((size_t)io * per + hv) * 2;
+    unsigned d0, d1;
+    if (draws) {   // injected 31-bit draws
+        const int32_t* d = draws + ((size_t)io * per + hv) * 2;
+        d0 = (unsigned)d[0];
+        d1 = (unsigned)d[1];
+    } else {       // one 64-bit number per (round, object, hypothesis, keypoint): two 31-bit draws
+        const unsigned long long z = mix64(seed, (unsigned long long)round * (unsigned long long)(per * n_obj_total) + (unsigned long long)i);
+        d0 = (unsigned)(z >> 33);
+        d1 = (unsigned)(z & 0x7fffffffull);
+    }
     const int* pl = pixlist + (size_t)io * list_stride;
-    const int p0 = pl[(unsigned)d[0] % (unsigned)s.tn], p1 = pl[(unsigned)d[1] % (unsigned)s.tn];
+    const int p0 = pl[d0 % (unsigned)s.tn], p1 = pl[d1 % (unsigned)s.tn];
     float c0x, c0y, d0x, d0y, c1x, c1y, d1x, d1y;
     pixel_record(vertex, ld, dir_off, img, H, W, p0, v, c0x, c0y, d0x, d0y);
     pixel_record(vertex, ld, dir_off, img, H, W, p1, v, c1x, c1y, d1x, d1y);
@@ -418,6 +456,7 @@ struct Workspace {
     int* counts;
     double* sums;
     int* nactive;
+    unsigned* thr;
     size_t bytes;
 };
 
@@ -438,6 +477,7 @@ Workspace carve(void* base, int batch, int h, int w, int objects, int hyp) {
     ws.counts = reinterpret_cast<int*>(take(no * hyp * KP * sizeof(int)));
     ws.sums = reinterpret_cast<double*>(take(no * KP * 5 * sizeof(double)));
     ws.nactive = reinterpret_cast<int*>(take(sizeof(int)));
+    ws.thr = reinterpret_cast<unsigned*>(take(no * sizeof(unsigned)));
     ws.bytes = p - reinterpret_cast<uintptr_t>(base) + 256;
     return ws;
 }
@@ -449,31 +489,61 @@ extern "C" size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects
     return carve(nullptr, batch, h, w, objects, hyp).bytes;
 }
 
+namespace {
+int ransac_vote(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h, int w, int objects, int kp, const int32_t* idx,
+                bool seeded, unsigned long long seed, int hyp, float inlier_thresh, float confidence, int max_iter, int min_num, int max_num, void* wsp,
+                float* out, int32_t* rounds_out, void* stream);
+}
+
 extern "C" int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h, int w, int objects,
                                   int kp, const int32_t* idx, int hyp, float inlier_thresh, float confidence, int max_iter, int min_num,
                                   int max_num, void* wsp, float* out, int32_t* rounds_out, void* stream) {
-    CP_REQUIRE(labels && vertex && idx && wsp && out, "cp_ransac_vote_f32: null pointer");
+    CP_REQUIRE(idx, "cp_ransac_vote_f32: null pointer");
+    return ransac_vote(labels, vertex, ld, dir_off, batch, h, w, objects, kp, idx, false, 0ull, hyp, inlier_thresh, confidence, max_iter, min_num, max_num, wsp, out,
+                       rounds_out, stream);
+}
+
+extern "C" int cp_ransac_vote_seeded_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h, int w, int objects,
+                                         int kp, unsigned long long seed, int hyp, float inlier_thresh, float confidence, int max_iter, int min_num,
+                                         int max_num, void* wsp, float* out, int32_t* rounds_out, void* stream) {
+    CP_REQUIRE(max_num >= 1, "cp_ransac_vote_seeded_f32: max_num must be positive");
+    return ransac_vote(labels, vertex, ld, dir_off, batch, h, w, objects, kp, nullptr, true, seed, hyp, inlier_thresh, confidence, max_iter, min_num, max_num, wsp, out,
+                       rounds_out, stream);
+}
+
+namespace {
+int ransac_vote(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h, int w, int objects, int kp, const int32_t* idx,
+                bool seeded, unsigned long long seed, int hyp, float inlier_thresh, float confidence, int max_iter, int min_num, int max_num, void* wsp,
+                float* out, int32_t* rounds_out, void* stream) {
+    CP_REQUIRE(labels && vertex && wsp && out, "cp_ransac_vote_f32: null pointer");
     CP_REQUIRE(kp == KP, "cp_ransac_vote_f32: built for %d keypoints (got %d)", KP, kp);
     CP_REQUIRE(batch > 0 && h > 0 && w > 0 && objects > 0 && objects < 255, "cp_ransac_vote_f32: bad sizes");
     CP_REQUIRE(hyp > 0 && hyp % HB == 0, "cp_ransac_vote_f32: hypotheses per round must be a multiple of %d", HB);
     CP_REQUIRE(max_iter >= 1 && dir_off >= 0 && dir_off + 2 * kp <= ld, "cp_ransac_vote_f32: bad max_iter / channel offsets");
     CP_REQUIRE((long long)h * w < (1LL << 31), "cp_ransac_vote_f32: image too large");
-    (void)max_num;  // sub-sampling above max_num (:295-301) is random in the reference: the caller applies it to `labels`
+    // sub-sampling above max_num (:295-301) is random in the reference: with injected draws the caller applies it to `labels`; the seeded entry
+    // thins inside the compaction (count, per-object keep probability, count and compact again with the same per-pixel decisions)
     hipStream_t st = (hipStream_t)stream;
     Workspace ws = carve(wsp, batch, h, w, objects, hyp);
     const int no = batch * objects;
     const int list_stride = h * w;
     const int rows = batch * h;
     (void)hipMemsetAsync(ws.sums, 0, (size_t)no * KP * 5 * sizeof(double), st);
-    CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt);
+    const unsigned* thr = nullptr;
+    CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, thr, seed);
+    if (seeded) {
+        CP_LAUNCH(thin_threshold_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, max_num, ws.thr);
+        thr = ws.thr;
+        CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, thr, seed);
+    }
     CP_LAUNCH(rowscan_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, min_num, ws.st);
-    CP_LAUNCH(compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, ws.pixlist, list_stride);
+    CP_LAUNCH(compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, ws.pixlist, list_stride, thr, seed);
     const int px_chunks = 8;
     const long long nhyp = (long long)no * hyp * KP;
     for (int r = 0; r < max_iter; ++r) {
-        const int32_t* draws = idx + (size_t)r * nhyp * 2;
+        const int32_t* draws = idx ? idx + (size_t)r * nhyp * 2 : nullptr;
         CP_LAUNCH(hypgen_kernel, dim3((unsigned)((nhyp + 255) / 256)), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist,
-                  list_stride, draws, hyp, ws.st, ws.hyp_pts, no, ws.counts);
+                  list_stride, draws, hyp, ws.st, ws.hyp_pts, no, ws.counts, seed, r);
         if (hyp % 64 == 0)
             CP_LAUNCH(vote_kernel<64>, dim3(hyp / 64, px_chunks, no), dim3(256), 0, st, vertex, ld, dir_off, h, w, objects, ws.pixlist, list_stride,
                       ws.hyp_pts, hyp, ws.st, ws.counts, inlier_thresh, px_chunks);
@@ -498,3 +568,4 @@ extern "C" int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, in
     CP_LAUNCH(refine_solve_kernel, dim3((no + 63) / 64), dim3(64), 0, st, ws.sums, ws.st, no, out, rounds_out);
     return cp::check_launch("cp_ransac_vote_f32");
 }
+}  // namespace

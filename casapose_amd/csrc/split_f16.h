@@ -1,9 +1,10 @@
 // Two-way fp16 split of fp32 operands for the bf16/fp16 matrix pipe ("f16x2": three products instead of the six of the exact bf16 split).
-//     hi = rn_f16(x),   lo = rn_f16(x - hi)            (x - hi is exact in fp32: at most 13 significant bits, |x - hi| <= 2^-12 |x|)
-// so |x - hi - lo| <= 2^-11 * 2^-12 |x| / 2 = 2^-24 |x|: the operand is reproduced to half an fp32 ulp, as long as `lo` is a NORMAL fp16
-// number (|x| >= 2^-2) or -- fp16 subnormals are honoured by v_cvt_pk_f16_f32 and by v_mfma_f32_32x32x16_f16 on gfx950, measured with
-// tools/debug/f16_probe.hip -- to an absolute 2^-25 below that.  The products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator
-// (11 x 11 bits); the dropped lo*lo is <= 2^-24 of the product.  Range: fp16 ends at 65504; with MODE.FP16_OVFL set a conversion clamps
+//     hi = rn_f16(x),   lo = rn_f16(x - hi)            (x - hi is exact in fp32: at most 13 significant bits, |x - hi| <= 2^-11 |x|)
+// lo keeps 11 of those 13 bits, so at most ONE unit of x's last place is lost: |x - hi - lo| <= 2^-23 |x| (one fp32 ulp), 0.75 * 2^-24 rms, and three
+// fp32 operands in four are reproduced exactly (tests/test_f16x2_arith.py) -- as long as `lo` is a NORMAL fp16 number (|x| >= 2^-2); below that
+// it is absolute (fp16 subnormals, spacing 2^-24: honoured by v_cvt_pk_f16_f32 and by v_mfma_f32_32x32x16_f16 on gfx950, measured with
+// tools/debug/f16_probe.hip).  The products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator (11 x 11 bits); the dropped lo*lo is
+// <= 2^-22 of the product.  Measured against fp64 the result is at or below the fp32 MFMA's error (tests/test_gpu_f16x2.py).  Range: fp16 ends at 65504; with MODE.FP16_OVFL set a conversion clamps
 // instead of producing inf and lo takes 11 bits of the remainder: no inf / NaN, the error of such an operand grows to <= 2^-12 of it (beyond
 // 131008: saturation).  Graceful, not fp32-level: the callers keep their operands inside the range.
 // WEIGHTS are multiplied by a power of two first (cp_f16x2_weight_scale: max |w| -> [2^11, 2^12)) so that their low parts are normal numbers;

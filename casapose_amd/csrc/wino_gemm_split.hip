@@ -101,7 +101,7 @@ __global__ void split_weights_kernel(const float* __restrict__ U, int groups, in
 
 // NPL = 3: the exact three-way split (six products, fp32-equivalent).  NPL = 2: hi + mid planes only (16 significand bits per operand, products
 // hi*hi, hi*mid, mid*hi): half the MFMAs, for the bf16 conv modes whose gates are 3e-2 -- NOT fp32-equivalent.  NPL = 2 with F16: the fp16
-// two-way split of split_f16.h (operands reproduced to 2^-24, products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16): fp32-level accuracy
+// two-way split of split_f16.h (operands reproduced to within one fp32 ulp, products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16): fp32-level accuracy
 // with half the MFMAs of the exact bf16 split; the weights come pre-multiplied by a power of two, the accumulators are multiplied by c_scale.
 template <int NPL, bool F16>
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {

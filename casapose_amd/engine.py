@@ -203,6 +203,7 @@ class FusedConv:
         d.cout, d.kh, d.kw = self.cout, self.kh, self.kw
         d.stride, d.dilation, d.pad = stride, dilation, pad
         d.num_sources = len(srcs)
+        self._srcs = list(srcs)   # (ForwardPlan.f16x2_operand_ranges reads the source tensors back)
         keep = [self.wp] if self.wp is not None else []
         for i, s in enumerate(srcs):
             cs = d.src[i]
@@ -312,7 +313,7 @@ WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "") == "split"
 WINO_GEMM_F32 = os.environ.get("CASAPOSE_WINO_GEMM", "") == "f32"
 TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
 # default arithmetic of the inference plan's convolutions (CasaposeNet(conv_mode=None)):
-#   "f16x2" (default since round 4) = every fp32 operand as an fp16 pair hi + lo (reproduced to 2^-24), the three exact products hi*hi, hi*lo, lo*hi
+#   "f16x2" (default since round 4) = every fp32 operand as an fp16 pair hi + lo (reproduced to within one fp32 ulp), the three exact products hi*hi, hi*lo, lo*hi
 #           accumulated in fp32 on the fp16 matrix pipe, for every layer the split kernels cover: fp32-LEVEL -- against fp64 its error is at or below
 #           the fp32 MFMA's on the GEMM, on single convolutions and on the whole network (tests/test_gpu_f16x2.py) -- with half the MFMAs of "split";
 #   "split" = exact three-way bf16 splits, six products (fp32-equivalent for any finite operand, no range conditions: the round-3 default);
@@ -830,6 +831,37 @@ class ForwardPlan:
                     and lib.cp_wino_output_input_applicable(ka["batch"], ka["in_h"], ka["in_w"], ka["dilation"], a.cout)):
                 a.fuse_next, b.skip_input = b, True
         self._wino_pending = []
+
+    def f16x2_operand_ranges(self) -> Dict[str, Optional[Tuple[float, float]]]:
+        """The range condition of the fp16 two-way split made checkable.  Call after a forward: for every layer this plan runs in
+        f16x2, (max |a| over the layer's source tensors, upper bound of the magnitude its split converts) -- the bound is max |a| itself for the
+        direct kernels (an interpolated / selected source is a convex combination of the stored one; the stem's input affine is applied), 100 x
+        max |a| for a Winograd layer (V = B^T d B: the rows of B^T sum to at most 10 in magnitude).  fp32-level accuracy needs the first number
+        >= ~1 and the second <= 65504.  None: the layer's input exists only inside a fused output -> input transform (it is the activated,
+        normalised output of the layer before it)."""
+        out: Dict[str, Optional[Tuple[float, float]]] = {}
+        for conv in self.convs:
+            if hasattr(conv, "gemm_flops"):   # WinoConv
+                if conv.planes != _lib.PLANES_F16X2:
+                    continue
+                if conv.skip_input:
+                    out[conv.name] = None
+                    continue
+                amax = max(float(s["data"].abs().max()) for s in conv.srcs)
+                out[conv.name] = (amax, 100.0 * amax)
+                continue
+            planes = conv.split_mode or conv.stem_split or ((conv._gemm or {}).get("planes", 0))
+            if planes != _lib.PLANES_F16X2:
+                continue
+            amax = 0.0
+            for sdict in conv._srcs:
+                a = float(sdict["data"].abs().max())
+                pre = sdict.get("pre")
+                if pre:
+                    a = a * float(pre[0].abs().max()) + float(pre[1].abs().max())
+                amax = max(amax, a)
+            out[conv.name] = (amax, amax)
+        return out
 
     def _bilinear_step(self, src, dst, sh, sw, c):
         lib = _lib.load()

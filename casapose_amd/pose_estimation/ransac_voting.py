@@ -18,9 +18,11 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     """mask [b,h,w,oc] one-hot object masks (no background channel), vertex [b,h,w,vn,2] or
     [b,h,w,vn*2] in (dy,dx) order.  Returns [b,oc,vn,2] keypoints in (x,y).
 
-    `draws` (int32 [max_iter,b,oc,round_hyp_num,vn,2], values in [0,2^31)) replaces the random
-    pixel-pair draws of :319-321 -- tests inject them; by default they come from torch.randint
-    on the device (`generator` makes them reproducible)."""
+    By default (round 4) every random number is made inside the library from one 64-bit seed (cp_ransac_vote_seeded_f32: counter-based draws per round,
+    and the random thinning of objects above `max_num` pixels, :295-301, inside the compaction) -- the seed comes from `generator` (reproducible) or
+    from torch's default CPU generator; nothing is synchronised and no draw tensor exists.  `draws` (int32 [max_iter,b,oc,round_hyp_num,vn,2],
+    values in [0,2^31)) replaces the pixel-pair draws of :319-321 -- tests inject them; on that path the thinning is done here with torch (it needs
+    the counts on the host)."""
     if not mask.is_cuda:
         raise _lib.CasaposeHipError("ransac_voting_layer_all_masks needs CUDA (ROCm) tensors; there is no CPU fallback")
     lib = _lib.load()
@@ -32,6 +34,16 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     counts = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
     check(lib.cp_mask_to_labels_f32(mask.to(torch.float32).contiguous().data_ptr(), b, h, w, oc, labels.data_ptr(), counts.data_ptr(), stream),
           "cp_mask_to_labels_f32")   # one pass instead of five PyTorch reductions / elementwise kernels over [b,h,w,oc]
+    ws = torch.empty(lib.cp_ransac_workspace_bytes(b, h, w, oc, vn, round_hyp_num), dtype=torch.uint8, device=mask.device)
+    out = torch.empty(b, oc, vn, 2, dtype=torch.float32, device=mask.device)
+    rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
+    if draws is None:
+        gen_dev = generator.device if generator is not None else torch.device("cpu")
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64, device=gen_dev, generator=generator).item())
+        check(lib.cp_ransac_vote_seeded_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, seed, round_hyp_num, float(inlier_thresh),
+                                            float(confidence), int(max_iter), int(min_num), int(max_num), ws.data_ptr(), out.data_ptr(), rounds.data_ptr(), stream),
+              "cp_ransac_vote_seeded_f32")
+        return (out, rounds) if return_rounds else out
     if int(counts.max()) > max_num:
         # random down-sampling of large masks (:295-301): keep a pixel with probability max_num / count
         keep_p = (max_num / counts.clamp(min=1).to(torch.float32)).clamp(max=1.0)  # [b,oc]
@@ -39,14 +51,9 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
         lab_l = labels.long()
         p_pix = torch.cat([torch.ones(b, 1, device=mask.device), keep_p], dim=1).gather(1, lab_l.reshape(b, -1)).reshape(b, h, w)
         labels = torch.where(u < p_pix, labels, torch.zeros_like(labels)).contiguous()
-    if draws is None:
-        draws = torch.randint(0, 2**31 - 1, (max_iter, b, oc, round_hyp_num, vn, 2), device=mask.device, dtype=torch.int32, generator=generator)
     if tuple(draws.shape) != (max_iter, b, oc, round_hyp_num, vn, 2) or draws.dtype != torch.int32:
         raise ValueError("draws must be int32 with shape [max_iter,b,oc,hyp,vn,2]")
     draws = draws.contiguous()
-    ws = torch.empty(lib.cp_ransac_workspace_bytes(b, h, w, oc, vn, round_hyp_num), dtype=torch.uint8, device=mask.device)
-    out = torch.empty(b, oc, vn, 2, dtype=torch.float32, device=mask.device)
-    rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
     check(lib.cp_ransac_vote_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, draws.data_ptr(), round_hyp_num,
                                  float(inlier_thresh), float(confidence), int(max_iter), int(min_num), int(max_num), ws.data_ptr(),
                                  out.data_ptr(), rounds.data_ptr(), stream), "cp_ransac_vote_f32")

@@ -307,6 +307,13 @@ int cp_ransac_vote_f32(const uint8_t* labels, const float* vertex, int ld, int d
                        int w, int objects, int kp, const int32_t* idx, int hyp, float inlier_thresh,
                        float confidence, int max_iter, int min_num, int max_num, void* ws, float* out,
                        int32_t* rounds_out, void* stream);
+/* The same voter with the random numbers made INSIDE the library from a 64-bit seed (counter-based: equal seeds give equal results, no state):
+ * the pixel-pair draws of every round, and the random thinning of objects above max_num pixels (:295-301: a pixel is kept with probability
+ * max_num / count) as part of the compaction -- no draw tensor (94 MB per call at the reference's settings), no pass over the mask outside. */
+int cp_ransac_vote_seeded_f32(const uint8_t* labels, const float* vertex, int ld, int dir_off, int batch, int h,
+                              int w, int objects, int kp, unsigned long long seed, int hyp, float inlier_thresh,
+                              float confidence, int max_iter, int min_num, int max_num, void* ws, float* out,
+                              int32_t* rounds_out, void* stream);
 size_t cp_ransac_workspace_bytes(int batch, int h, int w, int objects, int kp, int hyp);
 
 /* GuidedBilinearUpsampling (_normalization_layers.py:569-664; casapose_c_gcu4_bilat): mask[n,Y,X] bit j = the low-resolution label of
@@ -347,8 +354,8 @@ int cp_wino_gemm_split_f32(const float* V, const void* Usplit, float* M, int row
 /* planes = 3: the above.  planes = 2: hi + mid planes only (16 significand bits per operand; products hi*hi, hi*mid, mid*hi): half the MFMAs, NOT
  * fp32-equivalent -- for the bf16 conv modes (BASELINE.json configs[2]; gates 3e-2).  Same pre-split weights. */
 int cp_wino_gemm_split_planes_f32(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, int planes, void* stream);
-/* planes = CP_PLANES_F16X2: the fp16 TWO-way split (csrc/split_f16.h): hi = rn_f16(x), lo = rn_f16(x - hi) reproduce an fp32 operand to 2^-24
- * relative (half an fp32 ulp) and the three products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16 -- fp32-level
+/* planes = CP_PLANES_F16X2: the fp16 TWO-way split (csrc/split_f16.h): hi = rn_f16(x), lo = rn_f16(x - hi) reproduce an fp32 operand to within
+ * one fp32 ulp (2^-23 worst case, 0.75 * 2^-24 rms, three operands in four exactly) and the three products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16 -- fp32-level
  * accuracy (measured against fp64 beside the fp32 MFMA and the exact bf16 split: tests/test_gpu_f16x2.py) with HALF the MFMAs of
  * the exact bf16 split.  fp16's range is handled by scaling: the weights are multiplied by a power of two before their split
  * (cp_f16x2_weight_scale(max |w|): max -> [2^11, 2^12), so that the low parts are normal numbers) and the kernel multiplies its accumulators by

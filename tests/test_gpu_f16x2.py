@@ -134,3 +134,32 @@ def test_f16x2_network_error_beside_the_other_modes(device):
     print("network error vs fp64 (segmentation, vector field): %s" % errs)
     for i in range(2):
         assert errs["f16x2"][i] <= 1.5 * max(errs["f32"][i], errs["split"][i]) + 1e-6, errs
+
+
+def test_f16x2_range_condition_is_checkable_and_holds_on_the_bench_network(device):
+    """ForwardPlan.f16x2_operand_ranges(): after a forward, max |a| of every layer input the fp16 split converts and the bound it implies (x 100 in the
+    Winograd domain).  On the network of the bench (he_uniform weights, randomised normalisation tables, uniform images: an UNTRAINED network, whose
+    activations grow through decoder 2 -- 1.2 at the stem, 1353 into block 10, 198 into the Winograd layer of block 1) every layer sits inside
+    [1, 65504], worst-case Winograd bound included (19776) -- the condition under which the mode is fp32-level."""
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    k, v, b, h, w = 9, 27, 2, 96, 128
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, base_model="resnet18", device=device, seed=1237,
+                                             conv_mode="f16x2")
+    rng = np.random.default_rng(1237)
+    params = net.get_parameters()
+    for name, val in params.items():
+        if name.endswith(".gamma") or name.endswith(".moving_variance"):
+            params[name] = rng.uniform(0.5, 1.5, val.shape).astype(np.float32)
+        elif name.endswith(".beta") or name.endswith(".moving_mean"):
+            params[name] = (0.1 * rng.standard_normal(val.shape)).astype(np.float32)
+    net.set_parameters(params)
+    img = (2.0 * torch.rand(b, h, w, 3, generator=torch.Generator().manual_seed(1)) - 1.0).to(device)
+    net([img], training=False)
+    torch.cuda.synchronize()
+    ranges = net._net.plan(b, h, w).f16x2_operand_ranges()
+    measured = {n: r for n, r in ranges.items() if r is not None}
+    print({n: (round(r[0], 2), round(r[1], 1)) for n, r in measured.items()})
+    assert len(measured) >= 20 and len(ranges) - len(measured) <= 4, ranges
+    for name, (amax, bound) in measured.items():
+        assert amax >= 1.0 and bound <= 65504.0, (name, amax, bound)

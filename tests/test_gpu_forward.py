@@ -566,8 +566,16 @@ def test_two_stream_forward_equals_the_single_stream_forward(device, monkeypatch
         return out.clone(), kp.clone()
 
     def same(a, b_):
+        # segmentation logits (decoder 1) everywhere; the vector fields are conditioned on the arg-max label map, so ONE pixel whose two top logits
+        # tie to the last bits changes them by O(1) inside that pixel's receptive field (seen: 1 of 24576 labels, |difference| 390): they are compared
+        # everywhere when the label maps agree, and on all but a small fraction of the pixels otherwise
         lab_a, lab_b = a[..., :k].argmax(-1), b_[..., :k].argmax(-1)
-        return float((a - b_).abs().max()) <= 1e-4 * float(a.abs().max()) and float((lab_a != lab_b).float().mean()) <= 1e-3
+        flips = float((lab_a != lab_b).float().mean())
+        seg_ok = float((a[..., :k] - b_[..., :k]).abs().max()) <= 1e-4 * float(a[..., :k].abs().max())
+        dv = (a[..., k:] - b_[..., k:]).abs().amax(-1)
+        tol = 1e-4 * float(a[..., k:].abs().max())
+        vec_ok = float(dv.max()) <= tol if flips == 0.0 else float((dv > tol).float().mean()) <= 2e-2
+        return seg_ok and flips <= 1e-3 and vec_ok
 
     one, kp_one = run()
     lib = _lib.load()
