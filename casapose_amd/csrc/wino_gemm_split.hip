@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         const int rslot = tid >> 3, rbase = (rslot & ~7) | (((rslot & 7) >> 1) + 4 * (rslot & 1));
 #endif
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-        float4 areg[4];
+        // Two register sets: chunk c travels in set c & 1, is requested two phases before it is stored (round 4, with the fp16 split: a phase is 24
+        // MFMAs per wave, and with ONE chunk in flight the operand latency was exposed -- the kernel without its A loads ran 25 % faster).  The loop
+        // is unrolled by two phases and every phase issues its four loads UNCONDITIONALLY (out of range past the end: they fetch nothing), so the
+        // compiler can count: the wait in front of a store leaves exactly the other set's four loads in flight.
+        float4 areg[2][4];
         unsigned aoff[4];
         int it = -1, q = p.nchunks;
         auto advance = [&]() {
@@ -146,46 +151,52 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
                 q = 0;
                 ++it;
                 const int tile = start + bidx + it * nb;
-                const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+                const int tm = tile / p.tiles_n;
                 const int m0 = tm * BM;
-                (void)tn;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)(m0 + rbase + 32 * i) * (unsigned)p.K + col4 * 4) * 4u;
             }
         };
-        auto issue = [&]() {
-            advance();
+        auto issue = [&](auto setc, bool valid) __attribute__((always_inline)) {
+            constexpr int S = decltype(setc)::value;
+            if (valid) advance();
+            const unsigned oob = valid ? 0u : 0x80000000u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], q * (BK * 4), 0));
+            for (int i = 0; i < 4; ++i) areg[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(aoff[i] | oob), q * (BK * 4), 0));
         };
-        auto store = [&](int buf) {
+        auto store = [&](auto setc, int buf) __attribute__((always_inline)) {
+            constexpr int S = decltype(setc)::value;
             unsigned char* a = smem + buf * STAGE_BYTES + rbase * ROWB + col4 * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 h, m, l;
-                if constexpr (F16) cp::split4h(areg[i], h, m);
-                else split4(areg[i], h, m, l);
+                if constexpr (F16) cp::split4h(areg[S][i], h, m);
+                else split4(areg[S][i], h, m, l);
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB) = h;
                 *reinterpret_cast<uint2*>(a + 32 * i * ROWB + SPLIT_BYTES) = m;
                 if constexpr (NPL == 3) *reinterpret_cast<uint2*>(a + 32 * i * ROWB + 2 * SPLIT_BYTES) = l;
             }
         };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
         // three LDS stages: chunk c + 2 is stored while the consumers multiply chunk c, so chunk c + 1 is complete one barrier early and its
         // first fragments can be read during chunk c instead of behind the barrier
-        issue();
-        store(0);
-        if (total_chunks > 1) {
-            issue();
-            store(1);
-        }
-        if (total_chunks > 2) issue();
+        issue(S0{}, true);                      // chunk 0
+        issue(S1{}, total_chunks > 1);          // chunk 1
+        store(S0{}, 0);
+        issue(S0{}, total_chunks > 2);          // chunk 2
+        if (total_chunks > 1) store(S1{}, 1);
+        issue(S1{}, total_chunks > 3);          // chunk 3
         CP_BARRIER();
         int st = 2;   // stage of chunk c + 2
-        for (int c = 0; c < total_chunks; ++c) {
-            if (c + 2 < total_chunks) {
-                store(st);
-                if (c + 3 < total_chunks) issue();
-            }
+        for (int c = 0; c < total_chunks; c += 2) {
+            if (c + 2 < total_chunks) store(S0{}, st);     // chunk c + 2 (requested two phases ago)
+            issue(S0{}, c + 4 < total_chunks);             // chunk c + 4
+            st = (st == 2) ? 0 : st + 1;
+            CP_BARRIER();
+            if (c + 1 >= total_chunks) break;
+            if (c + 3 < total_chunks) store(S1{}, st);     // chunk c + 3
+            issue(S1{}, c + 5 < total_chunks);             // chunk c + 5
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
         }

@@ -160,6 +160,6 @@ def test_f16x2_range_condition_is_checkable_and_holds_on_the_bench_network(devic
     ranges = net._net.plan(b, h, w).f16x2_operand_ranges()
     measured = {n: r for n, r in ranges.items() if r is not None}
     print({n: (round(r[0], 2), round(r[1], 1)) for n, r in measured.items()})
-    assert len(measured) >= 20 and len(ranges) - len(measured) <= 4, ranges
+    assert len(measured) >= 20 and len(ranges) - len(measured) <= 6, ranges   # (None: inputs that exist only inside a fused output -> input transform)
     for name, (amax, bound) in measured.items():
         assert amax >= 1.0 and bound <= 65504.0, (name, amax, bound)
