@@ -317,6 +317,12 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 
 }  // namespace
 
+namespace cp {
+bool wino_gemm_wide_applicable(int rows, int group_rows, int k, int n);   // wino_gemm_wide.hip
+int wino_gemm_wide_launch(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, float c_scale, unsigned a_bytes, unsigned b_bytes,
+                          hipStream_t stream);
+}
+
 extern "C" size_t cp_wino_split_weights_bytes(int groups, int n, int k) {
     if (groups <= 0 || n <= 0 || k <= 0 || k % 16) return 0;
     const size_t nb32 = (size_t)((n + 127) / 128) * 4;
@@ -367,6 +373,8 @@ extern "C" int cp_wino_gemm_split_scaled_f32(const float* V, const void* Usplit,
     g.nb32 = g.tiles_n * 4;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.c_scale = c_scale;
+    if (planes == CP_PLANES_F16X2 && cp::wino_gemm_wide_applicable(rows, group_rows, k, n))   // 128 x 256 tiles, both operands through LDS (wino_gemm_wide.hip)
+        return cp::wino_gemm_wide_launch(V, Usplit, M, rows, group_rows, k, n, c_scale, g.a_bytes, g.b_bytes, (hipStream_t)stream);
     const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

@@ -163,3 +163,35 @@ def test_f16x2_range_condition_is_checkable_and_holds_on_the_bench_network(devic
     assert len(measured) >= 20 and len(ranges) - len(measured) <= 6, ranges   # (None: inputs that exist only inside a fused output -> input transform)
     for name, (amax, bound) in measured.items():
         assert amax >= 1.0 and bound <= 65504.0, (name, amax, bound)
+
+
+@pytest.mark.parametrize("rows,group,n,k", [(2 * 384, 384, 256, 128), (3 * 128, 128, 512, 96), (1280, 640, 256, 32), (36 * 256, 256, 512, 512)])
+def test_wide_f16x2_gemm_equals_the_narrow_kernel_bit_for_bit(device, rows, group, n, k):
+    """csrc/wino_gemm_wide.hip (128 x 256 block tiles, both operands staged in LDS, weight fragments by DMA) takes every f16x2 GEMM whose N is a multiple
+    of 256; wino_gemm_split.hip (128 x 128, weights from L2) takes the rest.  Same split, same products in the same order, same fp32 accumulation over
+    K: the wide kernel's M must equal, BIT FOR BIT, the narrow kernel's results for the two / four 128-column halves (each computed as its own
+    N = 128 problem with the SAME weight scale); odd chunk counts (K = 96, 32), one chunk per tile, more tiles than blocks."""
+    from casapose_amd import _lib
+    from casapose_amd._lib import check
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream(device).cuda_stream
+    g = torch.Generator().manual_seed(rows + n + k)
+    V = torch.randn(rows, k, generator=g).relu_().to(device)
+    U = (torch.randn(rows // group, n, k, generator=g) * 0.1).to(device)
+    scale = float(lib.cp_f16x2_weight_scale(float(U.abs().max())))
+
+    def gemm(Upart, ncols):
+        Us = torch.empty(lib.cp_wino_split_weights_bytes(rows // group, ncols, k), dtype=torch.uint8, device=device)
+        check(lib.cp_wino_split_weights_scaled_f32(Upart.data_ptr(), rows // group, ncols, k, _lib.PLANES_F16X2, scale, Us.data_ptr(), st), "split weights")
+        M = torch.full((rows, ncols), float("nan"), device=device)
+        check(lib.cp_wino_gemm_split_scaled_f32(V.data_ptr(), Us.data_ptr(), M.data_ptr(), rows, group, k, ncols, _lib.PLANES_F16X2, 1.0 / scale, st), "gemm")
+        return M
+
+    wide = gemm(U, n)
+    parts = torch.cat([gemm(U[:, c:c + 128].contiguous(), 128) for c in range(0, n, 128)], dim=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wide).all()
+    assert torch.equal(wide, parts), float((wide - parts).abs().max())
+    ref = torch.cat([V[i * group:(i + 1) * group].double() @ U[i].double().T for i in range(rows // group)])
+    assert float((wide.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * (k ** 0.5)

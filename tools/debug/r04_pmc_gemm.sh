@@ -9,13 +9,13 @@ for shape in "512 512" "256 256" "128 128"; do
   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_MISC --kernel-trace -d $O/$tag/p3 -o p3 --output-format csv -- python3 $R/tools/debug/gemm_one.py $shape 4 > $O/$tag.p3.log 2>&1
   echo "plain" > $O/$tag/plain.log
   echo "== $tag" >> $O/summary.txt
-  python3 $R/tools/pmc_parse.py $O/$tag wino_gemm_split >> $O/summary.txt 2>&1
+  python3 $R/tools/pmc_parse.py $O/$tag wino_gemm_ >> $O/summary.txt 2>&1
   python3 - >> $O/summary.txt 2>&1 <<PY
 import csv, collections
 agg = collections.defaultdict(list)
 try:
     for r in csv.DictReader(open("$O/$tag/p3/p3_counter_collection.csv")):
-        if "wino_gemm_split" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "wino_gemm_" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items(): print("  %-24s %.4g" % (k, sum(v[1:]) / max(len(v[1:]), 1)))
 except Exception as e: print("p3:", e)
 PY
