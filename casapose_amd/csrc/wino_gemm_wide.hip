@@ -198,17 +198,28 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
     int buf = 0;   // LDS stage of the current chunk (c % 3)
     CP_BARRIER();  // chunks 0 and 1 are in LDS
     read_ab(0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // (nothing pending at the loop's top on the entry path either)
     for (int c = 0; c < total_chunks; ++c) {
         const int nbuf = (buf == 2) ? 0 : buf + 1;
+        // Fences pin the order: twelve fragment reads, then the 24 MFMAs that do NOT depend on them (768 cycles: the LDS latency is hidden), twice per
+        // chunk.  Left alone the scheduler sinks every read to just in front of its first use (register pressure: 224 VGPRs) and the second half of
+        // the chunk waits for its twelve reads one by one.
         read_ab(buf, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_step(0);
-        if (c + 1 < total_chunks) read_ab(nbuf, 0, 0);   // the next chunk's first fragments: both its stages have been complete since the last barrier
+        __builtin_amdgcn_sched_barrier(0);
+        // the next chunk's first fragments: both its stages have been complete since the last barrier.  UNCONDITIONAL (after the last chunk it reads a
+        // stale stage and nobody uses it): a branch here splits the loop body into blocks, and the sinking pass then moves the reads of the first
+        // group down into the block of their first use, past the fences
+        read_ab(nbuf, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_step(1);
-        // the reads above go out behind the first MFMAs of the second step, not in front of the barrier
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
-        CP_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0) through the BUILTIN (simm16 0xc07f: vmcnt / expcnt at their maxima): the wait-count pass reads it and knows that nothing is
+        // pending at the loop's top -- with the wait inside an asm string it assumed the twelve reads above still in flight there and put an
+        // lgkmcnt(0) between the next iteration's reads and the MFMAs that do not need them
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("s_barrier" ::: "memory");
         buf = nbuf;
         if (++q == p.nchunks) {
             const int tile = start + bidx + it * nb;
