@@ -78,3 +78,21 @@ def test_a_split_dot_product_is_as_good_as_an_fp32_one(k, a_scale, w_scale):
     assert rep_scaled <= 4e-8, rep_scaled
     if w_scale < 0.1:
         assert rep_plain > 2.0 * rep_scaled, (rep_plain, rep_scaled)
+
+
+def test_training_weight_scale_is_cached_between_rescale_points(monkeypatch):
+    """train_engine.f16x2_scale: max |w| needs the host, so the power-of-two scale of the opt-in f16x2 forward is re-read every
+    F16X2_RESCALE_EVERY refreshes and kept (16x headroom) in between."""
+    import torch
+
+    from casapose_amd import train_engine as te
+
+    monkeypatch.setattr(te, "F16X2_RESCALE_EVERY", 4)
+    cache = {}
+    w = torch.full((8,), 0.03)
+    s0 = te.f16x2_scale(cache, w)
+    assert 2048.0 <= 0.03 * s0 < 4096.0
+    w.mul_(3.0)                                   # weights move between rescale points: the scale stays
+    assert [te.f16x2_scale(cache, w) for _ in range(3)] == [s0, s0, s0]
+    s4 = te.f16x2_scale(cache, w)                 # fifth call = refresh 4: re-read
+    assert 2048.0 <= 0.09 * s4 < 4096.0 and s4 == s0 / 2.0
