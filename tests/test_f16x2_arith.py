@@ -95,4 +95,4 @@ def test_training_weight_scale_is_cached_between_rescale_points(monkeypatch):
     w.mul_(3.0)                                   # weights move between rescale points: the scale stays
     assert [te.f16x2_scale(cache, w) for _ in range(3)] == [s0, s0, s0]
     s4 = te.f16x2_scale(cache, w)                 # fifth call = refresh 4: re-read
-    assert 2048.0 <= 0.09 * s4 < 4096.0 and s4 == s0 / 2.0
+    assert 2048.0 <= 0.09 * s4 < 4096.0 and s4 == s0 / 4.0
