@@ -153,14 +153,27 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch, accuracy=None):
         # vector fields are conditioned on the arg-max label map, which random weights put on ties.
         t0 = time.perf_counter()
         p64 = R.to_torch({k: np.asarray(v) for k, v in accuracy["params"].items()}, dtype=torch.float64, requires_grad=False)
+        q64 = R.prepare_inference(p64)
+        img64 = torch.from_numpy(accuracy["image"]).double()
         with torch.no_grad():
-            ref = R.forward_infer_fast(R.prepare_inference(p64), torch.from_numpy(accuracy["image"]).double())[..., :seg_dim].numpy()
+            ref = R.forward_infer_fast(q64, img64)[..., :seg_dim].numpy()
         den = float(np.abs(ref).max())
+        # ... and the VECTOR FIELD (round 5): decoder 2 is conditioned on the hard label map, which random weights put on arg-max ties, so each mode's
+        # field is compared with an fp64 evaluation conditioned on that mode's OWN label map (the one its forward computed on the device)
+        vec, vref = {}, {}
+        for m, lab in accuracy.get("labels", {}).items():
+            key = lab.tobytes()
+            if key not in vref:
+                with torch.no_grad():
+                    vref[key] = R.forward_infer_fast(q64, img64, labels=torch.from_numpy(lab.astype(np.int64)))[..., seg_dim:].numpy()
+            vec[m] = float("%.3g" % (float(np.abs(accuracy["vertex"][m].astype(np.float64) - vref[key]).max()) / float(np.abs(vref[key]).max())))
         acc = {"what": "max |segmentation logit - fp64 logit| / max |fp64 logit| for image 0 of the bench batch, per convolution arithmetic run in this line "
-                       "(fp64 = the CPU restatement in double precision with the bench's parameters)",
+                       "(fp64 = the CPU restatement in double precision with the bench's parameters); vector_field_per_conv_mode: the same for the 27 "
+                       "vector-field channels, the fp64 evaluation conditioned on the label map the device computed in that mode",
                "per_conv_mode": {m: float("%.3g" % (float(np.abs(v.astype(np.float64) - ref).max()) / den)) for m, v in accuracy["logits"].items()},
+               "vector_field_per_conv_mode": vec, "label_maps_compared": len(vref),
                "seconds": round(time.perf_counter() - t0, 1)}
-        _log("cpu baseline: fp64 accuracy check %s" % acc["per_conv_mode"])
+        _log("cpu baseline: fp64 accuracy check %s, vector field %s" % (acc["per_conv_mode"], vec))
     return {"value": round(best, 3), "accuracy_vs_fp64": acc, "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
             "what": "CPU restatement (PyTorch-CPU fp32, oneDNN, %d threads), not TensorFlow" % threads, "cpu": _cpu_model_name(),
             "thread_probe_s_per_image": {str(k): round(v, 3) for k, v in timing.items()},
@@ -770,9 +783,20 @@ def main():
         except Exception as exc:  # the probe is an annotation: never fail the bench line over it
             result["roofline"]["sustained_on_this_box"] = {"error": str(exc)}
     _log("roofline section done")
-    accuracy = {"params": params, "image": img[:1].cpu().numpy(), "logits": {}} if rank == 0 else None
+    accuracy = {"params": params, "image": img[:1].cpu().numpy(), "logits": {}, "vertex": {}, "labels": {}} if rank == 0 else None
+
+    def one_image(net_, mode):   # image 0 alone: logits, vector field and the label map the device conditioned decoder 2 on
+        o = net_([img[:1]], training=False)
+        accuracy["logits"][mode] = o[..., :seg_dim].cpu().numpy()
+        accuracy["vertex"][mode] = o[..., seg_dim:].cpu().numpy()
+        accuracy["labels"][mode] = net_._net.plan(1, H, W).labels[0].cpu().numpy()
+
     if rank == 0:
-        accuracy["logits"][net._net.conv_mode] = net([img[:1]], training=False)[..., :seg_dim].cpu().numpy()
+        # the f16x2 range guard's findings on the timed plan (engine.ForwardPlan._run_calibrating): layers rescaled or moved to the exact split
+        rep = dict(net._net.plan(B, H, W).f16x2_report)
+        one_image(net, net._net.conv_mode)
+        result["config"]["f16x2_guard"] = {"enabled": bool(net._net.f16x2_guard), "layers_checked": len(rep),
+                                           "not_plain_f16x2": {n: "%s (max %.3g)" % (r[1], r[0]) for n, r in rep.items() if r[1] != "f16x2"}}
     if rank == 0 and world == 1 and not args.no_optin and net._net.conv_mode in ("split", "f16x2"):
         # the same workload in the other fp32 arithmetics, measured in the same run and reported BESIDE the headline, each with its own roofline:
         # conv_mode="f32" (v_mfma_f32_32x32x2_f32 in every convolution, the round-1/2 headline) and -- when the headline is the fp16 two-way split --
@@ -803,7 +827,7 @@ def main():
                 step2()
             torch.cuda.synchronize(dev)
             dt2 = time.perf_counter() - t1
-            accuracy["logits"][other] = net2([img[:1]], training=False)[..., :seg_dim].cpu().numpy()
+            one_image(net2, other)
             result[key] = {
                 "value": round(B * args.steps / dt2, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 4),
                 # (random-weight label maps sit on ties, so keypoints are not comparable between two runs; the logits are)

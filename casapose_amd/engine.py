@@ -12,6 +12,7 @@ the Keras names of the reference so weights map 1:1.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -151,6 +152,7 @@ class FusedConv:
         self.head_w: Optional[torch.Tensor] = None
         self.head_cout = 0
         self._gemm: Optional[dict] = None   # set by enable_gemm_split() for the CURRENT binding only
+        self.head_in_scale, self._head_tabs = 1.0, None   # f16x2 range guard: power of two on the fused head's operand (set_head_in_scale)
         self.deep_bf16 = False              # bf16 conv mode: this binding runs on csrc/conv_bf16d.hip (set by ForwardPlan)
 
     def _make_planes(self, key: int, image: torch.Tensor, planes: int, stream: Optional[int]) -> torch.Tensor:
@@ -195,6 +197,7 @@ class FusedConv:
         d = self.desc
         self._gemm = None   # a GEMM route decided for an earlier shape must not survive a re-bind (rows would be stale: out-of-bounds launch)
         self.deep_bf16 = False
+        self.head_in_scale, self._head_tabs, self._epi_tabs = 1.0, None, (scale, shift)
         eh = (self.kh - 1) * dilation + 1
         ew = (self.kw - 1) * dilation + 1
         d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -269,6 +272,44 @@ class FusedConv:
         self._gemm = dict(Us=Us, rows=rows, k=cin, planes=planes, c_scale=c_scale)
         return True
 
+    def set_head_in_scale(self, factor: float):
+        """The fused 1x1 head of an f16x2 binding converts this layer's activated output t = act(v * scale + shift), which exists in registers only.
+        Multiply the tables by a power of two: act(2^e x) = 2^e act(x) exactly for ReLU / leaky ReLU, so the head sees 2^e t and its accumulator
+        factor (head_descale) takes 2^-e.  Only where nothing else receives t (no out_act) and a table exists."""
+        d = self.desc
+        scale, shift = self._epi_tabs
+        if not d.head_out or d.out_act or scale is None or self.split_mode != _lib.PLANES_F16X2:
+            raise _lib.CasaposeHipError("%s: no fused f16x2 head whose operand could be scaled" % self.name)
+        self.head_in_scale = float(factor)
+        self._head_tabs = (scale * factor, shift * factor)
+        d.scale, d.shift = self._head_tabs[0].data_ptr(), self._head_tabs[1].data_ptr()
+
+    def f16x2_active(self) -> bool:
+        """does the CURRENT binding convert operands with the fp16 two-way split?"""
+        return _lib.PLANES_F16X2 in (self.split_mode, self.stem_split, (self._gemm or {}).get("planes", 0))
+
+    def input_amax(self) -> float:
+        """max |a| over what this binding's loaders convert: the stored source tensors (an interpolated / selected source is a convex combination of
+        the stored one), through the input affine where the stem has one.  Synchronises; calibration only."""
+        amax = 0.0
+        for sdict in self._srcs:
+            a = float(sdict["data"].abs().max())
+            pre = sdict.get("pre")
+            if pre:
+                a = a * float(pre[0].abs().max()) + float(pre[1].abs().max())
+            amax = max(amax, a)
+        return amax
+
+    def demote_to_exact_split(self, kernel_hwio: Optional[np.ndarray] = None):
+        """this binding's f16x2 launches on the exact three-way bf16 split instead (planes are made on first use)"""
+        if self.split_mode == _lib.PLANES_F16X2:
+            self.split_mode = 3
+        if self.stem_split == _lib.PLANES_F16X2:
+            self.stem_split = 3
+        if self._gemm is not None and self._gemm["planes"] == _lib.PLANES_F16X2:
+            if kernel_hwio is None or not self.enable_gemm_split(kernel_hwio, 3):
+                raise _lib.CasaposeHipError("%s: cannot re-route the 1x1 GEMM to the exact split" % self.name)
+
     def run(self, stream: int):
         lib = _lib.load()
         g = self._gemm
@@ -292,7 +333,7 @@ class FusedConv:
             head = self.head_split_weights(self.split_mode, stream).data_ptr() if self.desc.head_out else None
             wsp = self.split_weights(self.split_mode, stream)
             check(lib.cp_conv2d_fwd_split_scaled(C.byref(self.desc), wsp.data_ptr(), head, self.split_mode, self._descale[self.split_mode],
-                                                 self._descale[-self.split_mode] if head else 1.0, stream), "cp_conv2d_fwd_split(%s)" % self.name)
+                                                 self._descale[-self.split_mode] / self.head_in_scale if head else 1.0, stream), "cp_conv2d_fwd_split(%s)" % self.name)
             return
         check(lib.cp_conv2d_fwd_f32(C.byref(self.desc), stream), "cp_conv2d_fwd_f32(%s)" % self.name)
 
@@ -319,6 +360,14 @@ TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
 #   "split" = exact three-way bf16 splits, six products (fp32-equivalent for any finite operand, no range conditions: the round-3 default);
 #   "f32"   = the fp32 MFMA everywhere;   "bf16" = bf16 operands (3e-2 gates)
 DEFAULT_INFER_CONV_MODE = "f16x2"
+# The range condition of f16x2 (csrc/split_f16.h) is CHECKED, per layer, on the first forward of every plan (and again after set_params / load_weights,
+# which drop the plans): a layer whose converted operands leave [F16X2_AMAX_LO, F16X2_AMAX_HI] runs on the exact three-way bf16 split instead (no range
+# condition), with one warning naming the layers.  Below LO the low halves are fp16 subnormals (absolute 2^-25: worse than 2^-24 of the tensor's
+# maximum); HI = 65504 / 8 leaves three octaves for later batches before a conversion clamps.  CASAPOSE_F16X2_GUARD=0 / CasaposeNet(f16x2_guard=False)
+# switch the check off (the unguarded plan of round 4: tests compare the two).
+F16X2_GUARD = os.environ.get("CASAPOSE_F16X2_GUARD", "1") != "0"
+F16X2_AMAX_LO = 0.5
+F16X2_AMAX_HI = 65504.0 / 8.0
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
@@ -385,6 +434,13 @@ class WinoConv:
             self.Us = split_wino_weights(self.U, 36, cout, self.ktot) if (WINO_GEMM_SPLIT or split_planes) else None
         self.desc = ConvDesc()  # the grouped GEMM
         self._keep: List = []
+        self.v_scale, self._vs_vec, self._next_tabs = 1.0, None, None
+        self.fuse_next, self.skip_input = None, False
+
+    def demote_to_exact_split(self):
+        """the fp16 two-way split of this layer's GEMM replaced by the exact three-way bf16 split (operands outside the fp16 range condition)"""
+        if self.planes == _lib.PLANES_F16X2:
+            self.Us, self.c_scale, self.planes = split_wino_weights(self.U, 36, self.cout, self.ktot), 1.0, 3
 
     @staticmethod
     def tiles(batch, h, w, dilation) -> Tuple[int, int]:
@@ -400,6 +456,7 @@ class WinoConv:
         if V.numel() < 36 * self.Tp * self.ktot or M.numel() < 36 * self.Tp * self.cout:
             raise ValueError("%s: Winograd scratch too small" % self.name)
         self.srcs, self.V, self.M = list(srcs), V, M
+        self.v_scale, self._vs_vec, self._next_tabs = 1.0, None, None   # f16x2 range guard (ForwardPlan._run_calibrating): power of two applied to V
         self.epi = dict(residual=residual, scale=scale, shift=shift, epi_label=epi_label, act=act, out_raw=out_raw, out_act=out_act)
         d = self.desc
         d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 36, 1, self.Tp, 1, self.Tp
@@ -419,6 +476,31 @@ class WinoConv:
         self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
         return in_h, in_w
 
+    def _input_transform(self, src_ptr: int, ld: int, cpad: int, nb: int, off: int, stream: int):
+        """V[.., off : off + cpad] = B^T d B of one source; with v_scale != 1 through the transform's per-channel input affine (x * 2^e + 0: exact)"""
+        lib = _lib.load()
+        if self.v_scale == 1.0:
+            check(lib.cp_wino_input_transform_f32(src_ptr, ld, cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off, stream),
+                  "cp_wino_input_transform_f32(%s)" % self.name)
+            return
+        if self._vs_vec is None or self._vs_vec[0] != self.v_scale:
+            n = max(c for c, _ in self.sources)
+            self._vs_vec = (self.v_scale, torch.full((n,), self.v_scale, dtype=torch.float32, device=self.V.device), torch.zeros(n, dtype=torch.float32, device=self.V.device))
+        check(lib.cp_wino_input_transform_pre_f32(src_ptr, ld, cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
+                                                  self._vs_vec[1].data_ptr(), self._vs_vec[2].data_ptr(), _lib.ACT_NONE, stream), "cp_wino_input_transform_pre_f32(%s)" % self.name)
+
+    def _tables_for_next(self):
+        """(scale, shift) pointers of this layer's epilogue when its fused output -> input transform writes the NEXT layer's V: the tables times the
+        next layer's v_scale (ReLU / leaky ReLU commute with a positive factor, a power of two is exact) -- the activated map itself is not stored"""
+        e, nxt = self.epi, self.fuse_next
+        if nxt.v_scale == 1.0:
+            return _ptr(e["scale"]), _ptr(e["shift"])
+        if e["scale"] is None:
+            raise _lib.CasaposeHipError("%s: cannot scale the fused transform's output without a normalisation table" % self.name)
+        if self._next_tabs is None or self._next_tabs[0] != nxt.v_scale:
+            self._next_tabs = (nxt.v_scale, e["scale"] * nxt.v_scale, e["shift"] * nxt.v_scale)
+        return self._next_tabs[1].data_ptr(), self._next_tabs[2].data_ptr()
+
     def chunks(self) -> List[Tuple[int, int, int]]:
         """[(first image, images, padded tiles)]: the batch is processed in groups of WINO_CHUNK images so that the two scratch tensors
         of a group (V: 36*Tp*K, M: 36*Tp*Cout floats -- 2.25x the layer's input and output) stay resident in the 256 MiB Infinity Cache
@@ -437,14 +519,14 @@ class WinoConv:
             for (cpad, _), s in zip(self.sources, self.srcs):
                 if getattr(self, "skip_input", False):   # the producer's fused output -> input transform has written V already
                     break
-                check(lib.cp_wino_input_transform_f32(at(s["data"], b0, s["ld"]), s["ld"], cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
-                                                      stream), "cp_wino_input_transform_f32(%s)" % self.name)
+                self._input_transform(at(s["data"], b0, s["ld"]), s["ld"], cpad, nb, off, stream)
                 off += cpad
             self.run_gemm(stream, tp)
             nxt = getattr(self, "fuse_next", None)
             if nxt is not None:   # Y = A^T M A + epilogue, then straight into the next layer's V (the activated map stays on chip)
+                sc_, sh_ = self._tables_for_next()
                 check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
-                                                             _ptr(e["scale"]), _ptr(e["shift"]), e["act"], at(e["out_raw"], b0, self.cout), self.cout, None, self.cout,
+                                                             sc_, sh_, e["act"], at(e["out_raw"], b0, self.cout), self.cout, None, self.cout,
                                                              self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
                 continue
             check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
@@ -462,8 +544,7 @@ class WinoConv:
         def t_in(stream):
             off = 0
             for (cpad, _), s in zip(self.sources, self.srcs):
-                check(lib.cp_wino_input_transform_f32(s["data"].data_ptr(), s["ld"], cpad, self.batch, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off,
-                                                      stream), "cp_wino_input_transform_f32(%s)" % self.name)
+                self._input_transform(s["data"].data_ptr(), s["ld"], cpad, self.batch, off, stream)
                 off += cpad
 
         def t_gemm(stream):
@@ -472,8 +553,9 @@ class WinoConv:
         def t_out(stream):
             nxt = getattr(self, "fuse_next", None)
             if nxt is not None:
+                sc_, sh_ = self._tables_for_next()
                 check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
-                                                             _ptr(e["scale"]), _ptr(e["shift"]), e["act"], _ptr(e["out_raw"]), self.cout, None, self.cout,
+                                                             sc_, sh_, e["act"], _ptr(e["out_raw"]), self.cout, None, self.cout,
                                                              self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
             else:
                 check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
@@ -497,7 +579,7 @@ class WinoConv:
         else:
             if self.Us is not None:
                 check(lib.cp_wino_gemm_split_scaled_f32(self.V.data_ptr(), self.Us.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, self.planes,
-                                                        self.c_scale, stream), "cp_wino_gemm_split_scaled_f32(%s)" % self.name)
+                                                        self.c_scale / self.v_scale, stream), "cp_wino_gemm_split_scaled_f32(%s)" % self.name)
             else:
                 check(lib.cp_wino_gemm_f32(self.V.data_ptr(), self.U.data_ptr(), self.M.data_ptr(), 36 * tp, tp, self.ktot, self.cout, stream),
                       "cp_wino_gemm_f32(%s)" % self.name)
@@ -551,6 +633,10 @@ class ForwardPlan:
         self.out_ld = K + V
         self.steps: List = []  # callables taking (stream)
         self.convs: List[FusedConv] = []
+        # f16x2 range guard: the first run() of this plan goes layer by layer, measures what every f16x2 layer is about to convert and demotes the
+        # layers outside the range condition to the exact split (ForwardPlan._run_calibrating); f16x2_report keeps what it saw
+        self.needs_calibration = bool(net.conv_planes == _lib.PLANES_F16X2 and net.f16x2_guard)
+        self.f16x2_report: Dict[str, Tuple[float, str]] = {}
         lib = _lib.load()
         P = net.device_tables
         hs = [h, h // 2, h // 4, h // 8]
@@ -606,13 +692,14 @@ class ForwardPlan:
             # bf16 matrix pipe (csrc/conv_hsplit.hip), 3 planes = exact three-way split (fp32-equivalent), 1 plane = bf16 operands; layers outside
             # its range (stem, strided and dilated layers, ...) keep the fp32-MFMA kernels
             layer.stem_split = 0
-            if net.conv_planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
-                layer.split_mode = net.conv_planes
-            elif (net.conv_planes and STEM_SPLIT and layer.wp_stem_split_f32 is not None and kw.get("stride", 1) == 2 and kw.get("pad", 0) == 3
+            planes = net.planes_for(layer.name)   # the net's conv mode, or the exact split for a layer the f16x2 guard has demoted
+            if planes and layer.wp_split_f32 is not None and lib.cp_conv_split_applicable(C.byref(layer.desc)):
+                layer.split_mode = planes
+            elif (planes and STEM_SPLIT and layer.wp_stem_split_f32 is not None and kw.get("stride", 1) == 2 and kw.get("pad", 0) == 3
                   and kw.get("dilation", 1) == 1 and lib.cp_conv_selected_tile(C.byref(layer.desc)) == _lib.TILE_STEM):
-                layer.stem_split = net.conv_planes   # conv0 on the bf16 matrix pipe (exact split / bf16 operands), csrc/conv_stem_split.hip
-            elif net.conv_planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
-                layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), net.conv_planes if net.conv_planes in (3, _lib.PLANES_F16X2) else 2)
+                layer.stem_split = planes   # conv0 on the bf16 matrix pipe (exact split / bf16 operands), csrc/conv_stem_split.hip
+            elif planes and layer.kh == 1 and layer.name + ".kernel" in net.params:
+                layer.enable_gemm_split(np.asarray(net.params[layer.name + ".kernel"], np.float32), planes if planes in (3, _lib.PLANES_F16X2) else 2)
             self.convs.append(layer)
             self.steps.append(layer.run)
 
@@ -832,6 +919,89 @@ class ForwardPlan:
                 a.fuse_next, b.skip_input = b, True
         self._wino_pending = []
 
+    def _run_calibrating(self, stream: int):
+        """One forward, layer by layer, fitting every f16x2 layer to what it is about to convert (host synchronisation per layer: first forward
+        of a plan only).  Three places convert fp32 activations to fp16 pairs, and each has its own exact remedy:
+          * a Winograd layer's GEMM converts V = B^T d B: max |V| is measured after the (own or fused) input transform; outside the band the
+            transform multiplies by a power of two (WinoConv.v_scale: exact) that brings max |V| to [2^10, 2^11) and the GEMM's accumulator factor
+            undoes it -- the weights' remedy (cp_f16x2_weight_scale) applied to the activations;
+          * a fused 1x1 head converts the activated 32-channel map that never reaches HBM: the layer runs once into a scratch map, which is
+            measured; outside the band the normalisation table feeding the activation is multiplied by the power of two (ReLU / leaky ReLU are
+            positively homogeneous: act(s x) = s act(x) exactly) and the head's accumulator factor undoes it (FusedConv.head_in_scale);
+          * the direct kernels, the stem and the 1x1 GEMMs convert stored tensors that other layers read too: outside the band the layer runs
+            on the exact three-way bf16 split (no range condition) -- for this plan and, through net.f16x2_fallback, for later plans.
+        Band: [F16X2_AMAX_LO, F16X2_AMAX_HI]."""
+        net = self.net
+        lo, hi = F16X2_AMAX_LO, F16X2_AMAX_HI
+        changed: List[str] = []
+
+        def pow2_to_band(amax: float) -> float:
+            return 2.0 ** (10 - math.floor(math.log2(amax)))   # amax * s in [2^10, 2^11): 32x headroom to 65504, low halves normal down to 2^-12 of the maximum
+
+        def note(name: str, amax: float, what: str, action: str):
+            self.f16x2_report[name] = (amax, action)
+            if action != "f16x2":
+                changed.append("%s (max |%s| = %.3g: %s)" % (name, what, amax, action))
+
+        prev_wino_out = None   # t_out of the Winograd layer just before, when it wrote the CURRENT layer's V (fused output -> input transform)
+        for st in self.steps:
+            owner = getattr(st, "__self__", None)
+            if isinstance(owner, WinoConv) and owner.planes == _lib.PLANES_F16X2:
+                if len(owner.chunks()) != 1 or WINO_GROUPED_CONV:   # batch groups share V: bound it from the sources (|B^T d B| <= 100 max |d|)
+                    vb = 100.0 * max(float(s_["data"].abs().max()) for s_ in owner.srcs)
+                    if vb > 0.0 and not (lo <= vb <= hi):
+                        owner.v_scale = pow2_to_band(vb)
+                    note(owner.name, vb, "V bound", "f16x2" if owner.v_scale == 1.0 else "f16x2, V x %g" % owner.v_scale)
+                    st(stream)
+                    prev_wino_out = None
+                    continue
+                micro = owner.micro_steps()
+                for i, (tag, fn) in enumerate(micro):
+                    if tag == "M":
+                        vmax = float(owner.V[:36 * owner.Tp * owner.ktot].view(36, owner.Tp, owner.ktot)[:, :owner.T].abs().max())   # (padding tiles are not written)
+                        if vmax > 0.0 and not (lo <= vmax <= hi):
+                            owner.v_scale = pow2_to_band(vmax)
+                            (prev_wino_out if owner.skip_input else micro[i - 1][1])(stream)   # the transform again, now scaled
+                        note(owner.name, vmax, "V", "f16x2" if owner.v_scale == 1.0 else "f16x2, V x %g" % owner.v_scale)
+                    fn(stream)
+                prev_wino_out = micro[-1][1] if owner.fuse_next is not None else None
+                continue
+            prev_wino_out = None
+            if isinstance(owner, FusedConv) and owner.f16x2_active():
+                amax = owner.input_amax()
+                if amax > 0.0 and not (lo <= amax <= hi):
+                    net.f16x2_fallback[owner.name] = "max |a| = %.3g outside [%g, %g]" % (amax, lo, hi)
+                    owner.demote_to_exact_split(net.params.get(owner.name + ".kernel"))
+                    note(owner.name, amax, "a", "exact bf16 split")
+                    st(stream)
+                    continue
+                d = owner.desc
+                if d.head_out and not d.out_act and d.scale:   # the fused head's operand: this layer's activated output, measured through a scratch map
+                    scratch = torch.empty(d.batch * d.out_h * d.out_w * owner.cout, dtype=torch.float32, device=net.device)
+                    d.out_act, d.out_act_ld = scratch.data_ptr(), owner.cout
+                    try:
+                        st(stream)
+                        hmax = float(scratch.abs().max())
+                    finally:
+                        d.out_act = None
+                    del scratch
+                    note(owner.name, amax, "a", "f16x2")
+                    if hmax > 0.0 and not (lo <= hmax <= hi):
+                        owner.set_head_in_scale(pow2_to_band(hmax))
+                        st(stream)
+                        note(owner.name + ":head", hmax, "head a", "f16x2, head input x %g" % owner.head_in_scale)
+                    else:
+                        note(owner.name + ":head", hmax, "head a", "f16x2")
+                    continue
+                note(owner.name, amax, "a", "f16x2")
+            st(stream)
+        self.needs_calibration = False
+        if changed and not net._f16x2_warned:
+            net._f16x2_warned = True
+            import warnings
+            warnings.warn("conv_mode f16x2: %d layer(s) outside the fp16 range condition [%g, %g] were rescaled by a power of two or moved to the exact bf16 split: %s"
+                          % (len(changed), lo, hi, "; ".join(changed)))
+
     def f16x2_operand_ranges(self) -> Dict[str, Optional[Tuple[float, float]]]:
         """The range condition of the fp16 two-way split made checkable.  Call after a forward: for every layer this plan runs in
         f16x2, (max |a| over the layer's source tensors, upper bound of the magnitude its split converts) -- the bound is max |a| itself for the
@@ -948,8 +1118,11 @@ class ForwardPlan:
         else:
             self.seg_input_ptr = None
         check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
-        for step in self.steps:
-            step(stream)
+        if self.needs_calibration:
+            self._run_calibrating(stream)
+        else:
+            for step in self.steps:
+                step(stream)
         if self.net.pvnet:
             _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
             return out
@@ -969,7 +1142,7 @@ class CasaposeNet:
                  decoder_dims: Sequence[int] = DECODER_DIMS_DEFAULT, fuse_upsample: bool = True, fuse_heads: bool = True,
                  partial: Sequence[bool] = PARTIAL_DEFAULT, guided: Sequence[bool] = GUIDED_DEFAULT, use_winograd: bool = True,
                  bilinear: Sequence[bool] = BILINEAR_DEFAULT, pvnet: bool = False, shared: Sequence[bool] = (False,) * 5,
-                 reuse_first: bool = False, skips2: bool = True, conv_mode: Optional[str] = None):
+                 reuse_first: bool = False, skips2: bool = True, conv_mode: Optional[str] = None, f16x2_guard: Optional[bool] = None):
         _lib.load()  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _lib.CasaposeHipError("casapose_amd runs on a ROCm GPU only (got device %s); there is no CPU fallback" % device)
@@ -992,13 +1165,21 @@ class CasaposeNet:
             raise ValueError("conv_mode must be f32, split, f16x2 or bf16 (got %r)" % mode)
         self.conv_mode = mode
         self.conv_planes = {"f32": 0, "split": 3, "f16x2": _lib.PLANES_F16X2, "bf16": 1}[mode]
+        self.f16x2_guard = F16X2_GUARD if f16x2_guard is None else bool(f16x2_guard)
+        self.f16x2_fallback: Dict[str, str] = {}   # layer -> why it left f16x2 (ForwardPlan._run_calibrating); reset by set_params
+        self._f16x2_warned = False
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self._twin: Optional["CasaposeNet"] = None   # the second half-batch's layer objects (two-stream forward)
         self._streams = None
         self.set_params(params)
 
+    def planes_for(self, layer_name: str) -> int:
+        """operand planes of one layer: the conv mode's, or 3 (exact split) once the f16x2 guard has demoted the layer"""
+        return 3 if (self.conv_planes == _lib.PLANES_F16X2 and layer_name in self.f16x2_fallback) else self.conv_planes
+
     def set_params(self, params: Dict[str, np.ndarray]):
         self.params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
+        self.f16x2_fallback, self._f16x2_warned = {}, False   # new parameters: every plan calibrates again on its first forward
         if getattr(self, "_twin", None) is not None:
             self._twin.set_params(params)
         dev = self.device
@@ -1098,11 +1279,14 @@ class CasaposeNet:
             self._twin = CasaposeNet(self.params, self.seg_dim, self.ver_dim, self.device, decoder_dims=self.decoder_dims, fuse_upsample=self.fuse_upsample,
                                      fuse_heads=self.fuse_heads, partial=self.partial, guided=self.guided, use_winograd=self.use_winograd,
                                      bilinear=self.bilinear, pvnet=False, shared=self.shared, reuse_first=self.reuse_first, skips2=self.skips2,
-                                     conv_mode=self.conv_mode)
+                                     conv_mode=self.conv_mode, f16x2_guard=self.f16x2_guard)
             self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
         if out is None:
             out = torch.empty(b, h, w, self.seg_dim + self.ver_dim, dtype=torch.float32, device=img.device)
         plans = [self.plan(hb, h, w), self._twin.plan(hb, h, w)]
+        for i, pl in enumerate(plans):   # f16x2 range guard: a plan's first forward runs layer by layer on the current stream
+            if pl.needs_calibration:
+                pl.run(img[i * hb:(i + 1) * hb], out=out[i * hb:(i + 1) * hb])
         seqs = [plans[0].micro_steps(img[:hb], out[:hb]), plans[1].micro_steps(img[hb:], out[hb:])]
         lib = _lib.load()
         cur = torch.cuda.current_stream(self.device)

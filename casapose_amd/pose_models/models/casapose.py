@@ -38,7 +38,7 @@ def CASAPose(layer_params, ver_dim, seg_dim, fcdim=256, s8dim=128, s4dim=64, s2d
         raise NotImplementedError("backbone %s is not built for MI355X yet" % base_model)
     return CasaposeModel("casapose_custom", ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights, output_lablemap=output_lablemap,
-                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True), conv_mode=kwargs.get("conv_mode"),
+                         device=kwargs.get("device"), seed=kwargs.get("seed"), fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True), conv_mode=kwargs.get("conv_mode"), f16x2_guard=kwargs.get("f16x2_guard"),
                          # reuse_conv (casapose.py:178-197,236-237,260): block i+1 and block i+6 share ONE one-input PartialConvolution
                          # `pv_block_{i+1}_{i+6}_conv2d` -- an ordinary SAME convolution on both sides (`partial_conv and not reuse_conv`, :261);
                          # with reuse_conv on block 1, block 6 normalises block 1's raw convolution output instead of convolving (:188-190,236)

@@ -111,7 +111,8 @@ class CasaposeModel:
                  input_segmentation_shape=None, weights=None, output_lablemap: bool = False, device=None, seed=None,
                  fuse_upsample: bool = True, fuse_heads: bool = True, partial: Sequence[bool] = engine.PARTIAL_DEFAULT,
                  guided: Sequence[bool] = engine.GUIDED_DEFAULT, bilinear: Sequence[bool] = engine.BILINEAR_DEFAULT, pvnet: bool = False,
-                 shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True, conv_mode: Optional[str] = None):
+                 shared: Sequence[bool] = (False,) * 5, reuse_first: bool = False, skips2: bool = True, conv_mode: Optional[str] = None,
+                 f16x2_guard: Optional[bool] = None):
         self.output_lablemap = bool(output_lablemap)
         self.name = name
         self.ver_dim, self.seg_dim = int(ver_dim), int(seg_dim)
@@ -134,7 +135,7 @@ class CasaposeModel:
         self._sharing = dict(shared=tuple(bool(v) for v in shared), reuse_first=bool(reuse_first), skips2=bool(skips2))
         self._params = initial_parameters(self.seg_dim, self.ver_dim, self._dims, seed, self._partial, self._pvnet, **self._sharing)
         self._net = engine.CasaposeNet(self._params, self.seg_dim, self.ver_dim, self.device, self._dims, fuse_upsample, fuse_heads,
-                                       self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet, conv_mode=conv_mode, **self._sharing)
+                                       self._partial, self._guided, bilinear=self._bilinear, pvnet=self._pvnet, conv_mode=conv_mode, f16x2_guard=f16x2_guard, **self._sharing)
         self._store: Optional[train_engine.ParamStore] = None   # training state (flat master weights + Adam moments)
         self._plan: Optional[train_engine.TrainPlan] = None
         self._params_stale = False                               # the store holds newer weights than self._params

@@ -20,7 +20,7 @@ def _conditional_impl(name, partial, guided, bilinear, sharing, ver_dim, seg_dim
     return CasaposeModel(name, ver_dim, seg_dim, (fcdim, s8dim, s4dim, s2dim, raw_dim), input_shape=input_shape,
                          input_segmentation_shape=input_segmentation_shape, weights=weights,
                          output_lablemap=output_lablemap, device=kwargs.get("device"), seed=kwargs.get("seed"),
-                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True), conv_mode=kwargs.get("conv_mode"),
+                         fuse_upsample=kwargs.get("fuse_upsample", True), fuse_heads=kwargs.get("fuse_heads", True), conv_mode=kwargs.get("conv_mode"), f16x2_guard=kwargs.get("f16x2_guard"),
                          partial=partial, guided=guided, bilinear=bilinear, **sharing)
 
 

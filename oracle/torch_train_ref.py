@@ -478,12 +478,12 @@ def prepare_inference(p: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return q
 
 
-def forward_infer_fast(q: Dict[str, torch.Tensor], img: torch.Tensor) -> torch.Tensor:
+def forward_infer_fast(q: Dict[str, torch.Tensor], img: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """casapose_c_gcu5 inference with the estimated mask (forward_train(..., labels=None, training=False)) as a CPU program someone would
     actually run: NCHW tensors in channels-last memory end to end (oneDNN's native layout, no per-layer permutes), folded normalisation
     (one fused multiply-add per layer), in-place activations, and the partial convolution as ONE 1x1 convolution to 9*Cout tap planes
     followed by nine masked shifted accumulations on the OUTPUT side (the tap mask is a per-pixel scalar, so (m x) W = m (x W), and every
-    decoder layer has Cout <= Cin).  img [B,H,W,3] -> [B,H,W,K+ver_dim]."""
+    decoder layer has Cout <= Cin).  img [B,H,W,3] -> [B,H,W,K+ver_dim]."""  # (test infrastructure: tests/, bench.cpu_baseline, smoke() only)
     def affine(name, x, act):   # act: 0 none, 1 relu, 2 leaky pair relu(t) - relu(-0.1 t) = leaky_relu(t, 0.1)
         y = torch.addcmul(q[name + ".shift"].view(1, -1, 1, 1), x, q[name + ".scale"].view(1, -1, 1, 1))
         return F.relu_(y) if act == 1 else (F.leaky_relu_(y, 0.1) if act == 2 else y)
@@ -518,7 +518,9 @@ def forward_infer_fast(q: Dict[str, torch.Tensor], img: torch.Tensor) -> torch.T
         y = affine(n + "_bn", conv(n + "_conv2d", inp, pad=1), 1 if i == 0 else 2)
         d1 = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=False) if 0 < i < 4 else y
     logits = conv("pv_final_conv_segmentation", d1)
-    labs = labels_pyramid(torch.argmax(logits, dim=1))               # [B,H,W] int64 and its three [::2, ::2] levels
+    # `labels` [B,H,W] (optional): condition decoder 2 on a GIVEN hard label map instead of the arg-max of these logits -- how the bench compares
+    # a device's vector field with fp64 without the arg-max ties of random weights deciding the comparison
+    labs = labels_pyramid(torch.argmax(logits, dim=1) if labels is None else labels.to(torch.int64))   # [B,H,W] int64 and its three [::2, ::2] levels
     lvl = [3, 3, 2, 1, 0]
 
     def partial(name, x, lab):
