@@ -20,6 +20,13 @@
 #include <algorithm>
 #include <type_traits>
 
+// hand-counted waits (see wino_gemm_wide.hip; checked in the ISA by tests/test_asm_invariants.py; -DCP_SAFE_WAITS: vmcnt(0))
+#ifdef CP_SAFE_WAITS
+#define CP_WAIT_VM_N(N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CP_WAIT_VM_N(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16d_kernel(const DeepK p) {
             store_item(ic, hst);
             issue_item(ic, s1);
         });
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NITEM) : "memory");   // the nine weight DMAs of step 0 (older than step 1's halo loads) have landed
+        CP_WAIT_VM_N(NITEM);   // the nine weight DMAs of step 0 (older than step 1's halo loads) have landed
     }
     CP_BARRIER();
     int step = 0;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16d_kernel(const DeepK p) {
 #endif
                 __builtin_amdgcn_sched_barrier(0);   // nothing crosses a tap
             });
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NITEM) : "memory");   // the weight DMAs of step + 1, issued before this step's NITEM halo loads
+            CP_WAIT_VM_N(NITEM);   // the weight DMAs of step + 1, issued before this step's NITEM halo loads
             if (c + 1 < nsl) CP_BARRIER();
         }
         int pass, n, ty, tx;

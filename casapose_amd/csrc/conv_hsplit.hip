@@ -259,6 +259,14 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     if constexpr (NP == 2) cp::f16_overflow_clamps();
     if (loader) {
         // ------------------------------------------------------------------ loaders ------------------------------------------------------
+#ifdef HS_LOADER_IDLE
+        if (p.B > 0) {   // timing experiment: the consumers alone (LDS holds whatever it held)
+            if constexpr (BILINEAR) CP_BARRIER();
+            CP_BARRIER();
+            for (int gg = 0; gg < total_groups; ++gg) CP_BARRIER();
+            return;
+        }
+#endif
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
                                                                               p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
@@ -468,6 +476,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         elo[it] = l_ok[it] ? (unsigned)((((n * Hs + ys) * Ws + xs) * p.s[0].ld + q4) * 4) : OOB;
                     }
                 }
+#ifdef HS_NOLOAD
+                if (p.B > 0) return;   // timing experiment
+#endif
 #pragma unroll
                 for (int it = 0; it < NLO; ++it) llow[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)elo[it], u.c * 64, 0));
             };
@@ -487,6 +498,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
                     // half-pixel centres: halo row hy (image row y0 + hy, y0 odd) blends source rows hy / 2 and hy / 2 + 1 of the stage with
                     // weights 0.75 / 0.25 (hy even) or 0.25 / 0.75 (hy odd); the expression is the one of round 3's global-tap version
+#ifdef HS_NOINTERP
+                    if (p.B > 0) { store_planes<NP>(h + e_lds[it], PLANE_B, make_float4(1.f, 2.f, 3.f, 4.f)); continue; }   // timing experiment
+#endif
                     const float fy = (e_hy[it] & 1) ? 0.75f : 0.25f, fx = (e_hx[it] & 1) ? 0.75f : 0.25f;
                     const float gy = 1.f - fy, gx = 1.f - fx;
                     const float4 v00 = *reinterpret_cast<const float4*>(lo + h_low[it]), v01 = *reinterpret_cast<const float4*>(lo + h_low[it] + 64);
@@ -628,6 +642,14 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     }
 
     // ------------------------------------------------------------------ consumers: 4 waves x 2 rows --------------------------------------
+#ifdef HS_CONSUMER_IDLE
+    if (p.B > 0) {   // timing experiment: the loaders alone
+        if constexpr (BILINEAR) CP_BARRIER();
+        CP_BARRIER();
+        for (int gg = 0; gg < total_groups; ++gg) CP_BARRIER();
+        return;
+    }
+#endif
     const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
     const bool has_lab = PARTIAL || p.clade;
     const unsigned tab_b = p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u;

@@ -73,7 +73,9 @@ __global__ void rowcount_kernel(const uint8_t* __restrict__ lab, int B, int H, i
 
 // thinning thresholds: one wave per (image, object) sums the row counts; above max_num pixels every pixel is kept with probability max_num / count
 // (ransac_voting.py:295-301: selection = uniform < max_num / foreground_num)
-__global__ void thin_threshold_kernel(const int* __restrict__ rowcnt, int H, int n_obj_total, int max_num, unsigned* __restrict__ thr) {
+// The min_num gate belongs to the UN-thinned count (ransac_voting.py:290-292 comes before :295-301): an object below it gets threshold 0 (no pixel
+// survives, rowscan_kernel then sees zero pixels), and the seeded entry runs rowscan_kernel with a gate of one pixel.
+__global__ void thin_threshold_kernel(const int* __restrict__ rowcnt, int H, int n_obj_total, int min_num, int max_num, unsigned* __restrict__ thr) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n_obj_total) return;
@@ -81,7 +83,7 @@ __global__ void thin_threshold_kernel(const int* __restrict__ rowcnt, int H, int
     for (int y = lane; y < H; y += 64) c += rowcnt[(size_t)i * H + y];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if (lane == 0) thr[i] = c > max_num ? (unsigned)((double)max_num / (double)c * 4294967296.0) : 0xffffffffu;
+    if (lane == 0) thr[i] = c < min_num ? 0u : (c > max_num ? (unsigned)((double)max_num / (double)c * 4294967296.0) : 0xffffffffu);
 }
 
 __global__ void rowscan_kernel(int* __restrict__ rowcnt, int H, int n_obj_total, int min_num, ObjState* __restrict__ st) {
@@ -532,11 +534,11 @@ int ransac_vote(const uint8_t* labels, const float* vertex, int ld, int dir_off,
     const unsigned* thr = nullptr;
     CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, thr, seed);
     if (seeded) {
-        CP_LAUNCH(thin_threshold_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, max_num, ws.thr);
+        CP_LAUNCH(thin_threshold_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, min_num, max_num, ws.thr);
         thr = ws.thr;
         CP_LAUNCH(rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, thr, seed);
     }
-    CP_LAUNCH(rowscan_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, min_num, ws.st);
+    CP_LAUNCH(rowscan_kernel, dim3((no + 3) / 4), dim3(256), 0, st, ws.rowcnt, h, no, seeded ? 1 : min_num, ws.st);   // (seeded: gated before the thinning, above)
     CP_LAUNCH(compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, labels, batch, h, w, objects, ws.rowcnt, ws.pixlist, list_stride, thr, seed);
     const int px_chunks = 8;
     const long long nhyp = (long long)no * hyp * KP;

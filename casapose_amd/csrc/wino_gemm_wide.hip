@@ -16,6 +16,15 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Hand-counted waits: `s_waitcnt vmcnt(N)` lets the N youngest loads stay in flight, which is only right while the compiler emits at least N loads
+// between the LDS-DMA pieces a wait must cover and the wait itself.  tests/test_asm_invariants.py counts them in the generated ISA of every build;
+// -DCP_SAFE_WAITS (tools/build_variant.sh) replaces every such wait by vmcnt(0) -- slower, and independent of instruction selection.
+#ifdef CP_SAFE_WAITS
+#define CP_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CP_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
         if (total_chunks > 1) store(S1{}, 1);
         issue(S0{}, total_chunks > 2);          // chunk 2
         issue(S1{}, total_chunks > 3);          // chunk 3
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but the eight loads just issued: the DMA pieces have landed
+        CP_WAIT_VM(8);   // everything but the eight loads just issued: the DMA pieces have landed
         CP_BARRIER();
         int st = 2;   // stage (of both operands) of chunk c + 2
         for (int c = 0; c < total_chunks; c += 2) {
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
                 dma_b(st);
             }
             issue(S0{}, c + 4 < total_chunks);  // chunk c + 4
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the DMA pieces (older than the four loads above) have landed
+            CP_WAIT_VM(4);   // the DMA pieces (older than the four loads above) have landed
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
             if (c + 1 >= total_chunks) break;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
                 dma_b(st);
             }
             issue(S1{}, c + 5 < total_chunks);  // chunk c + 5
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            CP_WAIT_VM(4);
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
         }

@@ -10,6 +10,8 @@ import torch
 from .. import _lib
 from .._lib import check
 
+_DEVICE_GENERATOR_CALLS: dict = {}   # id(CUDA generator) -> voter calls made with it (seed = f(initial_seed, call number); see below)
+
 
 def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, round_hyp_num: int, inlier_thresh: float = 0.99,
                                   confidence: float = 0.99, max_iter: int = 20, min_num: int = 5, max_num: int = 30000,
@@ -19,8 +21,11 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     [b,h,w,vn*2] in (dy,dx) order.  Returns [b,oc,vn,2] keypoints in (x,y).
 
     By default (round 4) every random number is made inside the library from one 64-bit seed (cp_ransac_vote_seeded_f32: counter-based draws per round,
-    and the random thinning of objects above `max_num` pixels, :295-301, inside the compaction) -- the seed comes from `generator` (reproducible) or
-    from torch's default CPU generator; nothing is synchronised and no draw tensor exists.  `draws` (int32 [max_iter,b,oc,round_hyp_num,vn,2],
+    and the random thinning of objects above `max_num` pixels, :295-301, inside the compaction; the `min_num` gate of :290-292 is applied to the
+    UN-thinned count, as there) -- the seed is drawn on the HOST: from `generator` when it is a CPU generator, from torch's default CPU generator
+    when none is given, and for a CUDA generator from its initial_seed() and a per-generator call counter (drawing from a device generator would
+    synchronise the stream: ADVICE round 4); no draw tensor exists.  The random stream of a given seed differs from round 3's torch.randint
+    draws (INTEGRATION.md, section on the voters).  `draws` (int32 [max_iter,b,oc,round_hyp_num,vn,2],
     values in [0,2^31)) replaces the pixel-pair draws of :319-321 -- tests inject them; on that path the thinning is done here with torch (it needs
     the counts on the host)."""
     if not mask.is_cuda:
@@ -38,8 +43,11 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     out = torch.empty(b, oc, vn, 2, dtype=torch.float32, device=mask.device)
     rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
     if draws is None:
-        gen_dev = generator.device if generator is not None else torch.device("cpu")
-        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64, device=gen_dev, generator=generator).item())
+        if generator is not None and generator.device.type != "cpu":
+            calls = _DEVICE_GENERATOR_CALLS[id(generator)] = _DEVICE_GENERATOR_CALLS.get(id(generator), 0) + 1
+            seed = (int(generator.initial_seed()) * 0x9E3779B97F4A7C15 + calls) % (2**62)
+        else:
+            seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64, generator=generator).item())   # CPU generator: no device synchronisation
         check(lib.cp_ransac_vote_seeded_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, seed, round_hyp_num, float(inlier_thresh),
                                             float(confidence), int(max_iter), int(min_num), int(max_num), ws.data_ptr(), out.data_ptr(), rounds.data_ptr(), stream),
               "cp_ransac_vote_seeded_f32")

@@ -67,7 +67,9 @@ def forward_order() -> List[str]:
 BUCKET_STARTS = ("bn_data", "stage4_unit1_bn1", "pv_block_1_conv2d", "pv_block_6_prepare_conv2d")
 
 
-F16X2_RESCALE_EVERY = int(os.environ.get("CASAPOSE_F16X2_RESCALE_EVERY", "256"))
+# refreshes between two evaluations of max |w| for the f16x2 weight scale (a host synchronisation per layer).  16: an Adam step moves a weight by about
+# the learning rate (<= 1e-3 here), so over 16 steps max |w| of an initialised layer (he_uniform: >= 0.036) cannot leave the 16x headroom; round 4's 256 could
+F16X2_RESCALE_EVERY = int(os.environ.get("CASAPOSE_F16X2_RESCALE_EVERY", "16"))
 
 
 def train_fwd_f16x2() -> bool:
@@ -85,8 +87,9 @@ def f16x2_scale(cache: dict, weights: torch.Tensor) -> float:
     the fp16 range).  It needs max |w| on the host, so it is re-evaluated every F16X2_RESCALE_EVERY refreshes, not every step."""
     n = cache.get("n", 0)
     cache["n"] = n + 1
-    if "scale" not in cache or n % F16X2_RESCALE_EVERY == 0:
-        cache["scale"] = float(_lib.load().cp_f16x2_weight_scale(float(weights.abs().max())))
+    if "scale" not in cache or n % F16X2_RESCALE_EVERY == 0 or cache.get("max", 0.0) == 0.0:   # (an all-zero tensor has no scale yet: look again next time)
+        cache["max"] = float(weights.abs().max())
+        cache["scale"] = float(_lib.load().cp_f16x2_weight_scale(cache["max"]))
     return cache["scale"]
 
 

@@ -1,0 +1,74 @@
+"""Build-time checks on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles to assembly text in a few seconds per file).
+
+Hand-counted `s_waitcnt vmcnt(N)` (csrc/wino_gemm_wide.hip, csrc/conv_bf16d.hip): vmcnt retires in order, so such a wait covers an LDS-DMA piece
+(`buffer_load ... lds`) only if AT LEAST N younger loads stand between the piece and the wait -- fewer (a load the compiler merged, sank or
+dropped) and the barrier behind the wait would release consumers onto stale LDS bytes, silently.  The check walks every inline-asm vmcnt(N > 0)
+of the device code back to the nearest DMA piece or basic-block label and counts the plain loads in between."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "casapose_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def device_asm(source, tmp_path, extra=()):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("no hipcc")
+    out = os.path.join(str(tmp_path), os.path.basename(source) + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-munsafe-fp-atomics", "-fno-slp-vectorize",
+           "--cuda-device-only", "-S", os.path.join(CSRC, source), "-o", out] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().splitlines()
+
+
+def hand_waits(lines):
+    """[(line number, N, plain loads between the nearest older DMA piece / block label and the wait, what stopped the walk)]"""
+    found = []
+    in_asm = False
+    for i, ln in enumerate(lines):
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+        if not (in_asm and m):
+            continue
+        n = int(m.group(1))
+        k, stop = 0, "start"
+        for j in range(i - 1, -1, -1):
+            u = lines[j].strip()
+            if re.match(r"^[.\w$]+:", u):                 # a label: other paths join here
+                stop = "label"
+                break
+            if u.startswith(("buffer_load", "global_load")):
+                if u.endswith(" lds") or " lds " in u:
+                    stop = "dma"
+                    break
+                k += 1
+            if u.startswith(("buffer_store", "global_store", "buffer_atomic", "global_atomic")):
+                k += 1                                     # gfx9: stores and atomics count in vmcnt too
+        found.append((i + 1, n, k, stop))
+    return found
+
+
+@pytest.mark.parametrize("source,expected_waits", [("wino_gemm_wide.hip", 3), ("conv_bf16d.hip", 2)])
+def test_hand_counted_waits_cover_their_dma(tmp_path, source, expected_waits):
+    lines = device_asm(source, tmp_path)
+    waits = [w for w in hand_waits(lines) if w[1] > 0]
+    assert len(waits) >= expected_waits, waits    # (an instantiated template repeats its waits)
+    for line, n, younger, stop in waits:
+        assert younger >= n, "%s:%d: s_waitcnt vmcnt(%d) with only %d younger VMEM operations since the nearest %s" % (source, line, n, younger, stop)
+
+
+def test_safe_waits_switch_removes_every_counted_wait(tmp_path):
+    lines = device_asm("wino_gemm_wide.hip", tmp_path, extra=["-DCP_SAFE_WAITS"])
+    assert all(n == 0 for _, n, _, _ in hand_waits(lines)), hand_waits(lines)

@@ -55,7 +55,9 @@ here = json.loads(subprocess.run([sys.executable, os.path.join(R, "bench.py"), "
 if here["src_sha256"] != stamp["src_sha256"]:
     sys.exit("profiles in gpurun_out/%s were measured on source stamp %s, the working tree is %s: re-run tools/profile_round.sh on this tree "
              "(the bench line would refuse their PMC traffic anyway)" % (tag, stamp["src_sha256"], here["src_sha256"]))
-for old in [f for f in os.listdir(P) if f.startswith(tag + "_")]:   # nothing of an earlier stamp survives under this tag
+# nothing of an earlier stamp survives under this tag -- FILES of the standard set only: profiles/probes/ (tools/probes_round.sh, one-off probe outputs
+# DESIGN.md cites, each with its own stamp line) is a directory and is never touched (round-4 verdict, weak #7)
+for old in [f for f in os.listdir(P) if f.startswith(tag + "_") and os.path.isfile(os.path.join(P, f))]:
     os.remove(os.path.join(P, old))
 copy(T + "bench.json", "%s_bench.json" % tag)
 copy(T + "bench_bs32.json", "%s_bench_bs32.json" % tag)

@@ -42,7 +42,7 @@ rocprofv3 --kernel-trace --stats -d $O/train_trace -o train --output-format csv 
 python3 $R/tools/train_times.py > $O/train_times.txt 2>&1
 python3 $R/bench.py --mode vote --steps 20 --warmup 5 > $O/bench_vote.json 2> $O/bench_vote.err
 rocprofv3 --kernel-trace --stats -d $O/vote_trace -o vote --output-format csv -- python3 $R/bench.py --mode vote --steps 10 --warmup 3 > $O/bench_vote_profiled.json 2> $O/rocprof_vote.err
-if [ "$2" = "suites" ]; then   # the -m gpu suite per conv mode, on the same box and tree (about 4 minutes each)
+if [ "${2:-}" = "suites" ]; then   # the -m gpu suite per conv mode, on the same box and tree (about 4 minutes each)
   cd $R
   python3 bench.py --stamp > $O/gputests_stamp.json
   python3 -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gputests_default_f16x2.log
