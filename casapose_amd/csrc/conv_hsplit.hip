@@ -45,7 +45,11 @@ constexpr int IPLANE_B = HP * 8;     // bytes of one image-halo plane (4 bf16 pe
 constexpr int NIT = (HP * 4 + 255) / 256;   // float4 halo elements per loader thread and slice
 constexpr int NIMG = (HP + 255) / 256;      // image-halo pixels per loader thread
 
-enum : int { HS_BILINEAR = 2, HS_PARTIAL = 4, HS_SEL = 8 };
+// HS_HEADK (round 5): the layer is a "head layer" -- 32 output channels, a normalisation table, leaky ReLU, a fused 1x1 head and NOTHING else (no
+// residual, no raw / activated output): blocks 5 and 10 of the decoders, 17 % of the forward.  Their epilogue is compiled without the operands it
+// does not have (three buffer descriptors and a dozen uniform flags fewer: the generic form reloads 350 spilled scalars per tile) and with the
+// per-channel table held in registers for the whole kernel.
+enum : int { HS_BILINEAR = 2, HS_PARTIAL = 4, HS_SEL = 8, HS_HEADK = 16 };
 
 struct SSrc {
     const float* data;
@@ -84,6 +88,20 @@ struct HSplitK {
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// -DHS_PROFILE (a variant build, tools/build_variant.sh): shader-clock time per section of the consumer / loader waves, summed over all waves into
+// hs_prof[] and read back through cp_hs_profile_read (exported by that variant only).  Sections: consumers 0 tile setup, 1 slice MFMA loops,
+// 2 image block, 3 epilogue, 4 waiting at barriers; loaders 8 phase work before the barrier, 9 waiting at barriers.
+#ifdef HS_PROFILE
+__device__ unsigned long long hs_prof[16];
+#define HSP_DECL unsigned long long hsp_t = __builtin_readcyclecounter(); unsigned hsp_acc[6] = {0, 0, 0, 0, 0, 0}
+#define HSP(i) do { const unsigned long long hsp_now = __builtin_readcyclecounter(); hsp_acc[i] += (unsigned)(hsp_now - hsp_t); hsp_t = hsp_now; } while (0)
+#define HSP_FLUSH(base) do { if (lane == 0) { for (int hsp_i = 0; hsp_i < 6; ++hsp_i) atomicAdd(&hs_prof[(base) + hsp_i], (unsigned long long)hsp_acc[hsp_i]); } } while (0)
+#else
+#define HSP_DECL
+#define HSP(i)
+#define HSP_FLUSH(base)
+#endif
 
 __device__ __forceinline__ unsigned pack_hi16(unsigned a_lo, unsigned b_hi) { return __builtin_amdgcn_perm(b_hi, a_lo, 0x07060302u); }
 
@@ -177,6 +195,10 @@ __global__ void hsplit_weights_kernel(const float* __restrict__ src, long long n
     }
 }
 
+// relu(t) - relu(-0.1 t) (casa_layer's LeakyReLU, casapose.py:98-105) in two instructions: max(t, 0.1 t).  Same value for every finite t -- t > 0: t
+// either way; t < 0: -fl(-0.1f * t) = fl(0.1f * t), rounding to nearest is symmetric -- only the sign of a zero result can differ (-0 for t = -0).
+__device__ __forceinline__ float leaky01(float t) { return fmaxf(t, 0.1f * t); }
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void hs_static_for(F&& f) {
     if constexpr (I < N) {
@@ -190,6 +212,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr bool PARTIAL = (MODE & HS_PARTIAL) != 0;
     constexpr bool BILINEAR = (MODE & HS_BILINEAR) != 0;   // source 0 is read at half resolution through a x2 half-pixel bilinear filter
     constexpr bool SEL = (MODE & HS_SEL) != 0;             // source 0 is read at half resolution through the guided-upsampling selection map
+    constexpr bool HEADK = (MODE & HS_HEADK) != 0;         // head layer: table + leaky ReLU + fused 1x1 head, no other output (TN == 1)
+    static_assert(!HEADK || TN == 1, "a fused head needs 32 output channels");
     constexpr int NV = 1;   // (round 3 fetched the four bilinear taps of source 0 from global memory: NV = 4; now a low-resolution tile is staged in LDS)
     constexpr unsigned OOB = 0x80000000u;
     static_assert(NP == 1 || NP == 2 || NP == 3, "1 = bf16, 2 = fp16 two-way split, 3 = exact bf16 split");
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr int LOW_R = HR / 2 + 1, LOW_C = COLS / 2 + 1, LOW_P = LOW_R * LOW_C;   // 6 x 18 = 108 source pixels
     constexpr int LOW_B = LOW_P * 64;
     unsigned char* lowb = hwl + 2 * NP * 1024;   // [2 stages][LOW_P][64 B]
-    const bool head = (TN == 1) && p.head_out != nullptr;
+    const bool head = HEADK || ((TN == 1) && p.head_out != nullptr);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= 4;
@@ -387,9 +411,19 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // weight groups: the tile's fragment stream is contiguous in memory, GROUP_B bytes per group; every tile reads the same stream
         const __amdgpu_buffer_rsrc_t rsw_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
         u32x4 lw[NWL];
+        // the weight cursor: groups are requested strictly in order (0, 1, 2, ...), so (group within the tile, pass of the tile) advance by
+        // increments -- round 4 divided by ngroups_tile and by tiles_per_pass for every group (two emulated integer divisions per phase)
+        int w_lg = 0, w_pass = bid / p.tiles_per_pass, w_rem = bid % p.tiles_per_pass;
+        const int g_q = g / p.tiles_per_pass, g_r = g % p.tiles_per_pass;
         auto issue_w = [&](int gg) {   // global group index -> group of the tile (wide groups first, the image block's group last)
-            const int kt = gg / ngroups_tile, lgw = gg - kt * ngroups_tile;
-            const int pass = (bid + kt * g) / p.tiles_per_pass;   // this block's kt-th tile belongs to that pass of output channels
+            (void)gg;   // (groups are requested in order)
+            const int lgw = w_lg, pass = w_pass;   // this block's current tile belongs to that pass of output channels
+            if (++w_lg == ngroups_tile) {
+                w_lg = 0;
+                w_pass += g_q;
+                w_rem += g_r;
+                if (w_rem >= p.tiles_per_pass) { w_rem -= p.tiles_per_pass; ++w_pass; }
+            }
             const unsigned base = (unsigned)(pass * tile_w_bytes) + (unsigned)lgw * GROUP_B;
             const unsigned len = (lgw < nslices * GPS) ? GROUP_B : IGROUP_B;
 #pragma unroll
@@ -459,9 +493,6 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 l_c[it] = pix % LOW_C;
                 l_lds[it] = (unsigned)(pix * 64 + (idx & 3) * 16);
             }
-            unsigned h_low[NIT];   // LDS offset of tap (0, 0) of this thread's halo elements inside a low-resolution stage
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) h_low[it] = (unsigned)(((e_hy[it] >> 1) * LOW_C + (e_hx[it] >> 1)) * 64 + (tid & 3) * 16);
             float4 llow[NLO];
             unsigned elo[NLO];
             int elo_k = -1, eo1_k = -1;
@@ -487,31 +518,66 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 for (int it = 0; it < NLO; ++it)
                     if (l_ok[it]) *reinterpret_cast<float4*>(lowb + stage * LOW_B + l_lds[it]) = llow[it];
             };
+            // Interpolation by 2 x 2 BLOCKS (round 5).  Half-pixel centres: halo rows 2 by, 2 by + 1 (image rows y0 - 1 + ..., y0 - 1 odd) both lie between
+            // source rows by and by + 1 of the stage -- weights 0.75 / 0.25 and 0.25 / 0.75 -- and likewise the columns, so the four halo pixels of a
+            // block share ONE 2 x 2 source neighbourhood: a task = (block, channel quad) reads four 16-byte source values and produces four halo
+            // values (round 4: a task per halo value, four reads each: 4x the LDS reads, 1.5x the arithmetic).  The horizontal blends are shared by the
+            // two rows; arithmetic on float pairs (v_pk_mul_f32 / v_pk_fma_f32: the loader waves carry no MFMAs for them to disturb).
+            // 5 x 17 blocks x 4 quads = 340 tasks on 256 threads.
+            constexpr int NBX = COLS / 2, NTASK = (HR / 2) * NBX * 4, NT = (NTASK + 255) / 256;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            unsigned t_low[NT], t_out[NT][4];
+            int t_by[NT], t_bx[NT];
+#pragma unroll
+            for (int sl = 0; sl < NT; ++sl) {
+                const int tk = sl * 256 + tid, blk = tk >> 2, q = tk & 3;
+                t_by[sl] = tk < NTASK ? blk / NBX : -1;
+                t_bx[sl] = blk % NBX;
+                t_low[sl] = (unsigned)(((blk / NBX) * LOW_C + blk % NBX) * 64 + q * 16);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int pix = (2 * (blk / NBX) + (o >> 1)) * COLS + 2 * (blk % NBX) + (o & 1);
+                    t_out[sl][o] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
+                }
+            }
             auto interp = [&](const Cur& u) {   // low-resolution stage u.s & 1 -> halo stage u.s & 1
                 const unsigned char* lo = lowb + (u.s & 1) * LOW_B;
                 unsigned char* h = halo + (u.s & 1) * (NP * PLANE_B);
                 const int y0 = u.t.ty * TH - 1, x0 = u.t.tx * 32 - 1;
+                // zero padding of the convolution applies to the UPSAMPLED map: only tiles on the image border have halo pixels outside it
+                const bool edge = (y0 < 0) | (x0 < 0) | (y0 + HR > p.H) | (x0 + COLS > p.Wd);
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    if (e_hy[it] >= 0x4000) continue;
-                    const int y = y0 + e_hy[it], x = x0 + e_hx[it];
-                    const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                    // half-pixel centres: halo row hy (image row y0 + hy, y0 odd) blends source rows hy / 2 and hy / 2 + 1 of the stage with
-                    // weights 0.75 / 0.25 (hy even) or 0.25 / 0.75 (hy odd); the expression is the one of round 3's global-tap version
+                for (int sl = 0; sl < NT; ++sl) {
+                    if (t_by[sl] < 0) continue;
 #ifdef HS_NOINTERP
-                    if (p.B > 0) { store_planes<NP>(h + e_lds[it], PLANE_B, make_float4(1.f, 2.f, 3.f, 4.f)); continue; }   // timing experiment
+                    if (p.B > 0) { for (int o = 0; o < 4; ++o) store_planes<NP>(h + t_out[sl][o], PLANE_B, make_float4(1.f, 2.f, 3.f, 4.f)); continue; }   // timing experiment
 #endif
-                    const float fy = (e_hy[it] & 1) ? 0.75f : 0.25f, fx = (e_hx[it] & 1) ? 0.75f : 0.25f;
-                    const float gy = 1.f - fy, gx = 1.f - fx;
-                    const float4 v00 = *reinterpret_cast<const float4*>(lo + h_low[it]), v01 = *reinterpret_cast<const float4*>(lo + h_low[it] + 64);
-                    const float4 v10 = *reinterpret_cast<const float4*>(lo + h_low[it] + LOW_C * 64), v11 = *reinterpret_cast<const float4*>(lo + h_low[it] + LOW_C * 64 + 64);
-                    float4 val;
-                    val.x = (v00.x * gx + v01.x * fx) * gy + (v10.x * gx + v11.x * fx) * fy;
-                    val.y = (v00.y * gx + v01.y * fx) * gy + (v10.y * gx + v11.y * fx) * fy;
-                    val.z = (v00.z * gx + v01.z * fx) * gy + (v10.z * gx + v11.z * fx) * fy;
-                    val.w = (v00.w * gx + v01.w * fx) * gy + (v10.w * gx + v11.w * fx) * fy;
-                    if (!inb) val = make_float4(0.f, 0.f, 0.f, 0.f);   // the convolution's zero padding is applied to the UPSAMPLED map
-                    store_planes<NP>(h + e_lds[it], PLANE_B, val);
+                    const float4 v00 = *reinterpret_cast<const float4*>(lo + t_low[sl]), v01 = *reinterpret_cast<const float4*>(lo + t_low[sl] + 64);
+                    const float4 v10 = *reinterpret_cast<const float4*>(lo + t_low[sl] + LOW_C * 64), v11 = *reinterpret_cast<const float4*>(lo + t_low[sl] + LOW_C * 64 + 64);
+                    f32x2 out[4][2];   // [2 dy + dx][channel pair]
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x2 a00 = c ? f32x2{v00.z, v00.w} : f32x2{v00.x, v00.y}, a01 = c ? f32x2{v01.z, v01.w} : f32x2{v01.x, v01.y};
+                        const f32x2 a10 = c ? f32x2{v10.z, v10.w} : f32x2{v10.x, v10.y}, a11 = c ? f32x2{v11.z, v11.w} : f32x2{v11.x, v11.y};
+                        // (v_left * gx + v_right * fx): even halo column fx = 0.25, odd 0.75 -- the expression of the per-value form
+                        const f32x2 te = a00 * 0.75f + a01 * 0.25f, to = a00 * 0.25f + a01 * 0.75f;   // upper source row
+                        const f32x2 be = a10 * 0.75f + a11 * 0.25f, bo = a10 * 0.25f + a11 * 0.75f;   // lower source row
+                        out[0][c] = te * 0.75f + be * 0.25f;   // even halo row: fy = 0.25
+                        out[1][c] = to * 0.75f + bo * 0.25f;
+                        out[2][c] = te * 0.25f + be * 0.75f;   // odd halo row: fy = 0.75
+                        out[3][c] = to * 0.25f + bo * 0.75f;
+                    }
+                    if (edge) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int y = y0 + 2 * t_by[sl] + (o >> 1), x = x0 + 2 * t_bx[sl] + (o & 1);
+                            const bool inb = ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.Wd);
+                            out[o][0] = inb ? out[o][0] : f32x2{0.f, 0.f};
+                            out[o][1] = inb ? out[o][1] : f32x2{0.f, 0.f};
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) store_planes<NP>(h + t_out[sl][o], PLANE_B, make_float4(out[o][0].x, out[o][0].y, out[o][1].x, out[o][1].y));
                 }
             };
             auto issue_direct = [&](const Cur& u) {
@@ -564,15 +630,26 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             cb = cc;
             step(cc);
             int lg = 0;
+            HSP_DECL;
             // (stores before issues inside a phase, as in the generic loop below: a wait then only meets loads that are a phase old)
             for (int gg = 0; gg < total_groups; ++gg) {
                 const bool more_w = gg + 1 < total_groups;
                 if (more_w) store_w((gg + 1) & 1);
                 const bool slice_phase = lg < nslices * GPS && lg % GPS == 0;   // first group of a slice
-                if (slice_phase) {
-                    step_a(ca);                                                  // interpolation / direct halo store (+ image / label halo stores)
-                    if (cb.s < total_slices && cb.c < p.nch0) store_low(cb.s & 1);
+                // Order inside a phase (round 5): (A) everything that CONSUMES the loads of the phase before -- register -> LDS stores; (B) every
+                // ISSUE for the phases to come; (C) the interpolation, LDS -> LDS and by far the longest piece, LAST: the loads of (B) are in flight
+                // behind it and have landed when the next phase's (A) asks for them.  Round 4 issued after the interpolation, so every phase began
+                // with a full memory latency (the loader's "work" time did not move when the interpolation itself got 2x cheaper).
+                const bool a_live = slice_phase && ca.s < total_slices;
+                if (a_live) {
+                    if (ca.c >= p.nch0) store_slice(ca.s & 1);
+                    if (ca.c == 0) {
+                        if (has_img) store_img(ca.k & 1);
+                        if (has_lab_l) store_lab(ca.k & 1);
+                    }
                 }
+                if (slice_phase && cb.s < total_slices && cb.c < p.nch0) store_low(cb.s & 1);
+                HSP(0);
                 if (more_w && gg + 2 < total_groups) issue_w(gg + 2);
                 if (slice_phase) {
                     if (cb.s < total_slices) {
@@ -583,13 +660,19 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         if (cb.c >= p.nch0) issue_direct(cb);
                     }
                     step_c(cc);
+                    HSP(2);
+                    if (a_live && ca.c < p.nch0) interp(ca);
+                    HSP(3);
                     step(ca);
                     step(cb);
                     step(cc);
                 }
                 if (++lg == ngroups_tile) lg = 0;
+                HSP(2);
                 CP_BARRIER();
+                HSP(1);
             }
+            HSP_FLUSH(8);
             return;
         }
         issue_tile_extras();
@@ -613,6 +696,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // them it waits with vmcnt(0)).  Measured against the old order (weight loads of group gg + 2 issued before the halo store): 1509 vs
         // 1506-1514 images/s -- no difference, the hand-over was not exposed; the order is kept because it cannot be the worse one.
         constexpr bool kStoresFirst = true;
+        HSP_DECL;
         for (int gg = 0; gg < total_groups; ++gg) {
             const bool more_w = gg + 1 < total_groups;
             if (more_w) {
@@ -636,8 +720,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 ++issued;
             }
             if (++lg == ngroups_tile) lg = 0;
+            HSP(0);
             CP_BARRIER();
+            HSP(1);
         }
+        HSP_FLUSH(8);
         return;
     }
 
@@ -699,16 +786,70 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         }
     };
 
+    // Epilogue (round 5: straight-line).  Round 4's form cost 0.31 ms of block 5's 0.73 (tools/debug/r05_hs_ablate.sh) -- not for its arithmetic: every
+    // `pok && ch < Cout ? offset : OOB`, every `if (nq >= 4) ... else if ...` store ladder and the short-circuit arg-max compiled into
+    // s_and_saveexec / s_cbranch_execz regions (87 of them in the two rows of a tile, each a dozen issue slots with the matrix pipe idle).  Now:
+    // conditions are combined bitwise and select an offset (an out-of-range buffer offset drops the access), operands that do not exist are
+    // skipped by UNIFORM branches only, and the head's stores are chosen by uniform comparisons with head_cout.  Same expressions, same results.
+    const __amdgpu_buffer_rsrc_t r_hlab = __builtin_amdgcn_make_buffer_rsrc((void*)((head && p.head_lab) ? (void*)p.head_lab : (void*)p.W), 0,
+                                                                             (head && p.head_lab) ? npix : 0u, 0x00020000);
+    const bool has_res = p.residual != nullptr, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr, has_act = p.out_act != nullptr;
+    // HEADK: the per-channel table of a layer without CLADE, loaded once; where no partial-convolution factor exists the weights' power-of-two
+    // descale is folded into its scale column (exact: a power of two commutes with the rounding of the product)
+    float4 hk_sc[4], hk_sh[4];
+    if constexpr (HEADK) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            hk_sc[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hk_sh[g4] = hk_sc[g4];
+            if (!p.clade) {
+                hk_sc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (g4 * 8 + kh * 4) * 4, 0, 0));
+                hk_sh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (g4 * 8 + kh * 4) * 4, 0, 0));
+                if constexpr (NP == 2 && !PARTIAL) {
+                    hk_sc[g4].x *= p.descale; hk_sc[g4].y *= p.descale; hk_sc[g4].z *= p.descale; hk_sc[g4].w *= p.descale;
+                }
+            }
+        }
+    }
     auto epilogue = [&](int n, int y0, int x0, int cbase) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = y0 + 2 * wave + r, x = x0 + lrow;
-            const bool pok = y < p.H && x < p.Wd;
+            const bool pok = (y < p.H) & (x < p.Wd);
             const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
             float f = 1.f;
             if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
             if constexpr (NP == 2) f *= p.descale;   // the weights' power-of-two scale, undone exactly
+            const unsigned tab_row = (unsigned)(clab[r] * (p.clade ? p.Cout : 0));
             float4 keep[4];
+            if constexpr (HEADK) {
+                // t = leaky((acc * f) * scale + shift), the generic form's expressions without the operands this layer does not have; pixels
+                // outside the image keep whatever they computed (a pixel is a column of the head's product and is not stored)
+                const bool fold = (NP == 2 && !PARTIAL);   // f == descale, already inside hk_sc
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 sc = hk_sc[g4], sh = hk_sh[g4];
+                    if (p.clade) {
+                        const unsigned to = (tab_row + (unsigned)(g4 * 8 + kh * 4)) * 4u;
+                        sc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+                        sh = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                        if (fold) { sc.x *= p.descale; sc.y *= p.descale; sc.z *= p.descale; sc.w *= p.descale; }
+                    }
+                    float4 t;
+                    if (fold) {
+                        t.x = acc[r][0][g4 * 4 + 0] * sc.x + sh.x;
+                        t.y = acc[r][0][g4 * 4 + 1] * sc.y + sh.y;
+                        t.z = acc[r][0][g4 * 4 + 2] * sc.z + sh.z;
+                        t.w = acc[r][0][g4 * 4 + 3] * sc.w + sh.w;
+                    } else {
+                        t.x = (acc[r][0][g4 * 4 + 0] * f) * sc.x + sh.x;
+                        t.y = (acc[r][0][g4 * 4 + 1] * f) * sc.y + sh.y;
+                        t.z = (acc[r][0][g4 * 4 + 2] * f) * sc.z + sh.z;
+                        t.w = (acc[r][0][g4 * 4 + 3] * f) * sc.w + sh.w;
+                    }
+                    keep[g4] = make_float4(leaky01(t.x), leaky01(t.y), leaky01(t.z), leaky01(t.w));
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float4 res[4], esc[4], esh[4];
@@ -719,13 +860,14 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                 for (int g4 = g0; g4 < g0 + PRE; ++g4) {
                     const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
-                    const unsigned o = (pok && ch < p.Cout) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB;
+                    const bool cok = ch < p.Cout;
                     res[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
                     esc[g4] = res[g4];
                     esh[g4] = res[g4];
-                    if (p.residual) res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)o, 0, 0));
-                    if (p.scale) {   // uniform branches: a layer without these operands issues no loads and waits for none
-                        const unsigned to = (ch < p.Cout) ? (unsigned)((clab[r] * (p.clade ? p.Cout : 0) + ch) * 4) : OOB;
+                    if (has_res)   // uniform branches: a layer without these operands issues no loads and waits for none
+                        res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)((pok & cok) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB), 0, 0));
+                    if (has_tab) {
+                        const unsigned to = cok ? (tab_row + (unsigned)ch) * 4u : OOB;
                         esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
                         esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
                     }
@@ -733,15 +875,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                 for (int g4 = g0; g4 < g0 + PRE; ++g4) {
                     const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
-                    const bool ok = pok && ch < p.Cout;
+                    const bool ok = pok & (ch < p.Cout);
                     float4 v;
                     v.x = acc[r][j][g4 * 4 + 0] * f + res[g4].x;
                     v.y = acc[r][j][g4 * 4 + 1] * f + res[g4].y;
                     v.z = acc[r][j][g4 * 4 + 2] * f + res[g4].z;
                     v.w = acc[r][j][g4 * 4 + 3] * f + res[g4].w;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    if (has_raw)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
                     float4 t = v;
-                    if (p.scale) {
+                    if (has_tab) {
                         t.x = v.x * esc[g4].x + esh[g4].x;
                         t.y = v.y * esc[g4].y + esh[g4].y;
                         t.z = v.z * esc[g4].z + esh[g4].z;
@@ -750,16 +893,20 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     if (p.act == CP_ACT_RELU) {
                         t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
                     } else if (p.act == CP_ACT_LEAKY01) {
-                        t.x = fmaxf(t.x, 0.f) - fmaxf(-0.1f * t.x, 0.f);
-                        t.y = fmaxf(t.y, 0.f) - fmaxf(-0.1f * t.y, 0.f);
-                        t.z = fmaxf(t.z, 0.f) - fmaxf(-0.1f * t.z, 0.f);
-                        t.w = fmaxf(t.w, 0.f) - fmaxf(-0.1f * t.w, 0.f);
+                        t.x = leaky01(t.x); t.y = leaky01(t.y); t.z = leaky01(t.z); t.w = leaky01(t.w);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
-                    if (j == 0) keep[g4] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (has_act)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    if (j == 0) {
+                        keep[g4].x = ok ? t.x : 0.f;
+                        keep[g4].y = ok ? t.y : 0.f;
+                        keep[g4].z = ok ? t.z : 0.f;
+                        keep[g4].w = ok ? t.w : 0.f;
+                    }
                 }
                 }
             }
+            }   // !HEADK
             if constexpr (TN == 1) {
                 if (head) {
                     // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel] on the same matrix pipe.  The order of K is free, so step m
@@ -800,21 +947,44 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) a2[e] *= p.head_descale;
                     }
+                    // stores: register g4 * 4 + e of lane half kh is head channel q = 8 g4 + 4 kh + e.  A group of eight channels that lies wholly
+                    // below head_cout goes out as one 16-byte store per lane; the group that straddles it as single dwords, one store per e that
+                    // ANY lane half still owns -- which stores exist is decided by uniform comparisons, which lanes take part by the offset
+                    const unsigned hbase = (pix * (unsigned)p.head_ld + (unsigned)(kh * 4)) * 4u;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int q0 = g4 * 8 + kh * 4;
-                        const int nq = pok ? p.head_cout - q0 : 0;
-                        const unsigned o = (pix * (unsigned)p.head_ld + (unsigned)q0) * 4u;
-                        const unsigned v0 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), v1 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]);
-                        const unsigned v2 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), v3 = __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3]);
-                        if (nq >= 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, v1, v2, v3}, r_head, (int)o, 0, 0);
-                        else if (nq == 3) __builtin_amdgcn_raw_buffer_store_b96(u32x3{v0, v1, v2}, r_head, (int)o, 0, 0);
-                        else if (nq == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v0, v1}, r_head, (int)o, 0, 0);
-                        else if (nq == 1) __builtin_amdgcn_raw_buffer_store_b32(v0, r_head, (int)o, 0, 0);
+                        const unsigned o = hbase + (unsigned)(g4 * 32);
+                        if (p.head_cout >= g4 * 8 + 8) {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]),
+                                                                         __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3])},
+                                                                   r_head, (int)(pok ? o : OOB), 0, 0);
+                        } else if (p.head_cout > g4 * 8) {
+                            const int left = p.head_cout - g4 * 8 - kh * 4;   // channels of this group this lane half still owns (<= 0: none)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (p.head_cout > g4 * 8 + e)   // lane half 0 owns q = 8 g4 + e
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + e]), r_head, (int)((pok & (e < left)) ? o + 4u * e : OOB), 0, 0);
+                        }
                     }
-                    if (p.head_lab) {   // the hard label map straight from the head's registers
-                        const int lab = cp::head_argmax(a2, kh, p.head_lab_classes);
-                        if (kh == 0 && pok) p.head_lab[pix] = (uint8_t)lab;
+                    if (p.head_lab) {   // the hard label map straight from the head's registers: first maximum wins (cp_argmax_labels)
+                        float best = -__builtin_inff();
+                        int bi = 0x7fffffff;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int q = g4 * 8 + kh * 4 + e;
+                                const float vq = a2[g4 * 4 + e];
+                                const bool take = (q < p.head_lab_classes) & (vq > best);
+                                best = take ? vq : best;
+                                bi = take ? q : bi;
+                            }
+                        const float ob = __shfl_xor(best, 32);
+                        const int oi = __shfl_xor(bi, 32);
+                        const bool other = (ob > best) | ((ob == best) & (oi < bi));
+                        bi = other ? oi : bi;
+                        bi = (bi == 0x7fffffff) ? 0 : bi;
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bi, r_hlab, (int)(((kh == 0) & pok) ? pix : OOB), 0, 0);
                     }
                 }
             }
@@ -834,6 +1004,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     TilePos ctile = first;
     if constexpr (BILINEAR) CP_BARRIER();   // the loaders' hand-over of the first low-resolution stage (their interpolation reads other threads' stores)
     CP_BARRIER();   // slice 0, the first weight group (and the first tile's image / label halo) are in LDS
+    HSP_DECL;
     int gs = 0, gg = 0;   // global slice / group counters
     for (int k = 0; k < my_tiles; ++k) {
         const int pass = ctile.n / p.B;
@@ -847,6 +1018,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
+        HSP(0);
         for (int c = 0; c < nslices; ++c, ++gs) {
             const unsigned char* hb = halo + (gs & 1) * (NP * PLANE_B);
             auto read_a = [&](int t, int slot) {
@@ -907,9 +1079,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #ifdef HS_NOEPI
                 if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) epilogue(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
 #else
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) epilogue(n, y0, x0, cbase);
+                HSP(1);
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) { epilogue(n, y0, x0, cbase); HSP(3); }
 #endif
                 CP_BARRIER();
+                HSP(4);
             }
         }
         // ---- image block: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1 ----
@@ -949,15 +1123,20 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     mfma_sub(s3 & (FAS - 1), sub & 1, j);
                 }
             }
+            HSP(2);
 #ifdef HS_NOEPI
             if (p.B < 0)
 #endif
             epilogue(n, y0, x0, cbase);
+            HSP(3);
             ++gg;
             CP_BARRIER();
+            HSP(4);
         }
     }
+    HSP_FLUSH(0);
 }
+
 
 template <int TN, int NP, int MODE>
 int launch_hsplit(HSplitK k, hipStream_t st) {
@@ -1170,19 +1349,37 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
     k.descale = w_descale; k.head_descale = head_descale;
     const int np = planes & 15;
-    const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0);
     const int tn = split_tn(d->cout);
+    const bool headk = tn == 1 && d->head_out && !d->residual && !d->out_raw && !d->out_act && d->scale && d->act == CP_ACT_LEAKY01 && d->cout == 32;
+    const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0) |
+                     (headk ? HS_HEADK : 0);
     hipStream_t st = (hipStream_t)stream;
 #define CP_HS(TN_, NP_, M_) if (tn == TN_ && np == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
 #define CP_HS4(TN_, NP_) CP_HS(TN_, NP_, 0) CP_HS(TN_, NP_, HS_BILINEAR) CP_HS(TN_, NP_, HS_PARTIAL) CP_HS(TN_, NP_, HS_PARTIAL | HS_SEL)
+#define CP_HSK(NP_) CP_HS(1, NP_, HS_HEADK) CP_HS(1, NP_, HS_HEADK | HS_BILINEAR) CP_HS(1, NP_, HS_HEADK | HS_PARTIAL) CP_HS(1, NP_, HS_HEADK | HS_PARTIAL | HS_SEL)
     CP_HS4(1, 3)
     CP_HS4(2, 3)
     CP_HS4(1, 2)
     CP_HS4(2, 2)
     CP_HS4(1, 1)
     CP_HS4(2, 1)
+    CP_HSK(3)
+    CP_HSK(2)
+    CP_HSK(1)
+#undef CP_HSK
 #undef CP_HS4
 #undef CP_HS
     cp::set_error("cp_conv2d_fwd_split: operand mode %d is not instantiated", mode);
     return CP_ERR_INVALID;
 }
+
+#ifdef HS_PROFILE
+extern "C" int cp_hs_profile_read(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hs_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hs_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

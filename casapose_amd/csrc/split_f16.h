@@ -22,13 +22,26 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // clamp fp16 overflows to +-65504 for the rest of the wave's life (conversions only; the MFMA accumulates in fp32)
 __device__ __forceinline__ void f16_overflow_clamps() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory"); }
 
+// Round 5: three instructions per PAIR of operands instead of six.  The low half lo = rn_f16(x - hi) is ONE mixed-precision instruction per element --
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 evaluate x * 1.0 - (float)hi in fp32 (exact: the difference has at most 13 significant bits) and round the result
+// to fp16 into the low / high half of the destination -- where the compiler's own form takes two v_cvt_f32_f16, a v_pk_add_f32 and a v_cvt_pk_f16_f32
+// (it folds fma(h, -1, x) back into a subtraction, so the instruction is written out).  Bit-identical to that form on 4.2 M operands from 1e-9 to 3e5,
+// signed zeros, subnormal halves and, with MODE.FP16_OVFL set, beyond 65504 (tools/debug/f16_mix_probe.hip, run on the MI355X).
 __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
     const f32x2_t x = {a, b};
     const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_SPLIT2H_PLAIN)
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(l) : "v"(a), "v"(b), "v"(hi));
+    lo = l;
+#else
     const f32x2_t r = x - __builtin_convertvector(h, f32x2_t);
     const f16x2_t l = __builtin_convertvector(r, f16x2_t);
-    hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
+#endif
 }
 
 __device__ __forceinline__ void split4h(const float4 v, uint2& hi, uint2& lo) {
