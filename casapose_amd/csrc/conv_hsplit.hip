@@ -85,6 +85,7 @@ struct HSplitK {
     uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
     int head_lab_classes;
     float descale, head_descale;   // NP = 2: 1 / (power of two the conv / head weights were multiplied by); 1 otherwise
+    int epi_split;                 // 1: the loader wave w + 4 runs the epilogue of row 1 of consumer wave w's rows (accumulators handed over through LDS)
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -242,7 +243,31 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr int LOW_R = HR / 2 + 1, LOW_C = COLS / 2 + 1, LOW_P = LOW_R * LOW_C;   // 6 x 18 = 108 source pixels
     constexpr int LOW_B = LOW_P * 64;
     unsigned char* lowb = hwl + 2 * NP * 1024;   // [2 stages][LOW_P][64 B]
+    // Round 5: the per-channel normalisation table of a layer WITHOUT class-adaptive rows, staged once: [scale | shift][TAB_C floats].  The generic
+    // epilogue then has no global loads unless the layer has a residual, so nothing of it waits on vmcnt -- where stores and loads share one
+    // in-order counter, every table load of row r + 1 also waited for the write acknowledgements of row r's stores (26 k of the 53 k cycles a
+    // 64-channel tile of stage 1 takes, tools/debug/hs_profile.py)
+    constexpr int TAB_C = 512;
+    float* tabl = reinterpret_cast<float*>(lowb + (BILINEAR ? 2 * LOW_B : 0));
+    const bool tab_lds = !HEADK && p.scale != nullptr && !p.clade && p.Cout <= TAB_C;
+    if (tab_lds) {
+        for (int i = (int)threadIdx.x; i < TAB_C; i += 512) {
+            tabl[i] = i < p.Cout ? p.scale[i] : 0.f;
+            tabl[TAB_C + i] = i < p.Cout ? p.shift[i] : 0.f;
+        }
+    }
     const bool head = HEADK || ((TN == 1) && p.head_out != nullptr);
+    // Epilogue split (round 5).  The epilogue is serial code on the consumer waves -- a quarter of all conv_hsplit time with the matrix pipe idle --
+    // while the loader waves of most layers wait at the barrier.  With epi_split a consumer wave keeps row 0 of its two rows and hands the
+    // accumulators of row 1 to its loader twin through `accst` ([wave][TN][4][64 lanes][16 B], the register layout as it is); the twin runs the
+    // same epilogue code for that row during the first phase of the NEXT tile, beside the consumers' MFMAs.
+    unsigned char* accst = reinterpret_cast<unsigned char*>(tabl + 2 * TAB_C);
+    constexpr bool CAN_SPLIT = NP <= 2 && TN <= 2;   // (the staging buffer does not fit beside three operand planes)
+    constexpr unsigned ACCST_B = 4u * TN * 4u * 1024u;   // one hand-over buffer: 16 KB per 32 output channels
+    // WHEN the twin works (a phase = one weight group, a barrier at its end): a head layer (three phases a tile: slice, slice, image + epilogue) takes
+    // the whole row during the image phase of the NEXT tile -- the one phase in which the loaders have nothing else to do -- out of the buffer of the
+    // tile's parity (two buffers: the consumers fill the other one at the end of that very phase); any other layer takes its 4 TN channel groups a
+    // few per phase over the phases 0 ... ngroups_tile - 2 of the next tile (one buffer: it is refilled in the last phase)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= 4;
@@ -279,6 +304,265 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     const int total_slices = my_tiles * nslices;
     const int ngroups_tile = nslices * GPS + (has_img ? 1 : 0);   // weight groups per tile: GPS per slice + the image block
     const int total_groups = my_tiles * ngroups_tile;
+    // Measured (bs 16, A/B in one call): head layers 0.518 -> 0.484 / 0.588 -> 0.555 ms with the split; the generic layers LOSE 10-20 % with their channel
+    // groups dealt over the phases (the loaders' phases are the critical ones there) -- so only head layers split unless epi_split == 2 forces it
+    // (a fused head outside the HS_HEADK form needs its whole row at once: never dealt)
+    const bool esplit = CAN_SPLIT && (HEADK ? p.epi_split != 0 : (p.epi_split == 2 && !head)) && nslices >= 2;   // (the twin latches the tile's labels one phase after the tile)
+
+    // ---- epilogue machinery, shared by both roles (round 5): a consumer wave w and the loader wave w + 4 can each take rows of the same tile ----
+    const int ew = wave & 3;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
+    const bool has_lab = PARTIAL || p.clade;
+    const unsigned tab_b = p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t r_tab_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.scale : (const void*)p.W), 0, tab_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tab_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.shift : (const void*)p.W), 0, tab_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? (const void*)p.residual : (const void*)p.W), 0,
+                                                                            p.residual ? npix * (unsigned)p.res_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_raw ? (void*)p.out_raw : (void*)p.W), 0,
+                                                                            p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
+                                                                            p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc((void*)(head ? (void*)p.head_out : (void*)p.W), 0,
+                                                                             head ? npix * (unsigned)p.head_ld * 4u : 0u, 0x00020000);
+    int pmask[2] = {0x1ff, 0x1ff}, clab[2] = {0, 0};
+    // labels of a tile come from the label halo the loaders staged with the tile's first slice: no global latency, no registers held
+    auto read_labels = [&](int parity) {
+        const unsigned short* lh = labh + parity * HP;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int centre = (2 * ew + r + 1) * COLS + lrow + 1;
+            const int lc = lh[centre];
+            if constexpr (PARTIAL) {
+                int m = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) m |= ((int)lh[centre + (tp / 3 - 1) * COLS + (tp % 3 - 1)] == lc) ? (1 << tp) : 0;
+                pmask[r] = (lc & 0xff00) ? 0 : m;
+            }
+            clab[r] = lc & 0xff;
+        }
+    };
+
+    // Epilogue (round 5: straight-line).  Round 4's form cost 0.31 ms of block 5's 0.73 (tools/debug/r05_hs_ablate.sh) -- not for its arithmetic: every
+    // `pok && ch < Cout ? offset : OOB`, every `if (nq >= 4) ... else if ...` store ladder and the short-circuit arg-max compiled into
+    // s_and_saveexec / s_cbranch_execz regions (87 of them in the two rows of a tile, each a dozen issue slots with the matrix pipe idle).  Now:
+    // conditions are combined bitwise and select an offset (an out-of-range buffer offset drops the access), operands that do not exist are
+    // skipped by UNIFORM branches only, and the head's stores are chosen by uniform comparisons with head_cout.  Same expressions, same results.
+    const __amdgpu_buffer_rsrc_t r_hlab = __builtin_amdgcn_make_buffer_rsrc((void*)((head && p.head_lab) ? (void*)p.head_lab : (void*)p.W), 0,
+                                                                             (head && p.head_lab) ? npix : 0u, 0x00020000);
+#if defined(HS_EPI_NOSTORE)   // timing experiments (variant builds only)
+    const bool has_res = p.residual != nullptr, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr && p.B < 0, has_act = p.out_act != nullptr && p.B < 0;
+#elif defined(HS_EPI_NORES)
+    const bool has_res = p.residual != nullptr && p.B < 0, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr, has_act = p.out_act != nullptr;
+#elif defined(HS_EPI_NORAW)
+    const bool has_res = p.residual != nullptr, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr && p.B < 0, has_act = p.out_act != nullptr;
+#else
+    const bool has_res = p.residual != nullptr, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr, has_act = p.out_act != nullptr;
+#endif
+    // HEADK: the per-channel table of a layer without CLADE, loaded once; where no partial-convolution factor exists the weights' power-of-two
+    // descale is folded into its scale column (exact: a power of two commutes with the rounding of the product)
+    float4 hk_sc[4], hk_sh[4];
+    if constexpr (HEADK) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            hk_sc[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hk_sh[g4] = hk_sc[g4];
+            if (!p.clade) {
+                hk_sc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (g4 * 8 + kh * 4) * 4, 0, 0));
+                hk_sh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (g4 * 8 + kh * 4) * 4, 0, 0));
+                if constexpr (NP == 2 && !PARTIAL) {
+                    hk_sc[g4].x *= p.descale; hk_sc[g4].y *= p.descale; hk_sc[g4].z *= p.descale; hk_sc[g4].w *= p.descale;
+                }
+            }
+        }
+    }
+    // pieces: bit j * 4 + g4 set = this call handles that group of four channels (generic form; a head layer's row is one piece)
+    auto epilogue = [&](f32x16 (&acc)[2][TN], int r_begin, int r_end, int n, int y0, int x0, int cbase, unsigned pieces) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r < r_begin || r >= r_end) continue;   // (uniform: the rows of a tile can be divided between a consumer wave and its loader twin)
+            const int y = y0 + 2 * ew + r, x = x0 + lrow;
+            const bool pok = (y < p.H) & (x < p.Wd);
+            const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
+            float f = 1.f;
+            if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
+            if constexpr (NP == 2) f *= p.descale;   // the weights' power-of-two scale, undone exactly
+            const unsigned tab_row = (unsigned)(clab[r] * (p.clade ? p.Cout : 0));
+            float4 keep[4];
+            if constexpr (HEADK) {
+                // t = leaky((acc * f) * scale + shift), the generic form's expressions without the operands this layer does not have; pixels
+                // outside the image keep whatever they computed (a pixel is a column of the head's product and is not stored)
+                const bool fold = (NP == 2 && !PARTIAL);   // f == descale, already inside hk_sc
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 sc = hk_sc[g4], sh = hk_sh[g4];
+                    if (p.clade) {
+                        const unsigned to = (tab_row + (unsigned)(g4 * 8 + kh * 4)) * 4u;
+                        sc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+                        sh = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                        if (fold) { sc.x *= p.descale; sc.y *= p.descale; sc.z *= p.descale; sc.w *= p.descale; }
+                    }
+                    float4 t;
+                    if (fold) {
+                        t.x = acc[r][0][g4 * 4 + 0] * sc.x + sh.x;
+                        t.y = acc[r][0][g4 * 4 + 1] * sc.y + sh.y;
+                        t.z = acc[r][0][g4 * 4 + 2] * sc.z + sh.z;
+                        t.w = acc[r][0][g4 * 4 + 3] * sc.w + sh.w;
+                    } else {
+                        t.x = (acc[r][0][g4 * 4 + 0] * f) * sc.x + sh.x;
+                        t.y = (acc[r][0][g4 * 4 + 1] * f) * sc.y + sh.y;
+                        t.z = (acc[r][0][g4 * 4 + 2] * f) * sc.z + sh.z;
+                        t.w = (acc[r][0][g4 * 4 + 3] * f) * sc.w + sh.w;
+                    }
+                    keep[g4] = make_float4(leaky01(t.x), leaky01(t.y), leaky01(t.z), leaky01(t.w));
+                }
+            } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 res[4], esc[4], esh[4];
+                // the 128-channel kernels have no registers to park a whole row's operands: they fetch per group of four channels
+                constexpr int PRE = (TN == 4) ? 1 : 4;
+#pragma unroll
+                for (int g0 = 0; g0 < 4; g0 += PRE) {
+#pragma unroll
+                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
+                    if (!((pieces >> (j * 4 + g4)) & 1u)) continue;
+                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
+                    const bool cok = ch < p.Cout;
+                    res[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    esc[g4] = res[g4];
+                    esh[g4] = res[g4];
+                    if (has_res)   // uniform branches: a layer without these operands issues no loads and waits for none
+                        res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)((pok & cok) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB), 0, 0));
+                    if (tab_lds) {
+                        const int cl = ch < TAB_C - 3 ? ch : 0;   // (channels past Cout are not stored; keep the read inside the table)
+                        esc[g4] = *reinterpret_cast<const float4*>(tabl + cl);
+                        esh[g4] = *reinterpret_cast<const float4*>(tabl + TAB_C + cl);
+                    } else if (has_tab) {
+                        const unsigned to = cok ? (tab_row + (unsigned)ch) * 4u : OOB;
+                        esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
+                        esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
+                    if (!((pieces >> (j * 4 + g4)) & 1u)) continue;
+                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
+                    const bool ok = pok & (ch < p.Cout);
+                    float4 v;
+                    v.x = acc[r][j][g4 * 4 + 0] * f + res[g4].x;
+                    v.y = acc[r][j][g4 * 4 + 1] * f + res[g4].y;
+                    v.z = acc[r][j][g4 * 4 + 2] * f + res[g4].z;
+                    v.w = acc[r][j][g4 * 4 + 3] * f + res[g4].w;
+                    if (has_raw)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    float4 t = v;
+                    if (has_tab) {
+                        t.x = v.x * esc[g4].x + esh[g4].x;
+                        t.y = v.y * esc[g4].y + esh[g4].y;
+                        t.z = v.z * esc[g4].z + esh[g4].z;
+                        t.w = v.w * esc[g4].w + esh[g4].w;
+                    }
+                    if (p.act == CP_ACT_RELU) {
+                        t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                    } else if (p.act == CP_ACT_LEAKY01) {
+                        t.x = leaky01(t.x); t.y = leaky01(t.y); t.z = leaky01(t.z); t.w = leaky01(t.w);
+                    }
+                    if (has_act)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                    if (j == 0) {
+                        keep[g4].x = ok ? t.x : 0.f;
+                        keep[g4].y = ok ? t.y : 0.f;
+                        keep[g4].z = ok ? t.z : 0.f;
+                        keep[g4].w = ok ? t.w : 0.f;
+                    }
+                }
+                }
+            }
+            }   // !HEADK
+            if constexpr (TN == 1) {
+                if (head) {
+                    // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel] on the same matrix pipe.  The order of K is free, so step m
+                    // takes, from lane half kh, the eight channels this lane already holds: 8*(2m) + 4*kh + 0..3 and 8*(2m+1) + 4*kh + 0..3
+                    // (the head weights are packed in that order); the activated values are split / rounded in registers.
+                    f32x16 a2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a2[e] = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        bf16x8 px[NP];
+                        if constexpr (NP == 3) {
+                            uint2 h0, m0, l0, h1, m1, l1;
+                            split4(keep[2 * m], h0, m0, l0);
+                            split4(keep[2 * m + 1], h1, m1, l1);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+                            px[2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                        } else if constexpr (NP == 2) {
+                            uint2 h0, l0, h1, l1;
+                            cp::split4h(keep[2 * m], h0, l0);
+                            cp::split4h(keep[2 * m + 1], h1, l1);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                        } else {
+                            const uint2 a = round4(keep[2 * m]), b = round4(keep[2 * m + 1]);
+                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+                        }
+                        bf16x8 hw[NP];
+#pragma unroll
+                        for (int sidx = 0; sidx < NP; ++sidx) hw[sidx] = *reinterpret_cast<const bf16x8*>(hwl + (unsigned)(m * NP + sidx) * 1024u + wlane);
+#pragma unroll
+                        for (int t6 = 0; t6 < NPROD; ++t6) {
+                            a2 = mfma_np<NP>(hw[prod_w<NP>(t6)], px[prod_p<NP>(t6)], a2);
+                        }
+                    }
+                    if constexpr (NP == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) a2[e] *= p.head_descale;
+                    }
+                    // stores: register g4 * 4 + e of lane half kh is head channel q = 8 g4 + 4 kh + e.  A group of eight channels that lies wholly
+                    // below head_cout goes out as one 16-byte store per lane; the group that straddles it as single dwords, one store per e that
+                    // ANY lane half still owns -- which stores exist is decided by uniform comparisons, which lanes take part by the offset
+                    const unsigned hbase = (pix * (unsigned)p.head_ld + (unsigned)(kh * 4)) * 4u;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const unsigned o = hbase + (unsigned)(g4 * 32);
+                        if (p.head_cout >= g4 * 8 + 8) {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]),
+                                                                         __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3])},
+                                                                   r_head, (int)(pok ? o : OOB), 0, 0);
+                        } else if (p.head_cout > g4 * 8) {
+                            const int left = p.head_cout - g4 * 8 - kh * 4;   // channels of this group this lane half still owns (<= 0: none)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (p.head_cout > g4 * 8 + e)   // lane half 0 owns q = 8 g4 + e
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + e]), r_head, (int)((pok & (e < left)) ? o + 4u * e : OOB), 0, 0);
+                        }
+                    }
+                    if (p.head_lab) {   // the hard label map straight from the head's registers: first maximum wins (cp_argmax_labels)
+                        float best = -__builtin_inff();
+                        int bi = 0x7fffffff;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int q = g4 * 8 + kh * 4 + e;
+                                const float vq = a2[g4 * 4 + e];
+                                const bool take = (q < p.head_lab_classes) & (vq > best);
+                                best = take ? vq : best;
+                                bi = take ? q : bi;
+                            }
+                        const float ob = __shfl_xor(best, 32);
+                        const int oi = __shfl_xor(bi, 32);
+                        const bool other = (ob > best) | ((ob == best) & (oi < bi));
+                        bi = other ? oi : bi;
+                        bi = (bi == 0x7fffffff) ? 0 : bi;
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bi, r_hlab, (int)(((kh == 0) & pok) ? pix : OOB), 0, 0);
+                    }
+                }
+            }
+        }
+    };
 
     if constexpr (NP == 2) cp::f16_overflow_clamps();
     if (loader) {
@@ -291,6 +575,45 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             return;
         }
 #endif
+        TilePos etile = first;   // the tile whose row-1 epilogue this wave owes (epi_split): the one BEFORE the tile the consumers are multiplying
+        int e_n = 0, e_y0 = 0, e_x0 = 0, e_cbase = 0, e_k = 0;
+        constexpr int NPIECE = HEADK ? 1 : 4 * TN;
+        const int e_q = HEADK ? 1 : (NPIECE + max(ngroups_tile - 1, 1) - 1) / max(ngroups_tile - 1, 1);   // channel groups per phase
+        // phase = index of the current phase inside the consumers' tile; last = the call after the block's last tile (everything that is left)
+        auto loader_epilogue = [&](int phase, bool last) __attribute__((always_inline)) {
+            if constexpr (CAN_SPLIT) {
+                if (phase == 0 || last) {   // latch the owed tile's position and labels (its label halo is overwritten later in this tile)
+                    const int pass = etile.n / p.B;
+                    e_n = etile.n - pass * p.B; e_y0 = etile.ty * TH; e_x0 = etile.tx * 32; e_cbase = pass * 32 * TN;
+                    if (has_lab) read_labels(e_k & 1);
+                }
+                unsigned pieces;
+                if (last) pieces = 0xffffffffu;
+                else if (HEADK) pieces = (phase == ngroups_tile - 1) ? 1u : 0u;
+                else {
+                    const int b0 = phase * e_q, b1 = min(NPIECE, b0 + e_q);
+                    pieces = b0 < b1 ? ((b1 >= 32 ? 0xffffffffu : ((1u << b1) - 1u)) & ~((1u << b0) - 1u)) : 0u;
+                }
+                if (pieces) {
+                    f32x16 accl[2][TN];
+                    const unsigned char* src = accst + (unsigned)(HEADK ? (e_k & 1) * ACCST_B : 0);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (HEADK || ((pieces >> (j * 4 + g4)) & 1u)) v = *reinterpret_cast<const float4*>(src + (unsigned)(((ew * TN + j) * 4 + g4) * 1024) + wlane);
+                            accl[1][j][g4 * 4 + 0] = v.x; accl[1][j][g4 * 4 + 1] = v.y; accl[1][j][g4 * 4 + 2] = v.z; accl[1][j][g4 * 4 + 3] = v.w;
+                            accl[0][j][g4 * 4 + 0] = v.x; accl[0][j][g4 * 4 + 1] = v.y; accl[0][j][g4 * 4 + 2] = v.z; accl[0][j][g4 * 4 + 3] = v.w;
+                        }
+                    epilogue(accl, 1, 2, e_n, e_y0, e_x0, e_cbase, pieces);
+                }
+                if (last || phase == ngroups_tile - 1) {   // this tile's row is done: the next one is owed
+                    next_tile(etile);
+                    ++e_k;
+                }
+            }
+        };
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.s[0].data, 0, p.s[0].bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s[1].data ? p.s[1].data : p.s[0].data), 0,
                                                                               p.s[1].data ? p.s[1].bytes : 0u, 0x00020000);
@@ -342,7 +665,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
             }
         };
-        auto issue_slice = [&](const TilePos& tp, int c) {
+        // part / nparts: only the elements it with it % nparts == part (the generic loop of the 64-channel kernels deals a slice's halo over the
+        // GPS weight-group phases of the slice before it; part = -1: all of them)
+        auto issue_slice = [&](const TilePos& tp, int c, int part = -1, int nparts = 1) {
             (void)tp;
             const int si = c >= p.nch0 ? 1 : 0;
             const int cs = (c - (si ? p.nch0 : 0)) * 64;   // uniform byte offset of the slice's first channel
@@ -351,21 +676,27 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #endif
             if (si == 0) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)
+                for (int it = 0; it < NIT; ++it) {
+                    if (part >= 0 && it % nparts != part) continue;
 #pragma unroll
                     for (int v = 0; v < NV; ++v) lv[it][v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)eo0[it][v], cs, 0));
+                }
             } else {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)eo1[it], cs, 0));
+                for (int it = 0; it < NIT; ++it) {
+                    if (part >= 0 && it % nparts != part) continue;
+                    lv[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)eo1[it], cs, 0));
+                }
             }
         };
-        auto store_slice = [&](int stage) {
+        auto store_slice = [&](int stage, int part = -1, int nparts = 1) {
 #ifdef HS_NOSTORE
             if (p.B > 0) return;   // timing experiment
 #endif
             unsigned char* h = halo + stage * (NP * PLANE_B);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
+                if (part >= 0 && it % nparts != part) continue;
                 if (e_hy[it] >= 0x4000) continue;
                 store_planes<NP>(h + e_lds[it], PLANE_B, lv[it][0]);
             }
@@ -667,11 +998,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     step(cb);
                     step(cc);
                 }
+                if (esplit && gg >= ngroups_tile) loader_epilogue(lg, false);   // row 1 of the tile before, beside the consumers' work on this one
                 if (++lg == ngroups_tile) lg = 0;
                 HSP(2);
                 CP_BARRIER();
                 HSP(1);
             }
+            if (esplit) loader_epilogue(0, true);   // the last tile's
             HSP_FLUSH(8);
             return;
         }
@@ -704,6 +1037,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 if (!kStoresFirst && gg + 2 < total_groups) issue_w(gg + 2);
             }
             bool fetch = false;
+            // (round 5, tried and dropped: dealing the halo store / request of a slice over the GPS weight-group phases of the 64-channel kernels --
+            //  every phase then stores registers whose neighbours were requested one phase ago, the compiler's vmcnt(0) in front of the store waits
+            //  for those too, and the latency is exposed in every phase instead of one in three: 10-35 % slower)
             if (lg < nslices * GPS && lg % GPS == 0) {             // first group of slice gs
                 if (gs + 1 < total_slices) {
                     store_slice((gs + 1) & 1);                     // halo stage read last during slice gs - 1
@@ -719,11 +1055,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 issue_slice(ftile, fc);
                 ++issued;
             }
+            if (esplit && gg >= ngroups_tile) loader_epilogue(lg, false);   // row 1 of the tile before, beside the consumers' work on this one
             if (++lg == ngroups_tile) lg = 0;
             HSP(0);
             CP_BARRIER();
             HSP(1);
         }
+        if (esplit) loader_epilogue(0, true);   // the last tile's
         HSP_FLUSH(8);
         return;
     }
@@ -737,20 +1075,6 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         return;
     }
 #endif
-    const unsigned npix = (unsigned)(p.B * p.H * p.Wd);
-    const bool has_lab = PARTIAL || p.clade;
-    const unsigned tab_b = p.scale ? (unsigned)((p.clade ? 256 : 1) * p.Cout * 4) : 0u;
-    const __amdgpu_buffer_rsrc_t r_tab_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.scale : (const void*)p.W), 0, tab_b, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_tab_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? (const void*)p.shift : (const void*)p.W), 0, tab_b, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? (const void*)p.residual : (const void*)p.W), 0,
-                                                                            p.residual ? npix * (unsigned)p.res_ld * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_raw ? (void*)p.out_raw : (void*)p.W), 0,
-                                                                            p.out_raw ? npix * (unsigned)p.raw_ld * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_act ? (void*)p.out_act : (void*)p.W), 0,
-                                                                            p.out_act ? npix * (unsigned)p.act_ld * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc((void*)(head ? (void*)p.head_out : (void*)p.W), 0,
-                                                                             head ? npix * (unsigned)p.head_ld * 4u : 0u, 0x00020000);
-    const unsigned wlane = (unsigned)lane * 16u;
     bf16x8 fw[2][NP];   // [slot][plane] weight fragments of one sub-step, read from the staged group
     auto ldw = [&](const unsigned char* wg, int sub, int slot) {
 #pragma unroll
@@ -768,227 +1092,20 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     f32x16 acc[2][TN];
     constexpr int FAS = (TN == 4) ? 1 : 2;   // pixel-fragment slots: double-buffered except in the 128-channel kernels (register budget)
     bf16x8 fa[FAS][2][NP];   // [slot][row][plane]
-    int pmask[2] = {0x1ff, 0x1ff}, clab[2] = {0, 0};
-    // labels of a tile come from the label halo the loaders staged with the tile's first slice: no global latency, no registers held
-    auto read_labels = [&](int parity) {
-        const unsigned short* lh = labh + parity * HP;
+    int dump_k = 0;   // tiles handed over so far (head layers alternate between two hand-over buffers)
+    auto finish_tile = [&](int n, int y0, int x0, int cbase) __attribute__((always_inline)) {
+        if constexpr (CAN_SPLIT) {
+            if (esplit) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int centre = (2 * wave + r + 1) * COLS + lrow + 1;
-            const int lc = lh[centre];
-            if constexpr (PARTIAL) {
-                int m = 0;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) m |= ((int)lh[centre + (tp / 3 - 1) * COLS + (tp % 3 - 1)] == lc) ? (1 << tp) : 0;
-                pmask[r] = (lc & 0xff00) ? 0 : m;
-            }
-            clab[r] = lc & 0xff;
-        }
-    };
-
-    // Epilogue (round 5: straight-line).  Round 4's form cost 0.31 ms of block 5's 0.73 (tools/debug/r05_hs_ablate.sh) -- not for its arithmetic: every
-    // `pok && ch < Cout ? offset : OOB`, every `if (nq >= 4) ... else if ...` store ladder and the short-circuit arg-max compiled into
-    // s_and_saveexec / s_cbranch_execz regions (87 of them in the two rows of a tile, each a dozen issue slots with the matrix pipe idle).  Now:
-    // conditions are combined bitwise and select an offset (an out-of-range buffer offset drops the access), operands that do not exist are
-    // skipped by UNIFORM branches only, and the head's stores are chosen by uniform comparisons with head_cout.  Same expressions, same results.
-    const __amdgpu_buffer_rsrc_t r_hlab = __builtin_amdgcn_make_buffer_rsrc((void*)((head && p.head_lab) ? (void*)p.head_lab : (void*)p.W), 0,
-                                                                             (head && p.head_lab) ? npix : 0u, 0x00020000);
-    const bool has_res = p.residual != nullptr, has_tab = p.scale != nullptr, has_raw = p.out_raw != nullptr, has_act = p.out_act != nullptr;
-    // HEADK: the per-channel table of a layer without CLADE, loaded once; where no partial-convolution factor exists the weights' power-of-two
-    // descale is folded into its scale column (exact: a power of two commutes with the rounding of the product)
-    float4 hk_sc[4], hk_sh[4];
-    if constexpr (HEADK) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            hk_sc[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            hk_sh[g4] = hk_sc[g4];
-            if (!p.clade) {
-                hk_sc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (g4 * 8 + kh * 4) * 4, 0, 0));
-                hk_sh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (g4 * 8 + kh * 4) * 4, 0, 0));
-                if constexpr (NP == 2 && !PARTIAL) {
-                    hk_sc[g4].x *= p.descale; hk_sc[g4].y *= p.descale; hk_sc[g4].z *= p.descale; hk_sc[g4].w *= p.descale;
-                }
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(accst + (unsigned)(HEADK ? (dump_k & 1) * ACCST_B : 0) + (unsigned)(((ew * TN + j) * 4 + g4) * 1024) + wlane) =
+                            make_float4(acc[1][j][g4 * 4 + 0], acc[1][j][g4 * 4 + 1], acc[1][j][g4 * 4 + 2], acc[1][j][g4 * 4 + 3]);
+                ++dump_k;
             }
         }
-    }
-    auto epilogue = [&](int n, int y0, int x0, int cbase) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int y = y0 + 2 * wave + r, x = x0 + lrow;
-            const bool pok = (y < p.H) & (x < p.Wd);
-            const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
-            float f = 1.f;
-            if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
-            if constexpr (NP == 2) f *= p.descale;   // the weights' power-of-two scale, undone exactly
-            const unsigned tab_row = (unsigned)(clab[r] * (p.clade ? p.Cout : 0));
-            float4 keep[4];
-            if constexpr (HEADK) {
-                // t = leaky((acc * f) * scale + shift), the generic form's expressions without the operands this layer does not have; pixels
-                // outside the image keep whatever they computed (a pixel is a column of the head's product and is not stored)
-                const bool fold = (NP == 2 && !PARTIAL);   // f == descale, already inside hk_sc
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float4 sc = hk_sc[g4], sh = hk_sh[g4];
-                    if (p.clade) {
-                        const unsigned to = (tab_row + (unsigned)(g4 * 8 + kh * 4)) * 4u;
-                        sc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
-                        sh = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
-                        if (fold) { sc.x *= p.descale; sc.y *= p.descale; sc.z *= p.descale; sc.w *= p.descale; }
-                    }
-                    float4 t;
-                    if (fold) {
-                        t.x = acc[r][0][g4 * 4 + 0] * sc.x + sh.x;
-                        t.y = acc[r][0][g4 * 4 + 1] * sc.y + sh.y;
-                        t.z = acc[r][0][g4 * 4 + 2] * sc.z + sh.z;
-                        t.w = acc[r][0][g4 * 4 + 3] * sc.w + sh.w;
-                    } else {
-                        t.x = (acc[r][0][g4 * 4 + 0] * f) * sc.x + sh.x;
-                        t.y = (acc[r][0][g4 * 4 + 1] * f) * sc.y + sh.y;
-                        t.z = (acc[r][0][g4 * 4 + 2] * f) * sc.z + sh.z;
-                        t.w = (acc[r][0][g4 * 4 + 3] * f) * sc.w + sh.w;
-                    }
-                    keep[g4] = make_float4(leaky01(t.x), leaky01(t.y), leaky01(t.z), leaky01(t.w));
-                }
-            } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float4 res[4], esc[4], esh[4];
-                // the 128-channel kernels have no registers to park a whole row's operands: they fetch per group of four channels
-                constexpr int PRE = (TN == 4) ? 1 : 4;
-#pragma unroll
-                for (int g0 = 0; g0 < 4; g0 += PRE) {
-#pragma unroll
-                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
-                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
-                    const bool cok = ch < p.Cout;
-                    res[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    esc[g4] = res[g4];
-                    esh[g4] = res[g4];
-                    if (has_res)   // uniform branches: a layer without these operands issues no loads and waits for none
-                        res[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)((pok & cok) ? (pix * (unsigned)p.res_ld + (unsigned)ch) * 4u : OOB), 0, 0));
-                    if (has_tab) {
-                        const unsigned to = cok ? (tab_row + (unsigned)ch) * 4u : OOB;
-                        esc[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_s, (int)to, 0, 0));
-                        esh[g4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_tab_b, (int)to, 0, 0));
-                    }
-                }
-#pragma unroll
-                for (int g4 = g0; g4 < g0 + PRE; ++g4) {
-                    const int ch = cbase + j * 32 + g4 * 8 + kh * 4;
-                    const bool ok = pok & (ch < p.Cout);
-                    float4 v;
-                    v.x = acc[r][j][g4 * 4 + 0] * f + res[g4].x;
-                    v.y = acc[r][j][g4 * 4 + 1] * f + res[g4].y;
-                    v.z = acc[r][j][g4 * 4 + 2] * f + res[g4].z;
-                    v.w = acc[r][j][g4 * 4 + 3] * f + res[g4].w;
-                    if (has_raw)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
-                    float4 t = v;
-                    if (has_tab) {
-                        t.x = v.x * esc[g4].x + esh[g4].x;
-                        t.y = v.y * esc[g4].y + esh[g4].y;
-                        t.z = v.z * esc[g4].z + esh[g4].z;
-                        t.w = v.w * esc[g4].w + esh[g4].w;
-                    }
-                    if (p.act == CP_ACT_RELU) {
-                        t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-                    } else if (p.act == CP_ACT_LEAKY01) {
-                        t.x = leaky01(t.x); t.y = leaky01(t.y); t.z = leaky01(t.z); t.w = leaky01(t.w);
-                    }
-                    if (has_act)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
-                    if (j == 0) {
-                        keep[g4].x = ok ? t.x : 0.f;
-                        keep[g4].y = ok ? t.y : 0.f;
-                        keep[g4].z = ok ? t.z : 0.f;
-                        keep[g4].w = ok ? t.w : 0.f;
-                    }
-                }
-                }
-            }
-            }   // !HEADK
-            if constexpr (TN == 1) {
-                if (head) {
-                    // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel] on the same matrix pipe.  The order of K is free, so step m
-                    // takes, from lane half kh, the eight channels this lane already holds: 8*(2m) + 4*kh + 0..3 and 8*(2m+1) + 4*kh + 0..3
-                    // (the head weights are packed in that order); the activated values are split / rounded in registers.
-                    f32x16 a2;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) a2[e] = 0.f;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        bf16x8 px[NP];
-                        if constexpr (NP == 3) {
-                            uint2 h0, m0, l0, h1, m1, l1;
-                            split4(keep[2 * m], h0, m0, l0);
-                            split4(keep[2 * m + 1], h1, m1, l1);
-                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
-                            px[2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                        } else if constexpr (NP == 2) {
-                            uint2 h0, l0, h1, l1;
-                            cp::split4h(keep[2 * m], h0, l0);
-                            cp::split4h(keep[2 * m + 1], h1, l1);
-                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                            px[1] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                        } else {
-                            const uint2 a = round4(keep[2 * m]), b = round4(keep[2 * m + 1]);
-                            px[0] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
-                        }
-                        bf16x8 hw[NP];
-#pragma unroll
-                        for (int sidx = 0; sidx < NP; ++sidx) hw[sidx] = *reinterpret_cast<const bf16x8*>(hwl + (unsigned)(m * NP + sidx) * 1024u + wlane);
-#pragma unroll
-                        for (int t6 = 0; t6 < NPROD; ++t6) {
-                            a2 = mfma_np<NP>(hw[prod_w<NP>(t6)], px[prod_p<NP>(t6)], a2);
-                        }
-                    }
-                    if constexpr (NP == 2) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) a2[e] *= p.head_descale;
-                    }
-                    // stores: register g4 * 4 + e of lane half kh is head channel q = 8 g4 + 4 kh + e.  A group of eight channels that lies wholly
-                    // below head_cout goes out as one 16-byte store per lane; the group that straddles it as single dwords, one store per e that
-                    // ANY lane half still owns -- which stores exist is decided by uniform comparisons, which lanes take part by the offset
-                    const unsigned hbase = (pix * (unsigned)p.head_ld + (unsigned)(kh * 4)) * 4u;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const unsigned o = hbase + (unsigned)(g4 * 32);
-                        if (p.head_cout >= g4 * 8 + 8) {
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 0]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 1]),
-                                                                         __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 2]), __builtin_bit_cast(unsigned, (float)a2[g4 * 4 + 3])},
-                                                                   r_head, (int)(pok ? o : OOB), 0, 0);
-                        } else if (p.head_cout > g4 * 8) {
-                            const int left = p.head_cout - g4 * 8 - kh * 4;   // channels of this group this lane half still owns (<= 0: none)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (p.head_cout > g4 * 8 + e)   // lane half 0 owns q = 8 g4 + e
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + e]), r_head, (int)((pok & (e < left)) ? o + 4u * e : OOB), 0, 0);
-                        }
-                    }
-                    if (p.head_lab) {   // the hard label map straight from the head's registers: first maximum wins (cp_argmax_labels)
-                        float best = -__builtin_inff();
-                        int bi = 0x7fffffff;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int q = g4 * 8 + kh * 4 + e;
-                                const float vq = a2[g4 * 4 + e];
-                                const bool take = (q < p.head_lab_classes) & (vq > best);
-                                best = take ? vq : best;
-                                bi = take ? q : bi;
-                            }
-                        const float ob = __shfl_xor(best, 32);
-                        const int oi = __shfl_xor(bi, 32);
-                        const bool other = (ob > best) | ((ob == best) & (oi < bi));
-                        bi = other ? oi : bi;
-                        bi = (bi == 0x7fffffff) ? 0 : bi;
-                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bi, r_hlab, (int)(((kh == 0) & pok) ? pix : OOB), 0, 0);
-                    }
-                }
-            }
-        }
+        epilogue(acc, 0, esplit ? 1 : 2, n, y0, x0, cbase, 0xffffffffu);
     };
 
     // one (tap, cout block) sub-step: NPROD x 2 MFMAs; smallest terms first
@@ -1077,10 +1194,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     if (FAS == 1 && st + 1 < GT) read_a(g3 * GT + st + 1, 0);
                 });
 #ifdef HS_NOEPI
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) epilogue(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) finish_tile(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
 #else
                 HSP(1);
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) { epilogue(n, y0, x0, cbase); HSP(3); }
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) { finish_tile(n, y0, x0, cbase); HSP(3); }
 #endif
                 CP_BARRIER();
                 HSP(4);
@@ -1127,7 +1244,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
 #ifdef HS_NOEPI
             if (p.B < 0)
 #endif
-            epilogue(n, y0, x0, cbase);
+            finish_tile(n, y0, x0, cbase);
             HSP(3);
             ++gg;
             CP_BARRIER();
@@ -1149,6 +1266,8 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : TN == 2 ? 3 : 1) * TN * NP * 1024 +
                  (size_t)2 * NP * 1024;   // + the fused head's weights
     if (MODE & HS_BILINEAR) lds += (size_t)2 * ((HR / 2 + 1) * (COLS / 2 + 1)) * 64;   // + two low-resolution stages of source 0
+    lds += (size_t)2 * 512 * 4;                                                         // + the per-channel normalisation table (TAB_C)
+    if (NP <= 2 && TN <= 2) lds += (size_t)4 * TN * 4 * 1024 * ((MODE & HS_HEADK) ? 2 : 1);   // + the accumulator hand-over(s) of the epilogue split
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1348,6 +1467,10 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
     k.descale = w_descale; k.head_descale = head_descale;
+    {   // epilogue split: on by default (CASAPOSE_HS_EPI_SPLIT=0 keeps both rows on the consumer waves: A/B measurements)
+        static const int split_env = getenv("CASAPOSE_HS_EPI_SPLIT") ? atoi(getenv("CASAPOSE_HS_EPI_SPLIT")) : 1;
+        k.epi_split = split_env;
+    }
     const int np = planes & 15;
     const int tn = split_tn(d->cout);
     const bool headk = tn == 1 && d->head_out && !d->residual && !d->out_raw && !d->out_act && d->scale && d->act == CP_ACT_LEAKY01 && d->cout == 32;

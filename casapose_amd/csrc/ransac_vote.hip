@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ ver
                     const float sd = dxv[v] * ex + dyv[v] * ey;
                     const float rhs = qv[v] * e2;
                     const float d = __builtin_fmaf(sd, __builtin_fabsf(sd), -rhs);   // > 0  <=>  s > 0 and s^2 > t^2 |d|^2 |e|^2
-                    c[v] = __popcll(__builtin_amdgcn_ballot_w64(d > 0.f && act));
+                    // (no `&& act`: a lane without a pixel has d = 0 and t^2 |d|^2 = 1, i.e. d = -|e|^2 < 0 for every valid hypothesis, and NaN for an
+                    //  invalid one -- the comparison is false by itself; the explicit mask cost a v_cndmask + v_cmp per test, 14 % of the loop's VALU)
+                    c[v] = __popcll(__builtin_amdgcn_ballot_w64(d > 0.f));
                     zmin = fminf(zmin, __builtin_fmaf(-1e-5f, rhs, __builtin_fabsf(d)));   // NaN (invalid hypothesis) leaves the minimum alone
                     if constexpr (CHECK_E2) e2min = fminf(e2min, e2);
                 }
