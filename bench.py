@@ -77,7 +77,12 @@ def _median_rate(fn, images, warmup=3, timed=10, budget_s=12.0):
     return images / ts[len(ts) // 2], len(ts)
 
 
-CPU_WORKER_THREADS = 32   # threads per CPU worker process: the count the thread probe of round 4 found best for one process on the GPU box's host
+# threads per CPU worker process and worker count (0 = one per block of threads, at most 8): CASAPOSE_CPU_WORKER_THREADS / CASAPOSE_CPU_WORKERS override
+# the defaults, which tools/debug/cpu_workers_probe.py measured on the GPU box's host (profiles/probes/r05_cpu_workers_probe.txt)
+# Measured there (256 logical CPUs = 2 x 64 cores x SMT 2): 8 x 32 -> 5.5-5.9 images/s, 4 x 32 -> 6.6, 8 x 16 -> 7.6, 32 x 4 / 64 x 2 -> 8.1, 16 x 8 -> 8.2-8.5:
+# one thread per PHYSICAL core in many small processes; the second hardware thread of a core only costs (the graph is memory-bound on the host).
+CPU_WORKER_THREADS = int(os.environ.get("CASAPOSE_CPU_WORKER_THREADS", "8"))
+CPU_WORKERS = int(os.environ.get("CASAPOSE_CPU_WORKERS", "0"))
 
 
 def cpu_worker(args):
@@ -85,17 +90,17 @@ def cpu_worker(args):
     restatement of the inference graph (oracle/torch_train_ref.forward_infer_fast + component filter + LS voter: the same program as the
     in-process leg), warms up, then WAITS for a line on stdin -- the parent sends it when the GPU legs are over -- and runs whole images
     (forward + filter + voting, bs 1, its own seed) for --cpu-seconds; prints {"images": n, "seconds": t}.  Never touches a GPU."""
+    idx, n = [int(v) for v in args.cpu_worker.split("/")]
+    cores = os.cpu_count()
+    first = (idx * CPU_WORKER_THREADS) % cores
+    try:   # BEFORE torch / OpenMP exist in this process: their threads inherit the mask (set afterwards, 8 x 32 floating threads took 24 s per image)
+        os.sched_setaffinity(0, set(range(first, min(first + CPU_WORKER_THREADS, cores))))
+    except OSError:
+        pass
     import numpy as np
     import torch
     from scipy import ndimage
 
-    idx, n = [int(v) for v in args.cpu_worker.split("/")]
-    cores = os.cpu_count()
-    first = (idx * CPU_WORKER_THREADS) % cores
-    try:
-        os.sched_setaffinity(0, set(range(first, min(first + CPU_WORKER_THREADS, cores))))
-    except OSError:
-        pass
     torch.set_num_threads(CPU_WORKER_THREADS)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import casapose_oracle as O
@@ -120,10 +125,10 @@ def cpu_worker(args):
                         keep[0][cc == 1 + int(sizes.argmax())] = o
             R.ls_voting_fast(torch.from_numpy(keep), out[..., seg_dim:seg_dim + 2 * kp], out[..., seg_dim + 2 * kp:], seg_dim - 1)
 
-    one()
-    one()
-    print("ready", flush=True)
+    print("ready", flush=True)   # network built; nothing has run yet: the host's cores stay free for the parent's GPU legs
     sys.stdin.readline()
+    one()
+    one()
     t0 = time.perf_counter()
     images = 0
     while time.perf_counter() - t0 < args.cpu_seconds:
@@ -134,13 +139,14 @@ def cpu_worker(args):
 
 def spawn_cpu_workers(args):
     """Start the CPU-baseline workers BEFORE this process touches the GPU (a process that has initialised the GPU must not be the one that
-    execs): one per block of CPU_WORKER_THREADS logical CPUs of the host, at most 8.  They build their network and wait; collect_cpu_workers()
+    execs): one per block of CPU_WORKER_THREADS logical CPUs over the first half of the host's logical CPUs (one thread per physical core), at most 16.  They build their network and wait; collect_cpu_workers()
     releases them together once the GPU legs are done, so they never compete with the timed GPU region for host cores."""
     import subprocess
 
     cores = os.cpu_count() or 1
-    n = max(1, min(8, cores // CPU_WORKER_THREADS))
-    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_WORKER_THREADS), MKL_NUM_THREADS=str(CPU_WORKER_THREADS), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    n = CPU_WORKERS if CPU_WORKERS > 0 else max(1, min(16, cores // (2 * CPU_WORKER_THREADS)))   # half the logical CPUs: one thread per core under SMT 2
+    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_WORKER_THREADS), MKL_NUM_THREADS=str(CPU_WORKER_THREADS), OMP_WAIT_POLICY="PASSIVE", KMP_BLOCKTIME="0",
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     procs = []
     for i in range(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d/%d" % (i, n), "--cpu-seconds", str(args.cpu_seconds),
@@ -149,13 +155,15 @@ def spawn_cpu_workers(args):
     return procs
 
 
-def collect_cpu_workers(procs, budget_s):
-    """Release the waiting workers at once and add up what they did: aggregate images/s = all images / the longest worker's time."""
+def wait_cpu_workers(procs):
+    """Block until every worker has built its network (or 120 s): called by the parent BEFORE its GPU warm-up, so that no worker is still importing
+    or building while the GPU legs are timed.  Returns the workers that are up; the others are killed."""
+    import select
+
     ready = []
     t0 = time.perf_counter()
-    for p in procs:   # a worker that is not up after 120 s (first import of torch on a cold box) is left out
+    for p in procs or []:   # a worker that is not up after 120 s (first import of torch on a cold box) is left out
         try:
-            import select
             r, _, _ = select.select([p.stdout], [], [], max(1.0, 120.0 - (time.perf_counter() - t0)))
             if r and p.stdout.readline().strip() == "ready":
                 ready.append(p)
@@ -163,6 +171,11 @@ def collect_cpu_workers(procs, budget_s):
         except Exception:
             pass
         p.kill()
+    return ready
+
+
+def collect_cpu_workers(ready, budget_s):
+    """Release the waiting workers at once and add up what they did: aggregate images/s = all images / the longest worker's time."""
     for p in ready:
         try:
             p.stdin.write("go\n")
@@ -759,6 +772,9 @@ def main():
         s, d, c = torch.split(out, [seg_dim, 2 * kp, kp], dim=3)
         return voter([s, d, c])
 
+    if cpu_workers:
+        cpu_workers = wait_cpu_workers(cpu_workers)   # all built and idle (blocked on stdin) before anything here is timed
+        _log("%d CPU-baseline workers ready" % len(cpu_workers))
     _log("model built, %d warm-up steps" % args.warmup)
     for _ in range(args.warmup):
         step()
