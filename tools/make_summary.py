@@ -166,7 +166,11 @@ if o2:
               % (o2["value"], o2["ms_per_step"], orf.get("frac", float("nan")), o2.get("max_logit_difference_vs_headline_rel", float("nan"))))
 acc = (b.get("cpu_baseline") or {}).get("accuracy_vs_fp64")
 if acc:
-    md.append("Accuracy inside the same line (`cpu_baseline.accuracy_vs_fp64`): %s -- %s.\n" % (json.dumps(acc["per_conv_mode"]), acc["what"]))
+    md.append("Accuracy inside the same line (`cpu_baseline.accuracy_vs_fp64`): logits %s, vector field %s -- %s.\n"
+              % (json.dumps(acc["per_conv_mode"]), json.dumps(acc.get("vector_field_per_conv_mode")), acc["what"]))
+gd = b["config"].get("f16x2_guard")
+if gd:
+    md.append("f16x2 range guard on the timed plan (`config.f16x2_guard`): %d layers checked, not plain f16x2: %s.\n" % (gd["layers_checked"], json.dumps(gd["not_plain_f16x2"]) if gd["not_plain_f16x2"] else "none"))
 md.append("`useful_tflops` %.1f = %.3f of the fp32-level peak of this arithmetic (%.0f TFLOP/s = dense 2-byte peak / %d products per fp32 product).\n"
           % (rf["useful_tflops"], rf["useful_frac_of_fp32_equiv_peak"], rf["fp32_equiv_peak"], int(rf.get("products_per_fp32_product", 6))))
 alone = []
@@ -184,8 +188,9 @@ if tl and "value" in tl:
                                                   % (tb["value"], tb["ms_per_step"])) if "value" in tb else ""))
 c = b.get("cpu_baseline")
 if c:
-    md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s (`%s`; host has %s threads, thread probe s/image: %s).\n"
-              % (c.get("cpu"), c["value"], c.get("what"), c.get("sample"), c.get("host_cores"), json.dumps(c.get("thread_probe_s_per_image"))))
+    md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s, %s (`%s`; host has %s logical CPUs; one process x %s threads: %s images/s).\n"
+              % (c.get("cpu"), c["value"], c.get("what"), c.get("shape", "one process"), c.get("sample"), c.get("host_cores"),
+                 (c.get("single_process") or {}).get("threads", c.get("cores")), (c.get("single_process") or {}).get("value", c["value"])))
 md.append(stats_table(os.path.join(P, "%s_bench_kernel_stats.csv" % tag), rows=18))
 mf = os.path.join(P, "%s_pmc_mfma.txt" % tag)
 if os.path.exists(mf):
@@ -220,8 +225,9 @@ if v:
     vr, rs = v["roofline"], v["ransac"]
     md.append("\n## Voting stage alone (`python bench.py --mode vote`)\n")
     md.append("Component filter + LS voter **%.0f images/s** (%.3f ms per 16-image batch); accumulation kernel %.0f us = %.0f GB/s = %.3f of the 8 TB/s HBM roofline; "
-              "RANSAC voter %.2f ms per 16-image round = %.3g cosine tests/s.\n" % (v["value"], v["ms_per_step"], vr["avg_launch_us"], vr["achieved"], vr["frac"],
-                                                                                  rs["ms_per_call"], rs["cosine_tests_per_s"]))
+              "RANSAC voter %.2f ms per 16-image round = %.3g cosine tests/s%s.\n" % (v["value"], v["ms_per_step"], vr["avg_launch_us"], vr["achieved"], vr["frac"],
+                                                                                  rs["ms_per_call"], rs["cosine_tests_per_s"],
+                                                                                  (" = %.2f of the fp32 VALU issue rate at %.1f vector instructions per test" % (rs["valu"]["frac"], rs["valu"]["instructions_per_test"])) if "valu" in rs else ""))
     md.append(stats_table(os.path.join(P, "%s_vote_kernel_stats.csv" % tag), rows=12))
 open(os.path.join(P, "%s_summary.md" % tag), "w").write("\n".join(md) + "\n")
 print("wrote profiles/%s_summary.md and profiles/%s_STAMP.json (%d files)" % (tag, tag, len(COPIED)))
