@@ -208,6 +208,16 @@ __device__ __forceinline__ void hs_static_for(F&& f) {
     }
 }
 
+// Taps per weight group (= per barrier phase).  32 output channels: the whole slice.  64 channels: the whole slice too where the LDS holds two
+// 9-tap groups (one or two operand planes: 36 / 72 KB of weight stages) -- round 5: with three taps per group (round 2-4) a slice was one loader-heavy
+// phase (halo stores + requests) followed by two light ones, and the consumers waited in the first while the loaders waited in the other two; with
+// three planes (exact split) three taps stay.  128 channels per pass: one tap.
+#ifdef HS_GT3   // (variant build for A/B measurements: round 4's three-tap groups)
+__host__ __device__ constexpr int hs_group_taps(int tn, int np) { return tn == 1 ? 9 : (tn == 2 ? 3 : 1); }
+#else
+__host__ __device__ constexpr int hs_group_taps(int tn, int np) { return tn == 1 ? 9 : (tn == 2 ? (np <= 2 ? 9 : 3) : 1); }
+#endif
+
 template <int TN, int NP, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr bool PARTIAL = (MODE & HS_PARTIAL) != 0;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     static_assert(NP == 1 || NP == 2 || NP == 3, "1 = bf16, 2 = fp16 two-way split, 3 = exact bf16 split");
     constexpr int NPROD = (NP == 3) ? 6 : (NP == 2) ? 3 : 1;
     constexpr unsigned FRAG_B = NP * 1024u;          // all planes of one (step, cout block) fragment
-    constexpr int GT = (TN == 1) ? 9 : (TN == 2) ? 3 : 1;   // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice),
+    constexpr int GT = hs_group_taps(TN, NP);               // taps per weight group: a whole slice for the 32-channel layers (one barrier per slice),
                                                             // a third of it for the 64-channel ones, one tap for 128 channels per pass (LDS budget)
     constexpr int GPS = 9 / GT;                      // groups per slice
     constexpr int GSUB = GT * TN;                    // (tap, cout block) sub-steps of a group; the image block is a group of 3 * TN sub-steps
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     // accumulators of row 1 to its loader twin through `accst` ([wave][TN][4][64 lanes][16 B], the register layout as it is); the twin runs the
     // same epilogue code for that row during the first phase of the NEXT tile, beside the consumers' MFMAs.
     unsigned char* accst = reinterpret_cast<unsigned char*>(tabl + 2 * TAB_C);
-    constexpr bool CAN_SPLIT = NP <= 2 && TN <= 2;   // (the staging buffer does not fit beside three operand planes)
+    constexpr bool CAN_SPLIT = NP <= 2 && TN == 1;   // (the hand-over buffer fits beside neither three operand planes nor the 64-channel kernels' 9-tap weight groups)
     constexpr unsigned ACCST_B = 4u * TN * 4u * 1024u;   // one hand-over buffer: 16 KB per 32 output channels
     // WHEN the twin works (a phase = one weight group, a barrier at its end): a head layer (three phases a tile: slice, slice, image + epilogue) takes
     // the whole row during the image phase of the NEXT tile -- the one phase in which the loaders have nothing else to do -- out of the buffer of the
@@ -1263,11 +1273,11 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     k.tiles_per_pass = k.B * k.tiles_y * k.tiles_x;
     k.ntiles = k.passes * k.tiles_per_pass;
     // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
-    size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * (TN == 1 ? 9 : TN == 2 ? 3 : 1) * TN * NP * 1024 +
+    size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * hs_group_taps(TN, NP) * TN * NP * 1024 +
                  (size_t)2 * NP * 1024;   // + the fused head's weights
     if (MODE & HS_BILINEAR) lds += (size_t)2 * ((HR / 2 + 1) * (COLS / 2 + 1)) * 64;   // + two low-resolution stages of source 0
     lds += (size_t)2 * 512 * 4;                                                         // + the per-channel normalisation table (TAB_C)
-    if (NP <= 2 && TN <= 2) lds += (size_t)4 * TN * 4 * 1024 * ((MODE & HS_HEADK) ? 2 : 1);   // + the accumulator hand-over(s) of the epilogue split
+    if (NP <= 2 && TN == 1) lds += (size_t)4 * TN * 4 * 1024 * ((MODE & HS_HEADK) ? 2 : 1);   // + the accumulator hand-over(s) of the epilogue split
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hsplit_kernel<TN, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

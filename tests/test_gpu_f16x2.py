@@ -302,7 +302,11 @@ def test_f16x2_guard_demotes_nothing_on_the_bench_network(device):
     from casapose_amd.pose_models.tfkeras import Classifiers
 
     k, v, b, h, w = 9, 27, 2, 96, 128
-    net = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, base_model="resnet18", device=device, seed=1237)
+    from casapose_amd import engine
+
+    assert engine.DEFAULT_INFER_CONV_MODE == "f16x2" and engine.F16X2_GUARD   # the library's defaults (the suite also runs under CASAPOSE_INFER_CONV_MODE=...)
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, base_model="resnet18", device=device, seed=1237,
+                                             conv_mode="f16x2")
     assert net._net.conv_mode == "f16x2" and net._net.f16x2_guard
     rng = np.random.default_rng(1237)
     params = net.get_parameters()
