@@ -6,12 +6,15 @@
 Every operand / epilogue mode the kernel covers: one and two sources, the 4-channel image source, ragged tiles (16-row x 32-column
 tiles), partial-convolution tap mask with 9/count, CLADE table + leaky pair, residual, dual outputs."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
 
 import casapose_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_conv import _labels, close, dev
 
 pytestmark = pytest.mark.gpu
@@ -280,3 +283,39 @@ def test_stem_on_the_bf16_pipe(device, planes, tol, hw):
         layer.run(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert float((raw - raw2).abs().max()) <= 2e-5 * float(raw2.abs().max())
+
+
+def test_head_layers_epilogue_split_is_bit_identical_to_the_unsplit_form(device):
+    """Round 5 (`epi_split`, csrc/conv_hsplit.hip): in the head layers a consumer wave hands the accumulators of its second row to the loader wave
+    w + 4, which runs the SAME epilogue code one tile later.  Nothing about the arithmetic changes, so the whole forward (logits, vector field, the
+    label map the fused head writes) must be BIT-identical with CASAPOSE_HS_EPI_SPLIT=0 and =1 -- at a size with several tiles per block, partial
+    tiles on the right / bottom edge and an odd number of tiles, in f16x2 and in the bf16 mode (the two arithmetics whose LDS budget admits the split).
+    The switch is read once per process: two child processes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from casapose_amd.pose_models.tfkeras import Classifiers
+dev = torch.device("cuda:0")
+out = []
+for mode in ("f16x2", "bf16"):
+    net = Classifiers.get("casapose_c_gcu5")(ver_dim=27, seg_dim=9, input_shape=(104, 200, 3), weights=None, base_model="resnet18", device=dev, seed=5, conv_mode=mode)
+    img = (2 * torch.rand(3, 104, 200, 3, generator=torch.Generator().manual_seed(2)) - 1).to(dev)
+    y = net([img], training=False)
+    lab = net._net.plan(3, 104, 200).labels[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    out.append(hashlib.sha256(y.cpu().numpy().tobytes() + lab.cpu().numpy().tobytes()).hexdigest())
+print(" ".join(out))
+''' % (ROOT, os.path.join(ROOT, "oracle"))
+    digests = {}
+    for split in ("0", "1"):
+        env = dict(os.environ, CASAPOSE_HS_EPI_SPLIT=split)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[split] = r.stdout.strip().splitlines()[-1]
+    assert digests["0"] == digests["1"], digests
