@@ -1,4 +1,6 @@
 # per-layer times of the forward plan with the conv_hsplit start stagger (CASAPOSE_HS_STAGGER units of s_sleep(32) per phase group)
+# (CASAPOSE_HS_STAGGER existed only in the experiment: HSplitK.stagger read from that variable in cp_conv2d_fwd_split, and at the top of the kernel
+#  `for (i < ((blockIdx.x >> 3) & 3) * p.stagger) __builtin_amdgcn_s_sleep(32);` -- result in profiles/probes/r05_hsplit_ablation.txt section 3)
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05s; rm -rf $O; mkdir -p $O
