@@ -77,12 +77,41 @@ def _median_rate(fn, images, warmup=3, timed=10, budget_s=12.0):
     return images / ts[len(ts) // 2], len(ts)
 
 
-# threads per CPU worker process and worker count (0 = one per block of threads, at most 8): CASAPOSE_CPU_WORKER_THREADS / CASAPOSE_CPU_WORKERS override
-# the defaults, which tools/debug/cpu_workers_probe.py measured on the GPU box's host (profiles/probes/r05_cpu_workers_probe.txt)
-# Measured there (256 logical CPUs = 2 x 64 cores x SMT 2): 8 x 32 -> 5.5-5.9 images/s, 4 x 32 -> 6.6, 8 x 16 -> 7.6, 32 x 4 / 64 x 2 -> 8.1, 16 x 8 -> 8.2-8.5:
-# one thread per PHYSICAL core in many small processes; the second hardware thread of a core only costs (the graph is memory-bound on the host).
-CPU_WORKER_THREADS = int(os.environ.get("CASAPOSE_CPU_WORKER_THREADS", "8"))
-CPU_WORKERS = int(os.environ.get("CASAPOSE_CPU_WORKERS", "0"))
+def cpu_quota():
+    """CPUs of run time the cgroup grants this process tree per period (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`), or None
+    without a limit.  The GPU box shows 256 logical CPUs and grants 16 (`1600000 100000`): 128 busy threads there are throttled to an eighth."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
+
+
+def cpu_worker_shape():
+    """(worker processes, threads per worker) of the CPU baseline; CASAPOSE_CPU_WORKERS / CASAPOSE_CPU_WORKER_THREADS override.
+    Without a CPU quota: 8 threads per worker, one worker per 8 PHYSICAL cores, at most 16 (measured on the 2 x 64-core host when nothing
+    throttled the box, profiles/probes/r05_cpu_workers_probe.txt).  Under a cgroup quota of Q CPUs (the GPU box: Q = 16 of 256 logical CPUs) the
+    throttle, not the core count, is the resource: 4 threads per worker and Q / 2 workers -- twice the quota in threads, because threads waiting
+    passively in a pool cost no quota -- measured 10.5-10.9 images/s there against 8.5-9.9 for 4 x 8 and 8.8 for 16 x 8
+    (profiles/probes/r05_cpu_quota_probe.txt)."""
+    cores, quota = os.cpu_count() or 1, cpu_quota()
+    env_t, env_n = int(os.environ.get("CASAPOSE_CPU_WORKER_THREADS", "0")), int(os.environ.get("CASAPOSE_CPU_WORKERS", "0"))
+    if quota is not None and quota < cores / 2:
+        threads = env_t or 4
+        workers = env_n or max(1, int(round(2.0 * quota / threads)))
+    else:
+        threads = env_t or 8
+        workers = env_n or max(1, min(16, cores // (2 * threads)))   # half the logical CPUs: one thread per core under SMT 2
+    return workers, threads
+
+
+CPU_WORKERS, CPU_WORKER_THREADS = cpu_worker_shape()
 
 
 def cpu_worker(args):
@@ -139,13 +168,14 @@ def cpu_worker(args):
 
 def spawn_cpu_workers(args):
     """Start the CPU-baseline workers BEFORE this process touches the GPU (a process that has initialised the GPU must not be the one that
-    execs): one per block of CPU_WORKER_THREADS logical CPUs over the first half of the host's logical CPUs (one thread per physical core), at most 16.  They build their network and wait; collect_cpu_workers()
+    execs): cpu_worker_shape() processes, each on its own block of CPU_WORKER_THREADS logical CPUs.  They build their network and wait; collect_cpu_workers()
     releases them together once the GPU legs are done, so they never compete with the timed GPU region for host cores."""
     import subprocess
 
     cores = os.cpu_count() or 1
-    n = CPU_WORKERS if CPU_WORKERS > 0 else max(1, min(16, cores // (2 * CPU_WORKER_THREADS)))   # half the logical CPUs: one thread per core under SMT 2
+    n = CPU_WORKERS
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_WORKER_THREADS), MKL_NUM_THREADS=str(CPU_WORKER_THREADS), OMP_WAIT_POLICY="PASSIVE", KMP_BLOCKTIME="0",
+               CASAPOSE_CPU_WORKERS=str(CPU_WORKERS), CASAPOSE_CPU_WORKER_THREADS=str(CPU_WORKER_THREADS),
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     procs = []
     for i in range(n):
@@ -241,7 +271,9 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch, accuracy=None, workers=None, wor
     # pool on the small layers); one bs-1 forward each decides, and `cores` below reports the count actually used
     probe = 2.0 * torch.rand(1, h, w, 3, generator=gen) - 1.0
     timing = {}
-    for n in sorted({min(cores, 32), cores}):  # the safe count first; then ONE forward with every core, kept only if it is faster
+    quota = cpu_quota()
+    counts = {min(cores, 32), cores} if quota is None or quota >= cores / 2 else {max(1, min(cores, 32, int(quota)))}   # under a cgroup quota: its CPUs, no more
+    for n in sorted(counts):  # the safe count first; then ONE forward with every core, kept only if it is faster
         if timing and min(timing.values()) < 2.0:
             # a 256-thread host took 74 s for ONE image in the all-cores probe (thread-pool overhead on the small layers) against 0.86 s
             # with 32 threads: when the capped count already runs an image in under 2 s the all-cores probe is skipped
@@ -301,12 +333,12 @@ def cpu_baseline(h, w, seg_dim, ver_dim, batch, accuracy=None, workers=None, wor
         _log("cpu baseline: %d processes x %d threads -> %.2f images/s" % (multi["processes"], multi["threads_per_process"], multi["images_per_s"]))
         return {"value": multi["images_per_s"], "accuracy_vs_fp64": acc, "unit": "images/s", "cores": multi["processes"] * multi["threads_per_process"],
                 "shape": "%d processes x %d threads, each pinned to its own block of logical CPUs, disjoint images" % (multi["processes"], multi["threads_per_process"]),
-                "host_cores": cores, "kind": "port", "what": "CPU restatement (PyTorch-CPU fp32, oneDNN), not TensorFlow", "cpu": _cpu_model_name(),
+                "host_cores": cores, "cpu_quota": cpu_quota(), "kind": "port", "what": "CPU restatement (PyTorch-CPU fp32, oneDNN), not TensorFlow", "cpu": _cpu_model_name(),
                 "sample": "%dx%d: every worker runs whole images (forward + component filter + LS voting, bs 1) for %.0f s after two warm-up images; value = all "
                           "images / the longest worker's time" % (h, w, worker_seconds),
                 "workers": multi, "single_process": {"value": round(best, 3), "threads": threads, "legs": legs,
                                                      "thread_probe_s_per_image": {str(k): round(v, 3) for k, v in timing.items()}}}
-    return {"value": round(best, 3), "accuracy_vs_fp64": acc, "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
+    return {"value": round(best, 3), "accuracy_vs_fp64": acc, "unit": "images/s", "cores": threads, "host_cores": cores, "cpu_quota": cpu_quota(), "kind": "port",
             "what": "CPU restatement (PyTorch-CPU fp32, oneDNN, %d threads), not TensorFlow" % threads, "cpu": _cpu_model_name(),
             "thread_probe_s_per_image": {str(k): round(v, 3) for k, v in timing.items()}, "workers": multi,
             "sample": "%dx%d, %s: warm-up + median of <= 10 timed iterations per leg (time-boxed); value = best forward + "

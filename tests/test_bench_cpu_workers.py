@@ -44,3 +44,47 @@ def test_spawn_wait_collect_adds_up_two_workers(monkeypatch):
     res = bench.collect_cpu_workers(ready, 1.0)
     assert res["processes"] == 2 and res["images"] == sum(res["per_process_images"]) >= 2
     assert abs(res["images_per_s"] - res["images"] / res["seconds"]) < 0.01 * res["images_per_s"] + 1e-3
+
+
+def test_worker_shape_follows_the_cgroup_quota(monkeypatch):
+    """256 visible logical CPUs with a 16-CPU cgroup quota (the GPU box) -> 8 x 4; no quota -> one worker per 8 physical cores, at most 16; the
+    environment overrides either."""
+    import bench
+    monkeypatch.delenv("CASAPOSE_CPU_WORKERS", raising=False)
+    monkeypatch.delenv("CASAPOSE_CPU_WORKER_THREADS", raising=False)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: 16.0)
+    assert bench.cpu_worker_shape() == (8, 4)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: None)
+    assert bench.cpu_worker_shape() == (16, 8)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: 200.0)   # a quota above the physical cores does not bind
+    assert bench.cpu_worker_shape() == (16, 8)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 8)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: None)
+    assert bench.cpu_worker_shape() == (1, 8)
+    monkeypatch.setenv("CASAPOSE_CPU_WORKERS", "3")
+    monkeypatch.setenv("CASAPOSE_CPU_WORKER_THREADS", "2")
+    assert bench.cpu_worker_shape() == (3, 2)
+
+
+def test_cpu_quota_reads_cgroup_v2(monkeypatch, tmp_path):
+    import builtins
+    import bench
+    real_open = builtins.open
+    files = {"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}
+
+    def fake_open(path, *a, **k):
+        if path in files:
+            f = tmp_path / "f"
+            f.write_text(files[path])
+            return real_open(f, *a, **k)
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+            raise FileNotFoundError(path)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert bench.cpu_quota() == 16.0
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert bench.cpu_quota() is None
+    del files["/sys/fs/cgroup/cpu.max"]
+    assert bench.cpu_quota() is None
