@@ -188,8 +188,9 @@ if tl and "value" in tl:
                                                   % (tb["value"], tb["ms_per_step"])) if "value" in tb else ""))
 c = b.get("cpu_baseline")
 if c:
-    md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s, %s (`%s`; host has %s logical CPUs; one process x %s threads: %s images/s).\n"
+    md.append("CPU baseline on the same box (%s): **%.2f images/s** -- %s, %s (`%s`; host has %s logical CPUs%s; one process x %s threads: %s images/s).\n"
               % (c.get("cpu"), c["value"], c.get("what"), c.get("shape", "one process"), c.get("sample"), c.get("host_cores"),
+                 (", of which the cgroup grants %g CPUs of run time" % c["cpu_quota"]) if c.get("cpu_quota") else "",
                  (c.get("single_process") or {}).get("threads", c.get("cores")), (c.get("single_process") or {}).get("value", c["value"])))
 md.append(stats_table(os.path.join(P, "%s_bench_kernel_stats.csv" % tag), rows=18))
 mf = os.path.join(P, "%s_pmc_mfma.txt" % tag)
