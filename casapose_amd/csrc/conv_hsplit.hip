@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         }
     };
 
-    // Epilogue (round 5: straight-line).  Round 4's form cost 0.31 ms of block 5's 0.73 (tools/debug/r05_hs_ablate.sh) -- not for its arithmetic: every
+    // Epilogue (round 5: straight-line).  Round 4's form cost 0.31 ms of block 5's 0.73 (tools/debug/hs_ablate.sh) -- not for its arithmetic: every
     // `pok && ch < Cout ? offset : OOB`, every `if (nq >= 4) ... else if ...` store ladder and the short-circuit arg-max compiled into
     // s_and_saveexec / s_cbranch_execz regions (87 of them in the two rows of a tile, each a dozen issue slots with the matrix pipe idle).  Now:
     // conditions are combined bitwise and select an offset (an out-of-range buffer offset drops the access), operands that do not exist are

@@ -1,7 +1,7 @@
 // The Winograd planes' grouped GEMM in the fp16 two-way split (split_f16.h) with a 128 x 256 block tile and BOTH operands staged in LDS
 // (round 4).  Why a second kernel beside wino_gemm_split.hip: with three products per fp32 product that kernel is bound by operand delivery, not
 // by the matrix pipe -- compiled without its A loads it runs 25 % faster, without its B fetches 16 %, without both 43 %
-// (tools/debug/r04_gemm_bound.sh).  Per 32-wide chunk a 128 x 128 block pulls 16 KB of V through L2 and its four consumer waves fetch 32 KB of
+// (round-4 probe, CHANGELOG 8.1).  Per 32-wide chunk a 128 x 128 block pulls 16 KB of V through L2 and its four consumer waves fetch 32 KB of
 // weight fragments from L2 (the two waves of a column pair fetch the same 8 KB).  Here
 //   * a block owns 128 rows x 256 columns: V is read half as often (N = 256: once; N = 512: twice), a chunk feeds 48 MFMAs per wave instead of 24;
 //   * the weight fragments of a chunk (32 KB, pre-split and fragment-major: 1 KB pieces) go global -> LDS by DMA (buffer_load ... lds) from the

@@ -30,8 +30,8 @@ cd $R
 {
   echo "$STAMP"
   for which in f16x2 split; do
-    echo "# wino_gemm alone (tools/debug/r04_pmc_gemm.sh), CASAPOSE_GEMM_ONE=$which"
-    CASAPOSE_GEMM_ONE=$([ $which = f16x2 ] && echo f16x2 || echo "") bash tools/debug/r04_pmc_gemm.sh 2>&1
+    echo "# wino_gemm alone (tools/debug/pmc_gemm.sh), CASAPOSE_GEMM_ONE=$which"
+    CASAPOSE_GEMM_ONE=$([ $which = f16x2 ] && echo f16x2 || echo "") bash tools/debug/pmc_gemm.sh 2>&1
     rm -rf gpurun_out/pmc_gemm
   done
 } > $O/pmc_gemm_isolated.txt 2>&1
