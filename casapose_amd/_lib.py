@@ -85,7 +85,7 @@ class ConvDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 300  # CP_ABI_VERSION of include/casapose_hip.h
+ABI_VERSION = 301  # CP_ABI_VERSION of include/casapose_hip.h
 PLANES_F16X2 = 0x12  # CP_PLANES_F16X2: the fp16 two-way split (three products, fp32-level accuracy)
 
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3
@@ -150,6 +150,10 @@ SYMBOLS = [
     ("cp_wino_split_weights_bytes", C.c_size_t, [_i, _i, _i]),
     ("cp_wino_split_weights_f32", _i, [_vp, _i, _i, _i, _vp, _vp]),
     ("cp_f16x2_weight_scale", C.c_float, [C.c_float]),
+    ("cp_f16x2_monitor_set", _i, [_vp]),
+    ("cp_f16x2_monitor_get", _vp, []),
+    ("cp_f16x2_range_check", _i, [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    ("cp_amax_f32", _i, [_vp, _ll, _ll, _ll, _vp, _vp]),
     ("cp_wino_split_weights_scaled_f32", _i, [_vp, _i, _i, _i, _i, C.c_float, _vp, _vp]),
     ("cp_wino_gemm_split_scaled_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _vp]),
     ("cp_wino_pack_weights_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

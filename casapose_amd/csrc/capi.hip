@@ -1,6 +1,8 @@
 // Library-level entry points of include/casapose_hip.h: error reporting and probing.
 #include "common.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <string>
 
@@ -29,6 +31,73 @@ int& persistent_blocks_ref() {
     return n;
 }
 }  // namespace cp
+
+namespace cp {
+uint32_t*& f16x2_monitor_ref() {
+    thread_local uint32_t* slot = nullptr;
+    return slot;
+}
+}  // namespace cp
+
+extern "C" int cp_f16x2_monitor_set(uint32_t* slot) {
+    CP_REQUIRE(((uintptr_t)slot & 15) == 0, "cp_f16x2_monitor_set: a slot is four 32-bit words, 16-byte aligned");
+    cp::f16x2_monitor_ref() = slot;
+    return CP_OK;
+}
+extern "C" uint32_t* cp_f16x2_monitor_get(void) { return cp::f16x2_monitor_ref(); }
+
+// The band check of the f16x2 range guard, for any caller: amax = what a monitor slot (or cp_amax_f32) measured on the operand AS CONVERTED (with
+// whatever power of two is already applied).  Returns 0 in the band [lo, hi] (or amax == 0: nothing to judge), 1 with *rescale = the power of two
+// that brings amax into [2^10, 2^11) (32x headroom to 65504, low halves normal down to 2^-12 of the maximum), 2 when no power of two in
+// [2^-24, 2^24] does or amax is not finite: run that layer on the exact three-way bf16 split (no range condition).
+extern "C" int cp_f16x2_range_check(float amax, float lo, float hi, float* rescale) {
+    if (rescale) *rescale = 1.f;
+    if (amax == 0.f) return 0;
+    if (!(amax > 0.f) || !std::isfinite(amax)) return 2;
+    if (amax >= lo && amax <= hi) return 0;
+    int e = 0;
+    (void)std::frexp(amax, &e);          // amax = m * 2^e, m in [0.5, 1)  ->  amax * 2^(11 - e) in [2^10, 2^11)
+    const int k = 11 - e;
+    if (k < -24 || k > 24) return 2;
+    if (rescale) *rescale = std::ldexp(1.f, k);
+    return 1;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long groups, long long group_stride, long long count, uint32_t* slot) {
+    // 16-byte loads where the group layout allows them (count and stride multiples of 4, base aligned: checked by the launcher through `vec`)
+    float a = 0.f;
+    const long long per = count >> 2, total = groups * per;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / per, j = i - g * per;
+        a = cp::amax4(a, *reinterpret_cast<const float4*>(x + g * group_stride + j * 4));
+    }
+    cp::monitor_flush(slot, a);
+    cp::monitor_count_launch(slot, threadIdx.x == 0);
+}
+__global__ __launch_bounds__(256) void amax_scalar_kernel(const float* __restrict__ x, long long groups, long long group_stride, long long count, uint32_t* slot) {
+    float a = 0.f;
+    const long long total = groups * count;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / count, j = i - g * count;
+        a = fmaxf(a, fabsf(x[g * group_stride + j]));
+    }
+    cp::monitor_flush(slot, a);
+    cp::monitor_count_launch(slot, threadIdx.x == 0);
+}
+}  // namespace
+
+// max |x| over `groups` runs of `count` floats, run g starting at x + g * group_stride, folded into slot[0] (atomic max of the bit pattern; the
+// caller zeroes the slot).  What the f16x2 calibration needs where no converting kernel reports by itself (a caller's own tensors).
+extern "C" int cp_amax_f32(const float* x, long long groups, long long group_stride, long long count, uint32_t* slot, void* stream) {
+    CP_REQUIRE(x && slot && groups > 0 && count > 0 && group_stride >= 0, "cp_amax_f32: bad arguments");
+    const bool vec = ((uintptr_t)x & 15) == 0 && count % 4 == 0 && group_stride % 4 == 0;
+    const long long items = vec ? groups * (count / 4) : groups * count;
+    const int blocks = (int)std::min<long long>((items + 255) / 256, 2048);
+    if (vec) CP_LAUNCH(amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, groups, group_stride, count, slot);
+    else CP_LAUNCH(amax_scalar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, groups, group_stride, count, slot);
+    return cp::check_launch("cp_amax_f32");
+}
 
 extern "C" int cp_set_persistent_blocks(int blocks) {
     CP_REQUIRE(blocks >= 8 && blocks <= 256 && blocks % 8 == 0, "cp_set_persistent_blocks: a multiple of 8 in [8, 256] (one block per CU, whole XCD rows)");

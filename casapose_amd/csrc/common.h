@@ -51,6 +51,30 @@ inline int check_launch(const char* what) {
 int& persistent_blocks_ref();   // capi.hip
 inline int persistent_blocks() { return persistent_blocks_ref(); }
 
+// ---- f16x2 range monitor (round 6) -------------------------------------------------------------------------------------------------
+// A monitor slot is four 32-bit words of device memory: [0] = bits of max |operand| over every fp32 value a launch converted to an fp16 pair
+// (atomic max on the bit pattern: monotone for non-negative floats, inf included), [1] = launches that reported, [2] = the same maximum for the
+// operand of a fused 1x1 head (the activated map that exists in registers only), [3] reserved.  cp_f16x2_monitor_set() arms the slot for the
+// CALLING THREAD's next launches; every kernel that converts activations (conv_hsplit, conv_stem_split, the split GEMMs) or writes the Winograd
+// planes another kernel converts (wino_in, wino_out_in) reads it at launch time.  A null slot costs one uniform branch per staged slice.
+uint32_t*& f16x2_monitor_ref();   // capi.hip (thread-local)
+inline uint32_t* f16x2_monitor() { return f16x2_monitor_ref(); }
+
+__device__ __forceinline__ float amax4(float acc, const float4 v) {
+    return fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), acc), fmaxf(fabsf(v.z), fabsf(v.w)));   // (v_max3_f32 with |.| modifiers; NaN operands are skipped)
+}
+
+// every lane of the wave calls it (wave-uniform control flow); word 0 or 2 of the slot
+__device__ __forceinline__ void monitor_flush(uint32_t* word, float amax) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(word, __builtin_bit_cast(uint32_t, amax));
+}
+// one thread of the launch (the caller names it: the reporting waves need not include thread 0)
+__device__ __forceinline__ void monitor_count_launch(uint32_t* slot, bool leader) {
+    if (blockIdx.x == 0 && leader) atomicAdd(slot + 1, 1u);
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b, b+8, b+16, ... land on the same
 // XCD (observed dispatch, MI355X_MICROARCH.md), so give each XCD one contiguous run of
 // logical tiles to keep operand panels in that XCD's L2.  Speed only, never correctness.

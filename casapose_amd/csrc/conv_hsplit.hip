@@ -86,6 +86,7 @@ struct HSplitK {
     int head_lab_classes;
     float descale, head_descale;   // NP = 2: 1 / (power of two the conv / head weights were multiplied by); 1 otherwise
     int epi_split;                 // 1: the loader wave w + 4 runs the epilogue of row 1 of consumer wave w's rows (accumulators handed over through LDS)
+    uint32_t* mon;                 // f16x2 range monitor slot (common.h) or null: max |x| of what the loaders convert -> [0], of the fused head's operand -> [2]
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -386,6 +387,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             }
         }
     }
+    float e_amax = 0.f, l_amax = 0.f;   // f16x2 range monitor (p.mon): this thread's maxima over the head operand / over what it staged as a loader
+    auto flush_mon = [&]() __attribute__((always_inline)) {
+        if constexpr (NP == 2) {
+            if (p.mon) {   // uniform
+                cp::monitor_flush(p.mon, l_amax);
+                cp::monitor_flush(p.mon + 2, e_amax);
+                cp::monitor_count_launch(p.mon, threadIdx.x == 0);
+            }
+        }
+    };
     // pieces: bit j * 4 + g4 set = this call handles that group of four channels (generic form; a head layer's row is one piece)
     auto epilogue = [&](f32x16 (&acc)[2][TN], int r_begin, int r_end, int n, int y0, int x0, int cbase, unsigned pieces) __attribute__((always_inline)) {
 #pragma unroll
@@ -492,6 +503,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             }   // !HEADK
             if constexpr (TN == 1) {
                 if (head) {
+                    if (NP == 2 && p.mon) {   // (uniform) the head's operand as it is converted below; pixels outside the image compute with padding and are not stored
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) e_amax = pok ? cp::amax4(e_amax, keep[g4]) : e_amax;
+                    }
                     // Fused 1x1 head: out[q][pixel] = sum_c Wh[c][q] * t[c][pixel] on the same matrix pipe.  The order of K is free, so step m
                     // takes, from lane half kh, the eight channels this lane already holds: 8*(2m) + 4*kh + 0..3 and 8*(2m+1) + 4*kh + 0..3
                     // (the head weights are packed in that order); the activated values are split / rounded in registers.
@@ -704,6 +719,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             if (p.B > 0) return;   // timing experiment
 #endif
             unsigned char* h = halo + stage * (NP * PLANE_B);
+            if (NP == 2 && p.mon) {   // (uniform; out-of-range elements loaded zeros)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) l_amax = cp::amax4(l_amax, lv[it][0]);
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (part >= 0 && it % nparts != part) continue;
@@ -722,6 +741,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         };
         auto store_img = [&](int parity) {
             unsigned char* h = imgh + parity * (NP * IPLANE_B);
+            if (NP == 2 && p.mon) {
+#pragma unroll
+                for (int it = 0; it < NIMG; ++it) l_amax = cp::amax4(l_amax, liv[it]);
+            }
 #pragma unroll
             for (int it = 0; it < NIMG; ++it) {
                 const int pix = it * 256 + tid;
@@ -855,6 +878,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 for (int it = 0; it < NLO; ++it) llow[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)elo[it], u.c * 64, 0));
             };
             auto store_low = [&](int stage) {
+                if (NP == 2 && p.mon) {   // the low-resolution source bounds its x2 interpolation (a convex combination)
+#pragma unroll
+                    for (int it = 0; it < NLO; ++it) l_amax = l_ok[it] ? cp::amax4(l_amax, llow[it]) : l_amax;
+                }
 #pragma unroll
                 for (int it = 0; it < NLO; ++it)
                     if (l_ok[it]) *reinterpret_cast<float4*>(lowb + stage * LOW_B + l_lds[it]) = llow[it];
@@ -1016,6 +1043,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             }
             if (esplit) loader_epilogue(0, true);   // the last tile's
             HSP_FLUSH(8);
+            flush_mon();
             return;
         }
         issue_tile_extras();
@@ -1073,6 +1101,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         }
         if (esplit) loader_epilogue(0, true);   // the last tile's
         HSP_FLUSH(8);
+        flush_mon();
         return;
     }
 
@@ -1262,6 +1291,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         }
     }
     HSP_FLUSH(0);
+    flush_mon();
 }
 
 
@@ -1477,6 +1507,7 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     k.head_out = d->head_out; k.head_cout = d->head_cout; k.head_ld = d->head_out_ld;
     k.head_lab = d->head_out ? d->head_label_out : nullptr; k.head_lab_classes = d->head_label_classes;
     k.descale = w_descale; k.head_descale = head_descale;
+    k.mon = planes == CP_PLANES_F16X2 ? cp::f16x2_monitor() : nullptr;
     {   // epilogue split: on by default (CASAPOSE_HS_EPI_SPLIT=0 keeps both rows on the consumer waves: A/B measurements)
         static const int split_env = getenv("CASAPOSE_HS_EPI_SPLIT") ? atoi(getenv("CASAPOSE_HS_EPI_SPLIT")) : 1;
         k.epi_split = split_env;

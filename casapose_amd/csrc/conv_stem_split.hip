@@ -46,6 +46,7 @@ struct StemSK {
     float* out_act; int act_ld;
     int B, H, Wd, Ho, Wo, tiles_y, tiles_x, ntiles;
     float descale;           // NP = 2: 1 / (the power of two the weights were multiplied by); 1 otherwise
+    uint32_t* mon;           // f16x2 range monitor slot (common.h) or null
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
             e_hx[i] = e % HC;
             e_lds[i] = (unsigned)((e / HC) * ROW_B + ((e_hx[i] & 1) * HCP + (e_hx[i] >> 1)) * 8);
         }
+        float l_amax = 0.f;
         auto fill = [&](int k, int stage) {
             int n, y0, x0;
             tile_pos(k, n, y0, x0);
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
                 if (inb[i]) {  // the affine applies to real pixels only: padding stays exactly zero
                     r.x = r.x * ps.x + pb.x; r.y = r.y * ps.y + pb.y; r.z = r.z * ps.z + pb.z; r.w = r.w * ps.w + pb.w;
                 }
+                if (NP == 2 && p.mon) l_amax = cp::amax4(l_amax, r);   // (uniform) the image through the input affine, as converted
                 if constexpr (NP == 3) {
                     uint2 a, b, c;
                     ss_split4(r, a, b, c);
@@ -164,6 +167,12 @@ __global__ __launch_bounds__(512, 2) void conv_stem_split_kernel(const StemSK p)
         for (int k = 0; k < my_tiles; ++k) {
             if (k + 1 < my_tiles) fill(k + 1, (k + 1) & 1);   // stage (k+1)&1 was last read for tile k-1
             CP_BARRIER();
+        }
+        if constexpr (NP == 2) {
+            if (p.mon) {
+                cp::monitor_flush(p.mon, l_amax);
+                cp::monitor_count_launch(p.mon, tid == 0);
+            }
         }
         return;
     }
@@ -335,6 +344,7 @@ extern "C" int cp_conv2d_fwd_stem_split_scaled(const cp_conv_desc* d, const void
     k.tiles_y = (k.Ho + TH - 1) / TH; k.tiles_x = (k.Wo + TW - 1) / TW;
     k.ntiles = k.B * k.tiles_y * k.tiles_x;
     k.descale = w_descale;
+    k.mon = planes == CP_PLANES_F16X2 ? cp::f16x2_monitor() : nullptr;
     if (planes == CP_PLANES_F16X2) return launch_stem_split<2>(k, (hipStream_t)stream);
     return planes == 3 ? launch_stem_split<3>(k, (hipStream_t)stream) : launch_stem_split<1>(k, (hipStream_t)stream);
 }

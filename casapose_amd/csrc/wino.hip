@@ -72,9 +72,11 @@ __device__ __forceinline__ float pre_act_f(float t, int act) {
 // 144 elements of a patch cost two compares and selects each and the transform turned from HBM-bound (102 us) into VALU-bound (173 us)
 template <int PRE>
 __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restrict__ src, int ld, int C, WinoGeom g, float* __restrict__ V, int ldv,
-                                                          int c_off, const float* __restrict__ pre_scale, const float* __restrict__ pre_shift, int pre_act) {
+                                                          int c_off, const float* __restrict__ pre_scale, const float* __restrict__ pre_shift, int pre_act,
+                                                          uint32_t* mon) {
     const int c4n = C >> 2;
     const long long total = (long long)g.T * c4n;
+    float amax = 0.f;   // f16x2 range monitor (common.h): max |V| over what this launch writes
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const int t = (int)(i / c4n);
@@ -113,9 +115,17 @@ __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restric
         for (int r = 0; r < 6; ++r) {
             float4 o[6];
             bt6(tt[r], o);
+            if (mon) {   // uniform
+#pragma unroll
+                for (int j = 0; j < 6; ++j) amax = cp::amax4(amax, o[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
         }
+    }
+    if (mon) {
+        cp::monitor_flush(mon, amax);
+        cp::monitor_count_launch(mon, threadIdx.x == 0);
     }
 }
 
@@ -237,7 +247,8 @@ __global__ __launch_bounds__(THREADS) void wino_out_kernel(const float* __restri
 // V' = B^T d B of layer B from there.  The raw output (a residual for later) and the activated map (when something else reads it too) are
 // still stored on request.  Thread = (tile, channel quad).
 template <int CS4, int MAXT>
-__global__ __launch_bounds__(MAXT) void wino_out_in_kernel(const float* __restrict__ M, int cout, WinoGeom g, WinoEpi e, float* __restrict__ V, int ldv, int c_off) {
+__global__ __launch_bounds__(MAXT) void wino_out_in_kernel(const float* __restrict__ M, int cout, WinoGeom g, WinoEpi e, float* __restrict__ V, int ldv, int c_off,
+                                                           uint32_t* mon) {
     extern __shared__ __attribute__((aligned(16))) float4 sub[];   // [(4 Tu + 2)][(4 Tv + 2)][CS4]
     const int RW = 4 * g.Tv + 2, RH = 4 * g.Tu + 2;
     const int slices = (cout / 4 + CS4 - 1) / CS4;
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(MAXT) void wino_out_in_kernel(const float* __restri
         }
     }
     __syncthreads();
+    float amax = 0.f;   // f16x2 range monitor (common.h): max |V'| over what this launch writes
     if (live) {
         float4 tt[6][6];  // (B^T d): column by column
 #pragma unroll
@@ -315,9 +327,17 @@ __global__ __launch_bounds__(MAXT) void wino_out_in_kernel(const float* __restri
         for (int r = 0; r < 6; ++r) {
             float4 o[6];
             bt6(tt[r], o);
+            if (mon) {   // uniform
+#pragma unroll
+                for (int j = 0; j < 6; ++j) amax = cp::amax4(amax, o[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
         }
+    }
+    if (mon) {   // (every thread of the block reaches this point: dead threads report 0)
+        cp::monitor_flush(mon, amax);
+        cp::monitor_count_launch(mon, threadIdx.x == 0);
     }
 }
 
@@ -497,7 +517,7 @@ extern "C" int cp_wino_input_transform_pre_f32(const float* src, int ld, int cha
     CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_input_transform_f32: bad geometry");
     CP_REQUIRE(!pre_scale || pre_act == CP_ACT_NONE || pre_act == CP_ACT_RELU || pre_act == CP_ACT_LEAKY01, "cp_wino_input_transform_pre_f32: unknown activation %d", pre_act);
     const dim3 grid(grid_for((long long)g.T * (channels / 4)));
-#define CP_WIN(P_) CP_LAUNCH(wino_in_kernel<P_>, grid, dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv, c_off, pre_scale, pre_shift, pre_act)
+#define CP_WIN(P_) CP_LAUNCH(wino_in_kernel<P_>, grid, dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv, c_off, pre_scale, pre_shift, pre_act, cp::f16x2_monitor())
     if (!pre_scale) CP_WIN(0);
     else if (pre_act == CP_ACT_RELU) CP_WIN(1 + CP_ACT_RELU);
     else if (pre_act == CP_ACT_LEAKY01) CP_WIN(1 + CP_ACT_LEAKY01);
@@ -588,9 +608,9 @@ extern "C" int cp_wino_output_input_transform_f32(const float* M, int cout, int 
     }
     const dim3 grid(batch * dilation * dilation * slices);
     if (quads == 8)
-        CP_LAUNCH((wino_out_in_kernel<8, 256>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off);
+        CP_LAUNCH((wino_out_in_kernel<8, 256>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off, cp::f16x2_monitor());
     else
-        CP_LAUNCH((wino_out_in_kernel<4, 384>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off);
+        CP_LAUNCH((wino_out_in_kernel<4, 384>), grid, dim3(threads), lds, (hipStream_t)stream, M, cout, g, e, V, ldv, c_off, cp::f16x2_monitor());
     return cp::check_launch("cp_wino_output_input_transform_f32");
 }
 

@@ -61,6 +61,7 @@ struct SplitK {
     int nb32;                 // 32-column blocks per group (N rounded up to 128, / 32)
     unsigned a_bytes, b_bytes;
     float c_scale;            // F16: 1 / (the power of two the weights were multiplied by before their split)
+    uint32_t* mon;            // F16: f16x2 range monitor slot (common.h) or null: max |A| over every row the producers convert
 };
 
 // pre-split one weight row segment: thread = (group, 32-column block, k16 step, lane).  F16: planes 0 / 1 = hi / lo of the fp16 two-way split of
@@ -164,9 +165,14 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) areg[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(aoff[i] | oob), q * (BK * 4), 0));
         };
+        float l_amax = 0.f;
         auto store = [&](auto setc, int buf) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             unsigned char* a = smem + buf * STAGE_BYTES + rbase * ROWB + col4 * 8;
+            if (F16 && p.mon) {   // uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) l_amax = cp::amax4(l_amax, areg[S][i]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 h, m, l;
@@ -199,6 +205,12 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             issue(S1{}, c + 5 < total_chunks);             // chunk c + 5
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
+        }
+        if constexpr (F16) {
+            if (p.mon) {
+                cp::monitor_flush(p.mon, l_amax);
+                cp::monitor_count_launch(p.mon, tid == 0);
+            }
         }
         return;
     }
@@ -373,6 +385,7 @@ extern "C" int cp_wino_gemm_split_scaled_f32(const float* V, const void* Usplit,
     g.nb32 = g.tiles_n * 4;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.c_scale = c_scale;
+    g.mon = planes == CP_PLANES_F16X2 ? cp::f16x2_monitor() : nullptr;
     if (planes == CP_PLANES_F16X2 && cp::wino_gemm_wide_applicable(rows, group_rows, k, n))   // 128 x 256 tiles, both operands through LDS (wino_gemm_wide.hip)
         return cp::wino_gemm_wide_launch(V, Usplit, M, rows, group_rows, k, n, c_scale, g.a_bytes, g.b_bytes, (hipStream_t)stream);
     const size_t lds = (size_t)NSTAGE * STAGE_BYTES;

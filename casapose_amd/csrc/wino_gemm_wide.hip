@@ -48,6 +48,7 @@ struct WideK {
     int rows, N, K, group_rows, nchunks, tiles_m, tiles_n, nb32;
     unsigned a_bytes, b_bytes;
     float c_scale;
+    uint32_t* mon;   // f16x2 range monitor slot (common.h) or null: max |A| over every row the producers convert
 };
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -101,9 +102,14 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) areg[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(aoff[i] | oob), q * (BK * 4), 0));
         };
+        float l_amax = 0.f;
         auto store = [&](auto setc, int buf) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             unsigned char* a = ast + buf * A_STAGE + rbase * ROWB + col4 * 8;
+            if (p.mon) {   // uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) l_amax = cp::amax4(l_amax, areg[S][i]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 h, l;
@@ -162,6 +168,10 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
             CP_WAIT_VM(4);
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
+        }
+        if (p.mon) {
+            cp::monitor_flush(p.mon, l_amax);
+            cp::monitor_count_launch(p.mon, tid == 0);
         }
         return;
     }
@@ -264,6 +274,7 @@ bool wino_gemm_wide_applicable(int rows, int group_rows, int k, int n) {
 int wino_gemm_wide_launch(const float* V, const void* Usplit, float* M, int rows, int group_rows, int k, int n, float c_scale, unsigned a_bytes, unsigned b_bytes,
                           hipStream_t stream) {
     WideK g{};
+    g.mon = cp::f16x2_monitor();
     g.A = V; g.B = reinterpret_cast<const unsigned char*>(Usplit); g.C = M;
     g.rows = rows; g.N = n; g.K = k; g.group_rows = group_rows; g.nchunks = k / BK;
     g.tiles_m = rows / BM; g.tiles_n = n / BN;

@@ -35,6 +35,16 @@ import weakref
 _LABEL_CACHE: Dict[int, Tuple["weakref.ReferenceType", torch.Tensor, int]] = {}
 
 
+def _remember_labels(out: torch.Tensor, labels: torch.Tensor):
+    """keep the label map of `out`; entries whose output tensor has died go first, then the oldest (round 6: a wholesale clear() above eight entries
+    could drop the map of an output the caller still holds)"""
+    for k in [k for k, (ref, _, _) in _LABEL_CACHE.items() if ref() is None]:
+        _LABEL_CACHE.pop(k, None)
+    while len(_LABEL_CACHE) >= 8:
+        _LABEL_CACHE.pop(next(iter(_LABEL_CACHE)))
+    _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), labels, out._version)
+
+
 def cached_labels(storage_ptr: int, shape: Tuple[int, int, int], version: Optional[int] = None) -> Optional[torch.Tensor]:
     hit = _LABEL_CACHE.get(storage_ptr)
     if hit is None:
@@ -154,6 +164,7 @@ class FusedConv:
         self._gemm: Optional[dict] = None   # set by enable_gemm_split() for the CURRENT binding only
         self.head_in_scale, self._head_tabs = 1.0, None   # f16x2 range guard: power of two on the fused head's operand (set_head_in_scale)
         self.deep_bf16 = False              # bf16 conv mode: this binding runs on csrc/conv_bf16d.hip (set by ForwardPlan)
+        self.mon_ptr: Optional[int] = None  # f16x2 range monitor: device address of this layer's slot while a forward runs armed (ForwardPlan._run_armed)
 
     def _make_planes(self, key: int, image: torch.Tensor, planes: int, stream: Optional[int]) -> torch.Tensor:
         """2-byte operand planes of an fp32 fragment image: 3 = exact bf16 split, 1 = bf16, PLANES_F16X2 = the fp16 two-way split of image * 2^e (the
@@ -288,18 +299,6 @@ class FusedConv:
         """does the CURRENT binding convert operands with the fp16 two-way split?"""
         return _lib.PLANES_F16X2 in (self.split_mode, self.stem_split, (self._gemm or {}).get("planes", 0))
 
-    def input_amax(self) -> float:
-        """max |a| over what this binding's loaders convert: the stored source tensors (an interpolated / selected source is a convex combination of
-        the stored one), through the input affine where the stem has one.  Synchronises; calibration only."""
-        amax = 0.0
-        for sdict in self._srcs:
-            a = float(sdict["data"].abs().max())
-            pre = sdict.get("pre")
-            if pre:
-                a = a * float(pre[0].abs().max()) + float(pre[1].abs().max())
-            amax = max(amax, a)
-        return amax
-
     def demote_to_exact_split(self, kernel_hwio: Optional[np.ndarray] = None):
         """this binding's f16x2 launches on the exact three-way bf16 split instead (planes are made on first use)"""
         if self.split_mode == _lib.PLANES_F16X2:
@@ -311,6 +310,18 @@ class FusedConv:
                 raise _lib.CasaposeHipError("%s: cannot re-route the 1x1 GEMM to the exact split" % self.name)
 
     def run(self, stream: int):
+        """One launch; while the plan runs armed (mon_ptr set) an f16x2 binding reports max |x| of what it converts into its monitor slot."""
+        if self.mon_ptr and self.f16x2_active():
+            lib = _lib.load()
+            lib.cp_f16x2_monitor_set(self.mon_ptr)
+            try:
+                self._launch(stream)
+            finally:
+                lib.cp_f16x2_monitor_set(None)
+            return
+        self._launch(stream)
+
+    def _launch(self, stream: int):
         lib = _lib.load()
         g = self._gemm
         if g is not None:
@@ -362,13 +373,23 @@ TRAIN_WINO_GEMM_SPLIT = os.environ.get("CASAPOSE_WINO_GEMM", "split") == "split"
 DEFAULT_INFER_CONV_MODE = "f16x2"
 # The range condition of f16x2 (csrc/split_f16.h) is CHECKED, per layer, on the first forward of every plan (and again after set_params / load_weights,
 # which drop the plans): a layer whose converted operands leave [F16X2_AMAX_LO, F16X2_AMAX_HI] gets an exact remedy -- a power of two on a Winograd layer's
-# V or on a fused head's operand, the exact three-way bf16 split for a direct layer (ForwardPlan._run_calibrating) -- with one warning naming the layers.  Below LO the low halves are fp16 subnormals (absolute 2^-25: worse than 2^-24 of the tensor's
+# V or on a fused head's operand, the exact three-way bf16 split for a direct layer (ForwardPlan._calibrate) -- with one warning naming the layers.  Below LO the low halves are fp16 subnormals (absolute 2^-25: worse than 2^-24 of the tensor's
 # maximum); HI = 65504 / 4 leaves two octaves for later batches before a conversion clamps (and a clamp is graceful, split_f16.h: the maximum over a
 # batch of 4800 tiles x 36 planes x K channels moves by tens of per cent between batches, not by factors).  CASAPOSE_F16X2_GUARD=0 / CasaposeNet(f16x2_guard=False)
 # switch the check off (the unguarded plan of round 4: tests compare the two).
 F16X2_GUARD = os.environ.get("CASAPOSE_F16X2_GUARD", "1") != "0"
 F16X2_AMAX_LO = 0.5
 F16X2_AMAX_HI = 65504.0 / 4.0
+# Round 6: the measurements come from the converting kernels themselves (monitor slots behind the C ABI: cp_f16x2_monitor_set, include/casapose_hip.h) and
+# the guard STAYS on after the calibration: EVERY forward of a guarded plan runs armed, so the slots are sticky maxima over everything the plan has
+# converted since they were last read (measured cost, A/B in one call: 2149.5 -> 2141.5 images/s, 0.37 %; CASAPOSE_F16X2_MONITOR=0 arms the calibration
+# passes only).  Every F16X2_MONITOR_EVERY-th forward the slots are copied to pinned host memory asynchronously, zeroed behind the copy, and judged at
+# the start of a later forward -- no synchronisation on the hot path.  A layer whose converted maximum has left [LO / SLACK, HI * SLACK] (a later
+# batch far above or below the one the plan was calibrated on) re-arms the calibration with one warning.  SLACK = 2 keeps HI * SLACK at half the
+# fp16 maximum: nothing clamps before the monitor reacts.
+F16X2_MONITOR = os.environ.get("CASAPOSE_F16X2_MONITOR", "1") != "0"
+F16X2_MONITOR_EVERY = max(1, int(os.environ.get("CASAPOSE_F16X2_MONITOR_EVERY", "8")))
+F16X2_MONITOR_SLACK = 2.0
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
@@ -437,6 +458,7 @@ class WinoConv:
         self._keep: List = []
         self.v_scale, self._vs_vec, self._next_tabs = 1.0, None, None
         self.fuse_next, self.skip_input = None, False
+        self.mon_ptr: Optional[int] = None   # f16x2 range monitor slot of THIS layer's V while a forward runs armed
 
     def demote_to_exact_split(self):
         """the fp16 two-way split of this layer's GEMM replaced by the exact three-way bf16 split (operands outside the fp16 range condition)"""
@@ -457,7 +479,7 @@ class WinoConv:
         if V.numel() < 36 * self.Tp * self.ktot or M.numel() < 36 * self.Tp * self.cout:
             raise ValueError("%s: Winograd scratch too small" % self.name)
         self.srcs, self.V, self.M = list(srcs), V, M
-        self.v_scale, self._vs_vec, self._next_tabs = 1.0, None, None   # f16x2 range guard (ForwardPlan._run_calibrating): power of two applied to V
+        self.v_scale, self._vs_vec, self._next_tabs = 1.0, None, None   # f16x2 range guard (ForwardPlan._calibrate): power of two applied to V
         self.epi = dict(residual=residual, scale=scale, shift=shift, epi_label=epi_label, act=act, out_raw=out_raw, out_act=out_act)
         d = self.desc
         d.batch, d.in_h, d.in_w, d.out_h, d.out_w = 36, 1, self.Tp, 1, self.Tp
@@ -477,8 +499,29 @@ class WinoConv:
         self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
         return in_h, in_w
 
+    def _armed(self, ptr: Optional[int]):
+        """context: the transform launched inside reports max |V| of what it writes into the monitor slot at `ptr` (None: nothing armed)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            lib = _lib.load()
+            if not ptr or WINO_GROUPED_CONV:   # (the grouped mode of the general kernel converts nothing to fp16)
+                yield
+                return
+            lib.cp_f16x2_monitor_set(ptr)
+            try:
+                yield
+            finally:
+                lib.cp_f16x2_monitor_set(None)
+        return cm()
+
     def _input_transform(self, src_ptr: int, ld: int, cpad: int, nb: int, off: int, stream: int):
         """V[.., off : off + cpad] = B^T d B of one source; with v_scale != 1 through the transform's per-channel input affine (x * 2^e + 0: exact)"""
+        with self._armed(self.mon_ptr if self.planes == _lib.PLANES_F16X2 else None):
+            self._input_transform_launch(src_ptr, ld, cpad, nb, off, stream)
+
+    def _input_transform_launch(self, src_ptr: int, ld: int, cpad: int, nb: int, off: int, stream: int):
         lib = _lib.load()
         if self.v_scale == 1.0:
             check(lib.cp_wino_input_transform_f32(src_ptr, ld, cpad, nb, self.h, self.w, self.dil, self.V.data_ptr(), self.ktot, off, stream),
@@ -526,9 +569,10 @@ class WinoConv:
             nxt = getattr(self, "fuse_next", None)
             if nxt is not None:   # Y = A^T M A + epilogue, then straight into the next layer's V (the activated map stays on chip)
                 sc_, sh_ = self._tables_for_next()
-                check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
-                                                             sc_, sh_, e["act"], at(e["out_raw"], b0, self.cout), self.cout, None, self.cout,
-                                                             self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
+                with self._armed(nxt.mon_ptr if nxt.planes == _lib.PLANES_F16X2 else None):   # it writes the NEXT layer's V
+                    check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
+                                                                 sc_, sh_, e["act"], at(e["out_raw"], b0, self.cout), self.cout, None, self.cout,
+                                                                 self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
                 continue
             check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, nb, self.h, self.w, self.dil, at(e["residual"], b0, self.cout), self.cout,
                                                    _ptr(e["scale"]), _ptr(e["shift"]), at(e["epi_label"], b0, 1, 1), e["act"], at(e["out_raw"], b0, self.cout),
@@ -555,9 +599,10 @@ class WinoConv:
             nxt = getattr(self, "fuse_next", None)
             if nxt is not None:
                 sc_, sh_ = self._tables_for_next()
-                check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
-                                                             sc_, sh_, e["act"], _ptr(e["out_raw"]), self.cout, None, self.cout,
-                                                             self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
+                with self._armed(nxt.mon_ptr if nxt.planes == _lib.PLANES_F16X2 else None):
+                    check(lib.cp_wino_output_input_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
+                                                                 sc_, sh_, e["act"], _ptr(e["out_raw"]), self.cout, None, self.cout,
+                                                                 self.V.data_ptr(), nxt.ktot, 0, stream), "cp_wino_output_input_transform_f32(%s)" % self.name)
             else:
                 check(lib.cp_wino_output_transform_f32(self.M.data_ptr(), self.cout, self.batch, self.h, self.w, self.dil, _ptr(e["residual"]), self.cout,
                                                        _ptr(e["scale"]), _ptr(e["shift"]), _ptr(e["epi_label"]), e["act"], _ptr(e["out_raw"]), self.cout,
@@ -635,9 +680,13 @@ class ForwardPlan:
         self.steps: List = []  # callables taking (stream)
         self.convs: List[FusedConv] = []
         # f16x2 range guard: the first run() of this plan goes layer by layer, measures what every f16x2 layer is about to convert and demotes the
-        # layers outside the range condition to the exact split (ForwardPlan._run_calibrating); f16x2_report keeps what it saw
+        # layers outside the range condition to the exact split (ForwardPlan._calibrate); f16x2_report keeps what it saw
         self.needs_calibration = bool(net.conv_planes == _lib.PLANES_F16X2 and net.f16x2_guard)
         self.f16x2_report: Dict[str, Tuple[float, str]] = {}
+        # ... and afterwards every forward runs armed; every F16X2_MONITOR_EVERY-th the slots are read back and judged without a synchronisation (_poll_monitor)
+        self._mon = self._mon_host = self._mon_event = None
+        self._since_monitor = 0
+        self.monitor_checks = self.monitor_fired = 0   # armed forwards judged so far / how many of them re-armed the calibration
         lib = _lib.load()
         P = net.device_tables
         hs = [h, h // 2, h // 4, h // 8]
@@ -920,88 +969,154 @@ class ForwardPlan:
                 a.fuse_next, b.skip_input = b, True
         self._wino_pending = []
 
-    def _run_calibrating(self, stream: int):
-        """One forward, layer by layer, fitting every f16x2 layer to what it is about to convert (host synchronisation per layer: first forward
-        of a plan only).  Three places convert fp32 activations to fp16 pairs, and each has its own exact remedy:
-          * a Winograd layer's GEMM converts V = B^T d B: max |V| is measured after the (own or fused) input transform; outside the band the
-            transform multiplies by a power of two (WinoConv.v_scale: exact) that brings max |V| to [2^10, 2^11) and the GEMM's accumulator factor
-            undoes it -- the weights' remedy (cp_f16x2_weight_scale) applied to the activations;
-          * a fused 1x1 head converts the activated 32-channel map that never reaches HBM: the layer runs once into a scratch map, which is
-            measured; outside the band the normalisation table feeding the activation is multiplied by the power of two (ReLU / leaky ReLU are
-            positively homogeneous: act(s x) = s act(x) exactly) and the head's accumulator factor undoes it (FusedConv.head_in_scale);
-          * the direct kernels, the stem and the 1x1 GEMMs convert stored tensors that other layers read too: outside the band the layer runs
-            on the exact three-way bf16 split (no range condition) -- for this plan and, through net.f16x2_fallback, for later plans.
-        Band: [F16X2_AMAX_LO, F16X2_AMAX_HI]."""
+    # ---- f16x2 range guard (the C-ABI side: cp_f16x2_monitor_set / cp_f16x2_range_check / cp_amax_f32) -----------------------------
+    def _run_armed(self, stream: int, fresh: bool = True):
+        """One forward with every f16x2 layer reporting into its monitor slot (slot i <-> self.convs[i]; include/casapose_hip.h): the converting
+        kernels fold max |x| of what they convert -- a direct layer's staged sources, the stem's image through its input affine, a 1x1 GEMM's rows,
+        the planes V a Winograd transform writes, the activated map a fused head converts in registers -- into the slot with one atomic per wave.
+        fresh = False keeps what earlier armed forwards left in the slots (the monitor's sticky maxima)."""
+        if self._mon is None:
+            self._mon = torch.zeros(4 * len(self.convs), dtype=torch.int32, device=self.net.device)
+            self._mon_host = torch.zeros(4 * len(self.convs), dtype=torch.int32).pin_memory()
+        elif fresh:
+            self._mon.zero_()
+        base = self._mon.data_ptr()
+        for i, c in enumerate(self.convs):
+            c.mon_ptr = base + 16 * i
+        try:
+            for step in self.steps:
+                step(stream)
+        finally:
+            for c in self.convs:
+                c.mon_ptr = None
+
+    def _judge(self, words: np.ndarray, lo: float, hi: float):
+        """[(layer, "in" | "head", max |x| as converted, status, power of two)] for every slot that reported; status as cp_f16x2_range_check:
+        0 inside [lo, hi], 1 rescale by the power of two, 2 no power of two helps (or not finite)"""
+        lib = _lib.load()
+        w = np.ascontiguousarray(words).view(np.uint32).reshape(-1, 4)
+        out = []
+        for i, c in enumerate(self.convs):
+            if int(w[i, 1]) == 0:
+                continue
+            for kind, bits in (("in", w[i, 0]), ("head", w[i, 2])):
+                if kind == "head" and (bits == 0 or isinstance(c, WinoConv)):
+                    continue
+                amax = float(np.array([bits], np.uint32).view(np.float32)[0])
+                r = C.c_float(1.0)
+                st = lib.cp_f16x2_range_check(amax, lo, hi, C.byref(r))
+                out.append((c, kind, amax, st, float(r.value)))
+        return out
+
+    def _producer_of(self, wl: "WinoConv") -> Optional["WinoConv"]:
+        for c in self.convs:
+            if isinstance(c, WinoConv) and c.fuse_next is wl:
+                return c
+        return None
+
+    def _calibrate(self, stream: int):
+        """Fit every f16x2 layer to what it converts: armed forwards (_run_armed), one host read per pass, exact remedies, repeated until a pass
+        finds every layer inside [F16X2_AMAX_LO, F16X2_AMAX_HI] (a layer downstream of a clamping one is measured again once that one is fixed;
+        the bench network settles in one pass, adversarial statistics in two or three).  Three places convert fp32 activations to fp16 pairs:
+          * a Winograd layer's GEMM converts V = B^T d B (measured where it is written: the layer's own input transform or the producing layer's
+            fused output -> input transform): the transform multiplies by a power of two (WinoConv.v_scale: exact) and the GEMM's accumulator
+            factor undoes it -- the weights' remedy (cp_f16x2_weight_scale) applied to the activations;
+          * a fused 1x1 head converts the activated 32-channel map that never reaches HBM (measured in the epilogue's registers): the normalisation
+            table feeding the activation is multiplied by the power of two (ReLU / leaky ReLU are positively homogeneous: act(s x) = s act(x)
+            exactly) and the head's accumulator factor undoes it (FusedConv.head_in_scale);
+          * the direct kernels, the stem and the 1x1 GEMMs convert stored tensors that other layers read too: the layer runs on the exact
+            three-way bf16 split (no range condition) -- for this plan and, through net.f16x2_fallback, for later plans (CasaposeNet.recalibrate()
+            forgets that).
+        The last pass IS the forward whose output run() returns.  Afterwards the monitor keeps watching (run(), _poll_monitor)."""
         net = self.net
         lo, hi = F16X2_AMAX_LO, F16X2_AMAX_HI
-        changed: List[str] = []
-
-        def pow2_to_band(amax: float) -> float:
-            return 2.0 ** (10 - math.floor(math.log2(amax)))   # amax * s in [2^10, 2^11): 32x headroom to 65504, low halves normal down to 2^-12 of the maximum
+        changed: Dict[str, str] = {}
 
         def note(name: str, amax: float, what: str, action: str):
             self.f16x2_report[name] = (amax, action)
             if action != "f16x2":
-                changed.append("%s (max |%s| = %.3g: %s)" % (name, what, amax, action))
+                changed[name] = "%s (max |%s| = %.3g: %s)" % (name, what, amax, action)
 
-        prev_wino_out = None   # t_out of the Winograd layer just before, when it wrote the CURRENT layer's V (fused output -> input transform)
-        for st in self.steps:
-            owner = getattr(st, "__self__", None)
-            if isinstance(owner, WinoConv) and owner.planes == _lib.PLANES_F16X2:
-                if len(owner.chunks()) != 1 or WINO_GROUPED_CONV:   # batch groups share V: bound it from the sources (|B^T d B| <= 100 max |d|)
-                    vb = 100.0 * max(float(s_["data"].abs().max()) for s_ in owner.srcs)
-                    if vb > 0.0 and not (lo <= vb <= hi):
-                        owner.v_scale = pow2_to_band(vb)
-                    note(owner.name, vb, "V bound", "f16x2" if owner.v_scale == 1.0 else "f16x2, V x %g" % owner.v_scale)
-                    st(stream)
-                    prev_wino_out = None
-                    continue
-                micro = owner.micro_steps()
-                for i, (tag, fn) in enumerate(micro):
-                    if tag == "M":
-                        vmax = float(owner.V[:36 * owner.Tp * owner.ktot].view(36, owner.Tp, owner.ktot)[:, :owner.T].abs().max())   # (padding tiles are not written)
-                        if vmax > 0.0 and not (lo <= vmax <= hi):
-                            owner.v_scale = pow2_to_band(vmax)
-                            (prev_wino_out if owner.skip_input else micro[i - 1][1])(stream)   # the transform again, now scaled
-                        note(owner.name, vmax, "V", "f16x2" if owner.v_scale == 1.0 else "f16x2, V x %g" % owner.v_scale)
-                    fn(stream)
-                prev_wino_out = micro[-1][1] if owner.fuse_next is not None else None
-                continue
-            prev_wino_out = None
-            if isinstance(owner, FusedConv) and owner.f16x2_active():
-                amax = owner.input_amax()
-                if amax > 0.0 and not (lo <= amax <= hi):
-                    net.f16x2_fallback[owner.name] = "max |a| = %.3g outside [%g, %g]" % (amax, lo, hi)
-                    owner.demote_to_exact_split(net.params.get(owner.name + ".kernel"))
-                    note(owner.name, amax, "a", "exact bf16 split")
-                    st(stream)
-                    continue
-                d = owner.desc
-                if d.head_out and not d.out_act and d.scale:   # the fused head's operand: this layer's activated output, measured through a scratch map
-                    scratch = torch.empty(d.batch * d.out_h * d.out_w * owner.cout, dtype=torch.float32, device=net.device)
-                    d.out_act, d.out_act_ld = scratch.data_ptr(), owner.cout
-                    try:
-                        st(stream)
-                        hmax = float(scratch.abs().max())
-                    finally:
-                        d.out_act = None
-                    del scratch
-                    note(owner.name, amax, "a", "f16x2")
-                    if hmax > 0.0 and not (lo <= hmax <= hi):
-                        owner.set_head_in_scale(pow2_to_band(hmax))
-                        st(stream)
-                        note(owner.name + ":head", hmax, "head a", "f16x2, head input x %g" % owner.head_in_scale)
+        settled = False
+        for _ in range(8):
+            self._run_armed(stream)
+            words = self._mon.cpu().numpy()   # (synchronises: calibration only)
+            acted = False
+            for c, kind, amax, st, r in self._judge(words, lo, hi):
+                if isinstance(c, WinoConv):
+                    a0 = amax / c.v_scale   # as the un-scaled transform would write it
+                    prod = self._producer_of(c) if c.skip_input else None
+                    can_scale = (not c.skip_input) or (prod is not None and prod.epi["scale"] is not None)
+                    if st == 1 and can_scale:
+                        c.v_scale *= r
+                        acted = True
+                    elif st != 0:
+                        c.demote_to_exact_split()
+                        c.v_scale = 1.0
+                        acted = True
+                    note(c.name, a0, "V", "exact bf16 split" if c.planes != _lib.PLANES_F16X2 else ("f16x2" if c.v_scale == 1.0 else "f16x2, V x %g" % c.v_scale))
+                elif kind == "in":
+                    if st != 0:
+                        net.f16x2_fallback[c.name] = "max |a| = %.3g outside [%g, %g]" % (amax, lo, hi)
+                        c.demote_to_exact_split(net.params.get(c.name + ".kernel"))
+                        note(c.name, amax, "a", "exact bf16 split")
+                        self.f16x2_report.pop(c.name + ":head", None)
+                        acted = True
                     else:
-                        note(owner.name + ":head", hmax, "head a", "f16x2")
-                    continue
-                note(owner.name, amax, "a", "f16x2")
-            st(stream)
+                        note(c.name, amax, "a", "f16x2")
+                elif c.name not in net.f16x2_fallback:   # the fused head's operand (a layer demoted in this very pass no longer converts it)
+                    a0 = amax / c.head_in_scale
+                    if st == 1:
+                        c.set_head_in_scale(c.head_in_scale * r)
+                        acted = True
+                    elif st != 0:
+                        net.f16x2_fallback[c.name] = "head operand max = %.3g" % a0
+                        c.demote_to_exact_split(net.params.get(c.name + ".kernel"))
+                        note(c.name, a0, "head a", "exact bf16 split")
+                        acted = True
+                        continue
+                    note(c.name + ":head", a0, "head a", "f16x2" if c.head_in_scale == 1.0 else "f16x2, head input x %g" % c.head_in_scale)
+            if not acted:
+                settled = True
+                break
         self.needs_calibration = False
+        self._since_monitor, self._mon_event = 0, None
+        self._mon.zero_()   # the monitor's window starts behind the calibration (a sticky maximum of the calibration batch would hide a later, smaller regime)
+        import warnings
+        if not settled:
+            warnings.warn("conv_mode f16x2: the range calibration did not settle in 8 passes; the plan keeps its last fit")
         if changed and not net._f16x2_warned:
             net._f16x2_warned = True
-            import warnings
             warnings.warn("conv_mode f16x2: %d layer(s) outside the fp16 range condition [%g, %g] were rescaled by a power of two or moved to the exact bf16 split: %s"
-                          % (len(changed), lo, hi, "; ".join(changed)))
+                          % (len(changed), lo, hi, "; ".join(changed.values())))
+
+    def _poll_monitor(self):
+        """judge an armed forward whose slots have arrived in pinned host memory (never waits): a layer outside [LO / SLACK, HI * SLACK] -- a batch far
+        from the one the plan was calibrated on -- re-arms the calibration, with a warning"""
+        ev = self._mon_event
+        if ev is None or not ev.query():
+            return
+        self._mon_event = None
+        lo, hi = F16X2_AMAX_LO / F16X2_MONITOR_SLACK, F16X2_AMAX_HI * F16X2_MONITOR_SLACK
+        out = [(c.name + (":head" if kind == "head" else ""), amax) for c, kind, amax, st, _ in self._judge(self._mon_host.numpy().copy(), lo, hi) if st != 0]
+        self.monitor_checks += 1
+        if out:
+            self.monitor_fired += 1
+            self.needs_calibration = True
+            self.net._f16x2_warned = False
+            import warnings
+            warnings.warn("conv_mode f16x2: the range monitor found %d layer(s) converting operands outside [%g, %g] (%s): this batch is far from the one the "
+                          "plan was calibrated on; calibrating again" % (len(out), lo, hi, "; ".join("%s max %.3g" % o for o in out[:6])))
+
+    def recalibrate(self):
+        """calibrate again on the next forward (keeps what net.f16x2_fallback has demoted: CasaposeNet.recalibrate() forgets that too)"""
+        self.needs_calibration = bool(self.net.conv_planes == _lib.PLANES_F16X2 and self.net.f16x2_guard)
+
+    def _device_amax(self, t: torch.Tensor) -> float:
+        """max |t| through cp_amax_f32 (diagnostics; synchronises)"""
+        slot = torch.zeros(4, dtype=torch.int32, device=t.device)
+        check(_lib.load().cp_amax_f32(t.data_ptr(), 1, 0, t.numel(), slot.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream), "cp_amax_f32")
+        return float(slot[:1].cpu().numpy().view(np.float32)[0])
 
     def f16x2_operand_ranges(self) -> Dict[str, Optional[Tuple[float, float]]]:
         """The range condition of the fp16 two-way split made checkable.  Call after a forward: for every layer this plan runs in
@@ -1018,7 +1133,7 @@ class ForwardPlan:
                 if conv.skip_input:
                     out[conv.name] = None
                     continue
-                amax = max(float(s["data"].abs().max()) for s in conv.srcs)
+                amax = max(self._device_amax(s["data"]) for s in conv.srcs)
                 out[conv.name] = (amax, 100.0 * amax)
                 continue
             planes = conv.split_mode or conv.stem_split or ((conv._gemm or {}).get("planes", 0))
@@ -1026,10 +1141,10 @@ class ForwardPlan:
                 continue
             amax = 0.0
             for sdict in conv._srcs:
-                a = float(sdict["data"].abs().max())
+                a = self._device_amax(sdict["data"])
                 pre = sdict.get("pre")
                 if pre:
-                    a = a * float(pre[0].abs().max()) + float(pre[1].abs().max())
+                    a = a * self._device_amax(pre[0]) + self._device_amax(pre[1])
                 amax = max(amax, a)
             out[conv.name] = (amax, amax)
         return out
@@ -1119,18 +1234,29 @@ class ForwardPlan:
         else:
             self.seg_input_ptr = None
         check(lib.cp_pad_channels_3to4(img.data_ptr(), self.img4.data_ptr(), B * h * w, stream), "cp_pad_channels_3to4")
+        guard = self.net.conv_planes == _lib.PLANES_F16X2 and self.net.f16x2_guard
+        if guard and not self.needs_calibration:
+            self._poll_monitor()   # (may re-arm the calibration: a finished armed forward found a layer outside the band)
         if self.needs_calibration:
-            self._run_calibrating(stream)
+            self._calibrate(stream)
+        elif guard and F16X2_MONITOR:
+            self._run_armed(stream, fresh=False)   # sticky: the slots keep the maxima of every forward since they were last read
+            self._since_monitor += 1
+            if self._since_monitor >= F16X2_MONITOR_EVERY and self._mon_event is None:
+                self._mon_host.copy_(self._mon, non_blocking=True)   # judged at the start of a later forward, when the copy has landed
+                self._mon.zero_()                                    # (stream-ordered behind the copy)
+                self._mon_event = torch.cuda.Event()
+                self._mon_event.record(torch.cuda.current_stream(img.device))
+                self._since_monitor = 0
         else:
             for step in self.steps:
                 step(stream)
+            self._since_monitor += 1
         if self.net.pvnet:
             _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
             return out
         if seg_input is None:  # labels[0] is the arg-max of THIS output's logits
-            if len(_LABEL_CACHE) > 8:
-                _LABEL_CACHE.clear()
-            _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), self.labels[0].clone(), out._version)
+            _remember_labels(out, self.labels[0].clone())
         else:
             _LABEL_CACHE.pop(out.untyped_storage().data_ptr(), None)
         return out
@@ -1167,12 +1293,21 @@ class CasaposeNet:
         self.conv_mode = mode
         self.conv_planes = {"f32": 0, "split": 3, "f16x2": _lib.PLANES_F16X2, "bf16": 1}[mode]
         self.f16x2_guard = F16X2_GUARD if f16x2_guard is None else bool(f16x2_guard)
-        self.f16x2_fallback: Dict[str, str] = {}   # layer -> why it left f16x2 (ForwardPlan._run_calibrating); reset by set_params
+        self.f16x2_fallback: Dict[str, str] = {}   # layer -> why it left f16x2 (ForwardPlan._calibrate); reset by set_params
         self._f16x2_warned = False
         self.plans: Dict[Tuple[int, int, int], ForwardPlan] = {}
         self._twin: Optional["CasaposeNet"] = None   # the second half-batch's layer objects (two-stream forward)
         self._streams = None
         self.set_params(params)
+
+    def recalibrate(self):
+        """Forget everything the f16x2 range guard has decided -- demoted layers (f16x2_fallback), powers of two on V and on the heads' operands -- and
+        calibrate again on the next forward.  For a caller whose first batch was not representative (a blank warm-up image); the monitor does the
+        incremental form of this by itself when a later batch leaves the band."""
+        self.f16x2_fallback, self._f16x2_warned = {}, False
+        self.plans.clear()
+        if self._twin is not None:
+            self._twin.recalibrate()
 
     def planes_for(self, layer_name: str) -> int:
         """operand planes of one layer: the conv mode's, or 3 (exact split) once the f16x2 guard has demoted the layer"""
@@ -1344,7 +1479,5 @@ class CasaposeNet:
             check(lib.cp_set_persistent_blocks(old_blocks), "cp_set_persistent_blocks")
         for s_ in streams.values():
             cur.wait_stream(s_)
-        if len(_LABEL_CACHE) > 8:
-            _LABEL_CACHE.clear()
-        _LABEL_CACHE[out.untyped_storage().data_ptr()] = (weakref.ref(out), torch.cat([plans[0].labels[0], plans[1].labels[0]]), out._version)
+        _remember_labels(out, torch.cat([plans[0].labels[0], plans[1].labels[0]]))
         return out

@@ -1030,6 +1030,7 @@ class TrainPlan:
             self.VERT_OFF = seg_dim
         self.group, self.world_size = group, world_size
         self.comm_timing = None   # start_comm_timing()
+        self.comm_log = None      # start_comm_log()
         self._buckets = None
         self._pending: List = []
         self.update_moving = True
@@ -1388,6 +1389,8 @@ class TrainPlan:
     # ---- distributed hooks ---------------------------------------------------------------------------
     def all_reduce_stats(self, table: torch.Tensor, local_pixels: int) -> int:
         """SUM the fp64 statistic table over the replicas; returns the global pixel count."""
+        if self.comm_log is not None:   # structure of the step's exchanges (comm_structure()): recorded with or without replicas
+            self.comm_log.append(("syncbn", table.numel() * table.element_size(), "blocking", "compute"))
         if self.comm_timing is not None and self.group is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1397,6 +1400,34 @@ class TrainPlan:
         else:
             parallel.all_reduce_sum_(table, self.group, self.world_size)
         return local_pixels * self.world_size
+
+    # ---- structure of the step's exchanges (round 6): what is launched, in which order, on which stream ---------------------------------
+    def start_comm_log(self):
+        """From the next step on, record every exchange point of a step in launch order: ("syncbn", bytes, "blocking", "compute") for a statistic
+        table all-reduce (the next kernel needs it), ("op", index) for every backward op, ("grad_bucket", bytes, "async", stream id of the
+        compute stream at launch, first op index) where a gradient bucket's all-reduce is launched, ("grad_wait", n) where the compute stream
+        waits for the buckets.  Recorded with or without replicas (a single replica launches no collective but passes the same points), so that
+        the overlap of the data-parallel step can be asserted structurally (tests/test_gpu_dp.py) and counted (bench.py --mode train)."""
+        self.comm_log = []
+
+    def comm_structure(self) -> dict:
+        """Per step, from the log of the LAST logged step: blocking collectives (SyncBN tables) and their payload, gradient buckets, their payload and
+        how many backward ops are launched AFTER each bucket's all-reduce (what its exchange can hide behind)."""
+        log = self.comm_log or []
+        last = len(log) - 1 - next((i for i, e in enumerate(reversed(log)) if e[0] == "step_begin"), len(log) - 1)
+        step = log[last + 1:] if log and log[last][0] == "step_begin" else log
+        bn = [e for e in step if e[0] == "syncbn"]
+        buckets, after = [], []
+        for i, e in enumerate(step):
+            if e[0] == "grad_bucket":
+                buckets.append(e)
+                after.append(sum(1 for x in step[i + 1:] if x[0] == "op"))
+        return {"blocking_collectives_per_step": len(bn), "blocking_payload_bytes_per_step": int(sum(e[1] for e in bn)),
+                "gradient_buckets": len(buckets), "gradient_payload_bytes_per_step": int(sum(e[1] for e in buckets)),
+                "backward_ops_launched_after_each_bucket": after, "backward_ops": sum(1 for e in step if e[0] == "op"),
+                "note": "structure of the data-parallel step, identical for every world size: the blocking calls sit on the critical path (global-batch "
+                        "statistics, as the reference's SyncBatchNormalization), each gradient bucket's all-reduce is launched asynchronously when the "
+                        "backward has passed the bucket's first layer"}
 
     # ---- communication accounting (bench.py --mode train with N > 1 ranks; tests/test_gpu_dp.py) ------------------
     def start_comm_timing(self):
@@ -1564,7 +1595,8 @@ class TrainPlan:
             t.has_grad = False
         self._pending = []
         multi = self.group is not None and (self.world_size > 1 or parallel.force_collectives())
-        if multi and self._buckets is None:
+        log = self.comm_log
+        if (multi or log is not None) and self._buckets is None:
             self._buckets = self._gradient_buckets()
         side = self._side
         main = torch.cuda.current_stream(self.out.device)
@@ -1579,9 +1611,15 @@ class TrainPlan:
                 op.backward(stream, wgrad_stream=side.cuda_stream)
             else:
                 op.backward(stream)
-            if multi:
+            if log is not None:
+                log.append(("op", i))
+            if multi or log is not None:
                 for first, a, e in self._buckets:
                     if first == i and not (a == 0):  # the bucket holding bn_data.beta is completed below
+                        if log is not None:
+                            log.append(("grad_bucket", 4 * (e - a), "async", stream, first))
+                        if not multi:
+                            continue
                         if side is not None:
                             main.wait_stream(side)   # the bucket's weight gradients come from the side stream
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
@@ -1592,10 +1630,13 @@ class TrainPlan:
         W0 = self.store.view("conv0.kernel").reshape(49, 3, 64)               # [tap][c][cout]
         dbeta = torch.einsum("tco,to->c", W0.double(), G.double())
         self.store.grad_view("bn_data.beta").copy_(dbeta)
-        if multi:
+        if multi or log is not None:
             for first, a, e in self._buckets:
                 if a == 0:
-                    self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
+                    if log is not None:
+                        log.append(("grad_bucket", 4 * (e - a), "async", stream, first))
+                    if multi:
+                        self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
 
     def all_reduce_grads(self):
         """Complete the gradient exchange started by backward() (or run it as one all-reduce if none is pending)."""
@@ -1603,6 +1644,8 @@ class TrainPlan:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        if self.comm_log is not None:
+            self.comm_log.append(("grad_wait", len(getattr(self, "_pending", None) or [])))
         if getattr(self, "_pending", None):
             for h in self._pending:
                 h.wait()
@@ -1619,6 +1662,8 @@ class TrainPlan:
         """One optimisation step.  kp_args (optional): keyword arguments of kp_loss_and_grad.  Returns the fp64 device
         vector [mask, vertex, proxy] (and, with kp_args, the keypoint loss as a second value)."""
         stream = torch.cuda.current_stream(img.device).cuda_stream
+        if self.comm_log is not None:
+            self.comm_log.append(("step_begin",))
         self.forward(img, cond_labels)
         sums = self.loss_and_grad(labels_ce, labels_fg, keypoints_yx, *weights, filter_with_segmentation=filter_with_segmentation)
         kp_loss = self.kp_loss_and_grad(**kp_args) if kp_args is not None else None

@@ -36,8 +36,9 @@ typedef enum cp_status {
 const char* cp_last_error(void);
 /* ABI version of the library: CP_ABI_VERSION of the header it was built from.  300 (round 3): cp_conv_desc starts with `struct_size`
  * and every entry point that takes a descriptor refuses one whose struct_size differs from the library's sizeof(cp_conv_desc)
- * (CP_ERR_INVALID, message in cp_last_error()) instead of reading fields a shorter or longer caller-side struct does not have. */
-#define CP_ABI_VERSION 300
+ * (CP_ERR_INVALID, message in cp_last_error()) instead of reading fields a shorter or longer caller-side struct does not have.
+ * 301 (round 6): + the f16x2 range-guard entry points (cp_f16x2_monitor_set / _get, cp_f16x2_range_check, cp_amax_f32); no struct changed. */
+#define CP_ABI_VERSION 301
 int cp_version(void);
 /* sizeof(cp_conv_desc) / sizeof(cp_conv_source) as this library was compiled: a binder checks them against its own declaration at load time */
 size_t cp_conv_desc_size(void);
@@ -188,6 +189,32 @@ int cp_conv_selected_tile(const cp_conv_desc* desc);
  * ---------------------------------------------------------------------------------- */
 enum { CP_PLANES_F16X2 = 0x12 };   /* `planes` code of the fp16 two-way split (two planes; see cp_wino_gemm_split_scaled_f32) */
 float cp_f16x2_weight_scale(float max_abs);   /* the power of two that brings max |w| into [2^11, 2^12) */
+/* ---- the f16x2 RANGE GUARD behind the C ABI (round 6; the load path it protects: test_casapose.py:225-228 followed by model(img, training=False)) ----
+ * The fp16 two-way split reproduces an fp32 operand to one ulp only while max |operand| of the converted tensor stays inside a band
+ * ([0.5, 65504 / 4]).  WEIGHTS are brought there by cp_f16x2_weight_scale; ACTIVATIONS are measured on the device:
+ *   - a MONITOR SLOT is four 32-bit words of device memory, 16-byte aligned, zeroed by the caller:
+ *       [0] bits of max |x| over every fp32 value the armed launches converted to an fp16 pair (atomic max of the bit pattern), [1] number of
+ *       launches that reported, [2] the same maximum for the operand of a fused 1x1 head (exists in registers only), [3] reserved;
+ *   - cp_f16x2_monitor_set(slot) arms `slot` for the CALLING THREAD's following launches (NULL disarms).  Reporting launches:
+ *       cp_conv2d_fwd_split_scaled / cp_conv2d_fwd_stem_split_scaled with CP_PLANES_F16X2 (what their loaders convert: the sources through the
+ *       stem's input affine; the low-resolution source of a bilinear x2 input, which bounds its interpolation; word [2]: the fused head's operand),
+ *       cp_wino_gemm_split_scaled_f32 with CP_PLANES_F16X2 (every row of V: arm it for a plain 1x1 GEMM only -- the padding rows of Winograd
+ *       planes hold stale data), cp_wino_input_transform_f32 / _pre_f32 and cp_wino_output_input_transform_f32 (the planes V they WRITE: arm
+ *       these, not the GEMM, for a Winograd layer).  A slot is sticky: maxima accumulate over launches and forwards until the caller zeroes it.
+ *       An un-armed launch pays one uniform branch per staged slice;
+ *   - cp_amax_f32 folds max |x| of a caller's own strided tensor into slot[0] (same atomic), for operands no kernel above converts;
+ *   - cp_f16x2_range_check(amax, lo, hi, &rescale): 0 = inside [lo, hi] (or amax == 0), 1 = multiply the operand by the power of two *rescale
+ *       (amax * rescale in [2^10, 2^11)) and the consumer's accumulator factor by its inverse -- exact; for V through
+ *       cp_wino_input_transform_pre_f32's per-channel scale, for a fused head through the normalisation table feeding its (positively homogeneous)
+ *       activation and head_descale --, 2 = no power of two in [2^-24, 2^24] helps or amax is not finite: run the layer with planes = 3.
+ * Protocol of the host layer (casapose_amd/engine.py, ForwardPlan): a plan's first forward runs armed, reads the slots back (one synchronisation),
+ * applies the remedies and repeats until every layer is in the band; afterwards every CASAPOSE_F16X2_MONITOR_EVERY-th forward runs armed, the
+ * slots are copied to pinned host memory asynchronously and judged at the start of a later forward -- no synchronisation on the hot path; a slot
+ * outside the band re-arms the calibration and raises one warning. */
+int cp_f16x2_monitor_set(uint32_t* slot);
+uint32_t* cp_f16x2_monitor_get(void);
+int cp_f16x2_range_check(float amax, float lo, float hi, float* rescale);
+int cp_amax_f32(const float* x, long long groups, long long group_stride, long long count, uint32_t* slot, void* stream);
 int cp_conv_split_applicable(const cp_conv_desc* desc);   /* 1 if cp_conv2d_fwd_split covers this descriptor */
 int cp_conv_split_weight_floats(int cout, int num_sources, const int* channels);
 size_t cp_conv_split_weight_bytes(int cout, int num_sources, const int* channels, int planes);

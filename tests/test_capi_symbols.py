@@ -124,7 +124,7 @@ def test_integration_doc_binding_is_current():
 def test_version_and_device_probe(lib):
     from casapose_amd import _lib
 
-    assert lib.cp_version() == _lib.ABI_VERSION == 300
+    assert lib.cp_version() == _lib.ABI_VERSION == 301
     text = open(os.path.join(ROOT, "include", "casapose_hip.h")).read()
     assert int(re.search(r"#define CP_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION
     assert lib.cp_device_count() >= 0  # 0 on the CPU-only build container; never raises
@@ -187,3 +187,34 @@ def test_argument_validation_reports_errors_without_a_gpu(lib):
     assert lib.cp_ls_vote_f32(None, 36, 0, 9, 27, None, 1, 8, 8, 8, 9, None, None, None) == -1
     assert lib.cp_argmax_labels(16, 4, 9, 10, 16, None) == -1  # ld < classes
     assert lib.cp_ls_vote_workspace_bytes(2, 8, 9) == 2 * 8 * 9 * 5 * 8
+
+
+def test_f16x2_range_check_known_answers(lib):
+    """cp_f16x2_range_check (round 6: the band check of the f16x2 range guard behind the C ABI): 0 inside [lo, hi] or for amax == 0, 1 with the power
+    of two that brings amax into [2^10, 2^11), 2 where no power of two in [2^-24, 2^24] does or amax is not finite.  Host function: runs without a GPU."""
+    lo, hi = 0.5, 65504.0 / 4.0
+    r = C.c_float(7.0)
+    for amax in (0.0, 0.5, 1.0, 1353.0, hi):
+        assert lib.cp_f16x2_range_check(amax, lo, hi, C.byref(r)) == 0 and r.value == 1.0, amax
+    for amax, want in ((0.49, 4096.0), (1e-2, 2.0 ** 17), (3e-5, 2.0 ** 26), (16377.0, 2.0 ** -3), (1e5, 2.0 ** -6), (3e3 * 100, 2.0 ** -8), (65504.0 * 4096, 2.0 ** -17)):
+        st = lib.cp_f16x2_range_check(amax, lo, hi, C.byref(r))
+        if want > 2.0 ** 24 or want < 2.0 ** -24:
+            assert st == 2 and r.value == 1.0, (amax, st, r.value)
+            continue
+        assert st == 1 and r.value == want and 1024.0 <= amax * r.value < 2048.0, (amax, st, r.value)
+    for bad in (float("inf"), float("nan"), -1.0, 1e-30, 3e38):
+        assert lib.cp_f16x2_range_check(bad, lo, hi, C.byref(r)) == 2 and r.value == 1.0, bad
+    assert lib.cp_f16x2_range_check(3.0, lo, hi, None) == 0   # the factor is optional
+
+
+def test_f16x2_monitor_slot_is_per_thread_state(lib):
+    import threading
+
+    assert lib.cp_f16x2_monitor_get() is None
+    assert lib.cp_f16x2_monitor_set(4096) == 0 and lib.cp_f16x2_monitor_get() == 4096
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.cp_f16x2_monitor_get()))
+    t.start(); t.join()
+    assert seen == [None]                      # another thread's launches are not armed
+    assert lib.cp_f16x2_monitor_set(4100) == -1 and b"16-byte" in lib.cp_last_error()   # a slot is four words, 16-byte aligned
+    assert lib.cp_f16x2_monitor_set(None) == 0 and lib.cp_f16x2_monitor_get() is None

@@ -204,8 +204,42 @@ def _rccl_worker(port, outdir):
     params, img, lab, kpts = _data()
     plan = TrainPlan(ParamStore(params, dev), K, 27, B, H, W, group=dist.group.WORLD, world_size=1)
     plan.refresh_weights(torch.cuda.current_stream(dev).cuda_stream)
-    out, sums, grad = _run(plan, dev, img, lab, kpts)                    # SyncBN fp64 tables, four asynchronous gradient buckets, all over RCCL
+    plan.start_comm_log()
+    waits = []
+    real_async = parallel.all_reduce_sum_async
+
+    class _Spy:   # the handles of the asynchronous bucket all-reduces: nobody may wait for one before all_reduce_grads()
+        def __init__(self, h):
+            self.h = h
+
+        def wait(self):
+            waits.append(len(plan.comm_log))
+            return self.h.wait()
+
+    parallel.all_reduce_sum_async = lambda t, group=None: _Spy(real_async(t, group))
+    try:
+        out, sums, grad = _run(plan, dev, img, lab, kpts)                # SyncBN fp64 tables, four asynchronous gradient buckets, all over RCCL
+    finally:
+        parallel.all_reduce_sum_async = real_async
     assert plan._buckets is not None and len(plan._buckets) == 4 and not plan._pending
+    # STRUCTURE of the exchange (round-5 verdict, item 8): the overlap with the backward is by construction, not assumed
+    log = plan.comm_log
+    compute = torch.cuda.current_stream(dev).cuda_stream
+    bidx = [i for i, e in enumerate(log) if e[0] == "grad_bucket"]
+    widx = [i for i, e in enumerate(log) if e[0] == "grad_wait"]
+    assert len(bidx) == 4 and len(widx) == 1 and log[widx[0]] == ("grad_wait", 4) and widx[0] > bidx[-1]
+    assert all(w > widx[0] for w in waits) and len(waits) == 4            # every handle is waited for inside all_reduce_grads(), none earlier
+    st = plan.comm_structure()
+    after = st["backward_ops_launched_after_each_bucket"]
+    for k, i in enumerate(bidx):
+        _, nbytes, kind, stream_id, first = log[i]
+        assert kind == "async" and stream_id == compute                   # launched from the compute stream's position in the backward ...
+        assert log[i - 1] == ("op", first)                                 # ... immediately after the op that completes the bucket,
+        assert after[k] == first or (k == 3 and after[k] == 0)             # with `first` backward ops still to be launched behind it
+    assert after[0] > after[1] > after[2] > after[3] == 0                  # decoder 2 | decoder 1 | stage 4 | rest: three of four buckets have work to hide behind
+    assert sum(log[i][1] for i in bidx) == 4 * plan.store.grad.numel() == st["gradient_payload_bytes_per_step"]   # the buckets tile the flat gradient
+    nbn = st["blocking_collectives_per_step"]
+    assert nbn >= 50 and st["blocking_payload_bytes_per_step"] == sum(e[1] for e in log if e[0] == "syncbn") and all(e[2:] == ("blocking", "compute") for e in log if e[0] == "syncbn")
     losses, st = parallel.reduce_step_log([1.0, 2.0, 3.0, 4.0, 5.0], [np.arange(3.0) + j for j in range(8)], 1, dev)
     assert losses == [1.0, 2.0, 3.0, 4.0, 5.0] and st.shape == (6, 3)
     np.savez(os.path.join(outdir, "rccl.npz"), out=out, sums=sums, grad=grad)
