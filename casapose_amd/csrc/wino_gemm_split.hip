@@ -105,9 +105,10 @@ __global__ void split_weights_kernel(const float* __restrict__ U, int groups, in
 // hi*hi, hi*mid, mid*hi): half the MFMAs, for the bf16 conv modes whose gates are 3e-2 -- NOT fp32-equivalent.  NPL = 2 with F16: the fp16
 // two-way split of split_f16.h (operands reproduced to within one fp32 ulp, products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16): fp32-level accuracy
 // with half the MFMAs of the exact bf16 split; the weights come pre-multiplied by a power of two, the accumulators are multiplied by c_scale.
-template <int NPL, bool F16>
+template <int NPL, bool F16, bool MON = false>
 __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p) {
     static_assert(!F16 || NPL == 2, "the fp16 split has two planes");
+    static_assert(!MON || F16, "the range monitor goes with the fp16 split");   // (a compile-time variant: no branch in the producers' counted load / store phases)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE stages][3 splits][128 rows][80 B]
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
         auto store = [&](auto setc, int buf) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             unsigned char* a = smem + buf * STAGE_BYTES + rbase * ROWB + col4 * 8;
-            if (F16 && p.mon) {   // uniform
+            if constexpr (MON) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l_amax = cp::amax4(l_amax, areg[S][i]);
             }
@@ -206,11 +207,9 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_kernel(const SplitK p)
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
         }
-        if constexpr (F16) {
-            if (p.mon) {
-                cp::monitor_flush(p.mon, l_amax);
-                cp::monitor_count_launch(p.mon, tid == 0);
-            }
+        if constexpr (MON) {
+            cp::monitor_flush(p.mon, l_amax);
+            cp::monitor_count_launch(p.mon, tid == 0);
         }
         return;
     }
@@ -394,10 +393,12 @@ extern "C" int cp_wino_gemm_split_scaled_f32(const float* V, const void* Usplit,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_split_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (planes == 3) CP_LAUNCH((wino_gemm_split_kernel<3, false>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
     else if (planes == 2) CP_LAUNCH((wino_gemm_split_kernel<2, false>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
+    else if (g.mon) CP_LAUNCH((wino_gemm_split_kernel<2, true, true>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
     else CP_LAUNCH((wino_gemm_split_kernel<2, true>), dim3(cp::persistent_blocks()), dim3(512), lds, (hipStream_t)stream, g);
     return cp::check_launch("cp_wino_gemm_split_f32");
 }

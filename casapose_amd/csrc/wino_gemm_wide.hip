@@ -53,6 +53,9 @@ struct WideK {
 
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// MON: the producers also fold max |A| into the f16x2 range monitor slot p.mon (a compile-time variant: a run-time branch inside store() would put
+// basic-block boundaries between the DMA pieces and the hand-counted waits that cover them, tests/test_asm_invariants.py)
+template <bool MON>
 __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ast = smem;                   // [NA][2 planes][128 rows][80 B]
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
         auto store = [&](auto setc, int buf) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             unsigned char* a = ast + buf * A_STAGE + rbase * ROWB + col4 * 8;
-            if (p.mon) {   // uniform
+            if constexpr (MON) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l_amax = cp::amax4(l_amax, areg[S][i]);
             }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_wide_kernel(const WideK p) {
             st = (st == 2) ? 0 : st + 1;
             CP_BARRIER();
         }
-        if (p.mon) {
+        if constexpr (MON) {
             cp::monitor_flush(p.mon, l_amax);
             cp::monitor_count_launch(p.mon, tid == 0);
         }
@@ -283,10 +286,12 @@ int wino_gemm_wide_launch(const float* V, const void* Usplit, float* M, int rows
     g.c_scale = c_scale;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    CP_LAUNCH(wino_gemm_wide_kernel, dim3(cp::persistent_blocks()), dim3(512), LDS_BYTES, stream, g);
+    if (g.mon) CP_LAUNCH(wino_gemm_wide_kernel<true>, dim3(cp::persistent_blocks()), dim3(512), LDS_BYTES, stream, g);
+    else CP_LAUNCH(wino_gemm_wide_kernel<false>, dim3(cp::persistent_blocks()), dim3(512), LDS_BYTES, stream, g);
     return cp::check_launch("cp_wino_gemm_split_f32 (wide)");
 }
 

@@ -44,11 +44,28 @@ def hand_waits(lines):
             continue
         n = int(m.group(1))
         k, stop = 0, "start"
-        for j in range(i - 1, -1, -1):
+        j = i
+        while j > 0:
+            j -= 1
             u = lines[j].strip()
-            if re.match(r"^[.\w$]+:", u):                 # a label: other paths join here
-                stop = "label"
-                break
+            lab = re.match(r"^([.\w$]+):", u)
+            if lab:                                        # a label: other paths join here
+                # Round 6: a label reached only by FORWARD branches closes a region that some paths skip -- the loads inside it are not counted (and a
+                # DMA piece inside it ends the walk), the walk continues in front of the earliest of those branches, where every path has passed.
+                # A label that a LATER instruction branches to is a loop header: the walk ends there, as before.
+                name = lab.group(1)
+                srcs = [q for q, v in enumerate(lines) if re.match(r"\s*s_cbranch\w*\s+" + re.escape(name) + r"\s*$", v) or re.match(r"\s*s_branch\s+" + re.escape(name) + r"\s*$", v)]
+                if not srcs:
+                    continue                               # fall-through only
+                if max(srcs) > j:
+                    stop = "label"
+                    break
+                first = min(srcs)
+                if any((" lds" in lines[q]) and lines[q].strip().startswith(("buffer_load", "global_load")) for q in range(first, j)):
+                    stop = "dma"
+                    break
+                j = first                                  # (the branch itself is no memory operation)
+                continue
             if u.startswith(("buffer_load", "global_load")):
                 if u.endswith(" lds") or " lds " in u:
                     stop = "dma"
