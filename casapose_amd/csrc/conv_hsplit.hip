@@ -85,11 +85,22 @@ struct HSplitK {
     uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
     int head_lab_classes;
     float descale, head_descale;   // NP = 2: 1 / (power of two the conv / head weights were multiplied by); 1 otherwise
+    int w_res;                     // 1: head layers keep their whole weight stream LDS-resident where it fits (A/B switch CASAPOSE_HS_WRES)
     int epi_split;                 // 1: the loader wave w + 4 runs the epilogue of row 1 of consumer wave w's rows (accumulators handed over through LDS)
     uint32_t* mon;                 // f16x2 range monitor slot (common.h) or null: max |x| of what the loaders convert -> [0], of the fused head's operand -> [2]
 };
 
+#ifdef HS_TRACE
+// -DHS_TRACE (a variant build): block 0's consumer wave 0 and loader wave 4 stamp the shader clock in front of and behind every barrier into hs_trace[]
+// ([role][2048] entries: even = arrival, odd = release; entry 0 of each role = s_memrealtime at kernel start for calibration), read back through
+// cp_hs_trace_read (exported by that variant only): the time line of the two roles, phase by phase.
+__device__ unsigned long long hs_trace[2][2048];
+#define HST(tag) do { asm volatile("; HST " #tag ::: "memory"); if (hst_on && hst_i < 2046) hs_trace[hst_role][hst_i++] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull); } while (0)
+#define CP_BARRIER() do { HST(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); HST(1); } while (0)
+#else
+#define HST(tag)
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // -DHS_PROFILE (a variant build, tools/build_variant.sh): shader-clock time per section of the consumer / loader waves, summed over all waves into
 // hs_prof[] and read back through cp_hs_profile_read (exported by that variant only).  Sections: consumers 0 tile setup, 1 slice MFMA loops,
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     unsigned char* imgh = smem + 2 * NP * PLANE_B;           // [2 tile parities][NP][HP][8 B]
     unsigned short* labh = reinterpret_cast<unsigned short*>(smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B);   // [2 tile parities][HP]: label | 0xff00 outside the image
     unsigned char* wst = smem + 2 * NP * PLANE_B + 2 * NP * IPLANE_B + 4 * HP;                                // [2 stages][GROUP_B] weight groups
-    unsigned char* hwl = wst + 2 * GROUP_B;                                                                   // [2 steps][NP][1 KB] fused-head weights
+    unsigned char* hwl = wst + ((HEADK && NP <= 2) ? 2 * GROUP_B + IGROUP_B : 2 * GROUP_B);   // (three planes leave no room for the resident form)                                                                   // [2 steps][NP][1 KB] fused-head weights
     // BILINEAR: source 0 is stored at half resolution; the (TH/2 + 2) x (32/2 + 2) source pixels a tile's halo interpolates from are staged
     // as fp32 ([2 stages][LOW_P pixels][16 channels]) and the four taps of every halo pixel come from there -- a slice costs 432 16-byte
     // global loads per block instead of 5440 (round 3: four taps per halo pixel from L2, which is what made the fused form slower than
@@ -286,11 +297,20 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     const int lane = tid & 63;
     const int lrow = lane & 31, kh = lane >> 5;
 
+#ifdef HS_TRACE
+    const int hst_role = wave >= 4 ? 1 : 0;
+    const bool hst_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+    int hst_i = 2;
+    if (hst_on) { hs_trace[hst_role][0] = __builtin_amdgcn_s_memrealtime(); hs_trace[hst_role][1] = __builtin_readcyclecounter(); }
+#endif
     const int bid = cp::xcd_remap(blockIdx.x, gridDim.x);
     const int g = (int)gridDim.x;
     const int my_tiles = (p.ntiles - bid + g - 1) / g;
     if (my_tiles <= 0) return;
-    struct TilePos { int tx, ty, n; };
+    // nb = n % B (the image), pass = n / B (the group of 32 TN output channels), kept by increments: round 6 found the loaders' per-tile requests spending
+    // 1.7-2 k cycles EACH (selection bytes, image halo, label halo, element offsets: 7 k of the 19 k cycles of a tile of block 10, tools/debug/hs_trace.py) --
+    // `inb ? ((tp.n % p.B) * H + y) * W + x : OOB` compiled into a branch per element with the 30-instruction emulated modulo inside it
+    struct TilePos { int tx, ty, n, nb, pass; };
     TilePos first;
     {
         int t = bid;
@@ -298,8 +318,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         t /= p.tiles_x;
         first.ty = t % p.tiles_y;
         first.n = t / p.tiles_y;
+        first.pass = first.n / p.B;
+        first.nb = first.n - first.pass * p.B;
     }
     const int d_tx = g % p.tiles_x, d_ty = (g / p.tiles_x) % p.tiles_y, d_n = g / (p.tiles_x * p.tiles_y);
+    const int d_pass = d_n / p.B, d_nb = d_n - d_pass * p.B;
     auto next_tile = [&](TilePos& t) {
         t.tx += d_tx;
         int cy = 0;
@@ -308,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         int cn = 0;
         if (t.ty >= p.tiles_y) { t.ty -= p.tiles_y; cn = 1; }
         t.n += d_n + cn;
+        t.nb += d_nb + cn;
+        t.pass += d_pass;
+        if (t.nb >= p.B) { t.nb -= p.B; ++t.pass; }
     };
     // TilePos.n runs over passes * B: pass = n / B selects 32*TN output channels (and their weight stream), n % B the image
     const int tile_w_bytes = (p.nch * 9 + (has_img ? 3 : 0)) * TN * (int)FRAG_B;   // one pass's weight stream
@@ -315,6 +341,11 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     const int total_slices = my_tiles * nslices;
     const int ngroups_tile = nslices * GPS + (has_img ? 1 : 0);   // weight groups per tile: GPS per slice + the image block
     const int total_groups = my_tiles * ngroups_tile;
+    // Round 6: RESIDENT weights for the head layers (blocks 5 / 10: two slices + the image block = 42 KB with two operand planes).  Every tile re-staged
+    // the same fragment stream through the loaders' registers -- three requests and three register -> LDS store phases a tile, in the role that
+    // bounds these layers (tools/debug/hs_trace.py: loaders 16-19 k cycles of work a tile against 10-12 k for the consumers).  Staged once per block.
+    constexpr unsigned WRES_B = 2 * GROUP_B + IGROUP_B;
+    const bool wres = HEADK && NP <= 2 && p.w_res != 0 && p.passes == 1 && (unsigned)tile_w_bytes <= WRES_B;
     // Measured (bs 16, A/B in one call): head layers 0.518 -> 0.484 / 0.588 -> 0.555 ms with the split; the generic layers LOSE 10-20 % with their channel
     // groups dealt over the phases (the loaders' phases are the critical ones there) -- so only head layers split unless epi_split == 2 forces it
     // (a fused head outside the HS_HEADK form needs its whole row at once: never dealt)
@@ -389,6 +420,9 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     }
     float e_amax = 0.f, l_amax = 0.f;   // f16x2 range monitor (p.mon): this thread's maxima over the head operand / over what it staged as a loader
     auto flush_mon = [&]() __attribute__((always_inline)) {
+#ifdef HS_TRACE
+        if (hst_on) { hs_trace[hst_role][2046] = __builtin_amdgcn_s_memrealtime(); hs_trace[hst_role][2047] = ((unsigned long long)hst_i << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); }
+#endif
         if constexpr (NP == 2) {
             if (p.mon) {   // uniform
                 cp::monitor_flush(p.mon, l_amax);
@@ -399,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     };
     // pieces: bit j * 4 + g4 set = this call handles that group of four channels (generic form; a head layer's row is one piece)
     auto epilogue = [&](f32x16 (&acc)[2][TN], int r_begin, int r_end, int n, int y0, int x0, int cbase, unsigned pieces) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(n), "+s"(y0), "+s"(x0), "+s"(cbase));   // (pins the tile-dependent arithmetic below to this point: see epilogue_t)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if (r < r_begin || r >= r_end) continue;   // (uniform: the rows of a tile can be divided between a consumer wave and its loader twin)
@@ -608,8 +643,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         auto loader_epilogue = [&](int phase, bool last) __attribute__((always_inline)) {
             if constexpr (CAN_SPLIT) {
                 if (phase == 0 || last) {   // latch the owed tile's position and labels (its label halo is overwritten later in this tile)
-                    const int pass = etile.n / p.B;
-                    e_n = etile.n - pass * p.B; e_y0 = etile.ty * TH; e_x0 = etile.tx * 32; e_cbase = pass * 32 * TN;
+                    const int pass = etile.pass;
+                    e_n = etile.nb; e_y0 = etile.ty * TH; e_x0 = etile.tx * 32; e_cbase = pass * 32 * TN;
                     if (has_lab) read_labels(e_k & 1);
                 }
                 unsigned pieces;
@@ -654,18 +689,42 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             e_lds[it] = (unsigned)(pix * 32 + (((q >> 1) ^ ((pix >> 3) & 1)) * 16) + (q & 1) * 8);
         }
         const int q4 = (tid & 3) * 4;
+        // Round 6: per-tile requests by strength reduction.  An element's pixel is (tile base) + (its own offset inside the halo): e_pof = hy * W + hx for
+        // the full-resolution sources and maps, e_sof = ((hy - 1) >> 1) * Ws + ((hx - 1) >> 1) for the half-resolution source of a guided x2 input (a
+        // tile starts at an odd image row / column minus ... : y = 8 ty - 1 + hy, so y >> 1 = 4 ty + ((hy - 1) >> 1)); a tile that does not touch the
+        // image border (most) needs no range test per element.  Before, every request recomputed ((n H + y) W + x) and its range test per element
+        // with three integer multiplies each: ~700 instructions per tile in the loaders of a head layer, 7 k of its 19 k cycles (tools/debug/hs_trace.py).
+        int e_pof[NIT], e_sof[NIT];
+        bool e_ok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            e_ok[it] = e_hy[it] < 0x4000;
+            e_pof[it] = e_ok[it] ? e_hy[it] * p.Wd + e_hx[it] : 0;
+            e_sof[it] = (SEL && e_ok[it]) ? ((e_hy[it] - 1) >> 1) * p.s[0].Ws + ((e_hx[it] - 1) >> 1) : 0;
+        }
+        auto tile_interior = [&](const TilePos& tp) { return tp.ty > 0 && tp.tx > 0 && tp.ty * TH + TH + 1 <= p.H && tp.tx * 32 + 33 <= p.Wd; };
         float4 lv[NIT][NV];
         float4 liv[NIMG];
         int selb[NIT];       // SEL: the selection byte of this element's pixel (constant over the slices of a tile)
         const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(SEL ? (const void*)p.s[0].sel : (const void*)p.W), 0,
                                                                               SEL ? p.lab_bytes : 0u, 0x00020000);
+        // Round 6: the selection bytes of a tile are requested ONE TILE AHEAD (selb_nx).  They feed the tile's element offsets, so requesting them with
+        // the tile itself put a whole memory round trip into the loaders' path once per tile -- 4-6 k cycles of the 19 k a tile of block 10 takes,
+        // with the consumers waiting at the barrier meanwhile (tools/debug/hs_trace.py: the "issue" section of that phase 6.0 k against 0.6-0.9 k).
+        int selb_nx[NIT];
         auto issue_sel = [&](const TilePos& tp) {
             if constexpr (SEL) {
+                const int tb = (tp.nb * p.H + tp.ty * TH - 1) * p.Wd + tp.tx * 32 - 1;   // (uniform)
+                if (tile_interior(tp)) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int y = tp.ty * TH - 1 + e_hy[it], x = tp.tx * 32 - 1 + e_hx[it];
-                    const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                    selb[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? (((tp.n % p.B) * p.H + y) * p.Wd + x) : (int)OOB, 0, 0);
+                    for (int it = 0; it < NIT; ++it) selb_nx[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, e_ok[it] ? tb + e_pof[it] : (int)OOB, 0, 0);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int y = tp.ty * TH - 1 + e_hy[it], x = tp.tx * 32 - 1 + e_hx[it];
+                        const bool inb = ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.Wd);
+                        selb_nx[it] = __builtin_amdgcn_raw_buffer_load_b8(rss, inb ? tb + e_pof[it] : (int)OOB, 0, 0);
+                    }
                 }
             }
         };
@@ -673,20 +732,28 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // once per tile: a slice only adds its uniform channel offset through the load's scalar offset -- no per-slice address arithmetic
         unsigned eo0[NIT][NV], eo1[NIT];
         auto tile_offsets = [&](const TilePos& tp) {
-            const int n = tp.n % p.B, y0 = tp.ty * TH, x0 = tp.tx * 32;
+            const int y0 = tp.ty * TH, x0 = tp.tx * 32;
+            const int tb = (tp.nb * p.H + y0 - 1) * p.Wd + x0 - 1;                                           // (uniform) pixel of the halo's corner
+            const int sb = SEL ? (tp.nb * p.s[0].Hs + (TH / 2) * tp.ty) * p.s[0].Ws + 16 * tp.tx : 0;        // ... and of its half-resolution source
+            const unsigned ld0b = (unsigned)p.s[0].ld * 4u, ld1b = (unsigned)p.s[1].ld * 4u, q4b = (unsigned)q4 * 4u;
+            const bool interior = tile_interior(tp);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
-                const bool inb = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                const unsigned pixel = (unsigned)((n * p.H + y) * p.Wd + x);
-                eo1[it] = inb ? (pixel * (unsigned)p.s[1].ld + (unsigned)q4) * 4u : OOB;
+                bool inb = e_ok[it];
+                if (!interior) {   // (uniform)
+                    const int y = y0 - 1 + e_hy[it], x = x0 - 1 + e_hx[it];
+                    inb = ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.Wd);
+                }
+                const unsigned pixel = (unsigned)(tb + e_pof[it]);
+                eo1[it] = inb ? pixel * ld1b + q4b : OOB;
                 if constexpr (BILINEAR) {
                     eo0[it][0] = OOB;   // source 0 goes through the low-resolution LDS tile (bilinear loader below)
                 } else if constexpr (SEL) {
                     const int sl = selb[it];
-                    eo0[it][0] = inb ? (unsigned)((((n * p.s[0].Hs + (y >> 1) + (sl >> 1)) * p.s[0].Ws + (x >> 1) + (sl & 1)) * p.s[0].ld + q4) * 4) : OOB;
+                    const unsigned sp = (unsigned)(sb + e_sof[it] + ((sl & 2) ? p.s[0].Ws : 0) + (sl & 1));
+                    eo0[it][0] = inb ? sp * ld0b + q4b : OOB;
                 } else {
-                    eo0[it][0] = inb ? (pixel * (unsigned)p.s[0].ld + (unsigned)q4) * 4u : OOB;
+                    eo0[it][0] = inb ? pixel * ld0b + q4b : OOB;
                 }
             }
         };
@@ -730,13 +797,29 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 store_planes<NP>(h + e_lds[it], PLANE_B, lv[it][0]);
             }
         };
+        // pixel elements (image halo, label halo): one per halo pixel, same strength reduction as the channel elements above
+        int i_hy[NIMG], i_hx[NIMG], i_pof[NIMG];
+        bool i_ok[NIMG];
+#pragma unroll
+        for (int it = 0; it < NIMG; ++it) {
+            const int pix = it * 256 + tid;
+            i_ok[it] = pix < HP;
+            i_hy[it] = pix / COLS;
+            i_hx[it] = pix % COLS;
+            i_pof[it] = i_ok[it] ? i_hy[it] * p.Wd + i_hx[it] : 0;
+        }
+        auto pixel_inb = [&](const TilePos& tp, int it, bool interior) -> bool {
+            if (interior) return i_ok[it];
+            const int y = tp.ty * TH - 1 + i_hy[it], x = tp.tx * 32 - 1 + i_hx[it];
+            return i_ok[it] & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.Wd);
+        };
         auto issue_img = [&](const TilePos& tp) {
+            const int tb = (tp.nb * p.H + tp.ty * TH - 1) * p.Wd + tp.tx * 32 - 1;
+            const bool interior = tile_interior(tp);
 #pragma unroll
             for (int it = 0; it < NIMG; ++it) {
-                const int pix = it * 256 + tid;
-                const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
-                const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)((((tp.n % p.B) * p.H + y) * p.Wd + x) * 16) : OOB), 0, 0));
+                const bool inb = pixel_inb(tp, it, interior);
+                liv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsi, (int)(inb ? (unsigned)(tb + i_pof[it]) * 16u : OOB), 0, 0));
             }
         };
         auto store_img = [&](int parity) {
@@ -757,12 +840,12 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                                                                                 has_lab_l ? p.lab_bytes : 0u, 0x00020000);
         int llab[NIMG];
         auto issue_lab = [&](const TilePos& tp) {
+            const int tb = (tp.nb * p.H + tp.ty * TH - 1) * p.Wd + tp.tx * 32 - 1;
+            const bool interior = tile_interior(tp);
 #pragma unroll
             for (int it = 0; it < NIMG; ++it) {
-                const int pix = it * 256 + tid;
-                const int y = tp.ty * TH - 1 + pix / COLS, x = tp.tx * 32 - 1 + pix % COLS;
-                const bool inb = pix < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
-                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? (((tp.n % p.B) * p.H + y) * p.Wd + x) : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
+                const bool inb = pixel_inb(tp, it, interior);
+                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? tb + i_pof[it] : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
             }
         };
         auto store_lab = [&](int parity) {
@@ -781,6 +864,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         const int g_q = g / p.tiles_per_pass, g_r = g % p.tiles_per_pass;
         auto issue_w = [&](int gg) {   // global group index -> group of the tile (wide groups first, the image block's group last)
             (void)gg;   // (groups are requested in order)
+            if (wres) return;   // (uniform) the whole stream is resident
             const int lgw = w_lg, pass = w_pass;   // this block's current tile belongs to that pass of output channels
             if (++w_lg == ngroups_tile) {
                 w_lg = 0;
@@ -797,6 +881,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             }
         };
         auto store_w = [&](int stage) {
+            if (wres) return;
 #pragma unroll
             for (int it = 0; it < NWL; ++it) {
                 const unsigned o = (unsigned)(it * 256 + tid) * 16u;
@@ -815,10 +900,18 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 next_tile(ftile);
             }
         };
-        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its element offsets, image halo, label halo, selection bytes
+        auto issue_tile_extras = [&]() {   // with slice 0 of a tile: its element offsets, image halo, label halo; the NEXT tile's selection bytes
             if (fc != 0) return;
-            issue_sel(ftile);
+            if constexpr (SEL) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) selb[it] = selb_nx[it];   // requested a tile ago
+            }
             tile_offsets(ftile);
+            if constexpr (SEL) {
+                TilePos nt = ftile;
+                next_tile(nt);       // (past the block's last tile: a valid address of some other tile, or out of range -- never used)
+                issue_sel(nt);
+            }
             if (has_img) issue_img(ftile);
             if (has_lab_l) issue_lab(ftile);
             img_pending = true;
@@ -829,6 +922,12 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             if (has_lab_l) store_lab(fk & 1);
             img_pending = false;
         };
+        if constexpr (HEADK) {
+            if (wres) {   // the tile's whole fragment stream, staged once (group g at g * GROUP_B, the image block's group behind the slices')
+                for (unsigned o = (unsigned)tid * 16u; o < (unsigned)tile_w_bytes; o += 256u * 16u)
+                    *reinterpret_cast<u32x4*>(wst + o) = __builtin_amdgcn_raw_buffer_load_b128(rsw_l, (int)o, 0, 0);
+            }
+        }
         if (head) {   // the fused head's weights: 2 steps x NP KB, staged once
             const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, 2u * NP * 1024u, 0x00020000);
             for (unsigned o = (unsigned)tid * 16u; o < 2u * NP * 1024u; o += 256u * 16u)
@@ -863,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             auto issue_low = [&](const Cur& u) {
                 if (u.k != elo_k) {   // first low-resolution slice of a tile: the tile's source offsets (edge-clamped, as the reference's resize)
                     elo_k = u.k;
-                    const int n = u.t.n % p.B, ys0 = u.t.ty * (TH / 2) - 1, xs0 = u.t.tx * 16 - 1;
+                    const int n = u.t.nb, ys0 = u.t.ty * (TH / 2) - 1, xs0 = u.t.tx * 16 - 1;
                     const int Hs = p.s[0].Hs, Ws = p.s[0].Ws;
 #pragma unroll
                     for (int it = 0; it < NLO; ++it) {
@@ -1018,6 +1117,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
                 if (slice_phase && cb.s < total_slices && cb.c < p.nch0) store_low(cb.s & 1);
                 HSP(0);
+                HST(2);
                 if (more_w && gg + 2 < total_groups) issue_w(gg + 2);
                 if (slice_phase) {
                     if (cb.s < total_slices) {
@@ -1029,8 +1129,10 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     }
                     step_c(cc);
                     HSP(2);
+                    HST(3);
                     if (a_live && ca.c < p.nch0) interp(ca);
                     HSP(3);
+                    HST(4);
                     step(ca);
                     step(cb);
                     step(cc);
@@ -1038,6 +1140,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 if (esplit && gg >= ngroups_tile) loader_epilogue(lg, false);   // row 1 of the tile before, beside the consumers' work on this one
                 if (++lg == ngroups_tile) lg = 0;
                 HSP(2);
+                HST(5);
                 CP_BARRIER();
                 HSP(1);
             }
@@ -1046,6 +1149,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             flush_mon();
             return;
         }
+        issue_sel(first);
         issue_tile_extras();
         issue_slice(ftile, 0);
         issue_w(0);
@@ -1086,14 +1190,17 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
                 ++gs;
             }
-            if (kStoresFirst && more_w && gg + 2 < total_groups) issue_w(gg + 2);
-            if (fetch) {
+            HST(2);
+            if (fetch) {   // (round 6: in front of this phase's weight request -- everything the new tile's requests wait for is then a phase old)
                 advance();
                 issue_tile_extras();
                 issue_slice(ftile, fc);
                 ++issued;
             }
+            if (kStoresFirst && more_w && gg + 2 < total_groups) issue_w(gg + 2);
+            HST(3);
             if (esplit && gg >= ngroups_tile) loader_epilogue(lg, false);   // row 1 of the tile before, beside the consumers' work on this one
+            HST(5);
             if (++lg == ngroups_tile) lg = 0;
             HSP(0);
             CP_BARRIER();
@@ -1163,8 +1270,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     HSP_DECL;
     int gs = 0, gg = 0;   // global slice / group counters
     for (int k = 0; k < my_tiles; ++k) {
-        const int pass = ctile.n / p.B;
-        const int n = ctile.n - pass * p.B, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
+        const int pass = ctile.pass;
+        const int n = ctile.nb, y0 = ctile.ty * TH, x0 = ctile.tx * 32;
         const int cbase = pass * 32 * TN;   // first output channel of this pass
         next_tile(ctile);
         if (has_lab) read_labels(k & 1);
@@ -1191,7 +1298,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             };
 #pragma unroll
             for (int g3 = 0; g3 < GPS; ++g3, ++gg) {   // GPS groups of GT taps, a barrier after each (the weight stage flips)
-                const unsigned char* wg = wst + (gg & 1) * GROUP_B;
+                const unsigned char* wg = wst + (wres ? (unsigned)(c * GPS + g3) : (unsigned)(gg & 1)) * GROUP_B;
                 read_a(g3 * GT, 0);
                 ldw(wg, 0, 0);
                 hs_static_for<0, GT>([&](auto stc) {
@@ -1236,7 +1343,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 if (g3 == GPS - 1 && c + 1 == nslices && !has_img && p.B < 0) finish_tile(n, y0, x0, cbase);   // timing experiment: never true, keeps the accumulators alive
 #else
                 HSP(1);
-                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) { finish_tile(n, y0, x0, cbase); HSP(3); }
+                HST(2);
+                if (g3 == GPS - 1 && c + 1 == nslices && !has_img) { finish_tile(n, y0, x0, cbase); HSP(3); HST(4); }
 #endif
                 CP_BARRIER();
                 HSP(4);
@@ -1245,7 +1353,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         // ---- image block: K = 9 taps x 4 channels (+12 zero) = 3 steps, lane half kh covers taps 4s+2kh, +1 ----
         if (has_img) {
             const unsigned char* ib = imgh + (k & 1) * (NP * IPLANE_B);
-            const unsigned char* wg = wst + (gg & 1) * GROUP_B;
+            const unsigned char* wg = wst + (wres ? (unsigned)(nslices * GPS) : (unsigned)(gg & 1)) * GROUP_B;
             ldw(wg, 0, 0);
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
@@ -1280,11 +1388,13 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                 }
             }
             HSP(2);
+            HST(3);
 #ifdef HS_NOEPI
             if (p.B < 0)
 #endif
             finish_tile(n, y0, x0, cbase);
             HSP(3);
+            HST(4);
             ++gg;
             CP_BARRIER();
             HSP(4);
@@ -1305,6 +1415,7 @@ int launch_hsplit(HSplitK k, hipStream_t st) {
     // halo 65 KB + image halo 16 KB + labels 1.4 KB + weight groups 54 / 36 KB (three planes): one block of 8 waves per CU
     size_t lds = (size_t)2 * NP * PLANE_B + (size_t)2 * NP * IPLANE_B + (size_t)2 * HP * 2 + (size_t)2 * hs_group_taps(TN, NP) * TN * NP * 1024 +
                  (size_t)2 * NP * 1024;   // + the fused head's weights
+    if ((MODE & HS_HEADK) && NP <= 2) lds += (size_t)3 * TN * NP * 1024;   // + room for the image block's group behind two slice groups (resident weights)
     if (MODE & HS_BILINEAR) lds += (size_t)2 * ((HR / 2 + 1) * (COLS / 2 + 1)) * 64;   // + two low-resolution stages of source 0
     lds += (size_t)2 * 512 * 4;                                                         // + the per-channel normalisation table (TAB_C)
     if (NP <= 2 && TN == 1) lds += (size_t)4 * TN * 4 * 1024 * ((MODE & HS_HEADK) ? 2 : 1);   // + the accumulator hand-over(s) of the epilogue split
@@ -1512,6 +1623,10 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
         static const int split_env = getenv("CASAPOSE_HS_EPI_SPLIT") ? atoi(getenv("CASAPOSE_HS_EPI_SPLIT")) : 1;
         k.epi_split = split_env;
     }
+    {
+        static const int wres_env = getenv("CASAPOSE_HS_WRES") ? atoi(getenv("CASAPOSE_HS_WRES")) : 1;
+        k.w_res = wres_env;
+    }
     const int np = planes & 15;
     const int tn = split_tn(d->cout);
     const bool headk = tn == 1 && d->head_out && !d->residual && !d->out_raw && !d->out_act && d->scale && d->act == CP_ACT_LEAKY01 && d->cout == 32;
@@ -1536,6 +1651,12 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     cp::set_error("cp_conv2d_fwd_split: operand mode %d is not instantiated", mode);
     return CP_ERR_INVALID;
 }
+
+#ifdef HS_TRACE
+extern "C" int cp_hs_trace_read(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hs_trace), sizeof(unsigned long long) * 2 * 2048) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef HS_PROFILE
 extern "C" int cp_hs_profile_read(unsigned long long* host_out, int reset) {
