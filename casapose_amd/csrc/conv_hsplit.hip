@@ -838,21 +838,22 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
         const bool has_lab_l = PARTIAL || p.clade;
         const __amdgpu_buffer_rsrc_t rsl_l = __builtin_amdgcn_make_buffer_rsrc((void*)(has_lab_l ? (const void*)p.label : (const void*)p.W), 0,
                                                                                 has_lab_l ? p.lab_bytes : 0u, 0x00020000);
-        int llab[NIMG];
+        int llab[NIMG], llab_out[NIMG];
         auto issue_lab = [&](const TilePos& tp) {
             const int tb = (tp.nb * p.H + tp.ty * TH - 1) * p.Wd + tp.tx * 32 - 1;
             const bool interior = tile_interior(tp);
 #pragma unroll
             for (int it = 0; it < NIMG; ++it) {
                 const bool inb = pixel_inb(tp, it, interior);
-                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? tb + i_pof[it] : (int)OOB, 0, 0) | (inb ? 0 : 0xff00);
+                llab[it] = __builtin_amdgcn_raw_buffer_load_b8(rsl_l, inb ? tb + i_pof[it] : (int)OOB, 0, 0);
+                llab_out[it] = inb ? 0 : 0xff00;   // (round 6: OR-ed in by store_lab -- here the OR waited for the load just issued, a round trip per tile)
             }
         };
         auto store_lab = [&](int parity) {
 #pragma unroll
             for (int it = 0; it < NIMG; ++it) {
                 const int pix = it * 256 + tid;
-                if (pix < HP) labh[parity * HP + pix] = (unsigned short)llab[it];
+                if (pix < HP) labh[parity * HP + pix] = (unsigned short)(llab[it] | llab_out[it]);
             }
         };
         // weight groups: the tile's fragment stream is contiguous in memory, GROUP_B bytes per group; every tile reads the same stream
