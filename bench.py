@@ -441,9 +441,9 @@ def _dtype_note_train():
     note = "f32"
     if parts:
         note += " (%s as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)" % " and ".join(parts)
-    if conv == "split" and os.environ.get("CASAPOSE_TRAIN_FWD", "split") == "f16x2":
+    if conv == "split" and os.environ.get("CASAPOSE_TRAIN_FWD", "f16x2") == "f16x2":
         note += ("; FORWARD launches of those groups as fp16 two-way splits on v_mfma_f32_32x32x16_f16 (three exact products per fp32 product, fp32-level error: "
-                 "tests/test_gpu_f16x2.py), backward launches as exact bf16 splits")
+                 "tests/test_gpu_f16x2.py; the operands' range watched by a device-side monitor, train_engine.TrainPlan._poll_f16x2), backward launches as exact bf16 splits")
     if conv == "bf16":
         note = "bf16 operands / f32 accumulate in the forward / data gradient / weight gradient of the 3x3 layers off the Winograd path; " + note + " elsewhere"
     return note
@@ -1098,6 +1098,17 @@ def main():
             leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
             result["training_leg"] = {k: leg[k] for k in keys}
             _log("training leg done: %.2f ms/step" % leg["ms_per_step"])
+            if "CASAPOSE_TRAIN_FWD" not in os.environ and "CASAPOSE_CONV_MODE" not in os.environ:
+                # the same steps with the EXACT three-way bf16 split in the forward too (the default of rounds 2-5; round 6 runs the forward in the fp16
+                # two-way split -- fp32-level, range-monitored -- and keeps the exact split in the backward)
+                os.environ["CASAPOSE_TRAIN_FWD"] = "split"
+                try:
+                    torch.cuda.empty_cache()
+                    leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
+                    result["training_leg_exact_split_forward"] = {k: leg[k] for k in keys}
+                    _log("exact-forward training leg done: %.2f ms/step" % leg["ms_per_step"])
+                finally:
+                    del os.environ["CASAPOSE_TRAIN_FWD"]
             if "CASAPOSE_CONV_MODE" not in os.environ:
                 # BASELINE configs[2] AS NAMED ("bs=32 bf16 convs"): the same three steps with the operands of the convolutions rounded to bf16
                 # (fp32 accumulate; gates 3e-2 on outputs + the convergence test, tests/test_gpu_train.py) beside the fp32-equivalent default
