@@ -659,6 +659,11 @@ def wino_eligible(kh: int, stride: int, dilation: int, pad: int, sources: Sequen
     direct_128 = f16x2 if WINO_DIRECT_UNDILATED_128 == "" else WINO_DIRECT_UNDILATED_128 == "1"
     if direct_128 and dilation == 1 and split_gemm and not WINO_MIN_K:
         min_k = 256
+        # Round 6 (tools/debug/wino_parts.py, bs 16): decoder block 2 (384 -> 128, undilated) takes 88 + 87 + 25 us as input transform + GEMM + output
+        # transform and 178 us on the direct f16x2 kernel (the same shape with a tap mask, block 7, runs there already): with <= 128 output channels
+        # the GEMM's M traffic is small but V (2.25 x the 384-channel input in fp32) is not.  Undilated layers of that width go direct whatever K.
+        if cout <= 128:
+            return False
     return kh == 3 and stride == 1 and pad == dilation and k >= min_k and k % 32 == 0 and cout >= WINO_MIN_COUT and cout % 4 == 0
 
 
