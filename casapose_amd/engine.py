@@ -499,22 +499,24 @@ class WinoConv:
         self._keep = [V, M, residual, scale, shift, epi_label, out_raw, out_act] + [s["data"] for s in srcs]
         return in_h, in_w
 
-    def _armed(self, ptr: Optional[int]):
+    class _Armed:
         """context: the transform launched inside reports max |V| of what it writes into the monitor slot at `ptr` (None: nothing armed)"""
-        import contextlib
+        __slots__ = ("ptr",)
 
-        @contextlib.contextmanager
-        def cm():
-            lib = _lib.load()
-            if not ptr or WINO_GROUPED_CONV:   # (the grouped mode of the general kernel converts nothing to fp16)
-                yield
-                return
-            lib.cp_f16x2_monitor_set(ptr)
-            try:
-                yield
-            finally:
-                lib.cp_f16x2_monitor_set(None)
-        return cm()
+        def __init__(self, ptr):
+            self.ptr = None if WINO_GROUPED_CONV else ptr   # (the grouped mode of the general kernel converts nothing to fp16)
+
+        def __enter__(self):
+            if self.ptr:
+                _lib.load().cp_f16x2_monitor_set(self.ptr)
+
+        def __exit__(self, *exc):
+            if self.ptr:
+                _lib.load().cp_f16x2_monitor_set(None)
+            return False
+
+    def _armed(self, ptr: Optional[int]):
+        return WinoConv._Armed(ptr)
 
     def _input_transform(self, src_ptr: int, ld: int, cpad: int, nb: int, off: int, stream: int):
         """V[.., off : off + cpad] = B^T d B of one source; with v_scale != 1 through the transform's per-channel input affine (x * 2^e + 0: exact)"""
@@ -986,13 +988,16 @@ class ForwardPlan:
         elif fresh:
             self._mon.zero_()
         base = self._mon.data_ptr()
+        only = os.environ.get("CASAPOSE_F16X2_MONITOR_ONLY", "")   # (measurement aid: arm one kernel family only -- "wino", "fused" or a layer-name prefix)
         for i, c in enumerate(self.convs):
             c.mon_ptr = base + 16 * i
+            if only and not ((only == "wino" and isinstance(c, WinoConv)) or (only == "fused" and isinstance(c, FusedConv)) or c.name.startswith(only)):
+                c.mon_ptr = None
         try:
             for step in self.steps:
                 step(stream)
         finally:
-            for c in self.convs:
+            for c in self.convs:   # (never left attached: a layer run outside a plan's forward must not write into a plan's slots)
                 c.mon_ptr = None
 
     def _judge(self, words: np.ndarray, lo: float, hi: float):
