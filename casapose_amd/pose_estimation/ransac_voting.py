@@ -10,7 +10,31 @@ import torch
 from .. import _lib
 from .._lib import check
 
-_DEVICE_GENERATOR_CALLS: dict = {}   # id(CUDA generator) -> voter calls made with it (seed = f(initial_seed, call number); see below)
+# The seed of a call made with a DEVICE generator is f(initial_seed, the generator's Philox offset), and the call advances that offset by four -- host-side
+# bookkeeping of the generator (get_offset / set_offset never touch the device), so the voter consumes the generator like any other sampler without a
+# synchronisation: `manual_seed(s)` restarts the sequence, `get_state()` / `set_state()` capture and restore it (a private call counter
+# keyed by id(generator) did neither, and could be inherited by a new generator at a recycled id).  Where a build has no offset accessors the old
+# counter remains as a fallback, now tied to the initial_seed it counts for.
+_DEVICE_GENERATOR_CALLS: dict = {}   # fallback only: id(generator) -> [initial_seed, calls]
+
+
+def _device_generator_seed(generator: torch.Generator) -> int:
+    seed0 = int(generator.initial_seed())
+    try:
+        off = int(generator.get_offset())
+        generator.set_offset(off + 4)
+        return (seed0 * 0x9E3779B97F4A7C15 + off // 4 + 1) % (2**62)
+    except (RuntimeError, AttributeError, NotImplementedError):
+        pass
+    key = id(generator)
+    ent = _DEVICE_GENERATOR_CALLS.pop(key, None)
+    if ent is None or ent[0] != seed0:
+        ent = [seed0, 0]
+    _DEVICE_GENERATOR_CALLS[key] = ent            # (re-inserted: most recently used last)
+    while len(_DEVICE_GENERATOR_CALLS) > 64:
+        _DEVICE_GENERATOR_CALLS.pop(next(iter(_DEVICE_GENERATOR_CALLS)))
+    ent[1] += 1
+    return (seed0 * 0x9E3779B97F4A7C15 + ent[1]) % (2**62)
 
 
 def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, round_hyp_num: int, inlier_thresh: float = 0.99,
@@ -44,8 +68,7 @@ def ransac_voting_layer_all_masks(mask: torch.Tensor, vertex: torch.Tensor, roun
     rounds = torch.empty(b, oc, dtype=torch.int32, device=mask.device)
     if draws is None:
         if generator is not None and generator.device.type != "cpu":
-            calls = _DEVICE_GENERATOR_CALLS[id(generator)] = _DEVICE_GENERATOR_CALLS.get(id(generator), 0) + 1
-            seed = (int(generator.initial_seed()) * 0x9E3779B97F4A7C15 + calls) % (2**62)
+            seed = _device_generator_seed(generator)
         else:
             seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64, generator=generator).item())   # CPU generator: no device synchronisation
         check(lib.cp_ransac_vote_seeded_f32(labels.data_ptr(), vert.data_ptr(), vert.shape[3], 0, b, h, w, oc, vn, seed, round_hyp_num, float(inlier_thresh),

@@ -219,6 +219,17 @@ def test_ransac_seeded_voter_draws_and_thins_inside_the_library(device):
     t1, t1b, t2 = vote(1, max_num=400), vote(1, max_num=400), vote(2, max_num=400)
     assert torch.equal(t1, t1b) and float((t1 - want).abs().max()) < 0.05 and float((t2 - want).abs().max()) < 0.05
     assert not torch.equal(t1, a)
-    # a CUDA generator is accepted as well
-    d = ransac_voting_layer_all_masks(mask, vert, 128, generator=torch.Generator(device=device).manual_seed(5))
+    # a CUDA generator is accepted as well, and is CONSUMED like by any sampler (round 6: its Philox offset advances per call, on the host): a second call
+    # draws differently, manual_seed restarts the sequence, get_state / set_state capture and restore it
+    gd = torch.Generator(device=device).manual_seed(5)
+    dv = lambda: ransac_voting_layer_all_masks(mask, vert, 128, generator=gd, max_num=400)   # noqa: E731  (thinned: the draws decide which pixels the refinement sums)
+    d = dv()
+    d2 = dv()
+    state = gd.get_state()
+    d3 = dv()
+    gd.set_state(state)
+    d3b = dv()
+    gd.manual_seed(5)
+    d1b = dv()
+    assert torch.equal(d, d1b) and torch.equal(d3, d3b) and not torch.equal(d, d2)
     assert float((d - want).abs().max()) < 0.05
