@@ -101,6 +101,9 @@ __device__ unsigned long long hs_trace[2][2048];
 #define HST(tag)
 #define CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+#ifndef HS_EPI_AUX
+#define HS_EPI_AUX 0   // cache policy bits of the generic epilogue's stores (variant builds: 2 = nt, 1 = sc0, 16 = sc1)
+#endif
 
 // -DHS_PROFILE (a variant build, tools/build_variant.sh): shader-clock time per section of the consumer / loader waves, summed over all waves into
 // hs_prof[] and read back through cp_hs_profile_read (exported by that variant only).  Sections: consumers 0 tile setup, 1 slice MFMA loops,
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     v.z = acc[r][j][g4 * 4 + 2] * f + res[g4].z;
                     v.w = acc[r][j][g4 * 4 + 3] * f + res[g4].w;
                     if (has_raw)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_raw, (int)(ok ? (pix * (unsigned)p.raw_ld + (unsigned)ch) * 4u : OOB), 0, HS_EPI_AUX);
                     float4 t = v;
                     if (has_tab) {
                         t.x = v.x * esc[g4].x + esh[g4].x;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                         t.x = leaky01(t.x); t.y = leaky01(t.y); t.z = leaky01(t.z); t.w = leaky01(t.w);
                     }
                     if (has_act)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r_act, (int)(ok ? (pix * (unsigned)p.act_ld + (unsigned)ch) * 4u : OOB), 0, HS_EPI_AUX);
                     if (j == 0) {
                         keep[g4].x = ok ? t.x : 0.f;
                         keep[g4].y = ok ? t.y : 0.f;
