@@ -17,8 +17,10 @@ def timed(fn, reps=20):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 sums = torch.zeros(72, dtype=torch.float64, device=dev)
+slot = torch.zeros(4, dtype=torch.int32, device=dev)
 for name, fn in (("torch.sum", lambda: x.sum()), ("torch.amax", lambda: x.amax()),
                  ("cp_bn_stats_f32 (36 channels)", lambda: _lib.check(lib.cp_bn_stats_f32(x.data_ptr(), x.numel() // 36, 36, 36, sums.data_ptr(), st))),
+                 ("cp_amax_f32 (the new reduction entry point)", lambda: _lib.check(lib.cp_amax_f32(x.data_ptr(), 1, 0, x.numel(), slot.data_ptr(), st))),
                  ("copy (read + write)", lambda: x.clone())):
     t = timed(fn)
     print("%-32s %7.1f us  %5.2f TB/s%s" % (name, t * 1e6, nbytes / t / 1e12, " (x2 bytes moved)" if "copy" in name else ""))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-layer table of the current tree (+ optional env A/B given as arguments, "-" = defaults) and the quick parity tests
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06_lt; mkdir -p $O
+O=gpurun_out/lt_ab; mkdir -p $O
 if [ "${TESTS:-1}" = "1" ]; then timeout 1200 python -m pytest tests/test_gpu_hsplit.py tests/test_gpu_forward.py tests/test_gpu_conv.py -m gpu -x -q 2>&1 | tail -5; fi
 for v in "${@:--}"; do
   ( if [ "$v" != "-" ]; then export $v; fi

@@ -1,7 +1,7 @@
 #!/bin/bash
 # training: gradient tests in the new default (f16x2 forward, monitored) and the step time beside the exact forward, one call
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06_train; mkdir -p $O
+O=gpurun_out/train_ab; mkdir -p $O
 timeout 1800 python -m pytest tests/test_gpu_train.py tests/test_gpu_fullsize.py tests/test_gpu_dp.py tests/test_gpu_scripts.py -m gpu -q -x 2>&1 | tail -8 | tee $O/tests.txt
 for v in "-" "CASAPOSE_TRAIN_FWD=split" "-" "CASAPOSE_TRAIN_FWD=split"; do
   ( if [ "$v" != "-" ]; then export $v; fi

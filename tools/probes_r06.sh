@@ -1,0 +1,28 @@
+#!/bin/bash
+# ONE GPU-box call for the round-6 probe outputs DESIGN.md argues from -> gpurun_out/r06_probes/ -> copy into profiles/probes/ (each file starts with a stamp line)
+#   hsplit_trace.txt     time line of conv_hsplit's two roles per barrier phase (HS_TRACE variant; build it here first:
+#                        FILES=conv_hsplit bash tools/build_variant.sh HS_TRACE -DHS_TRACE)
+#   wino_parts.txt       input transform / GEMM / output transform of every Winograd layer, timed separately, with the bytes each moves
+#   hbm_read_probe.txt   what a pure read stream of the LS voter's 708 MB achieves on the box (the voter's ceiling)
+#   monitor_cost.txt     the forward with and without the always-armed f16x2 range monitor, alternating, one call
+set -u
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_probes; rm -rf $O; mkdir -p $O; cd $R
+STAMP="# stamp $(python3 bench.py --stamp)   ($(date -u +%Y-%m-%dT%H:%MZ), tools/probes_r06.sh)"
+{ echo "$STAMP"; echo "# tools/debug/hs_trace.py (HS_TRACE variant of conv_hsplit): block 0, consumer wave 0 / loader wave 4; per barrier phase 'tag:cycles since the previous stamp'"
+  echo "# consumers: 2 slice MFMA loop done, 3 image block done, 4 epilogue done, 0 barrier arrival, 1 release; loaders: 2 register -> LDS stores done, 3 requests done, 4 interpolation done, 5 twin epilogue done"
+  CASAPOSE_HIP_LIB=$R/variants/lib_HS_TRACE.so HS_TRACE_ROWS=9 python3 tools/debug/hs_trace.py stage1_unit1_conv1 stage1_unit1_conv2 stage2_unit2_conv1 pv_block_3_conv2d pv_block_4_conv2d pv_block_5_conv2d pv_block_6_prepare_conv2d pv_block_8_prepare_conv2d pv_block_9_prepare_conv2d pv_block_10_prepare_conv2d 2>&1 | grep -v amdgpu.ids
+} > $O/hsplit_trace.txt
+{ echo "$STAMP"; python3 tools/debug/wino_parts.py 2>&1 | grep -v amdgpu.ids
+  echo "# decoder block 2 on the Winograd path again (CASAPOSE_WINO_DIRECT_128=0) against the direct kernel (default), per-layer table rows:"
+  CASAPOSE_WINO_DIRECT_128=0 python3 tools/layer_times.py --reps 10 2>/dev/null | grep "pv_block_2_\|stage2_unit2_conv1\|whole"
+  python3 tools/layer_times.py --reps 10 2>/dev/null | grep "pv_block_2_\|stage2_unit2_conv1\|whole"
+} > $O/wino_parts.txt
+{ echo "$STAMP"; python3 tools/debug/hbm_read_probe.py 2>&1 | grep -v amdgpu.ids
+  echo "# the voter itself (bench.py --mode vote):"
+  python3 bench.py --mode vote --steps 20 --warmup 5 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({k: d[k] for k in ('value','ms_per_step','roofline') if k in d}))"
+} > $O/hbm_read_probe.txt
+{ echo "$STAMP"; echo "# bash tools/debug/ab_bench.sh: forward + component filter + LS voting, 30 steps; CASAPOSE_F16X2_MONITOR=0 = calibration only, '-' = every forward armed (default)"
+  bash tools/debug/ab_bench.sh CASAPOSE_F16X2_MONITOR=0 - CASAPOSE_F16X2_MONITOR=0 - CASAPOSE_F16X2_MONITOR=0 - 2>&1
+} > $O/monitor_cost.txt
+ls -la $O; head -5 $O/wino_parts.txt
