@@ -179,6 +179,7 @@ SYMBOLS = [
     ("cp_head1x1_dgrad_f32", _i, [_vp, _i, _i, _ll, _vp, _i, _vp, _i, _i, _vp]),
     ("cp_head1x1_wgrad_f32", _i, [_vp, _i, _vp, _i, _ll, _i, _vp, _i, _vp]),
     ("cp_head1x1_fwd_affine_f32", _i, [_vp, _i, _ll, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    ("cp_head1x1_fwd_affine_record_f32", _i, [_vp, _i, _ll, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     ("cp_head1x1_wgrad_affine_f32", _i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _ll, _i, _vp, _i, _vp]),
     ("cp_head1x1_bn_bwd_reduce_f32", _i, [_vp, _i, _vp, _i, _i, _ll, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("cp_head1x1_bn_bwd_apply_f32", _i, [_vp, _i, _vp, _i, _i, _ll, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _vp, _vp, _i, _vp]),

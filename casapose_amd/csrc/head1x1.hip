@@ -169,9 +169,18 @@ __device__ __forceinline__ float head_act_grad(float t, int act) {
 }
 
 // out[p][q] = sum_c act(fma(x[p][c], scale[l_p][c], shift[l_p][c])) W[c][q]
+// RECORD: the head writes COMPLETE output records out[p][0 .. pre_n + cout) = [pre[p][0 .. pre_n) | its own cout columns].  A head that writes
+// its 9 or 27 columns into 36-float records leaves every 128-byte line partly written, and a partly dirty line costs the memory system a
+// read-modify-write: 556 us for the 9-column head into the records against 209 us into dense rows of 9 floats at bs 32 / 448 x 448
+// (tools/debug/head_probe.py).  So the FIRST head writes dense rows and the LAST one copies them in front of its own columns: whole lines
+// only.  The copy is dealt over the wave by ELEMENT (32 pixels x pre_n floats, 64 per round: with dense prefix rows a round is one
+// contiguous 256-byte load), requested before the group's MFMAs and stored behind them, next to the head columns of the same pixels.
+constexpr int PRE_ROUNDS = 8;   // 32 * pre_n <= 64 * PRE_ROUNDS: pre_n <= 16
+template <bool RECORD>
 __global__ __launch_bounds__(256) void head_fwd_affine_kernel(const float* __restrict__ x, int ld_x, long long pixels, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const uint8_t* __restrict__ labels, int classes, int act,
-                                                              const float* __restrict__ w, int cout, float* __restrict__ out, int ld_out) {
+                                                              const float* __restrict__ w, int cout, float* __restrict__ out, int ld_out,
+                                                              const float* __restrict__ pre, int ld_pre, int pre_n) {
     extern __shared__ float4 ftab[];   // [2][classes * 8]
     float4* tab[2] = {ftab, ftab + classes * 8};
     for (int i = threadIdx.x; i < classes * 8; i += 256) {
@@ -184,6 +193,19 @@ __global__ __launch_bounds__(256) void head_fwd_affine_kernel(const float* __res
     float wb[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) wb[m] = row < cout ? w[(16 * h + m) * cout + row] : 0.f;
+    // element e = 64 t + lane of a group's prefix block: pixel e / pre_n, float e % pre_n -- the same for every group, kept as 32-bit offsets
+    const int pre_e = 32 * pre_n, pre_rounds = (pre_e + 63) >> 6;
+    int pre_pix[PRE_ROUNDS], pre_in[PRE_ROUNDS], pre_out[PRE_ROUNDS];
+    if constexpr (RECORD) {
+        const uint32_t magic = 65536u / (uint32_t)pre_n + 1u;   // e / pre_n == (e * magic) >> 16 for e < 1024, pre_n <= 32
+#pragma unroll
+        for (int t = 0; t < PRE_ROUNDS; ++t) {
+            const uint32_t e = 64u * t + lane, pix = (e * magic) >> 16, f = e - pix * pre_n;
+            pre_pix[t] = (int)e < pre_e ? (int)pix : 32;   // (32 = never inside a group)
+            pre_in[t] = (int)(pix * ld_pre + f);
+            pre_out[t] = (int)(pix * ld_out + f);
+        }
+    }
     const long long groups = (pixels + 31) >> 5;
     const long long gstep = (long long)gridDim.x * 4;
     auto load = [&](long long g, float4 (&a)[4], int& l) {
@@ -201,10 +223,17 @@ __global__ __launch_bounds__(256) void head_fwd_affine_kernel(const float* __res
     };
     float4 a[4], an[4];
     int l, ln;
-    long long g = (long long)blockIdx.x * 4 + wave;
+    long long g = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
     load(g, a, l);
     for (; g < groups; g += gstep) {
         load(g + gstep, an, ln);
+        float pv[PRE_ROUNDS];
+        const int rem = pixels - g * 32 < 32 ? (int)(pixels - g * 32) : 32;   // pixels of this group
+        if constexpr (RECORD) {
+#pragma unroll
+            for (int t = 0; t < PRE_ROUNDS; ++t)
+                if (t < pre_rounds) pv[t] = pre_pix[t] < rem ? (pre + g * 32 * ld_pre)[pre_in[t]] : 0.f;
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -222,12 +251,18 @@ __global__ __launch_bounds__(256) void head_fwd_affine_kernel(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, wb[4 * i + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, wb[4 * i + 3], acc, 0, 0, 0);
         }
+        float* const o = RECORD ? out + pre_n : out;
         if (row < cout) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long pp = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (pp < pixels) out[pp * ld_out + row] = acc[r];
+                if (pp < pixels) o[pp * ld_out + row] = acc[r];
             }
+        }
+        if constexpr (RECORD) {
+#pragma unroll
+            for (int t = 0; t < PRE_ROUNDS; ++t)
+                if (t < pre_rounds && pre_pix[t] < rem) (out + g * 32 * ld_out)[pre_out[t]] = pv[t];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = an[i];
@@ -453,9 +488,16 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(HeadBn k, const 
     }
 }
 
-int grid_for_groups(long long pixels) {
-    const long long blocks = ((pixels + 31) / 32 + 3) / 4;
-    return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+// Grid-stride kernels, one wave per 32-pixel group at a time: as many blocks as are RESIDENT at once (occupancy x 256 CUs) and no more -- a grid
+// of 1.3 or 2.7 resident sets leaves the chip a third empty for its last round (the kernels run for 0.2-0.5 ms, a round is most of that:
+// cp_head1x1_bn_bwd_reduce_f32 476 -> 388 us at bs 32 / 448 x 448).
+template <typename K>
+int grid_for_groups(K kernel, size_t lds, long long pixels, long long groups_per_wave = 1) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    const long long resident = 256LL * per_cu;
+    const long long blocks = ((pixels + 31) / 32 + 4 * groups_per_wave - 1) / (4 * groups_per_wave);
+    return (int)(blocks < 1 ? 1 : (blocks > resident ? resident : blocks));
 }
 
 }  // namespace
@@ -463,7 +505,7 @@ int grid_for_groups(long long pixels) {
 extern "C" int cp_head1x1_fwd_f32(const float* x, int ld_x, long long pixels, const float* w, int cout, float* out, int ld_out, void* stream) {
     CP_REQUIRE(x && w && out && pixels > 0 && cout > 0 && cout <= 32, "cp_head1x1_fwd_f32: bad arguments (32 input channels, 1 <= cout <= 32)");
     CP_REQUIRE(ld_x >= CIN && ld_x % 4 == 0 && ((uintptr_t)x & 15) == 0 && ld_out >= cout, "cp_head1x1_fwd_f32: x rows must be 16-byte aligned float4 rows of >= 32 channels");
-    CP_LAUNCH(head_fwd_kernel, dim3(grid_for_groups(pixels)), dim3(256), 0, (hipStream_t)stream, x, ld_x, pixels, w, cout, out, ld_out);
+    CP_LAUNCH(head_fwd_kernel, dim3(grid_for_groups(head_fwd_kernel, 0, pixels)), dim3(256), 0, (hipStream_t)stream, x, ld_x, pixels, w, cout, out, ld_out);
     return cp::check_launch("cp_head1x1_fwd_f32");
 }
 
@@ -471,9 +513,9 @@ extern "C" int cp_head1x1_dgrad_f32(const float* dy, int ld_dy, int dy_row_float
                                     int accumulate, void* stream) {
     CP_REQUIRE(dy && w && dx && pixels > 0 && cout > 0 && cout <= 32 && ld_dy >= cout && dy_row_floats >= cout && ld_dx >= CIN, "cp_head1x1_dgrad_f32: bad arguments");
     if (dy_row_floats >= 32 && ld_dy % 4 == 0 && ((uintptr_t)dy & 15) == 0)
-        CP_LAUNCH(head_dgrad_kernel<true>, dim3(grid_for_groups(pixels)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, pixels, w, cout, dx, ld_dx, accumulate);
+        CP_LAUNCH(head_dgrad_kernel<true>, dim3(grid_for_groups(head_dgrad_kernel<true>, 0, pixels)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, pixels, w, cout, dx, ld_dx, accumulate);
     else
-        CP_LAUNCH(head_dgrad_kernel<false>, dim3(grid_for_groups(pixels)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, pixels, w, cout, dx, ld_dx, accumulate);
+        CP_LAUNCH(head_dgrad_kernel<false>, dim3(grid_for_groups(head_dgrad_kernel<false>, 0, pixels)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, pixels, w, cout, dx, ld_dx, accumulate);
     return cp::check_launch("cp_head1x1_dgrad_f32");
 }
 
@@ -483,7 +525,7 @@ extern "C" int cp_head1x1_wgrad_f32(const float* x, int ld_x, const float* dy, i
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate)
         if (hipMemsetAsync(dw, 0, sizeof(float) * CIN * cout, st) != hipSuccess) return cp::check_launch("cp_head1x1_wgrad_f32 memset");
-    int blocks = grid_for_groups(pixels);
+    int blocks = grid_for_groups(head_wgrad_kernel, 0, pixels);
     if (blocks > 1024) blocks = 1024;
     CP_LAUNCH(head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, ld_x, dy, ld_dy, pixels, cout, dw);
     return cp::check_launch("cp_head1x1_wgrad_f32");
@@ -495,9 +537,25 @@ extern "C" int cp_head1x1_fwd_affine_f32(const float* x, int ld_x, long long pix
     CP_REQUIRE(ld_x >= CIN && ld_x % 4 == 0 && ((uintptr_t)x & 15) == 0 && ld_out >= cout, "cp_head1x1_fwd_affine_f32: x rows must be 16-byte aligned float4 rows of >= 32 channels");
     CP_REQUIRE(classes >= 1 && classes <= MAX_CLASSES && (classes == 1 || labels) && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "cp_head1x1_fwd_affine_f32: 1 <= classes <= 64, labels for the class-adaptive form, 16-byte aligned tables");
-    CP_LAUNCH(head_fwd_affine_kernel, dim3(grid_for_groups(pixels)), dim3(256), 2 * (size_t)classes * 32 * sizeof(float), (hipStream_t)stream, x, ld_x, pixels, scale, shift, labels, classes, act, w,
-              cout, out, ld_out);
+    const size_t lds = 2 * (size_t)classes * 32 * sizeof(float);
+    CP_LAUNCH(head_fwd_affine_kernel<false>, dim3(grid_for_groups(head_fwd_affine_kernel<false>, lds, pixels)), dim3(256), lds, (hipStream_t)stream, x, ld_x, pixels,
+              scale, shift, labels, classes, act, w, cout, out, ld_out, (const float*)nullptr, 0, 0);
     return cp::check_launch("cp_head1x1_fwd_affine_f32");
+}
+
+extern "C" int cp_head1x1_fwd_affine_record_f32(const float* x, int ld_x, long long pixels, const float* scale, const float* shift, const uint8_t* labels,
+                                                int classes, int act, const float* w, int cout, const float* prefix, int ld_prefix, int prefix_n,
+                                                float* out, int ld_out, void* stream) {
+    CP_REQUIRE(x && w && out && scale && shift && prefix && pixels > 0 && cout > 0 && cout <= 32, "cp_head1x1_fwd_affine_record_f32: bad arguments (32 input channels, 1 <= cout <= 32)");
+    CP_REQUIRE(ld_x >= CIN && ld_x % 4 == 0 && ((uintptr_t)x & 15) == 0, "cp_head1x1_fwd_affine_record_f32: x rows must be 16-byte aligned float4 rows of >= 32 channels");
+    CP_REQUIRE(prefix_n >= 1 && prefix_n <= 2 * PRE_ROUNDS && ld_prefix >= prefix_n && ld_out >= prefix_n + cout,
+               "cp_head1x1_fwd_affine_record_f32: 1 <= prefix_n <= 16, rows of >= prefix_n floats in, records of >= prefix_n + cout floats out");
+    CP_REQUIRE(classes >= 1 && classes <= MAX_CLASSES && (classes == 1 || labels) && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+               "cp_head1x1_fwd_affine_record_f32: 1 <= classes <= 64, labels for the class-adaptive form, 16-byte aligned tables");
+    const size_t lds = 2 * (size_t)classes * 32 * sizeof(float);
+    CP_LAUNCH(head_fwd_affine_kernel<true>, dim3(grid_for_groups(head_fwd_affine_kernel<true>, lds, pixels)), dim3(256), lds, (hipStream_t)stream, x, ld_x, pixels,
+              scale, shift, labels, classes, act, w, cout, out, ld_out, prefix, ld_prefix, prefix_n);
+    return cp::check_launch("cp_head1x1_fwd_affine_record_f32");
 }
 
 extern "C" int cp_head1x1_wgrad_affine_f32(const float* x, int ld_x, const float* scale, const float* shift, const uint8_t* labels, int classes, int act,
@@ -508,10 +566,11 @@ extern "C" int cp_head1x1_wgrad_affine_f32(const float* x, int ld_x, const float
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate)
         if (hipMemsetAsync(dw, 0, sizeof(float) * CIN * cout, st) != hipSuccess) return cp::check_launch("cp_head1x1_wgrad_affine_f32 memset");
-    int blocks = grid_for_groups(pixels);
-    if (blocks > 1024) blocks = 1024;
     const size_t lds = sizeof(float) * (4 * 16 * 64 + 2 * (size_t)classes * 32);
-    if (labels && classes > 1)
+    const bool lab = labels && classes > 1;
+    int blocks = lab ? grid_for_groups(head_wgrad_affine_kernel<true>, lds, pixels) : grid_for_groups(head_wgrad_affine_kernel<false>, lds, pixels);
+    if (blocks > 1024) blocks = 1024;
+    if (lab)
         CP_LAUNCH(head_wgrad_affine_kernel<true>, dim3(blocks), dim3(256), lds, st, x, ld_x, scale, shift, labels, classes, act, dy, ld_dy, pixels, cout, dw);
     else
         CP_LAUNCH(head_wgrad_affine_kernel<false>, dim3(blocks), dim3(256), lds, st, x, ld_x, scale, shift, labels, classes, act, dy, ld_dy, pixels, cout, dw);
@@ -547,9 +606,7 @@ extern "C" int cp_head1x1_bn_bwd_reduce_f32(const float* x, int ld_x, const floa
         if (hipMemsetAsync(chan, 0, 64 * sizeof(double), st) != hipSuccess) return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32 memset");
     }
     const size_t lds = (nred + 64) * sizeof(double) + 3 * (size_t)classes * 32 * sizeof(float);
-    long long blocks = ((pixels >> 5) + 31) / 32;   // a wave takes runs of 8 groups: >= 1 run per wave
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    const int blocks = grid_for_groups(head_bn_bwd_reduce_kernel, lds, pixels, 8);   // a wave takes runs of 8 groups: >= 1 run per wave
     CP_LAUNCH(head_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), lds, st, k, red, chan);
     return cp::check_launch("cp_head1x1_bn_bwd_reduce_f32");
 }
@@ -564,6 +621,6 @@ extern "C" int cp_head1x1_bn_bwd_apply_f32(const float* x, int ld_x, const float
         return rc;
     CP_REQUIRE(chan && dx && ld_dx >= CIN && global_pixels > 0 && (!row_scale || ((uintptr_t)row_scale & 15) == 0), "cp_head1x1_bn_bwd_apply_f32: bad arguments");
     const size_t lds = 3 * (size_t)classes * 32 * sizeof(float);
-    CP_LAUNCH(head_bn_bwd_apply_kernel, dim3(grid_for_groups(pixels)), dim3(256), lds, (hipStream_t)stream, k, chan, 1.0 / global_pixels, row_scale, dx, ld_dx);
+    CP_LAUNCH(head_bn_bwd_apply_kernel, dim3(grid_for_groups(head_bn_bwd_apply_kernel, lds, pixels)), dim3(256), lds, (hipStream_t)stream, k, chan, 1.0 / global_pixels, row_scale, dx, ld_dx);
     return cp::check_launch("cp_head1x1_bn_bwd_apply_f32");
 }

@@ -434,6 +434,7 @@ class ConvOp:
                           and tap_label is None and row_scale is None and residual is None and srcs[0][1] % 4 == 0
                           and os.environ.get("CASAPOSE_HEAD_CONV", "stream") != "generic")
         self._out_ptr_ld = out_ptr_ld
+        self.record_prefix = None   # (tensor, ld, floats): dense rows this head copies in front of its own columns (TrainPlan._whole_records)
         # fused normalisation around a Winograd layer (TrainPlan._fuse_winograd): `stats_to` = the normalisation op whose batch statistics this
         # op's output transform accumulates; `pre_norm[s]` = the normalisation op whose normalise + activate this op's input transform of
         # source s applies itself (its stored activation is then never written)
@@ -697,6 +698,16 @@ class ConvOp:
                            stats=self.stats_to.sums.data_ptr() if self.stats_to is not None else None, mon=mon)
             return
         lib = _lib.load()
+        if self.head_fast and self.pre_bn is not None and self.record_prefix is not None:
+            bn = self.pre_bn
+            st_, off, old_ = self._out_ptr_ld
+            pre, pre_ld, pre_n = self.record_prefix
+            assert off == pre_n
+            check(lib.cp_head1x1_fwd_affine_record_f32(bn.x.data.data_ptr(), bn.x.c, self.batch * self.out_h * self.out_w, bn.scale.data_ptr(), bn.shift.data_ptr(),
+                                                       _ptr(bn.labels), bn.classes, bn.act, self.layer.master.data_ptr(), self.layer.cout,
+                                                       pre.data_ptr(), pre_ld, pre_n, st_.data_ptr(), old_, stream),
+                  "cp_head1x1_fwd_affine_record_f32(%s)" % self.layer.name)
+            return
         if self.head_fast and self.pre_bn is not None:
             bn = self.pre_bn
             st_, off, old_ = self._out_ptr_ld
@@ -1301,7 +1312,8 @@ class TrainPlan:
             if self.cond_labels is not None:
                 self.labels[0].copy_(self.cond_labels)
             else:
-                check(lib.cp_argmax_labels(self.out.data_ptr(), self.out_ld, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
+                logits, ld_ = (self.seg_dense, K) if getattr(self, "seg_dense", None) is not None else (self.out, self.out_ld)
+                check(lib.cp_argmax_labels(logits.data_ptr(), ld_, K, B * h * w, self.labels[0].data_ptr(), stream), "cp_argmax_labels")
             lab = (C.c_void_p * 4)(*[t.data_ptr() for t in self.labels])
             pn = (C.c_void_p * 4)(*[t.data_ptr() for t in self.pnorm])
             sl = (C.c_void_p * 3)(*[t.data_ptr() for t in self.sel])
@@ -1394,6 +1406,25 @@ class TrainPlan:
             if ld % 4 or off % 4 or ld - off % ld < 32:
                 continue
             bn.head, op.pre_bn = op, bn
+        self._whole_records()
+
+    def _whole_records(self):
+        """Both fused heads write slices of the same [pixels][K + V] records, and a head that fills 36 or 108 bytes of every 144 leaves each
+        128-byte line partly written: the memory system answers with a read-modify-write (556 us for the 9-column head into the records against
+        209 us into dense rows, tools/debug/head_probe.py).  So the segmentation head writes DENSE rows of K logits (self.seg_dense; the arg-max
+        reads those) and the vertex head, the last writer, copies them in front of its own columns: cp_head1x1_fwd_affine_record_f32 writes
+        complete records.  CASAPOSE_HEAD_RECORDS=0 keeps the two slice writers."""
+        self.seg_dense = None
+        K, V = self.seg_dim, self.ver_dim
+        heads = [op for op in self.ops if isinstance(op, ConvOp) and op.head_fast and op.pre_bn is not None]
+        if os.environ.get("CASAPOSE_HEAD_RECORDS", "1") == "0" or len(heads) != 2 or K > 16 or K + V != self.out_ld:
+            return
+        seg, ver = heads
+        if seg._out_ptr_ld != (self.out, 0, self.out_ld) or ver._out_ptr_ld != (self.out, K, self.out_ld) or seg.layer.cout != K or ver.layer.cout != V:
+            return
+        self.seg_dense = torch.zeros(self.out.shape[0] * self.out.shape[1] * self.out.shape[2], K, dtype=torch.float32, device=self.out.device)
+        seg._out_ptr_ld = (self.seg_dense, 0, K)
+        ver.record_prefix = (self.seg_dense, K, K)
 
     def _fuse_winograd(self):
         """Normalisation layers next to Winograd convolutions: the producer's output transform owns (tile, 4 channels) per lane and accumulates

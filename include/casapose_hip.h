@@ -491,6 +491,14 @@ int cp_head1x1_wgrad_f32(const float* x, int ld_x, const float* dy, int ld_dy, l
  * cp_head1x1_dgrad_f32's output.  pixels % 32 == 0; every dout row has >= 32 readable floats from `dout` on (columns >= cout ignored). */
 int cp_head1x1_fwd_affine_f32(const float* x, int ld_x, long long pixels, const float* scale, const float* shift, const uint8_t* labels, int classes,
                               int act, const float* w, int cout, float* out, int ld_out, void* stream);
+/* The same forward writing COMPLETE output records (round 6): out[p][0 .. prefix_n) = prefix[p][0 .. prefix_n) (dense rows another head
+ * wrote: the segmentation logits), out[p][prefix_n + q] = this head's column q.  Two heads that each fill a slice of [pixels][K + V] records
+ * leave every 128-byte line partly written, which costs a read-modify-write in the memory system (2.2-2.7x the time of the same bytes
+ * written as whole lines); with this entry point the last head is the only writer of the records.  1 <= prefix_n <= 16,
+ * ld_out >= prefix_n + cout (== for whole lines). */
+int cp_head1x1_fwd_affine_record_f32(const float* x, int ld_x, long long pixels, const float* scale, const float* shift, const uint8_t* labels,
+                                     int classes, int act, const float* w, int cout, const float* prefix, int ld_prefix, int prefix_n, float* out,
+                                     int ld_out, void* stream);
 int cp_head1x1_wgrad_affine_f32(const float* x, int ld_x, const float* scale, const float* shift, const uint8_t* labels, int classes, int act,
                                 const float* dy, int ld_dy, long long pixels, int cout, float* dw, int accumulate, void* stream);
 int cp_head1x1_bn_bwd_reduce_f32(const float* x, int ld_x, const float* dout, int ld_dout, int dout_row_floats, long long pixels, const float* w, int cout,

@@ -287,6 +287,15 @@ def test_fused_head_normalisation_kernels(device, hip_lib, classes, act, cout, o
     out1 = torch.zeros(n, 40, device=device)
     check(lib.cp_head1x1_fwd_affine_f32(xd.data_ptr(), c, n, scd.data_ptr(), shd.data_ptr(), lp, classes, act, wd.data_ptr(), cout, out1.data_ptr(), 40, st))
     assert torch.equal(out0, out1), "same fma, same activation, same MFMA chain: bit-identical head output"
+    # ... and as the writer of COMPLETE records: [dense prefix rows | this head's columns], bit for bit, nothing written beyond them
+    for pre_n, ld_pre in ((9, 9), (14, 16), (1, 3)):
+        pref = torch.randn(n, ld_pre, device=device)
+        ldr = pre_n + cout + (0 if pre_n == 9 else 3)
+        rec = torch.full((n, ldr), 7.0, device=device)
+        check(lib.cp_head1x1_fwd_affine_record_f32(xd.data_ptr(), c, n, scd.data_ptr(), shd.data_ptr(), lp, classes, act, wd.data_ptr(), cout, pref.data_ptr(),
+                                                   ld_pre, pre_n, rec.data_ptr(), ldr, st))
+        assert torch.equal(rec[:, :pre_n], pref[:, :pre_n]) and torch.equal(rec[:, pre_n:pre_n + cout], out1[:, :cout])
+        assert bool((rec[:, pre_n + cout:] == 7.0).all())
     dw1 = torch.full((c, cout), 3.0, device=device)
     check(lib.cp_head1x1_wgrad_affine_f32(xd.data_ptr(), c, scd.data_ptr(), shd.data_ptr(), lp, classes, act, dptr, ldo, n, cout, dw1.data_ptr(), 1, st))
     assert rel(dw1.cpu().numpy() - 3.0, dw0.cpu().numpy()) < 1e-5

@@ -10,6 +10,9 @@ if len(sys.argv) > 1:
 from casapose_amd import _lib
 from casapose_amd._lib import check
 
+if len(sys.argv) > 1:   # an older build of the same ABI may lack the newest entry points: bind what it has
+    have = C.CDLL(os.environ["CASAPOSE_HIP_LIB"])
+    _lib.SYMBOLS[:] = [s for s in _lib.SYMBOLS if hasattr(have, s[0])]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream(dev).cuda_stream
@@ -58,6 +61,11 @@ for cout, off, classes in ((9, 0, 1), (27, 9, 9)):
     row("fwd_affine  cout %2d into dense rows of %d floats" % (cout, cout), us, xb + n * cout * 4 / 1e6)
     us = timed(lambda: check(lib.cp_head1x1_fwd_affine_f32(x.data_ptr(), c, n, sc.data_ptr(), sh.data_ptr(), lp, classes, 2, w.data_ptr(), cout, padded.data_ptr(), 32, st)))
     row("fwd_affine  cout %2d into rows of 32 floats" % cout, us, xb + n * cout * 4 / 1e6)
+    if hasattr(lib, "cp_head1x1_fwd_affine_record_f32") and off:
+        pref = torch.randn(n, off, device=dev, generator=g)
+        us = timed(lambda: check(lib.cp_head1x1_fwd_affine_record_f32(x.data_ptr(), c, n, sc.data_ptr(), sh.data_ptr(), lp, classes, 2, w.data_ptr(), cout, pref.data_ptr(), off, off,
+                                                                      rec.data_ptr(), 36, st)))
+        row("fwd_affine  cout %2d + %d copied floats = whole records" % (cout, off), us, xb + n * (cout + 2 * off) * 4 / 1e6)
     us = timed(lambda: check(lib.cp_head1x1_fwd_f32(x.data_ptr(), c, n, w.data_ptr(), cout, rec.data_ptr() + 4 * off, 36, st)))
     row("fwd (no affine)  cout %2d into the records" % cout, us, xb + n * cout * 4 / 1e6)
     mean, rstd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
