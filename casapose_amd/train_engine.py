@@ -87,6 +87,17 @@ def train_fwd_f16x2() -> bool:
     return os.environ.get("CASAPOSE_TRAIN_FWD", "f16x2") == "f16x2"
 
 
+def train_bwd_f16x2() -> bool:
+    """The Winograd DATA-GRADIENT GEMMs of the training plan in the fp16 two-way split as well (round 6; CASAPOSE_TRAIN_BWD=split keeps the exact
+    three-way bf16 split).  A gradient has no natural magnitude, so the operand gets one: the input transform of dY multiplies by 2^e (its
+    per-channel affine with a constant table: exact), the GEMM's accumulator factor takes 2^-e.  e comes from the monitor slot the transform
+    reports max |V| into: the FIRST backward of a plan runs on the exact split with the slots armed and is followed by one synchronous reading
+    (like the inference plan's calibration); from then on the slots are judged with the forward's, every F16X2_TRAIN_CHECK_EVERY steps without a
+    synchronisation, and e follows when the maximum has drifted out of [2^7, 2^13] (target [2^10, 2^11): 8x headroom to the band's end, 32x to
+    fp16's clamp).  A non-finite maximum returns the op to the exact split."""
+    return os.environ.get("CASAPOSE_TRAIN_BWD", "f16x2") == "f16x2"
+
+
 # steps between two readings of the forward range monitor (asynchronous copy to pinned memory, judged at the start of a later step)
 F16X2_TRAIN_CHECK_EVERY = max(1, int(os.environ.get("CASAPOSE_F16X2_TRAIN_CHECK_EVERY", "16")))
 
@@ -524,7 +535,7 @@ class ConvOp:
     def setup_winograd(self):
         """Decide which of this op's convolutions (forward, per-source data gradient) take the Winograd path and return the
         scratch sizes (floats of V, floats of M) they need; bind_winograd() completes the descriptors."""
-        from .engine import WinoConv, wino_eligible
+        from .engine import TRAIN_WINO_GEMM_SPLIT, WinoConv, wino_eligible
 
         L = self.layer
         self.wino_fwd = None
@@ -554,6 +565,8 @@ class ConvOp:
         for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
             if ent is not None and L.cout % 32 == 0 and wino_eligible(3, 1, self.dil, self.dil, [(L.cout, L.cout)], cr, split_gemm=split_gemm):
                 self.wino_dgrad[s] = dict(U=torch.zeros(36 * cr * L.cout, dtype=torch.float32, device=dev), ktot=L.cout, cout=cr, tp=tp, desc=ConvDesc(), c0=c0)
+                if L.mode_planes == 3 and TRAIN_WINO_GEMM_SPLIT and train_bwd_f16x2():   # (e = None while the exact split runs and the slot measures)
+                    self.wino_dgrad[s]["f16"] = dict(e=None, mon=None, dead=False)
                 nv, nm = max(nv, 36 * tp * L.cout), max(nm, 36 * tp * cr)
             c0 += cr
         if self.wino_fwd is not None or self.wino_dgrad:
@@ -588,8 +601,30 @@ class ConvOp:
                     w["c_scale"] = 1.0 / scale
                     check(lib.cp_wino_split_weights_scaled_f32(w["U"].data_ptr(), 36, w["cout"], w["ktot"], _lib.PLANES_F16X2, scale, w["Us"].data_ptr(), stream),
                           "cp_wino_split_weights_scaled_f32(%s)" % L.name)
+                elif w.get("f16") is not None and w["f16"]["e"] is not None:   # a data gradient in the fp16 two-way split (train_bwd_f16x2)
+                    if w.get("Us16") is None:
+                        w["Us16"] = torch.empty(lib.cp_wino_split_weights_bytes(36, w["cout"], w["ktot"]), dtype=torch.uint8, device=w["U"].device)
+                        w["cache"] = {}
+                    scale = f16x2_scale(w["cache"], w["U"])
+                    w["c_scale"] = 2.0 ** (-w["f16"]["e"]) / scale
+                    check(lib.cp_wino_split_weights_scaled_f32(w["U"].data_ptr(), 36, w["cout"], w["ktot"], _lib.PLANES_F16X2, scale, w["Us16"].data_ptr(), stream),
+                          "cp_wino_split_weights_scaled_f32(dgrad %s)" % L.name)
+                    w["Us"] = w["Us16"]
                 else:
-                    w["Us"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us"), stream=stream)
+                    w.pop("c_scale", None)
+                    w["Us"] = w["Us3"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us3"), stream=stream)
+
+    def set_dgrad_exponent(self, w: dict, e: Optional[int], stream: int):
+        """the power of two the transformed dY of this Winograd data gradient is multiplied by (None: back to the exact split); re-packs the weights"""
+        f = w["f16"]
+        f["e"] = e
+        if e is not None:
+            if w.get("ps") is None:
+                dev = w["U"].device
+                w["ps"] = torch.empty(w["ktot"], dtype=torch.float32, device=dev)
+                w["pb"] = torch.zeros(w["ktot"], dtype=torch.float32, device=dev)
+            w["ps"].fill_(2.0 ** e)
+        self._refresh_winograd(stream)
 
     def bind_winograd(self, V: torch.Tensor, M: torch.Tensor, M2: Optional[torch.Tensor] = None):
         self._wV, self._wM, self._wM2 = V, M, (M2 if M2 is not None else M)
@@ -795,7 +830,8 @@ class ConvOp:
                 out["bf16"] += 2.0 * float(self.batch * self.in_h * self.in_w) * L.k * L.k * ent["cin"] * cr
             elif s in getattr(self, "wino_dgrad", {}):
                 w = self.wino_dgrad[s]
-                out[wino_pipe] += wino_mult * 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
+                f16 = w.get("f16") is not None and w["f16"]["e"] is not None
+                out[wino_pipe] += (3.0 if f16 else wino_mult) * 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
             else:
                 m_in = float(self.batch * self.in_h * self.in_w)
                 d = 2.0 * m_in * L.k * L.k * ent["cin"] * cr
@@ -930,7 +966,11 @@ class ConvOp:
                     t.has_grad = True
                     continue
             if s in getattr(self, "wino_dgrad", {}):  # stride 1, so the data gradient lives on the forward's input grid
-                self._wino_run(self.wino_dgrad[s], [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream)
+                w = self.wino_dgrad[s]
+                f = w.get("f16")
+                pre = {0: (w["ps"].data_ptr(), w["pb"].data_ptr(), _lib.ACT_NONE)} if f is not None and f["e"] is not None else None
+                self._wino_run(w, [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream, pre=pre,
+                               mon=f["mon"] if f is not None and not f["dead"] else None)
                 t.has_grad = True
                 continue
             g = ent["desc"]
@@ -1094,6 +1134,7 @@ class TrainPlan:
         self.group, self.world_size = group, world_size
         self._f16x2_mon = self._f16x2_host = self._f16x2_event = None   # range monitor of the f16x2 forward (_poll_f16x2)
         self._f16x2_steps, self.f16x2_checks, self.f16x2_demoted = 0, 0, []
+        self._bwd_f16, self._bwd_calibrated, self.f16x2_bwd_moves = None, False, []   # Winograd data gradients in f16x2 (train_bwd_f16x2)
         self.comm_timing = None   # start_comm_timing()
         self.comm_log = None      # start_comm_log()
         self._buckets = None
@@ -1567,16 +1608,42 @@ class TrainPlan:
         return self.out_view
 
     # ---- range monitor of the f16x2 forward (round 6) -------------------------------------------------------------------------------
+    def _bwd_slots(self):
+        """[(op, Winograd data-gradient entry)] of the data gradients that run (or will run) in the fp16 two-way split"""
+        if self._bwd_f16 is None:
+            self._bwd_f16 = [(op, w) for op in self.ops if isinstance(op, ConvOp) for w in getattr(op, "wino_dgrad", {}).values() if w.get("f16") is not None]
+        return self._bwd_f16
+
     def _arm_f16x2(self):
-        """one monitor slot per convolution op whose forward runs in the fp16 two-way split (slot i <-> self.ops[i])"""
+        """one monitor slot per convolution op whose forward runs in the fp16 two-way split (slot i <-> self.ops[i]), then one per Winograd data
+        gradient of train_bwd_f16x2()"""
+        bwd = self._bwd_slots()
         if self._f16x2_mon is None:
             dev = self.out.device
-            self._f16x2_mon = torch.zeros(4 * len(self.ops), dtype=torch.int32, device=dev)
-            self._f16x2_host = torch.zeros(4 * len(self.ops), dtype=torch.int32).pin_memory()
+            self._f16x2_mon = torch.zeros(4 * (len(self.ops) + len(bwd)), dtype=torch.int32, device=dev)
+            self._f16x2_host = torch.zeros(4 * (len(self.ops) + len(bwd)), dtype=torch.int32).pin_memory()
         base = self._f16x2_mon.data_ptr()
         for i, op in enumerate(self.ops):
             if isinstance(op, ConvOp):
                 op.mon_ptr = base + 16 * i if op.layer.fwd_f16x2 else None
+        for j, (_, w) in enumerate(bwd):
+            w["f16"]["mon"] = base + 16 * (len(self.ops) + j)
+
+    def _calibrate_bwd(self, stream: int):
+        """after the plan's FIRST backward (exact split, slots armed): one synchronous reading gives every Winograd data gradient its exponent"""
+        self._bwd_calibrated = True
+        bwd = self._bwd_slots()
+        if not bwd or self._f16x2_mon is None:
+            return
+        n0 = len(self.ops)
+        w32 = self._f16x2_mon[4 * n0:].cpu().numpy().view(np.uint32).reshape(-1, 4)
+        self._f16x2_mon[4 * n0:].zero_()
+        for j, (op, w) in enumerate(bwd):
+            if int(w32[j, 1]) == 0 or w["f16"]["e"] is not None:
+                continue
+            amax = float(w32[j, :1].view(np.float32)[0])
+            if np.isfinite(amax) and amax > 0.0:
+                op.set_dgrad_exponent(w, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
 
     def _read_f16x2(self, dev):
         """every F16X2_TRAIN_CHECK_EVERY-th step: the slots (sticky maxima over the steps since the last reading) travel to pinned host memory, are
@@ -1595,7 +1662,7 @@ class TrainPlan:
         from . import engine
 
         if self._f16x2_mon is None:
-            if any(isinstance(op, ConvOp) and op.layer.fwd_f16x2 for op in self.ops):
+            if any(isinstance(op, ConvOp) and op.layer.fwd_f16x2 for op in self.ops) or self._bwd_slots():
                 self._arm_f16x2()
             return
         ev = self._f16x2_event
@@ -1614,6 +1681,23 @@ class TrainPlan:
                 op.demote_forward_to_exact_split(stream)
                 op.mon_ptr = None
                 out.append("%s (max %.3g)" % (op.layer.name, amax))
+        n0 = len(self.ops)
+        for j, (op, bw) in enumerate(self._bwd_slots()):   # data gradients: the slot holds max |V * 2^e|; e follows a drift, a non-finite maximum ends it
+            f = bw["f16"]
+            if f["dead"] or int(w[n0 + j, 1]) == 0:
+                continue
+            amax = float(w[n0 + j, :1].view(np.float32)[0])
+            if not np.isfinite(amax):
+                f["dead"] = True
+                op.set_dgrad_exponent(bw, None, stream)
+                out.append("%s data gradient (max %.3g)" % (op.layer.name, amax))
+            elif f["e"] is None:
+                if amax > 0.0:
+                    op.set_dgrad_exponent(bw, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
+            elif amax > 0.0 and not (2.0 ** 7 <= amax < 2.0 ** 13):
+                e = int(np.clip(f["e"] + 10 - int(np.floor(np.log2(amax))), -100, 100))
+                self.f16x2_bwd_moves.append((op.layer.name, f["e"], e))
+                op.set_dgrad_exponent(bw, e, stream)
         self.f16x2_checks += 1
         if out:
             self.f16x2_demoted += out
@@ -1767,6 +1851,8 @@ class TrainPlan:
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
         if side is not None:
             main.wait_stream(side)
+        if not self._bwd_calibrated:
+            self._calibrate_bwd(stream)
         # d beta of bn_data from the padding-channel entries of conv0's weight gradient (see __init__)
         G = self.conv0.dwp[self.g_idx.reshape(-1)].view(49, 64)            # [tap][cout]
         W0 = self.store.view("conv0.kernel").reshape(49, 3, 64)               # [tap][c][cout]
