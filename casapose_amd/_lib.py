@@ -162,6 +162,7 @@ SYMBOLS = [
     ("cp_wino_weight_grad_f32", _i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _i, _vp]),
     ("cp_wino_wgrad_split_applicable", _i, [_i, _i, _i, _i]),
     ("cp_wino_wgrad_split_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("cp_wino_wgrad_split_scaled_f32", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     ("cp_wino_input_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cp_wino_output_transform_f32", _i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     ("cp_conv_stem_split_weight_floats", _i, []),

@@ -380,7 +380,8 @@ __device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&m)[6]) {
     m[5] = y[3];
 }
 
-__global__ __launch_bounds__(THREADS) void wino_dy_kernel(const float* __restrict__ dy, int ld, int C, WinoGeom g, float* __restrict__ dM) {
+__global__ __launch_bounds__(THREADS) void wino_dy_kernel(const float* __restrict__ dy, int ld, int C, WinoGeom g, float* __restrict__ dM, uint32_t* mon) {
+    float amax = 0.f;   // f16x2 range monitor (common.h): max |dM| over what this launch writes (the weight-gradient GEMM may convert it to fp16 pairs)
     const int c4n = C >> 2;
     const long long total = (long long)g.Tp * c4n;  // the padding tiles are ZEROED: the weight-gradient GEMM reduces over all Tp rows
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -416,7 +417,15 @@ __global__ __launch_bounds__(THREADS) void wino_dy_kernel(const float* __restric
             a6(tt[r], o);
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (size_t)(r * 6 + j) * plane) = o[j];
+            if (mon) {   // uniform
+#pragma unroll
+                for (int j = 0; j < 6; ++j) amax = cp::amax4(amax, o[j]);
+            }
         }
+    }
+    if (mon) {
+        cp::monitor_flush(mon, amax);
+        cp::monitor_count_launch(mon, threadIdx.x == 0);
     }
 }
 
@@ -627,7 +636,7 @@ extern "C" int cp_wino_dy_transform_f32(const float* dy, int ld, int channels, i
     CP_REQUIRE(dy && dM && channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0, "cp_wino_dy_transform_f32: bad arguments");
     WinoGeom g;
     CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_dy_transform_f32: bad geometry");
-    CP_LAUNCH(wino_dy_kernel, dim3(grid_for((long long)g.Tp * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, dy, ld, channels, g, dM);
+    CP_LAUNCH(wino_dy_kernel, dim3(grid_for((long long)g.Tp * (channels / 4))), dim3(THREADS), 0, (hipStream_t)stream, dy, ld, channels, g, dM, cp::f16x2_monitor());
     return cp::check_launch("cp_wino_dy_transform_f32");
 }
 

@@ -7,6 +7,9 @@
 // terms and six bf16 x bf16 products (each exact in fp32) are accumulated in fp32 -- the arithmetic of wino_gemm_split.hip / conv_wgrad_split.hip,
 // fp32-equivalent -- or, with planes = 1, operands are rounded to bf16 (CASAPOSE_CONV_MODE=bf16).  The reference obtains this product from
 // tf.GradientTape (train_casapose.py:594-611 -> Conv2DBackpropFilter of the layers.Conv2D call sites of resnet.py:97-103, casapose.py:71-74).
+// Round 6, planes = CP_PLANES_F16X2: both operands as fp16 pairs (split_f16.h: hi = rn_f16(x s), lo = rn_f16(x s - hi), three exact products per
+// fp32 product instead of six), each multiplied by a power of two s the CALLER picks so that its maximum sits inside fp16's band (a gradient has
+// no natural magnitude: cp_wino_dy_transform_f32 reports max |dM| into the armed monitor slot); the accumulators take 1 / (s_a s_b) on the way out.
 //
 // The reduction runs over the ROWS of both operands, so the MFMA fragments (8 consecutive t of one column per lane) are transposes of the
 // [t][channel] layout in HBM: ds_read_b64_tr_b16 from an LDS image kept in the native layout delivers them without shuffles (conv_wgrad_split.hip).
@@ -19,8 +22,10 @@
 // block a contiguous share of the (tile, slab) stream: concurrent blocks then sat in different tiles, nothing was shared and the kernel ran at
 // the 3.7 GB of a 4x re-read: 125 TF/s-equivalent, 177 with bf16 operands.)  An item ends with fp32 atomics into the zeroed dU.
 #include "common.h"
+#include "split_f16.h"
 
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -43,6 +48,7 @@ struct TnK {
     int tiles_n, tiles_k, steps;   // steps = slabs of the whole row range
     int lc, chunks;                // slabs per chunk, chunks per plane
     int items;                     // G * chunks * tiles_n * tiles_k
+    float sa, sb, descale;         // f16x2: powers of two on the operands, 1 / (sa sb) on the accumulators
 };
 
 #define TN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -77,9 +83,15 @@ __device__ __forceinline__ uint4 round8(const float4 v0, const float4 v1) {   //
     return make_uint4(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]), pack_hi16(r[4], r[5]), pack_hi16(r[6], r[7]));
 }
 
-template <int NP>
-__device__ __forceinline__ void store_planes(unsigned char* dst, int plane_stride, const float4 v0, const float4 v1) {
-    if constexpr (NP == 3) {
+template <int NP, bool F16>
+__device__ __forceinline__ void store_planes(unsigned char* dst, int plane_stride, const float4 v0, const float4 v1, float s) {
+    if constexpr (F16) {
+        uint2 h0, l0, h1, l1;
+        cp::split4h(make_float4(v0.x * s, v0.y * s, v0.z * s, v0.w * s), h0, l0);
+        cp::split4h(make_float4(v1.x * s, v1.y * s, v1.z * s, v1.w * s), h1, l1);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(dst + plane_stride) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else if constexpr (NP == 3) {
         uint4 h, m, l;
         split8(v0, v1, h, m, l);
         *reinterpret_cast<uint4*>(dst) = h;
@@ -116,8 +128,9 @@ __device__ __forceinline__ Item decode(const TnK& p, int q) {
     return r;
 }
 
-template <int NP>
+template <int NP, bool F16>
 __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
+    static_assert(!F16 || NP == 2, "the fp16 two-way split has two planes");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PLANE = BLK * ROWB, SLOT = NP * PLANE;   // one operand of one slab: [plane][block][row][32 ch]
     constexpr int D = 3;                                   // register sets of the loaders = slabs in flight
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
 
     if (wave >= 4) {
         // ------------------------------------------------ loaders ---------------------------------------------------------------
+        if constexpr (F16) cp::f16_overflow_clamps();
         const int L = (wave - 4) * 64 + lane;   // 0..255
         const int oct = L & 3;                  // 8 channels of a 32-channel block
         const int blk = (L >> 2) & 3;           // 16 consecutive lanes cover 512 contiguous bytes of one row (4 blocks x 32 channels)
@@ -172,8 +186,8 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
             unsigned char* bb = Bs + (T & 1) * SLOT + blk * ROWB + oct * 16;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                store_planes<NP>(ab + (row0 + 16 * i) * 64, PLANE, ar[d][i][0], ar[d][i][1]);
-                store_planes<NP>(bb + (row0 + 16 * i) * 64, PLANE, br[d][i][0], br[d][i][1]);
+                store_planes<NP, F16>(ab + (row0 + 16 * i) * 64, PLANE, ar[d][i][0], ar[d][i][1], p.sa);
+                store_planes<NP, F16>(bb + (row0 + 16 * i) * 64, PLANE, br[d][i][0], br[d][i][1], p.sb);
             }
         };
 #pragma unroll
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + (r & 3) + 8 * (r >> 2);
-                    atomicAdd(dst + (size_t)n * p.K, acc[i][j][r]);
+                    atomicAdd(dst + (size_t)n * p.K, F16 ? acc[i][j][r] * p.descale : acc[i][j][r]);
                     acc[i][j][r] = 0.f;
                 }
             }
@@ -246,7 +260,13 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
                     f32x16& c = acc[i][q];
                     bf16x8(&aa)[NP] = a[j & 1][i];
                     bf16x8(&bb)[NP] = b[j & 1][q];
-                    if constexpr (NP == 3) {   // smallest products first
+                    if constexpr (F16) {   // lo * hi, hi * lo, hi * hi
+                        const cp::f16x8_t a0 = __builtin_bit_cast(cp::f16x8_t, aa[0]), a1 = __builtin_bit_cast(cp::f16x8_t, aa[1]);
+                        const cp::f16x8_t b0 = __builtin_bit_cast(cp::f16x8_t, bb[0]), b1 = __builtin_bit_cast(cp::f16x8_t, bb[1]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+                    } else if constexpr (NP == 3) {   // smallest products first
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bb[0], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bb[2], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[1], bb[1], c, 0, 0, 0);
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_split_kernel(const TnK p) {
     for (; T < NTP; ++T) TN_BARRIER();
 }
 
-template <int NP>
+template <int NP, bool F16>
 int launch(TnK k, hipStream_t st) {
     k.tiles_n = k.N / 128;
     k.tiles_k = k.K / 128;
@@ -284,10 +304,10 @@ int launch(TnK k, hipStream_t st) {
     const size_t lds = (size_t)2 * NSLOT * NP * BLK * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_split_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_split_kernel<NP, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    CP_LAUNCH((wino_wgrad_split_kernel<NP>), dim3((unsigned)grid), dim3(512), lds, st, k);
+    CP_LAUNCH((wino_wgrad_split_kernel<NP, F16>), dim3((unsigned)grid), dim3(512), lds, st, k);
     return cp::check_launch("cp_wino_wgrad_split_f32");
 }
 
@@ -298,8 +318,15 @@ extern "C" int cp_wino_wgrad_split_applicable(int groups, int rows, int n, int k
 }
 
 extern "C" int cp_wino_wgrad_split_f32(const float* dm, const float* v, float* du, int groups, int rows, int n, int k, int planes, void* stream) {
+    return cp_wino_wgrad_split_scaled_f32(dm, v, du, groups, rows, n, k, planes, 1.f, 1.f, stream);
+}
+
+extern "C" int cp_wino_wgrad_split_scaled_f32(const float* dm, const float* v, float* du, int groups, int rows, int n, int k, int planes, float dm_scale,
+                                              float v_scale, void* stream) {
     CP_REQUIRE(dm && v && du, "cp_wino_wgrad_split_f32: null pointer");
-    CP_REQUIRE(planes == 1 || planes == 3, "cp_wino_wgrad_split_f32: planes must be 3 (exact split) or 1 (bf16)");
+    CP_REQUIRE(planes == 1 || planes == 3 || planes == CP_PLANES_F16X2, "cp_wino_wgrad_split_f32: planes must be 3 (exact split), 1 (bf16) or CP_PLANES_F16X2");
+    CP_REQUIRE(planes == CP_PLANES_F16X2 ? (dm_scale > 0.f && v_scale > 0.f && std::isfinite(dm_scale) && std::isfinite(v_scale)) : (dm_scale == 1.f && v_scale == 1.f),
+               "cp_wino_wgrad_split_scaled_f32: operand factors are positive powers of two with CP_PLANES_F16X2 and 1 otherwise");
     CP_REQUIRE(cp_wino_wgrad_split_applicable(groups, rows, n, k),
                "cp_wino_wgrad_split_f32: n and k must be multiples of 128 and each operand smaller than 2 GiB (groups %d, rows %d, n %d, k %d)", groups, rows, n, k);
     CP_REQUIRE((((uintptr_t)dm) | ((uintptr_t)v) | ((uintptr_t)du)) % 16 == 0, "cp_wino_wgrad_split_f32: operands must be 16-byte aligned");
@@ -315,5 +342,9 @@ extern "C" int cp_wino_wgrad_split_f32(const float* dm, const float* v, float* d
     p.K = k;
     p.a_bytes = (unsigned)((size_t)groups * rows * n * 4);
     p.b_bytes = (unsigned)((size_t)groups * rows * k * 4);
-    return planes == 3 ? launch<3>(p, st) : launch<1>(p, st);
+    p.sa = dm_scale;
+    p.sb = v_scale;
+    p.descale = 1.f / (dm_scale * v_scale);
+    if (planes == CP_PLANES_F16X2) return launch<2, true>(p, st);
+    return planes == 3 ? launch<3, false>(p, st) : launch<1, false>(p, st);
 }

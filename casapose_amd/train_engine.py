@@ -561,6 +561,8 @@ class ConvOp:
                                  V=torch.zeros(36 * tp * ktot, dtype=torch.float32, device=dev),  # padding tiles stay zero
                                  dU=torch.empty(36 * L.cout * ktot, dtype=torch.float32, device=dev), wdesc=ConvDesc())
             nv, nm = max(nv, 36 * tp * ktot), max(nm, 36 * tp * L.cout)
+            if L.mode_planes == 3 and TRAIN_WINO_GEMM_SPLIT and train_bwd_f16x2():   # the weight-gradient GEMM in f16x2: transformed dY x 2^e
+                self.wino_fwd["wg16"] = dict(e=None, mon=None, dead=False)
         c0 = 0
         for s, (ent, (cp, cr)) in enumerate(zip(L.dgrad, L.sources)):
             if ent is not None and L.cout % 32 == 0 and wino_eligible(3, 1, self.dil, self.dil, [(L.cout, L.cout)], cr, split_gemm=split_gemm):
@@ -805,8 +807,9 @@ class ConvOp:
             w = self.wino_fwd
             g = 2.0 * 36 * w["tp"] * w["ktot"] * w["cout"]
             out[wino_pipe] += (3.0 if (L.fwd_f16x2 and TRAIN_WINO_GEMM_SPLIT) else wino_mult) * g      # forward GEMM
-            if self.wino_wgrad_split():          # weight gradient: grouped GEMM over the 36 planes, exact splits on the bf16 pipe or fp32 MFMA
-                out["bf16"] += (1.0 if self.layer.mode_planes == 1 else 6.0) * g
+            if self.wino_wgrad_split():          # weight gradient: grouped GEMM over the 36 planes, exact splits / f16x2 on the 2-byte pipe or fp32 MFMA
+                wg16 = w.get("wg16") is not None and w["wg16"]["e"] is not None and L.fwd_f16x2
+                out["bf16"] += (1.0 if self.layer.mode_planes == 1 else (3.0 if wg16 else 6.0)) * g
             else:
                 out["f32"] += g
         else:
@@ -905,13 +908,27 @@ class ConvOp:
             w = self.wino_fwd
             cin, cout = self._cin, L.cout
             wM = self._wM2 if side else self._wM   # the side stream transforms dY into a scratch of its own (the data gradients use _wM)
-            check(lib.cp_wino_dy_transform_f32(dy, dy_ld, cout, self.batch, self.in_h, self.in_w, self.dil, wM.data_ptr(), stream),
-                  "cp_wino_dy_transform_f32(%s)" % L.name)
+            f = w.get("wg16") if self.wino_wgrad_split() else None
+            arm = f is not None and not f["dead"] and f["mon"]
+            if arm:
+                lib.cp_f16x2_monitor_set(f["mon"])   # the transform reports max |dM|
+            try:
+                check(lib.cp_wino_dy_transform_f32(dy, dy_ld, cout, self.batch, self.in_h, self.in_w, self.dil, wM.data_ptr(), stream),
+                      "cp_wino_dy_transform_f32(%s)" % L.name)
+            finally:
+                if arm:
+                    lib.cp_f16x2_monitor_set(None)
             if self.wino_wgrad_split():   # the grouped GEMM dU[p] = dM[p]^T V[p] on the bf16 matrix pipe (exact splits; csrc/wino_wgrad_split.hip)
                 # exact splits (fp32-equivalent) by default; CASAPOSE_CONV_MODE=bf16 rounds the operands of this GEMM to bf16 like the other weight gradients
-                check(lib.cp_wino_wgrad_split_f32(wM.data_ptr(), w["V"].data_ptr(), w["dU"].data_ptr(), 36, w["tp"], cout, w["ktot"],
-                                                  1 if self.layer.mode_planes == 1 else 3, stream),
-                      "cp_wino_wgrad_split_f32(%s)" % L.name)
+                if f is not None and f["e"] is not None and L.fwd_f16x2:
+                    # fp16 two-way split (train_bwd_f16x2): dM x 2^e from its monitor slot; V as it is -- the forward's monitor keeps it in the band
+                    # (a forward that left the band is demoted: L.fwd_f16x2 turns False and this GEMM returns to the exact split with it)
+                    check(lib.cp_wino_wgrad_split_scaled_f32(wM.data_ptr(), w["V"].data_ptr(), w["dU"].data_ptr(), 36, w["tp"], cout, w["ktot"],
+                                                             _lib.PLANES_F16X2, 2.0 ** f["e"], 1.0, stream), "cp_wino_wgrad_split_scaled_f32(%s)" % L.name)
+                else:
+                    check(lib.cp_wino_wgrad_split_f32(wM.data_ptr(), w["V"].data_ptr(), w["dU"].data_ptr(), 36, w["tp"], cout, w["ktot"],
+                                                      1 if self.layer.mode_planes == 1 else 3, stream),
+                          "cp_wino_wgrad_split_f32(%s)" % L.name)
             else:
                 check(lib.cp_conv2d_wgrad_f32(C.byref(w["wdesc"]), wM.data_ptr(), cout, w["dU"].data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(wino %s)" % L.name)
             c0 = k0 = 0
@@ -1609,10 +1626,25 @@ class TrainPlan:
 
     # ---- range monitor of the f16x2 forward (round 6) -------------------------------------------------------------------------------
     def _bwd_slots(self):
-        """[(op, Winograd data-gradient entry)] of the data gradients that run (or will run) in the fp16 two-way split"""
+        """[(op, state, entry)] of the backward GEMMs that run (or will run) in the fp16 two-way split: Winograd data gradients (entry = the
+        wino_dgrad dict, its weights are re-packed when the exponent moves) and Winograd weight gradients (entry None)"""
         if self._bwd_f16 is None:
-            self._bwd_f16 = [(op, w) for op in self.ops if isinstance(op, ConvOp) for w in getattr(op, "wino_dgrad", {}).values() if w.get("f16") is not None]
+            self._bwd_f16 = []
+            for op in self.ops:
+                if not isinstance(op, ConvOp):
+                    continue
+                self._bwd_f16 += [(op, w["f16"], w) for w in getattr(op, "wino_dgrad", {}).values() if w.get("f16") is not None]
+                wf = getattr(op, "wino_fwd", None)
+                if wf is not None and wf.get("wg16") is not None:
+                    self._bwd_f16.append((op, wf["wg16"], None))
         return self._bwd_f16
+
+    @staticmethod
+    def _set_bwd_exponent(op, f, entry, e, stream):
+        if entry is not None:
+            op.set_dgrad_exponent(entry, e, stream)
+        else:
+            f["e"] = e
 
     def _arm_f16x2(self):
         """one monitor slot per convolution op whose forward runs in the fp16 two-way split (slot i <-> self.ops[i]), then one per Winograd data
@@ -1626,8 +1658,8 @@ class TrainPlan:
         for i, op in enumerate(self.ops):
             if isinstance(op, ConvOp):
                 op.mon_ptr = base + 16 * i if op.layer.fwd_f16x2 else None
-        for j, (_, w) in enumerate(bwd):
-            w["f16"]["mon"] = base + 16 * (len(self.ops) + j)
+        for j, (_, f, _e) in enumerate(bwd):
+            f["mon"] = base + 16 * (len(self.ops) + j)
 
     def _calibrate_bwd(self, stream: int):
         """after the plan's FIRST backward (exact split, slots armed): one synchronous reading gives every Winograd data gradient its exponent"""
@@ -1638,12 +1670,12 @@ class TrainPlan:
         n0 = len(self.ops)
         w32 = self._f16x2_mon[4 * n0:].cpu().numpy().view(np.uint32).reshape(-1, 4)
         self._f16x2_mon[4 * n0:].zero_()
-        for j, (op, w) in enumerate(bwd):
-            if int(w32[j, 1]) == 0 or w["f16"]["e"] is not None:
+        for j, (op, f, entry) in enumerate(bwd):
+            if int(w32[j, 1]) == 0 or f["e"] is not None:
                 continue
             amax = float(w32[j, :1].view(np.float32)[0])
             if np.isfinite(amax) and amax > 0.0:
-                op.set_dgrad_exponent(w, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
+                self._set_bwd_exponent(op, f, entry, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
 
     def _read_f16x2(self, dev):
         """every F16X2_TRAIN_CHECK_EVERY-th step: the slots (sticky maxima over the steps since the last reading) travel to pinned host memory, are
@@ -1682,22 +1714,24 @@ class TrainPlan:
                 op.mon_ptr = None
                 out.append("%s (max %.3g)" % (op.layer.name, amax))
         n0 = len(self.ops)
-        for j, (op, bw) in enumerate(self._bwd_slots()):   # data gradients: the slot holds max |V * 2^e|; e follows a drift, a non-finite maximum ends it
-            f = bw["f16"]
+        for j, (op, f, entry) in enumerate(self._bwd_slots()):
+            # backward GEMMs: a data gradient's slot holds max |V 2^e| (the transform applies the factor), a weight gradient's max |dM| (the GEMM
+            # applies it); e follows a drift out of [2^7, 2^13), a non-finite maximum ends the f16x2 run of that GEMM
             if f["dead"] or int(w[n0 + j, 1]) == 0:
                 continue
             amax = float(w[n0 + j, :1].view(np.float32)[0])
+            scaled = amax * (2.0 ** f["e"] if (entry is None and f["e"] is not None) else 1.0)
             if not np.isfinite(amax):
                 f["dead"] = True
-                op.set_dgrad_exponent(bw, None, stream)
-                out.append("%s data gradient (max %.3g)" % (op.layer.name, amax))
+                self._set_bwd_exponent(op, f, entry, None, stream)
+                out.append("%s %s gradient (max %.3g)" % (op.layer.name, "data" if entry is not None else "weight", amax))
             elif f["e"] is None:
                 if amax > 0.0:
-                    op.set_dgrad_exponent(bw, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
-            elif amax > 0.0 and not (2.0 ** 7 <= amax < 2.0 ** 13):
-                e = int(np.clip(f["e"] + 10 - int(np.floor(np.log2(amax))), -100, 100))
+                    self._set_bwd_exponent(op, f, entry, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
+            elif scaled > 0.0 and not (2.0 ** 7 <= scaled < 2.0 ** 13):
+                e = int(np.clip(f["e"] + 10 - int(np.floor(np.log2(scaled))), -100, 100))
                 self.f16x2_bwd_moves.append((op.layer.name, f["e"], e))
-                op.set_dgrad_exponent(bw, e, stream)
+                self._set_bwd_exponent(op, f, entry, e, stream)
         self.f16x2_checks += 1
         if out:
             self.f16x2_demoted += out

@@ -414,6 +414,12 @@ int cp_wino_weight_grad_f32(const float* dU, int channels, int cout, int ldk, in
  * (cp_wino_wgrad_split_applicable); du is overwritten. */
 int cp_wino_wgrad_split_applicable(int groups, int rows, int n, int k);
 int cp_wino_wgrad_split_f32(const float* dm, const float* v, float* du, int groups, int rows, int n, int k, int planes, void* stream);
+/* The same GEMM with planes = CP_PLANES_F16X2 (round 6): both operands as fp16 pairs, three exact products per fp32 product.  dm is multiplied
+ * by dm_scale and v by v_scale before the split (powers of two the caller picks so that each operand's maximum sits in [0.5, 65504 / 4]:
+ * cp_wino_dy_transform_f32 and the input transforms report those maxima into the armed monitor slot), du takes 1 / (dm_scale v_scale).
+ * planes 1 / 3 with factors of 1 are cp_wino_wgrad_split_f32. */
+int cp_wino_wgrad_split_scaled_f32(const float* dm, const float* v, float* du, int groups, int rows, int n, int k, int planes, float dm_scale,
+                                   float v_scale, void* stream);
 int cp_wino_input_transform_f32(const float* src, int ld, int channels, int batch, int h, int w, int dilation, float* V, int ldv,
                                 int c_off, void* stream);
 int cp_wino_output_transform_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,

@@ -168,3 +168,33 @@ def test_wino_weight_gradient_gemm_on_the_bf16_pipe(device, planes, groups, rows
         check(lib.cp_conv2d_wgrad_f32(C.byref(d), dmt.data_ptr(), n, f32.data_ptr(), 0, stream), "cp_conv2d_wgrad_f32(grouped)")
         e32 = (np.abs(f32.cpu().numpy().astype(np.float64) - ref) / scale).max()
         assert err <= 2.0 * e32 + 1e-7, (err, e32)
+
+
+@pytest.mark.parametrize("groups,rows,n,k,mag", [(36, 384, 256, 384, 3e-5), (5, 200, 128, 256, 40.0), (2, 2176, 512, 512, 1e-5)])
+def test_wino_weight_gradient_gemm_in_the_fp16_two_way_split(device, groups, rows, n, k, mag):
+    """cp_wino_wgrad_split_scaled_f32 with CP_PLANES_F16X2: a gradient-like operand of arbitrary magnitude is brought into fp16's band by the power of
+    two cp_f16x2_range_check derives from its maximum (what the training plan reads from the monitor slot of cp_wino_dy_transform_f32); error
+    against fp64 no worse than the exact split's gate and within 2x of the fp32-MFMA grouped GEMM."""
+    from casapose_amd import _lib
+    from casapose_amd._lib import check
+
+    lib = _lib.load()
+    rng = np.random.default_rng(groups + rows + n + k)
+    dm = (rng.standard_normal((groups, rows, n)) * np.exp(rng.uniform(-3, 3, (1, 1, n))) * mag).astype(np.float32)
+    v = (rng.standard_normal((groups, rows, k)) * 3.0).astype(np.float32)
+    ref = np.einsum("gtn,gtk->gnk", dm.astype(np.float64), v.astype(np.float64))
+    dmt, vt = torch.from_numpy(dm).to(device), torch.from_numpy(v).to(device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rescale = C.c_float(0.0)
+    assert lib.cp_f16x2_range_check(float(np.abs(dm).max()), 0.5, 65504.0 / 4, C.byref(rescale)) in (0, 1)
+    du = torch.full((groups, n, k), 3.0, device=device)
+    check(lib.cp_wino_wgrad_split_scaled_f32(dmt.data_ptr(), vt.data_ptr(), du.data_ptr(), groups, rows, n, k, _lib.PLANES_F16X2, rescale.value, 1.0, stream))
+    ex = torch.empty((groups, n, k), device=device)
+    check(lib.cp_wino_wgrad_split_f32(dmt.data_ptr(), vt.data_ptr(), ex.data_ptr(), groups, rows, n, k, 3, stream))
+    torch.cuda.synchronize()
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    err = (np.abs(du.cpu().numpy().astype(np.float64) - ref) / scale).max()
+    err3 = (np.abs(ex.cpu().numpy().astype(np.float64) - ref) / scale).max()
+    assert err < 1e-5 and err <= 4.0 * err3 + 2e-7, (err, err3)
+    # factors other than 1 belong to the fp16 form only
+    assert lib.cp_wino_wgrad_split_scaled_f32(dmt.data_ptr(), vt.data_ptr(), du.data_ptr(), groups, rows, n, k, 3, 2.0, 1.0, stream) != 0
