@@ -94,7 +94,12 @@ def train_bwd_f16x2() -> bool:
     reports max |V| into: the FIRST backward of a plan runs on the exact split with the slots armed and is followed by one synchronous reading
     (like the inference plan's calibration); from then on the slots are judged with the forward's, every F16X2_TRAIN_CHECK_EVERY steps without a
     synchronisation, and e follows when the maximum has drifted out of [2^7, 2^13] (target [2^10, 2^11): 8x headroom to the band's end, 32x to
-    fp16's clamp).  A non-finite maximum returns the op to the exact split."""
+    fp16's clamp).  A non-finite maximum returns the op to the exact split.
+    The DIRECT 3x3 layers' data gradients (csrc/conv_hsplit.hip converts its source as it is) get their magnitude from ONE power of two on the
+    loss instead (TrainPlan.loss_exp: the loss weights are multiplied by 2^E, every gradient of the backward carries the factor, the flat
+    gradient is multiplied by 2^-E before anything reads it -- all exact): E puts the LARGEST max |dY| of those layers at [2^10, 2^11), the
+    layers whose own maximum then sits inside [1, 2^13] run on the fp16 pair (measured spread between the layers of this network: 2^9 - 2^12.5,
+    tools/debug/grad_ranges.py), the others stay on the exact split.  max |dY| comes from cp_amax_f32 passes on the check steps only."""
     return os.environ.get("CASAPOSE_TRAIN_BWD", "f16x2") == "f16x2"
 
 
@@ -616,6 +621,31 @@ class ConvOp:
                     w.pop("c_scale", None)
                     w["Us"] = w["Us3"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us3"), stream=stream)
 
+    def direct_dgrad_split(self) -> bool:
+        """True when this op has a data gradient that runs on conv_hsplit as an exact three-way split and may move to the fp16 pair
+        (train_bwd_f16x2): 3x3 / stride 1 / no dilation, not a Winograd / deep-bf16 / 1x1-GEMM route"""
+        L = self.layer
+        if not (train_bwd_f16x2() and L.mode_planes == 3 and L.k == 3 and self.stride == 1 and self.dil == 1) or getattr(self, "gemm", None) is not None:
+            return False
+        for s, ent in enumerate(L.dgrad):
+            if ent is None or ent["split"] is None or ent.get("deep") or s in getattr(self, "wino_dgrad", {}):
+                continue
+            if ent["split"]["np"] in (3, _lib.PLANES_F16X2):
+                return True
+        return False
+
+    def set_direct_dgrad_f16x2(self, on: bool, stream: int):
+        """the direct data gradients of this op on the fp16 two-way split (weights x 2^k re-packed as two fp16 planes) or back on the exact split"""
+        L = self.layer
+        self.bw16["on"] = on
+        for s, ent in enumerate(L.dgrad):
+            if ent is None or ent["split"] is None or ent.get("deep") or s in getattr(self, "wino_dgrad", {}):
+                continue
+            sp = ent["split"]
+            if sp["np"] in (3, _lib.PLANES_F16X2):
+                sp["np"] = _lib.PLANES_F16X2 if on else 3
+        L._refresh_split(stream)
+
     def set_dgrad_exponent(self, w: dict, e: Optional[int], stream: int):
         """the power of two the transformed dY of this Winograd data gradient is multiplied by (None: back to the exact split); re-packs the weights"""
         f = w["f16"]
@@ -995,7 +1025,7 @@ class ConvOp:
             g.residual = t.grad.data_ptr() if t.has_grad else None
             sp = ent["split"]
             if sp is not None and lib.cp_conv_split_applicable(C.byref(g)):
-                check(lib.cp_conv2d_fwd_split(C.byref(g), sp["planes"].data_ptr(), None, sp["np"], stream), "dgrad split(%s)" % L.name)
+                check(lib.cp_conv2d_fwd_split_scaled(C.byref(g), sp["planes"].data_ptr(), None, sp["np"], sp["descale"], 1.0, stream), "dgrad split(%s)" % L.name)
             else:
                 check(lib.cp_conv2d_fwd_f32(C.byref(g), stream), "dgrad(%s)" % L.name)
             t.has_grad = True
@@ -1151,7 +1181,8 @@ class TrainPlan:
         self.group, self.world_size = group, world_size
         self._f16x2_mon = self._f16x2_host = self._f16x2_event = None   # range monitor of the f16x2 forward (_poll_f16x2)
         self._f16x2_steps, self.f16x2_checks, self.f16x2_demoted = 0, 0, []
-        self._bwd_f16, self._bwd_calibrated, self.f16x2_bwd_moves = None, False, []   # Winograd data gradients in f16x2 (train_bwd_f16x2)
+        self._bwd_f16, self._bwd_calibrated, self.f16x2_bwd_moves = None, False, []   # backward GEMMs in f16x2 (train_bwd_f16x2)
+        self.loss_exp, self._dout_scale, self._unscale_pending = 0, 1.0, False         # power of two on the loss (direct data gradients in f16x2)
         self.comm_timing = None   # start_comm_timing()
         self.comm_log = None      # start_comm_log()
         self._buckets = None
@@ -1637,6 +1668,9 @@ class TrainPlan:
                 wf = getattr(op, "wino_fwd", None)
                 if wf is not None and wf.get("wg16") is not None:
                     self._bwd_f16.append((op, wf["wg16"], None))
+                if op.direct_dgrad_split():   # direct 3x3 data gradient(s) on conv_hsplit: entry "direct", state on / off instead of an exponent
+                    op.bw16 = dict(on=False, mon=None, dead=False, e=None)
+                    self._bwd_f16.append((op, op.bw16, "direct"))
         return self._bwd_f16
 
     @staticmethod
@@ -1645,6 +1679,42 @@ class TrainPlan:
             op.set_dgrad_exponent(entry, e, stream)
         else:
             f["e"] = e
+
+    def _set_loss_exponent(self, e_new: int, stream: int):
+        """move the power of two on the loss; the Winograd GEMMs' own exponents move the other way at the same moment (their operands carry it)"""
+        d = e_new - self.loss_exp
+        if d == 0:
+            return
+        self.loss_exp = e_new
+        for op, f, entry in self._bwd_slots():
+            if entry != "direct" and f["e"] is not None and not f["dead"]:
+                self._set_bwd_exponent(op, f, entry, f["e"] - d, stream)
+
+    def _judge_direct(self, vals, stream: int):
+        """vals: {slot index j: max |dY| as measured, i.e. including the loss factor in force}.  Moves the loss exponent when the largest of them
+        has left [2^7, 2^13), then switches every direct data gradient on (inside [1, 2^13]) or off (outside [0.25, 2^14])."""
+        bwd = self._bwd_slots()
+        live = {j: v for j, v in vals.items() if np.isfinite(v) and v > 0.0}
+        if not live:
+            return
+        top = max(live.values())
+        shift = 0
+        if not (2.0 ** 7 <= top < 2.0 ** 13):
+            shift = 10 - int(np.floor(np.log2(top)))
+            self._set_loss_exponent(int(np.clip(self.loss_exp + shift, -100, 100)), stream)
+        for j, v in vals.items():
+            op, f, _ = bwd[j]
+            if f["dead"]:
+                continue
+            if not np.isfinite(v):
+                f["dead"] = True
+                op.set_direct_dgrad_f16x2(False, stream)
+                continue
+            v2 = v * 2.0 ** shift
+            if not f["on"] and 1.0 <= v2 <= 2.0 ** 13:
+                op.set_direct_dgrad_f16x2(True, stream)
+            elif f["on"] and not (0.25 <= v2 <= 2.0 ** 14):
+                op.set_direct_dgrad_f16x2(False, stream)
 
     def _arm_f16x2(self):
         """one monitor slot per convolution op whose forward runs in the fp16 two-way split (slot i <-> self.ops[i]), then one per Winograd data
@@ -1670,12 +1740,16 @@ class TrainPlan:
         n0 = len(self.ops)
         w32 = self._f16x2_mon[4 * n0:].cpu().numpy().view(np.uint32).reshape(-1, 4)
         self._f16x2_mon[4 * n0:].zero_()
+        direct = {}
         for j, (op, f, entry) in enumerate(bwd):
             if int(w32[j, 1]) == 0 or f["e"] is not None:
                 continue
             amax = float(w32[j, :1].view(np.float32)[0])
-            if np.isfinite(amax) and amax > 0.0:
+            if entry == "direct":
+                direct[j] = amax
+            elif np.isfinite(amax) and amax > 0.0:
                 self._set_bwd_exponent(op, f, entry, int(np.clip(10 - int(np.floor(np.log2(amax))), -100, 100)), stream)
+        self._judge_direct(direct, stream)   # (moves the Winograd exponents just set by the loss exponent it chooses)
 
     def _read_f16x2(self, dev):
         """every F16X2_TRAIN_CHECK_EVERY-th step: the slots (sticky maxima over the steps since the last reading) travel to pinned host memory, are
@@ -1714,12 +1788,16 @@ class TrainPlan:
                 op.mon_ptr = None
                 out.append("%s (max %.3g)" % (op.layer.name, amax))
         n0 = len(self.ops)
+        direct = {}
         for j, (op, f, entry) in enumerate(self._bwd_slots()):
             # backward GEMMs: a data gradient's slot holds max |V 2^e| (the transform applies the factor), a weight gradient's max |dM| (the GEMM
             # applies it); e follows a drift out of [2^7, 2^13), a non-finite maximum ends the f16x2 run of that GEMM
             if f["dead"] or int(w[n0 + j, 1]) == 0:
                 continue
             amax = float(w[n0 + j, :1].view(np.float32)[0])
+            if entry == "direct":
+                direct[j] = amax
+                continue
             scaled = amax * (2.0 ** f["e"] if (entry is None and f["e"] is not None) else 1.0)
             if not np.isfinite(amax):
                 f["dead"] = True
@@ -1732,6 +1810,7 @@ class TrainPlan:
                 e = int(np.clip(f["e"] + 10 - int(np.floor(np.log2(scaled))), -100, 100))
                 self.f16x2_bwd_moves.append((op.layer.name, f["e"], e))
                 self._set_bwd_exponent(op, f, entry, e, stream)
+        self._judge_direct(direct, stream)
         self.f16x2_checks += 1
         if out:
             self.f16x2_demoted += out
@@ -1746,6 +1825,9 @@ class TrainPlan:
         B, h, w = self.batch, self.h, self.w
         stream = torch.cuda.current_stream(self.out.device).cuda_stream
         assert labels_ce.dtype == torch.uint8 and labels_fg.dtype == torch.uint8 and keypoints_yx.dtype == torch.float32
+        # the power of two on the loss (train_bwd_f16x2): on the GRADIENT only -- the kernels' loss sums do not contain the weights
+        self._dout_scale = S = 2.0 ** self.loss_exp
+        mask_w, vertex_w, proxy_w = mask_w * S, vertex_w * S, proxy_w * S
         assert tuple(keypoints_yx.shape) == (B, self.seg_dim - 1, kp, 2) and keypoints_yx.is_contiguous()
         oc = self.seg_dim - 1
         if self.pvnet and oc > 1 and self.ver_dim == oc * 2 * kp:   # separated vector fields: per-object slices (compute_loss, train_casapose.py:57,97-125)
@@ -1804,13 +1886,15 @@ class TrainPlan:
             check(lib.cp_kp_reproj_loss_f32(self.ls_coords.data_ptr(), gt_xy.data_ptr(), affine.data_ptr(), avail.data_ptr(), B, oc, kp, max_pixel_error,
                                             kp_w, self.ls_g.data_ptr(), self.kp_loss_val.data_ptr(), stream), "cp_kp_reproj_loss_f32")
         loss = self.kp_loss_val[0]
+        if self._dout_scale != 1.0:   # this term's gradient joins one that carries the loss factor
+            self.ls_g.mul_(self._dout_scale)
         coef = None
         if confidence_regularization:
             cnt = self.kp_counts[0, :, 1:].sum(dim=1, keepdim=True).double()       # foreground pixels of the target mask
             safe = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
             cl = torch.where(cnt > 0, self.kp_conf_sums / safe, torch.zeros_like(self.kp_conf_sums))
             loss = loss + torch.abs(cl - 0.7).mean()
-            coef = (kp_w * torch.sign(cl - 0.7) / (B * kp) / safe * (cnt > 0)).to(torch.float32).contiguous()
+            coef = (kp_w * self._dout_scale * torch.sign(cl - 0.7) / (B * kp) / safe * (cnt > 0)).to(torch.float32).contiguous()
         if backward:
             check(lib.cp_ls_vote_bwd_f32(out.data_ptr(), self.out_ld, K, conf_off, vote_labels.data_ptr(), B, h, w, oc, kp, self.ls_sums.data_ptr(),
                                          self.ls_g.data_ptr(), self.ls_pu.data_ptr(), labels_gt.data_ptr() if coef is not None else None, _ptr(coef),
@@ -1862,8 +1946,13 @@ class TrainPlan:
         main = torch.cuda.current_stream(self.out.device)
         if side is not None:
             side.wait_stream(main)   # the forward's activations and the loss gradient are ready
+        # the direct data gradients' operand range: max |dY| by a reduction pass of its own, on the step before a reading of the slots only
+        check_now = self._f16x2_mon is not None and (not self._bwd_calibrated or self._f16x2_steps >= F16X2_TRAIN_CHECK_EVERY - 1)
         for i in range(len(self.ops) - 1, -1, -1):
             op = self.ops[i]
+            if check_now and isinstance(op, ConvOp) and getattr(op, "bw16", None) is not None and op.bw16["mon"] and not op.bw16["dead"]:
+                dy_, ld_ = op._dy()
+                check(_lib.load().cp_amax_f32(dy_, op.batch * op.out_h * op.out_w, ld_, op.layer.cout, op.bw16["mon"], stream), "cp_amax_f32(dY %s)" % op.layer.name)
             if side is not None and isinstance(op, ConvOp):
                 ev = torch.cuda.Event()
                 ev.record(main)                 # dY of this layer is complete on the main stream
@@ -1899,6 +1988,16 @@ class TrainPlan:
                         log.append(("grad_bucket", 4 * (e - a), "async", stream, first))
                     if multi:
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
+        if self._dout_scale != 1.0:   # the loss carried a power of two (loss_exp): take it out of the flat gradient -- behind the exchange if one is in flight
+            if self._pending:
+                self._unscale_pending = True
+            else:
+                self._unscale_grads(stream)
+
+    def _unscale_grads(self, stream: int):
+        g = self.store.grad
+        check(_lib.load().cp_axpby_f32(g.data_ptr(), 1.0 / self._dout_scale, g.data_ptr(), 0.0, g.numel(), g.data_ptr(), stream), "cp_axpby_f32(gradient / loss factor)")
+        self._dout_scale, self._unscale_pending = 1.0, False
 
     def all_reduce_grads(self):
         """Complete the gradient exchange started by backward() (or run it as one all-reduce if none is pending)."""
@@ -1912,6 +2011,8 @@ class TrainPlan:
             for h in self._pending:
                 h.wait()
             self._pending = []
+            if self._unscale_pending:
+                self._unscale_grads(torch.cuda.current_stream(self.out.device).cuda_stream)
         else:
             parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
         if timed:

@@ -1038,3 +1038,71 @@ def test_f16x2_forward_monitor_moves_an_out_of_band_layer_to_the_exact_split(dev
     e_first, e_last = float((first - ref).abs().max()) / scale, float((last - ref).abs().max()) / scale
     print("error against the exact forward: clamping f16x2 forward %.2e, after the demotion %.2e" % (e_first, e_last))
     assert e_last <= 1e-4 and e_first > 10 * e_last, (e_first, e_last)
+
+
+@pytest.mark.gpu
+def test_backward_in_the_fp16_two_way_split_matches_the_exact_split(device, monkeypatch):
+    """Round 6: the backward GEMMs of the 3x3 layers in the fp16 two-way split (train_engine.train_bwd_f16x2).  The first backward of a plan runs on
+    the exact split and measures; from the second on the Winograd data / weight gradients carry their own power of two, the loss carries one for the
+    direct layers' data gradients, and the flat gradient is taken back by it before anything reads it.  With identical parameters and inputs the
+    gradient of the SECOND step-free backward must agree with an all-exact plan's to fp32 level, GEMMs must actually have moved, and a loss 1000
+    times smaller must be followed by the exponents (no synchronisation) with the same agreement."""
+    from casapose_amd import train_engine as TE
+
+    monkeypatch.setattr(TE, "F16X2_TRAIN_CHECK_EVERY", 1)
+    for v_ in ("CASAPOSE_TRAIN_FWD", "CASAPOSE_CONV_MODE", "CASAPOSE_TRAIN_BWD"):
+        monkeypatch.delenv(v_, raising=False)
+    k, v, b, h, w = 4, 27, 2, 96, 128
+    params = O.init_params(k, v, seed=5, dtype=np.float32)
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy(rng.uniform(-1, 1, (b, h, w, 3)).astype(np.float32)).to(device)
+    lab = np.zeros((b, h, w), np.uint8)
+    lab[:, 10:60, 12:70] = 1
+    lab[:, 40:90, 60:120] = 2
+    lab[:, 5:30, 90:125] = 3
+    labd = torch.from_numpy(lab).to(device)
+    kpts = torch.from_numpy(rng.uniform(0, min(h, w), (b, k - 1, 9, 2)).astype(np.float32)).to(device)
+
+    def plan_for(bwd):
+        monkeypatch.setenv("CASAPOSE_TRAIN_BWD", bwd)
+        plan = TE.TrainPlan(TE.ParamStore(params, device), k, v, b, h, w)
+        plan.refresh_weights(torch.cuda.current_stream(device).cuda_stream)
+        return plan
+
+    def grad_of(plan, wts):
+        plan.forward(img, cond_labels=labd)
+        plan.loss_and_grad(labd, labd, kpts, *wts)
+        plan.backward()
+        torch.cuda.synchronize()
+        return plan.store.grad.double().cpu().numpy().copy()
+
+    def rel(a, b_):
+        return float(np.abs(a - b_).max() / np.abs(b_).max())
+
+    wts = (1.0, 0.5, 0.015)
+    exact = plan_for("split")
+    ref = grad_of(exact, wts)
+    plan = plan_for("f16x2")
+    g0 = grad_of(plan, wts)          # exact split, measuring; calibrated synchronously at its end
+    assert rel(g0, ref) < 2e-5
+    slots = plan._bwd_slots()
+    kinds = {"direct": [f for _, f, e in slots if e == "direct"], "wino": [f for _, f, e in slots if e != "direct"]}
+    assert kinds["direct"] and kinds["wino"]
+    assert sum(1 for f in kinds["direct"] if f["on"]) >= len(kinds["direct"]) // 2, [f["on"] for f in kinds["direct"]]
+    assert all(f["e"] is not None for f in kinds["wino"])
+    assert plan.loss_exp > 0   # gradients of a mean loss are far below fp16's band
+    g1 = grad_of(plan, wts)          # fp16 pairs
+    assert rel(g1, ref) < 2e-5, rel(g1, ref)
+    # per-variable view of the same comparison: every tensor of the flat gradient agrees, not only the largest
+    st = plan.store
+    worst = max(rel(g1[off:off + int(np.prod(shape))], ref[off:off + int(np.prod(shape))]) for _, (off, shape) in st.offsets.items()
+                if np.abs(ref[off:off + int(np.prod(shape))]).max() > 0)
+    assert worst < 5e-4, worst
+    # a loss 1000 times smaller: the slots report it, the exponents follow at the start of a later step
+    small = tuple(x * 1e-3 for x in wts)
+    e_before = plan.loss_exp
+    for _ in range(3):
+        gs = grad_of(plan, small)
+    assert plan.loss_exp >= e_before + 8, (e_before, plan.loss_exp)
+    refs = grad_of(exact, small)
+    assert rel(gs, refs) < 2e-5, rel(gs, refs)
