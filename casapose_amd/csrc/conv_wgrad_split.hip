@@ -7,6 +7,9 @@
 // tf.GradientTape, train_casapose.py:594-611 -> Conv2DBackpropFilter).
 //   NP = 3  fp32-EQUIVALENT: both operands are split exactly into three bf16 terms, six products per fp32 product, fp32 accumulation
 //   NP = 1  operands rounded to bf16 (BASELINE.json configs[2])
+//   NP = 2  (round 6, planes = CP_PLANES_F16X2) both operands as fp16 pairs (split_f16.h): three exact products per fp32 product.  Both operands
+//           must sit inside fp16's band as they are: X is what the forward converted (its monitor watches it), dY carries the power of two the
+//           training plan puts on the loss (train_engine.train_bwd_f16x2).
 //
 // The reduction runs over PIXELS, so both MFMA operands are needed pixel-major ("transposed") while the tensors are [pixel][channel] in
 // HBM.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive k (= pixels) of one row (= channel) per lane; ds_read_b64_tr_b16 delivers exactly
@@ -21,6 +24,7 @@
 // and issue 6 MFMAs per (tap, 16 pixels).  One barrier per row.  The tile is flushed with fp32 atomics when the block moves to another
 // (ci, co) tile (summation order not fixed, as in cp_conv2d_wgrad_f32).
 #include "common.h"
+#include "split_f16.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -145,7 +149,13 @@ __device__ __forceinline__ uint2 round4(const float4 v) {
 
 template <int NP>
 __device__ __forceinline__ void store_planes(unsigned char* dst, int plane_stride, const float4 v0, const float4 v1) {
-    if constexpr (NP == 3) {
+    if constexpr (NP == 2) {   // fp16 pair: hi, lo
+        uint2 h0, l0, h1, l1;
+        cp::split4h(v0, h0, l0);
+        cp::split4h(v1, h1, l1);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(dst + plane_stride) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else if constexpr (NP == 3) {
         uint4 h, m, l;
         split8(v0, v1, h, m, l);
         *reinterpret_cast<uint4*>(dst) = h;
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
     const int NTP = (NT + D - 1) / D * D;
 
     if (wave >= 4) {
+        if constexpr (NP == 2) cp::f16_overflow_clamps();
         // ------------------------------------------------ loaders ---------------------------------------------------------------
         const int lw = wave - 4;
         const int oct = lane & 3;
@@ -313,7 +324,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
             if constexpr (IMG) {
                 if (lane < 17 && i_px < XC) {
                     unsigned char* ib = Is + (T & 3) * ISLOT + i_px * 8;
-                    if constexpr (NP == 3) {
+                    if constexpr (NP == 2) {
+                        uint2 h, l;
+                        cp::split4h(ir[d], h, l);
+                        *reinterpret_cast<uint2*>(ib) = h;
+                        *reinterpret_cast<uint2*>(ib + IPLANE) = l;
+                    } else if constexpr (NP == 3) {
                         uint2 h, m, l;
                         split4(ir[d], h, m, l);
                         *reinterpret_cast<uint2*>(ib) = h;
@@ -465,7 +481,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
                     }
                 }
                 f32x16& c = acc[t];
-                if constexpr (NP == 3) {
+                if constexpr (NP == 2) {   // lo * hi, hi * lo, hi * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, aa[1]), __builtin_bit_cast(cp::f16x8_t, bb[0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, aa[0]), __builtin_bit_cast(cp::f16x8_t, bb[1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, aa[0]), __builtin_bit_cast(cp::f16x8_t, bb[0]), c, 0, 0, 0);
+                } else if constexpr (NP == 3) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bb[0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bb[2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[1], bb[1], c, 0, 0, 0);
@@ -518,7 +538,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(const WSplitK p) {
                         }
                     }
                     f32x16& c = acci[b];
-                    if constexpr (NP == 3) {
+                    if constexpr (NP == 2) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, a[0][1]), __builtin_bit_cast(cp::f16x8_t, bi[0]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, a[0][0]), __builtin_bit_cast(cp::f16x8_t, bi[1]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cp::f16x8_t, a[0][0]), __builtin_bit_cast(cp::f16x8_t, bi[0]), c, 0, 0, 0);
+                    } else if constexpr (NP == 3) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], bi[0], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bi[2], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bi[1], c, 0, 0, 0);
@@ -610,7 +634,7 @@ extern "C" int cp_conv_wgrad_split_applicable(const cp_conv_desc* d) { return ap
 extern "C" int cp_conv2d_wgrad_split(const cp_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int accumulate, int planes, void* stream) {
     CP_REQUIRE_DESC(d, "cp_conv2d_wgrad_split");
     CP_REQUIRE(dy && dw_packed, "cp_conv2d_wgrad_split: null pointer");
-    CP_REQUIRE(planes == 1 || planes == 3, "cp_conv2d_wgrad_split: planes must be 3 (exact split) or 1 (bf16)");
+    CP_REQUIRE(planes == 1 || planes == 3 || planes == CP_PLANES_F16X2, "cp_conv2d_wgrad_split: planes must be 3 (exact split), 1 (bf16) or CP_PLANES_F16X2");
     CP_REQUIRE(applicable(d), "cp_conv2d_wgrad_split: descriptor not covered (3x3 / stride 1 / pad 1, direct sources with 32-multiple channels + "
                               "an optional trailing 4-channel source, cout a multiple of 32); see cp_conv_wgrad_split_applicable");
     CP_REQUIRE(dy_ld >= d->cout && dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0, "cp_conv2d_wgrad_split: dy_ld must be a multiple of 4 and >= cout, dy 16-byte aligned");
@@ -651,7 +675,8 @@ extern "C" int cp_conv2d_wgrad_split(const cp_conv_desc* d, const float* dy, int
         k.img_bytes = (unsigned)((long long)d->batch * d->in_h * d->in_w * in.ld * 4);
     }
     int rc;
-    if (planes == 3) rc = d->tap_label ? launch_shape<3, true>(k, st) : launch_shape<3, false>(k, st);
+    if (planes == CP_PLANES_F16X2) rc = d->tap_label ? launch_shape<2, true>(k, st) : launch_shape<2, false>(k, st);
+    else if (planes == 3) rc = d->tap_label ? launch_shape<3, true>(k, st) : launch_shape<3, false>(k, st);
     else rc = d->tap_label ? launch_shape<1, true>(k, st) : launch_shape<1, false>(k, st);
     if (rc != CP_OK) return rc;
     if (first_small_chunk >= 0 && !img_inside) return cp::wgrad_f32_chunks(d, dy, dy_ld, dw_packed, first_small_chunk, st);

@@ -621,6 +621,11 @@ class ConvOp:
                     w.pop("c_scale", None)
                     w["Us"] = w["Us3"] = split_wino_weights(w["U"], 36, w["cout"], w["ktot"], out=w.get("Us3"), stream=stream)
 
+    def wgrad_f16x2(self) -> bool:
+        """the direct weight gradient on fp16 pairs: dY inside the band (the switch its data gradient uses) and X too (the forward still f16x2)"""
+        b = getattr(self, "bw16", None)
+        return b is not None and b["on"] and not b["dead"] and self.layer.fwd_f16x2
+
     def direct_dgrad_split(self) -> bool:
         """True when this op has a data gradient that runs on conv_hsplit as an exact three-way split and may move to the fp16 pair
         (train_bwd_f16x2): 3x3 / stride 1 / no dilation, not a Winograd / deep-bf16 / 1x1-GEMM route"""
@@ -851,7 +856,7 @@ class ConvOp:
             wp = self.wgrad_planes()             # weight gradient: conv_wgrad_split.hip (32-multiple sources; the image source stays fp32) or fp32 MFMA
             if wp:
                 big = sum(s[1] for s in L.sources if s[0] != 4)
-                out["bf16"] += (6.0 if wp == 3 else 1.0) * direct * big / cin
+                out["bf16"] += ((3.0 if self.wgrad_f16x2() else 6.0) if wp == 3 else 1.0) * direct * big / cin
                 out["f32"] += direct * (cin - big) / cin
             else:
                 out["f32"] += direct
@@ -970,6 +975,8 @@ class ConvOp:
                 k0 += cp_
         else:
             planes = self.wgrad_planes()
+            if planes == 3 and self.wgrad_f16x2():
+                planes = _lib.PLANES_F16X2   # both operands inside fp16's band: X watched by the forward's monitor, dY carrying the loss factor
             if planes:   # bf16 matrix pipe (csrc/conv_wgrad_split.hip): same packed result
                 check(lib.cp_conv2d_wgrad_split(C.byref(d), dy, dy_ld, L.dwp.data_ptr(), 0, planes, stream), "cp_conv2d_wgrad_split(%s)" % L.name)
             else:
@@ -1668,7 +1675,8 @@ class TrainPlan:
                 wf = getattr(op, "wino_fwd", None)
                 if wf is not None and wf.get("wg16") is not None:
                     self._bwd_f16.append((op, wf["wg16"], None))
-                if op.direct_dgrad_split():   # direct 3x3 data gradient(s) on conv_hsplit: entry "direct", state on / off instead of an exponent
+                if op.direct_dgrad_split() or (train_bwd_f16x2() and op.wgrad_planes() == 3):
+                    # direct 3x3 data / weight gradients (conv_hsplit, conv_wgrad_split): entry "direct", state on / off instead of an exponent
                     op.bw16 = dict(on=False, mon=None, dead=False, e=None)
                     self._bwd_f16.append((op, op.bw16, "direct"))
         return self._bwd_f16

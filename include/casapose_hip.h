@@ -475,7 +475,8 @@ int cp_conv2d_wgrad_f32(const cp_conv_desc* desc, const float* dy, int dy_ld, fl
 /* The same product on the bf16 matrix pipe (csrc/conv_wgrad_split.hip), the backward partner of cp_conv2d_fwd_split: 3x3 / stride 1 / pad 1,
  * direct sources whose channel counts are multiples of 32 plus an optional trailing 4-channel source (the image: its columns are computed by
  * the fp32 kernel), cout a multiple of 32, tap_label as above.  planes = 3: both operands split exactly into three bf16 terms, six products per
- * fp32 product, fp32 accumulation (fp32-equivalent); planes = 1: operands rounded to bf16 (BASELINE.json configs[2]).  Same dw_packed layout,
+ * fp32 product, fp32 accumulation (fp32-equivalent); planes = 1: operands rounded to bf16 (BASELINE.json configs[2]); planes = CP_PLANES_F16X2
+ * (round 6): both operands as fp16 pairs, three exact products -- the caller keeps max |x| and max |dy| inside [0.5, 65504 / 4] (cp_amax_f32).  Same dw_packed layout,
  * same accumulate flag, same unfixed summation order as cp_conv2d_wgrad_f32. */
 int cp_conv_wgrad_split_applicable(const cp_conv_desc* desc);
 int cp_conv2d_wgrad_split(const cp_conv_desc* desc, const float* dy, int dy_ld, float* dw_packed, int accumulate, int planes, void* stream);

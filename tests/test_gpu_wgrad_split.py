@@ -56,7 +56,7 @@ def reference_hwio(xs, sources, dy, lab):
     return g
 
 
-@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("planes", [3, 1, 0x12])   # 0x12 = CP_PLANES_F16X2: fp16 pairs, operands inside fp16's band as they are (round 6)
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_wgrad_split_matches_fp64_and_fp32_kernel(device, case, planes):
     from casapose_amd import _lib
@@ -99,13 +99,13 @@ def test_wgrad_split_matches_fp64_and_fp32_kernel(device, case, planes):
     g = reference_hwio(xs, sources, dy[..., :cout], lab).astype(np.float32)
     ref = np.zeros((cout, ktot), np.float32)
     check(lib.cp_conv_pack_weights_host(g.ctypes.data, 0, 3, 3, cout, len(sources), chans, real, ref.ctypes.data), "cp_conv_pack_weights_host")
-    tol = 3e-5 if planes == 3 else 2e-2
+    tol = 2e-2 if planes == 1 else 3e-5
     got_h = got.cpu().numpy()
     # padding columns of the packed rows (image channel 3, the K padding up to a multiple of 32) carry no gradient
     used = ref != 0
     assert rel(got_h * used, ref) < tol, "against fp64"
     assert rel(f32.cpu().numpy() * used, ref) < 3e-5
-    if planes == 3:
+    if planes != 1:
         assert rel(got_h * used, ref) <= 4 * max(rel(f32.cpu().numpy() * used, ref), 1e-6), "no worse than the fp32 MFMA kernel"
     # accumulate = 1 adds onto the previous content
     check(lib.cp_conv2d_wgrad_split(C.byref(d), dyt.data_ptr(), ldo, got.data_ptr(), 1, planes, stream), "cp_conv2d_wgrad_split")
