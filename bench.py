@@ -443,7 +443,14 @@ def _dtype_note_train():
         note += " (%s as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16: six products, fp32 accumulate, fp32-equivalent; all other kernels fp32 MFMA)" % " and ".join(parts)
     if conv == "split" and os.environ.get("CASAPOSE_TRAIN_FWD", "f16x2") == "f16x2":
         note += ("; FORWARD launches of those groups as fp16 two-way splits on v_mfma_f32_32x32x16_f16 (three exact products per fp32 product, fp32-level error: "
-                 "tests/test_gpu_f16x2.py; the operands' range watched by a device-side monitor, train_engine.TrainPlan._poll_f16x2), backward launches as exact bf16 splits")
+                 "tests/test_gpu_f16x2.py; the operands' range watched by a device-side monitor, train_engine.TrainPlan._poll_f16x2)")
+        if os.environ.get("CASAPOSE_TRAIN_BWD", "f16x2") == "f16x2":
+            note += ("; BACKWARD launches of the 3x3 layers (data and weight gradients, Winograd and direct) in the same fp16 two-way split from the second "
+                     "step on -- gradients brought into fp16's band by powers of two (one on the loss, one per Winograd GEMM; exact), chosen from "
+                     "device-side maxima without a synchronisation; the first step and any GEMM outside the band run the exact bf16 split "
+                     "(`f16x2_backward` in this line, train_engine.train_bwd_f16x2)")
+        else:
+            note += ", backward launches as exact bf16 splits"
     if conv == "bf16":
         note = "bf16 operands / f32 accumulate in the forward / data gradient / weight gradient of the 3x3 layers off the Winograd path; " + note + " elsewhere"
     return note
@@ -585,8 +592,22 @@ def train_leg(B, H, W, steps, warmup, dev, rank, world):
                      "direct_equivalent_tflops": round(3.0 * fwd_flops * args.steps / dt / 1e12, 3), "traffic": None,
                      "kernel": "all convolution launches of the step (forward, data gradient, weight gradient; conv_f32 / conv_halo / conv_hsplit / wino_gemm(_split) / conv_wgrad(_split))"},
         "losses": {"mask": float(sums[0]), "vertex": float(sums[1]), "proxy": float(sums[2]), "keypoint": float(kpl)},
+        "f16x2_backward": _f16x2_backward_state(plan),
     }
     return result
+
+
+def _f16x2_backward_state(plan):
+    """what the backward of the timed steps ran on: the power of two on the loss, the backward GEMMs on fp16 pairs / on the exact split"""
+    slots = plan._bwd_slots() if hasattr(plan, "_bwd_slots") else []
+    if not slots:
+        return None
+    direct = [f for _, f, e in slots if e == "direct"]
+    wino = [f for _, f, e in slots if e != "direct"]
+    exps = [f["e"] for f in wino if f["e"] is not None]
+    return {"loss_exponent": plan.loss_exp, "direct_layers_on_fp16_pairs": sum(1 for f in direct if f["on"]), "direct_layers": len(direct),
+            "winograd_gemms_on_fp16_pairs": len(exps), "winograd_gemms": len(wino), "winograd_exponents": [min(exps), max(exps)] if exps else None,
+            "returned_to_exact_split": list(plan.f16x2_demoted), "range_readings": plan.f16x2_checks}
 
 
 def bench_vote(args):
@@ -1093,22 +1114,23 @@ def main():
         dog = threading.Timer(args.train_leg_timeout, give_up)
         dog.daemon = True
         dog.start()
-        keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "losses", "comm_exposed_ms", "comm", "comm_structure")
+        keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "losses", "comm_exposed_ms", "comm", "comm_structure",
+                "f16x2_backward")
         try:
             leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
             result["training_leg"] = {k: leg[k] for k in keys}
             _log("training leg done: %.2f ms/step" % leg["ms_per_step"])
-            if "CASAPOSE_TRAIN_FWD" not in os.environ and "CASAPOSE_CONV_MODE" not in os.environ:
-                # the same steps with the EXACT three-way bf16 split in the forward too (the default of rounds 2-5; round 6 runs the forward in the fp16
-                # two-way split -- fp32-level, range-monitored -- and keeps the exact split in the backward)
-                os.environ["CASAPOSE_TRAIN_FWD"] = "split"
+            if "CASAPOSE_TRAIN_FWD" not in os.environ and "CASAPOSE_TRAIN_BWD" not in os.environ and "CASAPOSE_CONV_MODE" not in os.environ:
+                # the same steps with the EXACT three-way bf16 split everywhere (the default of rounds 2-5; round 6 runs forward and backward in the
+                # fp16 two-way split -- fp32-level, range-monitored)
+                os.environ["CASAPOSE_TRAIN_FWD"] = os.environ["CASAPOSE_TRAIN_BWD"] = "split"
                 try:
                     torch.cuda.empty_cache()
                     leg = train_leg(32, 448, 448, 3, 1, dev, rank, world)
-                    result["training_leg_exact_split_forward"] = {k: leg[k] for k in keys}
-                    _log("exact-forward training leg done: %.2f ms/step" % leg["ms_per_step"])
+                    result["training_leg_exact_split"] = {k: leg[k] for k in keys}
+                    _log("exact-split training leg done: %.2f ms/step" % leg["ms_per_step"])
                 finally:
-                    del os.environ["CASAPOSE_TRAIN_FWD"]
+                    del os.environ["CASAPOSE_TRAIN_FWD"], os.environ["CASAPOSE_TRAIN_BWD"]
             if "CASAPOSE_CONV_MODE" not in os.environ:
                 # BASELINE configs[2] AS NAMED ("bs=32 bf16 convs"): the same three steps with the operands of the convolutions rounded to bf16
                 # (fp32 accumulate; gates 3e-2 on outputs + the convergence test, tests/test_gpu_train.py) beside the fp32-equivalent default

@@ -75,7 +75,7 @@ copy(T + "pmc_mfma/summary.txt", "%s_pmc_mfma.txt" % tag)
 copy(T + "bench_train.json", "%s_bench_train.json" % tag)
 copy(T + "bench_train_f32.json", "%s_bench_train_conv_mode_f32.json" % tag)
 copy(T + "bench_train_bf16.json", "%s_bench_train_conv_mode_bf16.json" % tag)
-copy(T + "bench_train_fwd_exact.json", "%s_bench_train_fwd_exact.json" % tag)
+copy(T + "bench_train_exact.json", "%s_bench_train_exact.json" % tag)
 copy(T + "train_trace/train_kernel_stats.csv", "%s_train_kernel_stats.csv" % tag)
 copy(T + "train_times.txt", "%s_train_times.txt" % tag)
 copy(T + "bench_vote.json", "%s_bench_vote.json" % tag)
@@ -213,7 +213,7 @@ tr = t["roofline"]
 extra = []
 for name, label in (("bench_train_conv_mode_f32.json", "`CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32` (fp32 MFMA everywhere)"),
                     ("bench_train_conv_mode_bf16.json", "`CASAPOSE_CONV_MODE=bf16` (operands rounded to bf16)"),
-                    ("bench_train_fwd_exact.json", "`CASAPOSE_TRAIN_FWD=split` (the forward on the exact three-way bf16 split too: the default of rounds 2-5)")):
+                    ("bench_train_exact.json", "`CASAPOSE_TRAIN_FWD=split CASAPOSE_TRAIN_BWD=split` (forward and backward on the exact three-way bf16 split: the default of rounds 2-5)")):
     x = load(name)
     if x:
         extra.append("%s: %.0f images/s (%.1f ms)" % (label, x["value"], x["ms_per_step"]))

@@ -37,7 +37,7 @@ CASAPOSE_INFER_CONV_MODE=split python3 $R/tools/layer_times.py > $O/layer_times_
 python3 $R/bench.py --mode train --steps 8 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err
 CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32 python3 $R/bench.py --mode train --steps 8 --warmup 3 > $O/bench_train_f32.json 2>> $O/bench_train.err
 CASAPOSE_CONV_MODE=bf16 python3 $R/bench.py --mode train --steps 8 --warmup 3 > $O/bench_train_bf16.json 2>> $O/bench_train.err
-CASAPOSE_TRAIN_FWD=split python3 $R/bench.py --mode train --steps 8 --warmup 3 > $O/bench_train_fwd_exact.json 2>> $O/bench_train.err
+CASAPOSE_TRAIN_FWD=split CASAPOSE_TRAIN_BWD=split python3 $R/bench.py --mode train --steps 8 --warmup 3 > $O/bench_train_exact.json 2>> $O/bench_train.err
 rocprofv3 --kernel-trace --stats -d $O/train_trace -o train --output-format csv -- python3 $R/bench.py --mode train --steps 5 --warmup 2 > $O/bench_train_profiled.json 2> $O/rocprof_train.err
 python3 $R/tools/train_times.py > $O/train_times.txt 2>&1
 python3 $R/bench.py --mode vote --steps 20 --warmup 5 > $O/bench_vote.json 2> $O/bench_vote.err
@@ -49,7 +49,7 @@ if [ "${2:-}" = "suites" ]; then   # the -m gpu suite per conv mode, on the same
   CASAPOSE_INFER_CONV_MODE=split python3 -m pytest tests -q -m gpu --ignore=tests/test_gpu_train.py --ignore=tests/test_gpu_scripts.py --ignore=tests/test_gpu_dp.py 2>&1 | tail -4 > $O/gputests_infer_conv_mode_split.log
   CASAPOSE_INFER_CONV_MODE=f32 python3 -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gputests_infer_conv_mode_f32.log
   CASAPOSE_CONV_MODE=f32 CASAPOSE_WINO_GEMM=f32 python3 -m pytest tests/test_gpu_train.py tests/test_gpu_scripts.py tests/test_gpu_dp.py -q -m gpu 2>&1 | tail -4 > $O/gputests_train_conv_mode_f32.log
-  CASAPOSE_TRAIN_FWD=split python3 -m pytest tests/test_gpu_train.py tests/test_gpu_fullsize.py -q -m gpu 2>&1 | tail -4 > $O/gputests_train_fwd_exact.log
+  CASAPOSE_TRAIN_FWD=split CASAPOSE_TRAIN_BWD=split python3 -m pytest tests/test_gpu_train.py tests/test_gpu_fullsize.py -q -m gpu 2>&1 | tail -4 > $O/gputests_train_exact.log
   cd /tmp
 fi
 python3 $R/bench.py --stamp > $O/stamp_end.json
