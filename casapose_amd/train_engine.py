@@ -1189,7 +1189,7 @@ class TrainPlan:
         self._f16x2_mon = self._f16x2_host = self._f16x2_event = None   # range monitor of the f16x2 forward (_poll_f16x2)
         self._f16x2_steps, self.f16x2_checks, self.f16x2_demoted = 0, 0, []
         self._bwd_f16, self._bwd_calibrated, self.f16x2_bwd_moves = None, False, []   # backward GEMMs in f16x2 (train_bwd_f16x2)
-        self.loss_exp, self._dout_scale, self._unscale_pending = 0, 1.0, False         # power of two on the loss (direct data gradients in f16x2)
+        self.loss_exp, self._dout_scale = 0, 1.0                                       # power of two on the loss (direct data gradients in f16x2)
         self.comm_timing = None   # start_comm_timing()
         self.comm_log = None      # start_comm_log()
         self._buckets = None
@@ -1979,6 +1979,7 @@ class TrainPlan:
                             continue
                         if side is not None:
                             main.wait_stream(side)   # the bucket's weight gradients come from the side stream
+                        self._unscale_grads(stream, a, e)   # (the loss factor is this replica's own: out before the sum over replicas)
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
         if side is not None:
             main.wait_stream(side)
@@ -1995,17 +1996,18 @@ class TrainPlan:
                     if log is not None:
                         log.append(("grad_bucket", 4 * (e - a), "async", stream, first))
                     if multi:
+                        self._unscale_grads(stream, a, e)
                         self._pending.append(parallel.all_reduce_sum_async(self.store.grad[a:e], self.group))
-        if self._dout_scale != 1.0:   # the loss carried a power of two (loss_exp): take it out of the flat gradient -- behind the exchange if one is in flight
-            if self._pending:
-                self._unscale_pending = True
-            else:
-                self._unscale_grads(stream)
+        # the loss carried a power of two (loss_exp): it leaves the flat gradient here -- bucket by bucket in front of each exchange above (the
+        # buckets tile the buffer; every replica has its OWN factor, so it must be gone before replicas are summed), in one piece otherwise
+        if not multi:
+            self._unscale_grads(stream, 0, self.store.grad.numel())
+        self._dout_scale = 1.0
 
-    def _unscale_grads(self, stream: int):
-        g = self.store.grad
-        check(_lib.load().cp_axpby_f32(g.data_ptr(), 1.0 / self._dout_scale, g.data_ptr(), 0.0, g.numel(), g.data_ptr(), stream), "cp_axpby_f32(gradient / loss factor)")
-        self._dout_scale, self._unscale_pending = 1.0, False
+    def _unscale_grads(self, stream: int, a: int, e: int):
+        if self._dout_scale != 1.0 and e > a:
+            g = self.store.grad[a:e]
+            check(_lib.load().cp_axpby_f32(g.data_ptr(), 1.0 / self._dout_scale, g.data_ptr(), 0.0, e - a, g.data_ptr(), stream), "cp_axpby_f32(gradient / loss factor)")
 
     def all_reduce_grads(self):
         """Complete the gradient exchange started by backward() (or run it as one all-reduce if none is pending)."""
@@ -2019,8 +2021,6 @@ class TrainPlan:
             for h in self._pending:
                 h.wait()
             self._pending = []
-            if self._unscale_pending:
-                self._unscale_grads(torch.cuda.current_stream(self.out.device).cuda_stream)
         else:
             parallel.all_reduce_sum_(self.store.grad, self.group, self.world_size)
         if timed:

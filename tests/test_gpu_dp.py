@@ -30,14 +30,26 @@ def _data():
     return params, img, lab, kpts
 
 
-def _run(plan, dev, img, lab, kpts):
+def _run(plan, dev, img, lab, kpts, before_second=None):
     labd = torch.from_numpy(lab).to(dev)
     out = plan.forward(torch.from_numpy(img).to(dev), cond_labels=labd).clone()
     sums = plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(dev), 1.0, 0.5, 0.015, filter_with_segmentation=False).clone()
     plan.backward()
     plan.all_reduce_grads()
     torch.cuda.synchronize()
-    return out.cpu().numpy(), sums.cpu().numpy(), plan.store.grad.cpu().numpy().copy()
+    # the same once more: from a plan's SECOND backward on its GEMMs run on fp16 pairs behind powers of two each replica picks from ITS OWN shard (one on
+    # the loss among them, train_engine.train_bwd_f16x2) -- they must be out of the flat gradient before the replicas are summed
+    first = plan.store.grad.cpu().numpy().copy()
+    if before_second is not None:
+        before_second()
+    plan.forward(torch.from_numpy(img).to(dev), cond_labels=labd)
+    plan.loss_and_grad(labd, labd, torch.from_numpy(kpts).to(dev), 1.0, 0.5, 0.015, filter_with_segmentation=False)
+    plan.backward()
+    plan.all_reduce_grads()
+    torch.cuda.synchronize()
+    second = plan.store.grad.cpu().numpy()
+    assert np.abs(second - first).max() < 1e-4 * np.abs(first).max(), "fp16-pair backward against the exact-split backward of the same step"
+    return out.cpu().numpy(), sums.cpu().numpy(), second.copy()
 
 
 def _worker(rank, world, port, outdir):
@@ -218,7 +230,8 @@ def _rccl_worker(port, outdir):
 
     parallel.all_reduce_sum_async = lambda t, group=None: _Spy(real_async(t, group))
     try:
-        out, sums, grad = _run(plan, dev, img, lab, kpts)                # SyncBN fp64 tables, four asynchronous gradient buckets, all over RCCL
+        # SyncBN fp64 tables, four asynchronous gradient buckets, all over RCCL; the structure below is read off the SECOND round's log (fp16-pair backward)
+        out, sums, grad = _run(plan, dev, img, lab, kpts, before_second=lambda: (plan.start_comm_log(), waits.clear()))
     finally:
         parallel.all_reduce_sum_async = real_async
     assert plan._buckets is not None and len(plan._buckets) == 4 and not plan._pending
