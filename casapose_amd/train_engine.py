@@ -557,7 +557,9 @@ class ConvOp:
         # comparison from 6e-5 to 3e-3 (the proxy-voting loss divides by |v|^2: gradients are very sensitive to the forward's last bits).
         # In the bf16 conv mode (3e-2 gates) the same layer does take the Winograd path: no bf16-pipe kernel covers a dilated 3x3 directly, so it
         # would otherwise be the one deep layer left on the fp32 MFMA (forward 0.60 ms at 99 TFLOP/s).
-        split_gemm = self.layer.mode_planes == 1 and self.dil > 1
+        # Round 6: the fp32-LEVEL default (forward in the fp16 two-way split, the config-13 comparison gated at 1e-2 like the fp32 MFMA's) takes it too:
+        # forward 0.59 -> Winograd GEMM on fp16 pairs, weight gradient through the Winograd planes instead of the fp32 MFMA kernel.
+        split_gemm = self.dil > 1 and (self.layer.mode_planes == 1 or (self.layer.fwd_f16x2 and os.environ.get("CASAPOSE_TRAIN_WINO_DILATED_128", "1") == "1"))
 
         if all(s[0] == s[1] for s in L.sources) and wino_eligible(3, 1, self.dil, self.pad, L.sources, L.cout, split_gemm=split_gemm):
             ktot = sum(s[0] for s in L.sources)
