@@ -68,7 +68,7 @@ __device__ __forceinline__ float pre_act_f(float t, int act) {
     return t;
 }
 
-// PRE: 0 = plain, 1 + act = normalise + activation `act` (CP_ACT_NONE / RELU / LEAKY01) -- compile-time: with a run-time activation switch the
+// PRE: 0 = plain, 4 = a per-channel factor only, 1 + act = normalise + activation `act` (CP_ACT_NONE / RELU / LEAKY01) -- compile-time: with a run-time activation switch the
 // 144 elements of a patch cost two compares and selects each and the transform turned from HBM-bound (102 us) into VALU-bound (173 us)
 template <int PRE>
 __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restrict__ src, int ld, int C, WinoGeom g, float* __restrict__ V, int ldv,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restric
         float4 ps = f4(1.f), pb = f4(0.f);
         if constexpr (PRE) {
             ps = *reinterpret_cast<const float4*>(pre_scale + c4 * 4);
-            pb = *reinterpret_cast<const float4*>(pre_shift + c4 * 4);
+            if constexpr (PRE != 4) pb = *reinterpret_cast<const float4*>(pre_shift + c4 * 4);
         }
         float4 tt[6][6];  // (B^T d): column by column
 #pragma unroll
@@ -97,7 +97,10 @@ __global__ __launch_bounds__(THREADS) void wino_in_kernel(const float* __restric
                 const int y = sy + g.d * (4 * tu + r - 1);
                 const bool ok = (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;  // outside the image (or before the sub-grid's first row/column): zero padding
                 col[r] = ok ? *reinterpret_cast<const float4*>(src + (((size_t)n * g.H + y) * g.W + x) * ld + c4 * 4) : f4(0.f);
-                if (PRE && ok) {
+                if constexpr (PRE == 4) {   // a per-channel factor only (no shift, no activation): zero padding stays zero, so no condition
+                    const float4 v = col[r];
+                    col[r] = make_float4(v.x * ps.x, v.y * ps.y, v.z * ps.z, v.w * ps.w);
+                } else if (PRE && ok) {
                     constexpr int ACT = PRE - 1;
                     const float4 v = col[r];
                     col[r] = make_float4(pre_act_f(__builtin_fmaf(v.x, ps.x, pb.x), ACT), pre_act_f(__builtin_fmaf(v.y, ps.y, pb.y), ACT),
@@ -520,14 +523,15 @@ extern "C" int cp_wino_input_transform_pre_f32(const float* src, int ld, int cha
                                                int c_off, const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
     CP_REQUIRE(src && V && channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0 && c_off >= 0 && c_off % 4 == 0 && c_off + channels <= ldv,
                "cp_wino_input_transform_f32: bad arguments");
-    CP_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr) && (((uintptr_t)pre_scale | (uintptr_t)pre_shift) & 15) == 0,
-               "cp_wino_input_transform_pre_f32: pre_scale and pre_shift come together, 16-byte aligned");
+    CP_REQUIRE((pre_scale || !pre_shift) && (pre_shift || !pre_scale || pre_act == CP_ACT_NONE) && (((uintptr_t)pre_scale | (uintptr_t)pre_shift) & 15) == 0,
+               "cp_wino_input_transform_pre_f32: pre_scale and pre_shift come together (pre_scale alone = a per-channel factor, no activation), 16-byte aligned");
     WinoGeom g;
     CP_REQUIRE(make_geom(batch, h, w, dilation, g) == CP_OK, "cp_wino_input_transform_f32: bad geometry");
     CP_REQUIRE(!pre_scale || pre_act == CP_ACT_NONE || pre_act == CP_ACT_RELU || pre_act == CP_ACT_LEAKY01, "cp_wino_input_transform_pre_f32: unknown activation %d", pre_act);
     const dim3 grid(grid_for((long long)g.T * (channels / 4)));
 #define CP_WIN(P_) CP_LAUNCH(wino_in_kernel<P_>, grid, dim3(THREADS), 0, (hipStream_t)stream, src, ld, channels, g, V, ldv, c_off, pre_scale, pre_shift, pre_act, cp::f16x2_monitor())
     if (!pre_scale) CP_WIN(0);
+    else if (!pre_shift) CP_WIN(4);
     else if (pre_act == CP_ACT_RELU) CP_WIN(1 + CP_ACT_RELU);
     else if (pre_act == CP_ACT_LEAKY01) CP_WIN(1 + CP_ACT_LEAKY01);
     else CP_WIN(1 + CP_ACT_NONE);

@@ -661,7 +661,6 @@ class ConvOp:
             if w.get("ps") is None:
                 dev = w["U"].device
                 w["ps"] = torch.empty(w["ktot"], dtype=torch.float32, device=dev)
-                w["pb"] = torch.zeros(w["ktot"], dtype=torch.float32, device=dev)
             w["ps"].fill_(2.0 ** e)
         self._refresh_winograd(stream)
 
@@ -1024,7 +1023,7 @@ class ConvOp:
             if s in getattr(self, "wino_dgrad", {}):  # stride 1, so the data gradient lives on the forward's input grid
                 w = self.wino_dgrad[s]
                 f = w.get("f16")
-                pre = {0: (w["ps"].data_ptr(), w["pb"].data_ptr(), _lib.ACT_NONE)} if f is not None and f["e"] is not None else None
+                pre = {0: (w["ps"].data_ptr(), None, _lib.ACT_NONE)} if f is not None and f["e"] is not None else None   # (a factor only: no shift table)
                 self._wino_run(w, [(dy, dy_ld, L.cout)], t.grad.data_ptr() if t.has_grad else None, t.grad.data_ptr(), stream, pre=pre,
                                mon=f["mon"] if f is not None and not f["dead"] else None)
                 t.has_grad = True

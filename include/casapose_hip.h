@@ -449,7 +449,8 @@ int cp_wino_output_input_transform_f32(const float* M, int cout, int batch, int 
  * normalisation -> activation -> convolution).  _stats: also accumulates stats[c] = sum, stats[cout + c] = sum of squares (fp64; zeroed by
  * the call) of the RAW output over the real pixels = the batch statistics cp_bn_stats_f32 would compute from out_raw.  _pre: applies
  * y = act(fma(x, pre_scale[c], pre_shift[c])) (cp_affine_act_f32's expression, per channel, both NULL = identity) to every real pixel as it
- * is loaded, so the activated tensor between a normalisation layer and a Winograd layer need not be stored. */
+ * is loaded, so the activated tensor between a normalisation layer and a Winograd layer need not be stored.  pre_scale alone (pre_shift
+ * NULL, pre_act CP_ACT_NONE; round 6) = a per-channel factor only: what brings a gradient into fp16's band in front of an f16x2 GEMM. */
 int cp_wino_output_transform_stats_f32(const float* M, int cout, int batch, int h, int w, int dilation, const float* residual, int residual_ld,
                                        const float* scale, const float* shift, const uint8_t* epi_label, int act, float* out_raw, int out_raw_ld,
                                        float* out_act, int out_act_ld, double* stats, void* stream);

@@ -352,6 +352,15 @@ def test_winograd_transforms_with_fused_normalisation(device, hip_lib, c, cout, 
         check(lib.cp_wino_input_transform_f32(y.data_ptr(), c, c, b, h, w, dil, v0.data_ptr(), c, 0, st))
         check(lib.cp_wino_input_transform_pre_f32(x.data_ptr(), c, c, b, h, w, dil, v1.data_ptr(), c, 0, sc.data_ptr(), sh.data_ptr(), act, st))
         assert torch.equal(v0, v1), "act %d" % act
+    # a per-channel factor alone (no shift table, no activation): the transform of the scaled tensor -- to rounding: the two instantiations contract
+    # B^T d B's multiply-adds differently, every one of them a correct rounding of the same sum
+    p2 = torch.from_numpy((2.0 ** rng.integers(-12, 13, c)).astype(np.float32)).to(device)
+    zero = torch.zeros(c, device=device)
+    check(lib.cp_wino_input_transform_pre_f32(x.data_ptr(), c, c, b, h, w, dil, v0.data_ptr(), c, 0, p2.data_ptr(), zero.data_ptr(), 0, st))
+    check(lib.cp_wino_input_transform_pre_f32(x.data_ptr(), c, c, b, h, w, dil, v1.data_ptr(), c, 0, p2.data_ptr(), None, 0, st))
+    v0c, v1c = v0.view(36 * tp, c), v1.view(36 * tp, c)
+    assert float(((v0c - v1c).abs().amax(0) / v0c.abs().amax(0).clamp_min(1e-30)).max()) < 2e-6
+    assert lib.cp_wino_input_transform_pre_f32(x.data_ptr(), c, c, b, h, w, dil, v1.data_ptr(), c, 0, p2.data_ptr(), None, 1, st) != 0   # an activation needs its shift
     m = torch.from_numpy(rng.standard_normal(36 * tp * cout).astype(np.float32)).to(device)
     res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(device)
     for r in (None, res):
