@@ -5,6 +5,9 @@
 #   wino_parts.txt       input transform / GEMM / output transform of every Winograd layer, timed separately, with the bytes each moves
 #   hbm_read_probe.txt   what a pure read stream of the LS voter's 708 MB achieves on the box (the voter's ceiling)
 #   monitor_cost.txt     the forward with and without the always-armed f16x2 range monitor, alternating, one call
+#   head_probe.txt       the training heads' kernels alone: partly written records against dense rows and whole records
+#   grad_ranges.txt      max |dY| per layer over six training steps (what the loss exponent has to span)
+#   train_backward_ab.txt  the training step with the backward on fp16 pairs / on the exact split, alternating, one call
 set -u
 : "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_probes; rm -rf $O; mkdir -p $O; cd $R
@@ -25,4 +28,17 @@ STAMP="# stamp $(python3 bench.py --stamp)   ($(date -u +%Y-%m-%dT%H:%MZ), tools
 { echo "$STAMP"; echo "# bash tools/debug/ab_bench.sh: forward + component filter + LS voting, 30 steps; CASAPOSE_F16X2_MONITOR=0 = calibration only, '-' = every forward armed (default)"
   bash tools/debug/ab_bench.sh CASAPOSE_F16X2_MONITOR=0 - CASAPOSE_F16X2_MONITOR=0 - CASAPOSE_F16X2_MONITOR=0 - 2>&1
 } > $O/monitor_cost.txt
+{ echo "$STAMP"; echo "# tools/debug/head_probe.py: the training step's 1x1 head kernels alone at bs 32 / 448 x 448 (partly written 36-float records against dense rows and whole records)"
+  python3 tools/debug/head_probe.py 2>&1 | grep -v amdgpu.ids
+  echo "# inference with the fused heads of blocks 5 / 10 writing dense scratch rows (timing only, '-' = the records): CASAPOSE_EXP_DENSE_HEADS is not in the tree; measured once at 7.47 -> 7.35 ms (CHANGELOG round 6)"
+} > $O/head_probe.txt
+{ echo "$STAMP"; echo "# tools/debug/grad_ranges.py: max |dY| per convolution op over six training steps (bs 8, 448 x 448, random initialisation)"
+  python3 tools/debug/grad_ranges.py 6 2>&1 | grep -v amdgpu.ids
+} > $O/grad_ranges.txt
+{ echo "$STAMP"; echo "# bash tools/debug/train_ab.sh: the training step (bs 32, 448 x 448, 8 timed steps) per backward arithmetic, alternating, one call: images/s, ms per step"
+  for v in "-" "CASAPOSE_TRAIN_BWD=split" "-" "CASAPOSE_TRAIN_BWD=split" "CASAPOSE_TRAIN_FWD=split CASAPOSE_TRAIN_BWD=split" "CASAPOSE_HEAD_RECORDS=0"; do
+    ( if [ "$v" != "-" ]; then export $v; fi
+      echo -n "[$v] "; python3 bench.py --mode train --steps 8 --warmup 3 2>/dev/null | python3 -c "import json,sys; p=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(p['value'], p['ms_per_step'], p['f16x2_backward'])" )
+  done
+} > $O/train_backward_ab.txt
 ls -la $O; head -5 $O/wino_parts.txt
