@@ -89,3 +89,31 @@ def test_hand_counted_waits_cover_their_dma(tmp_path, source, expected_waits):
 def test_safe_waits_switch_removes_every_counted_wait(tmp_path):
     lines = device_asm("wino_gemm_wide.hip", tmp_path, extra=["-DCP_SAFE_WAITS"])
     assert all(n == 0 for _, n, _, _ in hand_waits(lines)), hand_waits(lines)
+
+
+def test_ransac_vote_loop_matches_the_instruction_count_the_bench_line_prices(tmp_path):
+    """bench.py --mode vote prices the RANSAC voter against the fp32 VALU issue rate with RANSAC_VALU_PER_HYPOTHESIS vector instructions per hypothesis
+    (nine cosine tests): a number read off the generated ISA once.  Re-read it from every build: the loops of vote_kernel<64> that hold
+    exactly nine ballot counts (s_bcnt1_i32_b64: one per keypoint test) are the hypothesis loop's common-path copies; their v_* instruction counts must
+    bracket the constant."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    lines = device_asm("ransac_vote.hip", tmp_path)
+    start = [i for i, l in enumerate(lines) if re.match(r"^_ZN\S*vote_kernelILi64E\S*:", l)]
+    assert start, "vote_kernel<64> not found in the device assembly"
+    s = start[0]
+    e = next(i for i in range(s, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[s:e]
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    counts = []
+    for i, l in enumerate(body):
+        m = re.match(r"\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"\s*s_branch\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:      # a backward branch closes a loop
+            seg = body[labels[m.group(1)]:i + 1]
+            if sum(1 for x in seg if "s_bcnt1_i32_b64" in x) == 9:
+                counts.append(sum(1 for x in seg if re.match(r"\s*v_", x)))
+    assert counts, "no loop with nine ballot counts: the voting loop changed shape -- recount bench.RANSAC_VALU_PER_HYPOTHESIS"
+    assert min(counts) - 3 <= bench.RANSAC_VALU_PER_HYPOTHESIS <= max(counts) + 3, (counts, bench.RANSAC_VALU_PER_HYPOTHESIS)
