@@ -716,6 +716,43 @@ def test_bf16_conv_mode_converges_like_the_fp32_equivalent_mode(device, monkeypa
     assert np.abs(c - a).max() > 1e-7, "identical curves: the bf16 mode did not take effect"
 
 
+def test_fp16_pair_training_tracks_the_exact_split_training(device, monkeypatch):
+    """Round 6: the plan's default runs forward AND backward GEMMs on fp16 pairs (three products per fp32 product, gradients behind powers of two that
+    follow device-side maxima).  30 optimisation steps from the same initialisation on the same batch, once in that default and once with the exact
+    three-way bf16 split in both directions: the loss curves must agree to 1 % (+ 0.005 absolute) at EVERY step -- the band the bf16-operand mode gets
+    3 % of -- and both must train.  With a reading of the range slots every 4 steps, so that exponents are re-judged several times on the way."""
+    from casapose_amd import engine as E
+    from casapose_amd import train_engine as TE
+
+    if not E.TRAIN_WINO_GEMM_SPLIT:
+        pytest.skip("CASAPOSE_WINO_GEMM=f32: no fp16-pair GEMMs in this process")
+    monkeypatch.setattr(TE, "F16X2_TRAIN_CHECK_EVERY", 4)
+    monkeypatch.delenv("CASAPOSE_CONV_MODE", raising=False)
+    b, h, w, k, steps = 4, 64, 64, 4, 30
+    curves, plans = {}, {}
+    for mode in ("split", "f16x2"):
+        monkeypatch.setenv("CASAPOSE_TRAIN_FWD", mode)
+        monkeypatch.setenv("CASAPOSE_TRAIN_BWD", mode)
+        params, store, plan, img, lab, kpts = _setup(device, b, h, w, k, seed=77)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        plan.refresh_weights(stream)
+        imgd, labd, kd = torch.from_numpy(img).to(device), torch.from_numpy(lab).to(device), torch.from_numpy(kpts).to(device)
+        hist = []
+        for _ in range(steps):
+            s = plan.train_step(imgd, labd, labd, kd, lr=1e-3, cond_labels=labd, weights=(1.0, 0.5, 0.015)).cpu().numpy()
+            hist.append(s[0] + 0.5 * s[1] + 0.015 * s[2])
+        curves[mode], plans[mode] = np.array(hist), plan
+    a, c = curves["split"], curves["f16x2"]
+    print("loss, exact split: %s" % np.round(a[::3], 4))
+    print("loss, fp16 pairs : %s" % np.round(c[::3], 4))
+    slots = plans["f16x2"]._bwd_slots()
+    assert slots and not plans["split"]._bwd_slots()
+    on = sum(1 for _, f, e in slots if (f["on"] if e == "direct" else f["e"] is not None))
+    assert on >= len(slots) // 2 and plans["f16x2"].f16x2_checks >= 3, (on, len(slots), plans["f16x2"].f16x2_checks)
+    assert np.all(np.isfinite(c)) and c[-1] < 0.6 * c[0] and a[-1] < 0.6 * a[0], (a[0], a[-1], c[0], c[-1])
+    assert np.all(np.abs(c - a) <= 0.01 * a + 0.005), "fp16-pair curve leaves the band: max deviation %.3g at step %d" % (np.abs(c - a).max(), int(np.abs(c - a).argmax()))
+
+
 # --------------------------------------------------------------------------------------------------
 # keypoint reprojection loss through the LS voter
 # --------------------------------------------------------------------------------------------------
