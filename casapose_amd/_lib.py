@@ -82,10 +82,13 @@ class ConvDesc(C.Structure):
         ("group_weight_stride", C.c_int),
         ("head_label_out", C.c_void_p),
         ("head_label_classes", C.c_int),
+        ("head_prefix", C.c_void_p),
+        ("head_prefix_n", C.c_int),
+        ("head_prefix_ld", C.c_int),
     ]
 
 
-ABI_VERSION = 301  # CP_ABI_VERSION of include/casapose_hip.h
+ABI_VERSION = 302  # CP_ABI_VERSION of include/casapose_hip.h
 PLANES_F16X2 = 0x12  # CP_PLANES_F16X2: the fp16 two-way split (three products, fp32-level accuracy)
 
 SRC_DIRECT, SRC_NEAREST_SEL, SRC_BILINEAR_X2, SRC_ZERO_INSERT_X2 = 0, 1, 2, 3

@@ -49,7 +49,7 @@ constexpr int NIMG = (HP + 255) / 256;      // image-halo pixels per loader thre
 // residual, no raw / activated output): blocks 5 and 10 of the decoders, 17 % of the forward.  Their epilogue is compiled without the operands it
 // does not have (three buffer descriptors and a dozen uniform flags fewer: the generic form reloads 350 spilled scalars per tile) and with the
 // per-channel table held in registers for the whole kernel.
-enum : int { HS_BILINEAR = 2, HS_PARTIAL = 4, HS_SEL = 8, HS_HEADK = 16 };
+enum : int { HS_BILINEAR = 2, HS_PARTIAL = 4, HS_SEL = 8, HS_HEADK = 16, HS_PREFIX = 32 };   // HS_PREFIX: a head layer that writes whole output records (head_pre_n)
 
 struct SSrc {
     const float* data;
@@ -85,6 +85,8 @@ struct HSplitK {
     uint8_t* head_lab;   // optional arg-max of the first head_lab_classes head channels
     int head_lab_classes;
     float descale, head_descale;   // NP = 2: 1 / (power of two the conv / head weights were multiplied by); 1 otherwise
+    int head_pre_n;                // HS_HEADK only: > 0 = head_out addresses whole output RECORDS; floats [0, head_pre_n) of a pixel's record are copied
+                                   // from the dense rows `residual` (row length res_ld: a head layer has no residual), the head's columns follow them
     int w_res;                     // 1: head layers keep their whole weight stream LDS-resident where it fits (A/B switch CASAPOSE_HS_WRES)
     int epi_split;                 // 1: the loader wave w + 4 runs the epilogue of row 1 of consumer wave w's rows (accumulators handed over through LDS)
     uint32_t* mon;                 // f16x2 range monitor slot (common.h) or null: max |x| of what the loaders convert -> [0], of the fused head's operand -> [2]
@@ -239,6 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
     constexpr bool BILINEAR = (MODE & HS_BILINEAR) != 0;   // source 0 is read at half resolution through a x2 half-pixel bilinear filter
     constexpr bool SEL = (MODE & HS_SEL) != 0;             // source 0 is read at half resolution through the guided-upsampling selection map
     constexpr bool HEADK = (MODE & HS_HEADK) != 0;         // head layer: table + leaky ReLU + fused 1x1 head, no other output (TN == 1)
+    constexpr bool PREFIX = (MODE & HS_PREFIX) != 0;       // ... that copies head_pre_n floats in front of its columns (whole output records)
+    static_assert(!PREFIX || HEADK, "only head layers write output records");
     static_assert(!HEADK || TN == 1, "a fused head needs 32 output channels");
     constexpr int NV = 1;   // (round 3 fetched the four bilinear taps of source 0 from global memory: NV = 4; now a low-resolution tile is staged in LDS)
     constexpr unsigned OOB = 0x80000000u;
@@ -443,6 +447,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
             const int y = y0 + 2 * ew + r, x = x0 + lrow;
             const bool pok = (y < p.H) & (x < p.Wd);
             const unsigned pix = (unsigned)((n * p.H + y) * p.Wd + x);
+            // whole output records (head_pre_n > 0, HS_HEADK): the record's first floats come from dense rows another head wrote.  Requested here, stored
+            // behind the head's own columns: lane half kh moves floats 4 kh .. 4 kh + 3, half 0 also floats 8 .. head_pre_n - 1 (8 <= head_pre_n <= 12)
+            u32x4 pre4 = {0u, 0u, 0u, 0u}, pre8 = {0u, 0u, 0u, 0u};
+            if constexpr (PREFIX) {
+                {
+                    const unsigned po = pix * (unsigned)p.res_ld * 4u;
+                    pre4 = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)(pok ? po + 16u * (unsigned)kh : OOB), 0, 0);
+                    if (p.head_pre_n > 8) pre8 = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)((pok & (kh == 0)) ? po + 32u : OOB), 0, 0);
+                }
+            }
             float f = 1.f;
             if constexpr (PARTIAL) f = p.norm ? 9.0f / (float)max(__popc(pmask[r]), 1) : 1.0f;
             if constexpr (NP == 2) f *= p.descale;   // the weights' power-of-two scale, undone exactly
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                     // stores: register g4 * 4 + e of lane half kh is head channel q = 8 g4 + 4 kh + e.  A group of eight channels that lies wholly
                     // below head_cout goes out as one 16-byte store per lane; the group that straddles it as single dwords, one store per e that
                     // ANY lane half still owns -- which stores exist is decided by uniform comparisons, which lanes take part by the offset
-                    const unsigned hbase = (pix * (unsigned)p.head_ld + (unsigned)(kh * 4)) * 4u;
+                    const unsigned hbase = (pix * (unsigned)p.head_ld + (unsigned)(kh * 4 + (PREFIX ? p.head_pre_n : 0))) * 4u;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const unsigned o = hbase + (unsigned)(g4 * 32);
@@ -600,6 +614,16 @@ __global__ __launch_bounds__(512, 2) void conv_hsplit_kernel(const HSplitK p) {
                             for (int e = 0; e < 4; ++e)
                                 if (p.head_cout > g4 * 8 + e)   // lane half 0 owns q = 8 g4 + e
                                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)a2[g4 * 4 + e]), r_head, (int)((pok & (e < left)) ? o + 4u * e : OOB), 0, 0);
+                        }
+                    }
+                    if constexpr (PREFIX) {
+                        {   // the copied floats complete the record's lines (each role copies the rows it finishes: handing row 1's copy to the consumer
+                            // wave as well was measured slower, 0.56 -> 0.66 ms for block 10)
+                            const unsigned ro = pix * (unsigned)p.head_ld * 4u;
+                            __builtin_amdgcn_raw_buffer_store_b128(pre4, r_head, (int)(pok ? ro + 16u * (unsigned)kh : OOB), 0, 0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (8 + e < p.head_pre_n) __builtin_amdgcn_raw_buffer_store_b32(pre8[e], r_head, (int)((pok & (kh == 0)) ? ro + 32u + 4u * e : OOB), 0, 0);
                         }
                     }
                     if (p.head_lab) {   // the hard label map straight from the head's registers: first maximum wins (cp_argmax_labels)
@@ -1634,8 +1658,17 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     const int np = planes & 15;
     const int tn = split_tn(d->cout);
     const bool headk = tn == 1 && d->head_out && !d->residual && !d->out_raw && !d->out_act && d->scale && d->act == CP_ACT_LEAKY01 && d->cout == 32;
+    if (d->head_out && d->head_prefix) {   // whole output records: the head-only instantiations carry the copy
+        CP_REQUIRE(headk, "cp_conv2d_fwd_split: head_prefix needs a head-only layer (32 channels, table, leaky ReLU, no other output)");
+        CP_REQUIRE(d->head_prefix_n >= 8 && d->head_prefix_n <= 12 && d->head_prefix_ld >= d->head_prefix_n && d->head_out_ld >= d->head_prefix_n + d->head_cout &&
+                   ((uintptr_t)d->head_out & 15) == 0 && d->head_out_ld % 4 == 0,
+                   "cp_conv2d_fwd_split: 8 <= head_prefix_n <= 12, prefix rows of >= head_prefix_n floats, 16-byte aligned records of >= head_prefix_n + head_cout floats");
+        k.residual = d->head_prefix;
+        k.res_ld = d->head_prefix_ld;
+        k.head_pre_n = d->head_prefix_n;
+    }
     const int mode = (d->tap_label ? HS_PARTIAL : 0) | (d->src[0].mode == CP_SRC_BILINEAR_X2 ? HS_BILINEAR : 0) | (d->src[0].mode == CP_SRC_NEAREST_SEL ? HS_SEL : 0) |
-                     (headk ? HS_HEADK : 0);
+                     (headk ? HS_HEADK : 0) | (k.head_pre_n ? HS_PREFIX : 0);
     hipStream_t st = (hipStream_t)stream;
 #define CP_HS(TN_, NP_, M_) if (tn == TN_ && np == NP_ && mode == (M_)) return launch_hsplit<TN_, NP_, (M_)>(k, st);
 #define CP_HS4(TN_, NP_) CP_HS(TN_, NP_, 0) CP_HS(TN_, NP_, HS_BILINEAR) CP_HS(TN_, NP_, HS_PARTIAL) CP_HS(TN_, NP_, HS_PARTIAL | HS_SEL)
@@ -1649,6 +1682,9 @@ extern "C" int cp_conv2d_fwd_split_scaled(const cp_conv_desc* d, const void* wei
     CP_HSK(3)
     CP_HSK(2)
     CP_HSK(1)
+    // whole output records: the last head of the network sits behind a partial convolution (decoder 2, casapose.py:107-142) -- those two forms only
+    CP_HS(1, 3, HS_HEADK | HS_PREFIX | HS_PARTIAL) CP_HS(1, 3, HS_HEADK | HS_PREFIX | HS_PARTIAL | HS_SEL)
+    CP_HS(1, 2, HS_HEADK | HS_PREFIX | HS_PARTIAL) CP_HS(1, 2, HS_HEADK | HS_PREFIX | HS_PARTIAL | HS_SEL)
 #undef CP_HSK
 #undef CP_HS4
 #undef CP_HS

@@ -390,6 +390,8 @@ F16X2_AMAX_HI = 65504.0 / 4.0
 F16X2_MONITOR = os.environ.get("CASAPOSE_F16X2_MONITOR", "1") != "0"
 F16X2_MONITOR_EVERY = max(1, int(os.environ.get("CASAPOSE_F16X2_MONITOR_EVERY", "8")))
 F16X2_MONITOR_SLACK = 2.0
+# the last fused head writes whole output records (ForwardPlan._whole_records); "0" = both heads write their slices
+WHOLE_RECORDS = os.environ.get("CASAPOSE_HEAD_RECORDS", "1") != "0"
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
@@ -956,6 +958,7 @@ class ForwardPlan:
             ver_head = L["pv_final_conv_vertex"]
             conv(ver_head, in_h=h, in_w=w, srcs=[dict(data=prev, ld=prev_c)], out_raw=self.img4, out_raw_ld=self.out_ld)
             self._out_bound.append((ver_head, K, "out_raw"))
+        self._whole_records(L, K, B * h * w, new)
         self._bind_winograd()
 
     def _bind_winograd(self):
@@ -1201,6 +1204,28 @@ class ForwardPlan:
         for step in self.steps[:self.encoder_steps]:
             step(stream)
         return [self.taps[n] for n in ("x2s", "x4s", "x8s", "x16s", "x32s")]
+
+    def _whole_records(self, L, K, pixels, new):
+        """Both fused heads write slices of the same [pixels][K + V] output records -- 36 and 108 of every 144 bytes, in launches far apart -- and a
+        partly written 128-byte line costs the memory system a read-modify-write (measured on the training heads: 2.2-2.7x the time of the same bytes
+        as whole lines; tools/debug/head_probe.py).  So block 5's head writes DENSE rows of K logits (self.seg_dense) and block 10's, the last
+        writer, copies them in front of its own columns (cp_conv_desc.head_prefix, the HS_PREFIX instantiations of csrc/conv_hsplit.hip): whole lines
+        only.  Where it applies: both heads fused on the 2-byte-pipe kernel, block 10 a partial convolution, 8 <= K <= 12, K + V a multiple of 4.
+        CASAPOSE_HEAD_RECORDS=0 keeps the two slice writers."""
+        self.seg_dense = None
+        b5, b10 = L.get("pv_block_5_conv2d"), L.get("pv_block_10_prepare_conv2d")
+        if (not WHOLE_RECORDS or not (self.labels_from_head and self.fuse_head2) or b5 is None or b10 is None or not (8 <= K <= 12) or self.out_ld % 4
+                or b5.split_mode not in (3, _lib.PLANES_F16X2) or b10.split_mode not in (3, _lib.PLANES_F16X2) or not b10.desc.tap_label
+                or b10.desc.head_cout + K != self.out_ld):
+            return
+        bound = {(id(l), f): o for l, o, f in self._out_bound}
+        if bound.get((id(b5), "head_out")) != 0 or bound.get((id(b10), "head_out")) != K:
+            return
+        self.seg_dense = new(pixels, K)
+        b5.desc.head_out, b5.desc.head_out_ld = self.seg_dense.data_ptr(), K
+        b10.desc.head_prefix, b10.desc.head_prefix_n, b10.desc.head_prefix_ld = self.seg_dense.data_ptr(), K, K
+        self._out_bound = [(l, o, f) for l, o, f in self._out_bound if not (l is b5 and f == "head_out") and not (l is b10 and f == "head_out")]
+        self._out_bound.append((b10, 0, "head_out"))   # block 10 addresses the record itself
 
     def micro_steps(self, img: torch.Tensor, out: torch.Tensor):
         """The launches of run(img, out=out) with the estimated mask as a list of (tag, fn(stream)): "M" = matrix-pipe kernels (convolutions, the

@@ -37,8 +37,9 @@ const char* cp_last_error(void);
 /* ABI version of the library: CP_ABI_VERSION of the header it was built from.  300 (round 3): cp_conv_desc starts with `struct_size`
  * and every entry point that takes a descriptor refuses one whose struct_size differs from the library's sizeof(cp_conv_desc)
  * (CP_ERR_INVALID, message in cp_last_error()) instead of reading fields a shorter or longer caller-side struct does not have.
- * 301 (round 6): + the f16x2 range-guard entry points (cp_f16x2_monitor_set / _get, cp_f16x2_range_check, cp_amax_f32); no struct changed. */
-#define CP_ABI_VERSION 301
+ * 301 (round 6): + the f16x2 range-guard entry points (cp_f16x2_monitor_set / _get, cp_f16x2_range_check, cp_amax_f32); no struct changed.
+ * 302 (round 6): cp_conv_desc ends with head_prefix / head_prefix_n / head_prefix_ld (whole output records from the last fused head). */
+#define CP_ABI_VERSION 302
 int cp_version(void);
 /* sizeof(cp_conv_desc) / sizeof(cp_conv_source) as this library was compiled: a binder checks them against its own declaration at load time */
 size_t cp_conv_desc_size(void);
@@ -145,6 +146,13 @@ typedef struct cp_conv_desc {
      * maximum wins, as cp_argmax_labels) -- the hard label map of pose_models.py:547-554 straight from the head's registers */
     uint8_t* head_label_out;
     int head_label_classes;
+    /* optional, with a fused head (round 6, ABI 302; cp_conv2d_fwd_split* with a head-only layer): whole output RECORDS.  head_out then addresses the
+     * record of a pixel (stride head_out_ld, 16-byte aligned); its floats [0, head_prefix_n) are copied from head_prefix[pixel * head_prefix_ld + j]
+     * (dense rows another head wrote), the head's channel q goes to float head_prefix_n + q.  Two heads that each write a slice of the records
+     * leave every 128-byte line partly written, which costs the memory system a read-modify-write; with this the last head writes whole lines.
+     * 8 <= head_prefix_n <= 12.  NULL: head_out addresses the head's first column, as before. */
+    const float* head_prefix;
+    int head_prefix_n, head_prefix_ld;
 } cp_conv_desc;
 
 enum { CP_TILE_AUTO = 0, CP_TILE_128x128 = 1, CP_TILE_64x128 = 2, CP_TILE_128x64 = 3, CP_TILE_128x32 = 4,

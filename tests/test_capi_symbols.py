@@ -124,7 +124,7 @@ def test_integration_doc_binding_is_current():
 def test_version_and_device_probe(lib):
     from casapose_amd import _lib
 
-    assert lib.cp_version() == _lib.ABI_VERSION == 301
+    assert lib.cp_version() == _lib.ABI_VERSION == 302
     text = open(os.path.join(ROOT, "include", "casapose_hip.h")).read()
     assert int(re.search(r"#define CP_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION
     assert lib.cp_device_count() >= 0  # 0 on the CPU-only build container; never raises
