@@ -390,8 +390,10 @@ F16X2_AMAX_HI = 65504.0 / 4.0
 F16X2_MONITOR = os.environ.get("CASAPOSE_F16X2_MONITOR", "1") != "0"
 F16X2_MONITOR_EVERY = max(1, int(os.environ.get("CASAPOSE_F16X2_MONITOR_EVERY", "8")))
 F16X2_MONITOR_SLACK = 2.0
-# the last fused head writes whole output records (ForwardPlan._whole_records); "0" = both heads write their slices
-WHOLE_RECORDS = os.environ.get("CASAPOSE_HEAD_RECORDS", "1") != "0"
+# the last fused head writes whole output records (ForwardPlan._whole_records).  Opt-in: three one-call A/Bs on three boxes gave +0.7 %, -0.1 % and -0.2 %
+# on the step (block 10's epilogue pays 0.05-0.06 ms for the copy; what comes back from the kernels that no longer share HBM with read-modify-writes
+# depends on the box) -- not a gain one can rely on.  The training plan's heads, stand-alone streaming kernels, do write whole records by default.
+WHOLE_RECORDS = os.environ.get("CASAPOSE_INFER_HEAD_RECORDS", "0") == "1"
 BF16_DEEP = os.environ.get("CASAPOSE_BF16_DEEP", "1") != "0"   # bf16 conv mode: deep layers on csrc/conv_bf16d.hip (0: two-plane Winograd)
 # images per Winograd batch group (0 = the whole batch in one go)
 WINO_CHUNK = int(os.environ.get("CASAPOSE_WINO_CHUNK", "0"))
@@ -1211,7 +1213,7 @@ class ForwardPlan:
         as whole lines; tools/debug/head_probe.py).  So block 5's head writes DENSE rows of K logits (self.seg_dense) and block 10's, the last
         writer, copies them in front of its own columns (cp_conv_desc.head_prefix, the HS_PREFIX instantiations of csrc/conv_hsplit.hip): whole lines
         only.  Where it applies: both heads fused on the 2-byte-pipe kernel, block 10 a partial convolution, 8 <= K <= 12, K + V a multiple of 4.
-        CASAPOSE_HEAD_RECORDS=0 keeps the two slice writers."""
+        Opt-in (CASAPOSE_INFER_HEAD_RECORDS=1): see WHOLE_RECORDS."""
         self.seg_dense = None
         b5, b10 = L.get("pv_block_5_conv2d"), L.get("pv_block_10_prepare_conv2d")
         if (not WHOLE_RECORDS or not (self.labels_from_head and self.fuse_head2) or b5 is None or b10 is None or not (8 <= K <= 12) or self.out_ld % 4

@@ -466,3 +466,30 @@ def test_f16x2_monitor_rearms_the_calibration_when_a_batch_leaves_the_band(devic
         # the vector field depends on the hard label map (decoder 2 is conditioned on the arg-max): compared where both devices' maps agree with each
         # other, against the oracle's field -- label near-ties of the oracle itself are excluded by the logits' gate above
         assert e16[1] <= 1.5 * e32[1] + 1e-6, (factor, e16, e32)
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "split"])
+def test_whole_output_records_from_the_last_fused_head_are_bit_identical(device, monkeypatch, mode):
+    """cp_conv_desc.head_prefix (ABI 302; the HS_PREFIX instantiations of csrc/conv_hsplit.hip): block 5's fused head writes dense rows of K logits and
+    block 10's copies them in front of its own columns, so that the [B,H,W,K+V] records are written as whole 128-byte lines by one launch.  An opt-in
+    (engine.WHOLE_RECORDS: its gain on the step depends on the box); same arithmetic, another store path: the output must equal the default plan's
+    bit for bit, in both 2-byte-pipe arithmetics, also on a second forward (calibrated plan) and on a ragged image size."""
+    from casapose_amd import engine
+    from casapose_amd.pose_models.tfkeras import Classifiers
+
+    k, v, b = 9, 27, 2
+    for h, w in ((96, 128), (72, 104)):
+        img = (2.0 * torch.rand(b, h, w, 3, generator=torch.Generator().manual_seed(h)) - 1.0).to(device)
+        outs = []
+        for whole in (False, True):
+            monkeypatch.setattr(engine, "WHOLE_RECORDS", whole)
+            net = Classifiers.get("casapose_c_gcu5")(ver_dim=v, seg_dim=k, input_shape=(h, w, 3), weights=None, base_model="resnet18", device=device, seed=1237,
+                                                     conv_mode=mode)
+            net([img], training=False)
+            out = net([img], training=False).clone()
+            plan = net._net.plan(b, h, w)
+            assert (plan.seg_dense is not None) == whole
+            if whole:
+                assert torch.equal(plan.seg_dense.view(b, h, w, k), out[..., :k])   # the dense rows ARE the logits the records carry
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])

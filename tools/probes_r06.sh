@@ -30,10 +30,10 @@ STAMP="# stamp $(python3 bench.py --stamp)   ($(date -u +%Y-%m-%dT%H:%MZ), tools
 } > $O/monitor_cost.txt
 { echo "$STAMP"; echo "# tools/debug/head_probe.py: the training step's 1x1 head kernels alone at bs 32 / 448 x 448 (partly written 36-float records against dense rows and whole records)"
   python3 tools/debug/head_probe.py 2>&1 | grep -v amdgpu.ids
-  echo "# inference: whole output records from block 10's fused head ('-', default) against the two slice writers (CASAPOSE_HEAD_RECORDS=0), alternating, one call"
-  bash tools/debug/ab_bench.sh - CASAPOSE_HEAD_RECORDS=0 - CASAPOSE_HEAD_RECORDS=0 - CASAPOSE_HEAD_RECORDS=0 2>&1
+  echo "# inference: whole output records from block 10's fused head (CASAPOSE_INFER_HEAD_RECORDS=1, opt-in) against the two slice writers ('-', default), alternating, one call"
+  bash tools/debug/ab_bench.sh CASAPOSE_INFER_HEAD_RECORDS=1 - CASAPOSE_INFER_HEAD_RECORDS=1 - CASAPOSE_INFER_HEAD_RECORDS=1 - 2>&1
+  CASAPOSE_INFER_HEAD_RECORDS=1 python3 tools/layer_times.py --reps 10 2>/dev/null | grep -E "pv_block_(5|10)_|whole"
   python3 tools/layer_times.py --reps 10 2>/dev/null | grep -E "pv_block_(5|10)_|whole"
-  CASAPOSE_HEAD_RECORDS=0 python3 tools/layer_times.py --reps 10 2>/dev/null | grep -E "pv_block_(5|10)_|whole"
 } > $O/head_probe.txt
 { echo "$STAMP"; echo "# tools/debug/grad_ranges.py: max |dY| per convolution op over six training steps (bs 8, 448 x 448, random initialisation)"
   python3 tools/debug/grad_ranges.py 6 2>&1 | grep -v amdgpu.ids
